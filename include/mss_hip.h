@@ -1,0 +1,224 @@
+/* mss_hip.h -- C ABI of libmss_hip.so, the MI355X (gfx950) kernels behind the dense-segmentation +
+ * OOD-scoring hot path of gaozhitong/MultiShiftSeg.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); every call is asynchronous
+ *     on that stream and performs no host synchronisation, allocation or free;
+ *   - return value: 0 = launched, MSS_ERR_* (>= 1001) = rejected precondition, other = hipError_t.
+ *     The reference only printf()s launch failures (ops/src/cuda/ms_deform_im2col_cuda.cuh:953-957);
+ *     callers of this ABI must raise on non-zero.
+ *   - activations inside the DeepLab path are NHWC fp32 with an explicit pixel stride (`ld*`,
+ *     in floats) so that kernels read/write channel slices of concat buffers in place.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference root).
+ */
+#ifndef MSS_HIP_H
+#define MSS_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSS_ABI_VERSION 1
+int mss_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * B1 -- MultiScaleDeformableAttention extension
+ * replaces ms_deform_attn_forward / ms_deform_attn_backward
+ *   lib/network/mask2former/modeling/pixel_decoder/ops/src/vision.cpp:18-21
+ *   .../ops/src/ms_deform_attn.h:25-66, .../ops/src/cuda/ms_deform_attn_cuda.cu:25-157
+ *   kernels: .../ops/src/cuda/ms_deform_im2col_cuda.cuh:242-304 (fwd), :306-925 (bwd variants)
+ * value [N,S,M,D]; spatial_shapes int64 [L,2]=(H_l,W_l); level_start_index int64 [L];
+ * sampling_loc [N,Lq,M,L,P,2] (x,y) in [0,1]; attn_weight [N,Lq,M,L,P]; out [N,Lq,M*D].
+ * forward: `out` may be uninitialised. backward: the callee zero-fills grad_value, grad_loc,
+ * grad_attn itself (the reference allocates them with at::zeros, ms_deform_attn_cuda.cu:126-128).
+ * There is no im2col_step argument: the whole batch is one launch (the reference's chunk loop,
+ * ms_deform_attn_cuda.cu:66-80, only bounds a temporary it needs and we do not). */
+int mss_msda_forward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                         const float* sampling_loc, const float* attn_weight, int N, int S, int M, int D, int L,
+                         int Lq, int P, float* out, void* stream);
+int mss_msda_forward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                         const double* sampling_loc, const double* attn_weight, int N, int S, int M, int D, int L,
+                         int Lq, int P, double* out, void* stream);
+int mss_msda_backward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                          const float* sampling_loc, const float* attn_weight, const float* grad_out, int N,
+                          int S, int M, int D, int L, int Lq, int P, float* grad_value, float* grad_loc,
+                          float* grad_attn, void* stream);
+int mss_msda_backward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                          const double* sampling_loc, const double* attn_weight, const double* grad_out, int N,
+                          int S, int M, int D, int L, int Lq, int P, double* grad_value, double* grad_loc,
+                          double* grad_attn, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * B2 -- DeepWV3Plus operator set (replaces the cuDNN/ATen ops under
+ *        lib/network/deepv3/deepv3.py:258-285 and lib/network/deepv3/wider_resnet.py:169-182)      */
+
+/* One bias-free 2-D convolution as an implicit GEMM on fp32 MFMA.
+ * replaces nn.Conv2d forward at deepv3.py:62-72,79-81,235-250 and wider_resnet.py:104-137,303-305 */
+typedef struct MssConvArgs {
+  const float* x;          /* input  NHWC [N,H,W,>=C], pixel stride ldx                         */
+  const float* w;          /* packed weights [R*S][Kpad][C] from mss_conv2d_pack_weights_f32     */
+  float* y;                /* output NHWC [N,OH,OW,>=K], pixel stride ldy                        */
+  const float* in_scale;   /* optional prologue  a = x*in_scale[c] + in_shift[c] (BatchNorm of   */
+  const float* in_shift;   /*   the producer, folded); sample n uses row n*in_ss_stride          */
+  const float* out_scale;  /* optional epilogue  y = acc*out_scale[k] + out_shift[k]             */
+  const float* out_shift;
+  const float* res;        /* optional residual  y += res[m*ldres + k]  (wider_resnet.py:181)    */
+  int N, H, W, C, ldx;
+  int OH, OW, K, Kpad, ldy;
+  int R, S, stride, dil, pad;
+  int in_ss_stride;        /* 0: one affine for all samples; C: one per sample (Dropout2d fold)  */
+  int in_relu, out_relu;   /* ReLU after the prologue affine / at the very end of the epilogue   */
+  int ldres;
+  int M, mtiles, ntiles;   /* filled in by the launcher                                          */
+} MssConvArgs;
+
+int mss_conv2d_forward_f32(MssConvArgs* args, void* stream);
+int mss_conv2d_kpad(int K);
+/* w [K][C][R][S] (nn.Conv2d.weight) -> packed [R*S][Kpad][Cp] (zero padded).
+ * flip=1 packs the data-gradient filter instead (K<->C swapped, taps rotated 180 degrees);
+ * then Kpad/Cp refer to the swapped roles. */
+int mss_conv2d_pack_weights_f32(const float* w, float* packed, int K, int C, int R, int S, int Kpad, int Cp,
+                                int flip, void* stream);
+/* weight gradient: dwp[tap][k][c] += sum_m dy[m][k]*act(x[m@tap][c]); dwp zeroed by the caller.
+ * replaces the autograd wgrad of nn.Conv2d for aspp/bot_aspp/bot_fine/ood_head
+ * (exps/DeepLab.yaml:10-11, train_deeplab.py:113-132) */
+int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dwp, int Cp, void* stream);
+int mss_conv2d_unpack_wgrad_f32(const float* packed, float* grad, int K, int C, int R, int S, int Kpad,
+                                int Cp, int accumulate, void* stream);
+
+/* image NCHW [N,C,H,W] -> NHWC [N,H,W,Cp] with channels C..Cp-1 zero (feeds mod1.conv1). */
+int mss_nchw_to_nhwc_pad_f32(const float* x, float* y, int N, int C, int H, int W, int Cp, void* stream);
+
+/* BatchNorm2d pieces (mynn.py:8-12 Norm2d = nn.BatchNorm2d, eps 1e-5, momentum 0.1).
+ * stats: per-channel batch mean and biased variance of an NHWC tensor (M pixels); `accum` is a
+ * zero-initialised double[2*C] workspace. */
+int mss_bn_stats_nhwc_f32(const float* x, long long M, int C, int ldx, double* accum, void* stream);
+/* finalise: from accum -> (mean, var) -> scale = gamma*rsqrt(var+eps), shift = beta-mean*scale;
+ * if running_mean != NULL also running = (1-mom)*running + mom*{mean, var*M/(M-1)}.
+ * save_mean / save_invstd (optional) are kept for the backward. */
+int mss_bn_finalize_train_f32(const double* accum, long long M, int C, const float* gamma, const float* beta,
+                              float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                              float* shift, float* save_mean, float* save_invstd, void* stream);
+/* eval mode: scale/shift from the running statistics. */
+int mss_bn_fold_eval_f32(const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+/* y = relu?(x*scale[c]+shift[c]) on NHWC rows (used where a fused prologue is not possible). */
+int mss_affine_relu_nhwc_f32(const float* x, int ldx, float* y, int ldy, long long M, int C, const float* scale,
+                             const float* shift, int relu, void* stream);
+/* backward of y = relu(bn_train(x)): given dy and x (pre-BN), scale/save_mean/save_invstd/gamma,
+ * accumulates per-channel sums into accum (double[2*C], zeroed by caller): sum(dz), sum(dz*xhat)
+ * where dz = dy * (y>0). */
+int mss_bn_relu_bwd_reduce_f32(const float* dy, int lddy, const float* x, int ldx, long long M, int C,
+                               const float* scale, const float* shift, const float* save_mean,
+                               const float* save_invstd, int relu, double* accum, void* stream);
+/* dx = gamma*invstd*(dz - sum_dz/M - xhat*sum_dzxhat/M) (train) or dz*scale (eval, accum==NULL);
+ * optional dgamma/dbeta outputs (added to, may be NULL). */
+int mss_bn_relu_bwd_apply_f32(const float* dy, int lddy, const float* x, int ldx, float* dx, int lddx,
+                              long long M, int C, const float* gamma, const float* scale, const float* shift,
+                              const float* save_mean, const float* save_invstd, int relu, const double* accum,
+                              float* dgamma, float* dbeta, void* stream);
+
+/* MaxPool2d(3, stride 2, padding 1) on NHWC (wider_resnet.py:353-355). */
+int mss_maxpool3s2_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int OH,
+                            int OW, void* stream);
+/* AdaptiveAvgPool2d(1) (deepv3.py:77,87): y[n][c] = mean over HW. */
+int mss_gap_nhwc_f32(const float* x, int ldx, float* y, int N, int HW, int C, void* stream);
+/* broadcast y[n][p][c] = relu?(v[n][c]*scale[c]+shift[c]) over HW pixels: the "Upsample" of the
+ * 1x1 image-pooling map (deepv3.py:86). */
+int mss_broadcast_rows_nhwc_f32(const float* v, float* y, int ldy, int N, int HW, int C, const float* scale,
+                                const float* shift, int relu, void* stream);
+/* backward of the broadcast: dv[n][c] = sum_p dy[n][p][c] */
+int mss_colsum_nhwc_f32(const float* dy, int lddy, float* dv, int N, int HW, int C, void* stream);
+
+/* F.interpolate(mode='bilinear', align_corners=True) (mynn.py:28-33) on NHWC, forward and its
+ * transpose (gather form, deterministic). Optional prologue affine+relu on the input. */
+int mss_upsample_ac_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N, int IH, int IW, int OH, int OW,
+                             int C, void* stream);
+int mss_upsample_ac_nhwc_bwd_f32(const float* dy, int lddy, float* dx, int lddx, int N, int IH, int IW, int OH,
+                                 int OW, int C, void* stream);
+
+/* The OOD-score tail (deepv3.py:251-253,279-283):
+ *   score[n,oy,ox] = bilinear_ac( -logsumexp_c dec2[n,:,:,c] )    dec2 NHWC [N,IH,IW,C] (ld)
+ *   logit[n,c,oy,ox] = bilinear_ac( dec1[n,:,:,c] )               written NCHW
+ *   label[n,oy,ox]  = argmax_c logit (first max wins, as torch.argmax), optional (uint8)
+ * Any of score/logit/label may be NULL. */
+int mss_ood_score_f32(const float* dec2, int ld2, const float* dec1, int ld1, int N, int IH, int IW, int C,
+                      int OH, int OW, float* score, float* logit_nchw, uint8_t* label, void* stream);
+/* backward: given dscore [N,OH,OW] and dlogit NCHW [N,C,OH,OW] (either may be NULL) produce
+ * ddec2 / ddec1 (NHWC, assigned). */
+int mss_ood_score_bwd_f32(const float* dec2, int ld2, const float* dscore, const float* dlogit_nchw, int N,
+                          int IH, int IW, int C, int OH, int OW, float* ddec2, int ldd2, float* ddec1, int ldd1,
+                          void* stream);
+
+/* Mask2Former anomaly score (train_m2f.py:387-407):
+ *   score[b,h,w] = 1 - max_{c<C} sum_q softmax(cls[b,q,:])[c] * sigmoid(mask[b,q,h,w])
+ * cls [B,Q,C+1], mask [B,Q,H,W] (row stride Wm >= W so a padded mask can be cropped in place). */
+int mss_m2f_score_f32(const float* cls, const float* mask, int B, int Q, int C, int H, int W, int Hm, int Wm,
+                      float* score, void* stream);
+
+/* Fused RelContrastiveLoss (lib/loss.py:34-156): value AND both gradients in a few streaming passes.
+ * The host side (multishiftseg_amd/loss.py) owns the workspaces and the call order:
+ *   pass1 -> select -> pass2 -> compact -> cin_bwd -> pairs x2 -> finalize
+ * Nothing here synchronises with the host; every normaliser is read from device counters. */
+typedef struct MssRclArgs {
+  const float* logit;      /* [B,C,H,W] NCHW                                          */
+  const float* score;      /* [B,H,W]                                                 */
+  int64_t* target;         /* [B,H,W] int64; mutated exactly like loss.py:110-111,115 */
+  int B, C, H, W;
+  float w_ce_orig, w_ce_aug, w_contras;   /* ce_weights[0], ce_weights[1], contras_weight */
+  float m0, m1, m2;                        /* inoutaug_contras_margins_tri                 */
+  int select;                              /* conduct_pixel_selection && 0 < ratio < 1     */
+  float selection_ratio;
+} MssRclArgs;
+/* counters: double[16]; slots 0 sum_ce_orig, 1 n_in_orig, 2 n_in_aug, 3 n_ood, 4 sum_c_in,
+ * 5 n_same_in, 6 sum_ce_aug_all, 7 sum_selected_ce, 8 n_selected, 9 sum_c_orig, 10 sum_c_aug,
+ * 11 n_pairs. pass1 zeroes them.
+ * pass1 (loss.py:46-60,90-96): lse[B*H*W], ce_aug[(B/2)*H*W] (+inf where ignored),
+ * kind[B*H*W] (0 void / 1 in-distribution / 2 OOD, from the UNmutated targets). */
+int mss_rcl_pass1_f32(const MssRclArgs* a, float* lse, float* ce_aug, uint8_t* kind, double* counters,
+                      void* stream);
+/* exact k-th smallest of ce_aug, k = int(float32(ratio) * float32(n_in_aug)) as torch computes
+ * it (loss.py:98-99); replaces torch.topk (loss.py:102). hist_ws: uint32[256]; sel: uint32[8]
+ * = {threshold key, n_less, k, n_equal_to_take, tie tickets, ...}. */
+int mss_rcl_select_f32(const float* ce_aug, long long n, const double* counters, float selection_ratio,
+                       uint32_t* hist_ws, uint32_t* sel, void* stream);
+/* pass2: dlogit (NCHW, assigned; may be NULL) = grad_scale * d loss / d logit, target mutation,
+ * counters[7..8]. */
+int mss_rcl_pass2_f32(const MssRclArgs* a, const float* lse, const float* ce_aug, const uint8_t* kind,
+                      uint32_t* sel, double* counters, float grad_scale, float* dlogit, void* stream);
+/* row-major ordered compaction of pixel indices into the three sets of loss.py:122-124
+ * (in-dist original half, in-dist augmented half, OOD); sizes to n_out (uint32[3]);
+ * block_counts: uint32[3 * mss_rcl_num_compact_blocks(B,H,W)]. */
+int mss_rcl_num_compact_blocks(int B, int H, int W);
+int mss_rcl_compact_f32(const uint8_t* kind, int B, int H, int W, int32_t* idx_orig, int32_t* idx_aug,
+                        int32_t* idx_ood, uint32_t* block_counts, uint32_t* n_out, void* stream);
+/* dscore of the consistency term (loss.py:141-145); ASSIGNS all of dscore, call before pairs. */
+int mss_rcl_cin_bwd_f32(const MssRclArgs* a, const uint8_t* kind, const double* counters, float grad_w,
+                        float* dscore, void* stream);
+/* hinge over n pairs (loss.py:129-137): sum_i relu(score[idx_a[perm_a[i]]] + margin -
+ * score[idx_o[perm_o[i]]]) -> counters[9 + slot]; dscore += -+ grad_w/n (atomics; may be NULL).
+ * perm_*: int64 permutations as torch.randperm returns them (parity mode: the caller injects
+ * the reference's own permutations). */
+int mss_rcl_pairs_f32(const float* score, const int32_t* idx_a, const int64_t* perm_a, const int32_t* idx_o,
+                      const int64_t* perm_o, long long n, float margin, double* counters, int slot, float grad_w,
+                      float* dscore, void* stream);
+/* same, but n = min(max_samples, n_out[0..2]) and the two permutations are keyed Feistel
+ * bijections evaluated on the fly: no host round trip, no materialised randperm. */
+int mss_rcl_pairs_device_f32(const float* score, const int32_t* idx_a, const int32_t* idx_o, const uint32_t* n_out,
+                             int set_a, long long max_samples, uint32_t seed_a, uint32_t seed_o, float margin,
+                             double* counters, int slot, float grad_w, float* dscore, void* stream);
+/* out: float[8] = {loss, ce_orig, ce_aug, c_orig, c_aug, c_in, -, -} (loss.py:73-88,147). */
+int mss_rcl_finalize_f32(const MssRclArgs* a, const double* counters, const uint32_t* sel, float* out,
+                         void* stream);
+
+/* Adam with L2-coupled weight decay (torch.optim.Adam semantics, train_deeplab.py:134-149). */
+int mss_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSS_HIP_H */

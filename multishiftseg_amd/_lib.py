@@ -1,0 +1,140 @@
+"""ctypes binding of libmss_hip.so (include/mss_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call returns
+non-zero, this module raises (the reference silently fell back to a slow PyTorch path inside a
+bare ``except``: ops/modules/ms_deform_attn.py:116-121).
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int, c_longlong, c_uint32, c_void_p
+
+import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so libmss_hip.so binds to the same runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmss_hip.so")
+
+MSS_ERR_BAD_ARG = 1001
+MSS_ERR_UNSUPPORTED = 1002
+
+
+class MssError(RuntimeError):
+    pass
+
+
+class MssConvArgs(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("w", c_void_p), ("y", c_void_p),
+        ("in_scale", c_void_p), ("in_shift", c_void_p),
+        ("out_scale", c_void_p), ("out_shift", c_void_p),
+        ("res", c_void_p),
+        ("N", c_int), ("H", c_int), ("W", c_int), ("C", c_int), ("ldx", c_int),
+        ("OH", c_int), ("OW", c_int), ("K", c_int), ("Kpad", c_int), ("ldy", c_int),
+        ("R", c_int), ("S", c_int), ("stride", c_int), ("dil", c_int), ("pad", c_int),
+        ("in_ss_stride", c_int), ("in_relu", c_int), ("out_relu", c_int),
+        ("ldres", c_int),
+        ("M", c_int), ("mtiles", c_int), ("ntiles", c_int),
+    ]
+
+
+class MssRclArgs(Structure):
+    _fields_ = [
+        ("logit", c_void_p), ("score", c_void_p), ("target", c_void_p),
+        ("B", c_int), ("C", c_int), ("H", c_int), ("W", c_int),
+        ("w_ce_orig", c_float), ("w_ce_aug", c_float), ("w_contras", c_float),
+        ("m0", c_float), ("m1", c_float), ("m2", c_float),
+        ("select", c_int), ("selection_ratio", c_float),
+    ]
+
+
+P = c_void_p
+I = c_int
+L = c_longlong
+F = c_float
+U = c_uint32
+
+# name -> argtypes, exactly the declarations of include/mss_hip.h
+SIGNATURES = {
+    "mss_abi_version": [],
+    "mss_msda_forward_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P, P],
+    "mss_msda_forward_f64": [P, P, P, P, P, I, I, I, I, I, I, I, P, P],
+    "mss_msda_backward_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P],
+    "mss_msda_backward_f64": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P],
+    "mss_conv2d_forward_f32": [POINTER(MssConvArgs), P],
+    "mss_conv2d_kpad": [I],
+    "mss_conv2d_pack_weights_f32": [P, P, I, I, I, I, I, I, I, P],
+    "mss_conv2d_wgrad_f32": [POINTER(MssConvArgs), P, I, P, I, P],
+    "mss_conv2d_unpack_wgrad_f32": [P, P, I, I, I, I, I, I, I, P],
+    "mss_nchw_to_nhwc_pad_f32": [P, P, I, I, I, I, I, P],
+    "mss_bn_stats_nhwc_f32": [P, L, I, I, P, P],
+    "mss_bn_finalize_train_f32": [P, L, I, P, P, F, F, P, P, P, P, P, P, P],
+    "mss_bn_fold_eval_f32": [P, P, P, P, F, I, P, P, P],
+    "mss_affine_relu_nhwc_f32": [P, I, P, I, L, I, P, P, I, P],
+    "mss_bn_relu_bwd_reduce_f32": [P, I, P, I, L, I, P, P, P, P, I, P, P],
+    "mss_bn_relu_bwd_apply_f32": [P, I, P, I, P, I, L, I, P, P, P, P, P, I, P, P, P, P],
+    "mss_maxpool3s2_nhwc_f32": [P, I, P, I, I, I, I, I, I, I, P],
+    "mss_gap_nhwc_f32": [P, I, P, I, I, I, P],
+    "mss_broadcast_rows_nhwc_f32": [P, P, I, I, I, I, P, P, I, P],
+    "mss_colsum_nhwc_f32": [P, I, P, I, I, I, P],
+    "mss_upsample_ac_nhwc_f32": [P, I, P, I, I, I, I, I, I, I, P],
+    "mss_upsample_ac_nhwc_bwd_f32": [P, I, P, I, I, I, I, I, I, I, P],
+    "mss_ood_score_f32": [P, I, P, I, I, I, I, I, I, I, P, P, P, P],
+    "mss_ood_score_bwd_f32": [P, I, P, P, I, I, I, I, I, I, P, I, P, I, P],
+    "mss_m2f_score_f32": [P, P, I, I, I, I, I, I, I, P, P],
+    "mss_rcl_pass1_f32": [POINTER(MssRclArgs), P, P, P, P, P],
+    "mss_rcl_select_f32": [P, L, P, F, P, P, P],
+    "mss_rcl_pass2_f32": [POINTER(MssRclArgs), P, P, P, P, P, F, P, P],
+    "mss_rcl_num_compact_blocks": [I, I, I],
+    "mss_rcl_compact_f32": [P, I, I, I, P, P, P, P, P, P],
+    "mss_rcl_cin_bwd_f32": [POINTER(MssRclArgs), P, P, F, P, P],
+    "mss_rcl_pairs_f32": [P, P, P, P, P, L, F, P, I, F, P, P],
+    "mss_rcl_pairs_device_f32": [P, P, P, P, I, L, U, U, F, P, I, F, P, P],
+    "mss_rcl_finalize_f32": [POINTER(MssRclArgs), P, P, P, P],
+    "mss_adam_step_f32": [P, P, P, P, L, F, F, F, F, F, I, P],
+}
+# entry points that return a plain value rather than a status code
+_VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_rcl_num_compact_blocks"}
+
+_lib = None
+
+
+def load():
+    """dlopen libmss_hip.so (once). Raises MssError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MssError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C multishiftseg_amd/csrc` (there is no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    """Call a status-returning entry point on the current torch stream; raise on non-zero."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream_ptr())
+    if rc != 0:
+        kind = {MSS_ERR_BAD_ARG: "bad argument", MSS_ERR_UNSUPPORTED: "unsupported shape"}.get(rc, "hipError_t")
+        raise MssError(f"{name} failed with code {rc} ({kind})")
+
+
+def value(name, *args):
+    assert name in _VALUE_RETURNING
+    return getattr(load(), name)(*args)

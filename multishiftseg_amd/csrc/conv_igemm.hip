@@ -1,0 +1,471 @@
+// Implicit-GEMM convolution on the fp32 matrix cores of MI355X (v_mfma_f32_32x32x2_f32).
+//
+// Replaces, for the DeepWV3Plus path, every nn.Conv2d the reference runs through cuDNN
+// (reference: lib/network/deepv3/deepv3.py:47-92,217-285; wider_resnet.py:64-182,288-364).
+// All 54 convs are bias-free, 1x1 or 3x3, stride 1/2, dilation 1/2/4/12/24/36, padding = dilation.
+//
+// GEMM view: C[m][k] = sum_{tap,c} A[m][(tap,c)] * Wp[tap][k][c]
+//   m   = output pixel (n, oy, ox)   -> MFMA row i
+//   k   = output channel             -> MFMA column j (lane & 31): stores are 128-B segments
+//   A   = NHWC input gathered at (oy*stride - pad + r*dil, ox*stride - pad + s*dil), zero outside
+// Activations are NHWC with an explicit pixel stride (ldx/ldy) so a conv can read from / write
+// into a channel slice of a wider (concat) tensor without a copy.
+//
+// Fused on the A side (prologue): per-channel affine + ReLU, i.e. eval- or train-mode
+// BatchNorm+ReLU of the *previous* layer (pre-activation blocks, wider_resnet.py:43-48,169-182);
+// the affine may be per-sample so that Dropout2d's channel mask folds in too.
+// Fused on the C side (epilogue): per-channel affine, residual add, ReLU.
+//
+// Taps that are dead for the whole 128-pixel tile (all rows fall in the zero padding, common
+// for dilation 12/24/36 on /8 maps) are skipped with a block-uniform decision.
+#include "mss_common.h"
+#include "../../include/mss_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
+  constexpr int LDK = BK + 4;            // +4 floats: ds_read_b128 of 16 distinct rows is conflict-free
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int CPR = BK / 4;            // float4 chunks per tile row
+  constexpr int RPP = NT / CPR;          // rows staged per pass
+  constexpr int A_LD = BM / RPP, B_LD = BN / RPP;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for 256 threads");
+
+  // all LDS in ONE dynamic array (a static __shared__ in front would shift its 16-B alignment)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* live_mask_p = reinterpret_cast<int*>(smem);  // first 16 B reserved
+  float* As = smem + 4;                   // [2][BM][LDK]
+  float* Bs = As + 2 * BM * LDK;          // [2][BN][LDK]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int v = mss_xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = v / p.ntiles, nt = v % p.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int chunk = tid % CPR;
+  const int row0 = tid / CPR;
+
+  // ---- per-thread descriptors of the A rows it stages ----
+  int a_nb[A_LD], a_iy0[A_LD], a_ix0[A_LD], a_n[A_LD];
+  const int ohw = p.OH * p.OW;
+  int my_live = 0;
+  if (tid == 0) *live_mask_p = 0;
+#pragma unroll
+  for (int j = 0; j < A_LD; ++j) {
+    int m = m0 + row0 + j * RPP;
+    if (m < p.M) {
+      int n = m / ohw, rem = m - n * ohw;
+      int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_n[j] = n;
+      a_nb[j] = n * p.H * p.W;
+      a_iy0[j] = oy * p.stride - p.pad;
+      a_ix0[j] = ox * p.stride - p.pad;
+      for (int t = 0; t < p.R * p.S; ++t) {
+        int iy = a_iy0[j] + (t / p.S) * p.dil, ix = a_ix0[j] + (t % p.S) * p.dil;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) my_live |= 1 << t;
+      }
+    } else {
+      a_n[j] = 0; a_nb[j] = 0; a_iy0[j] = -0x40000000; a_ix0[j] = -0x40000000;
+    }
+  }
+  __syncthreads();
+  if (my_live) atomicOr(live_mask_p, my_live);
+  __syncthreads();
+  const int live = *live_mask_p;
+  const int nlive = __popc(live);
+  const int cblocks = p.C / BK;
+  const int n_it = nlive * cblocks;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 areg[A_LD], breg[B_LD];
+
+  // iteration state of the *loader* (runs one step ahead of the MFMA loop)
+  int ld_tap = -1, ld_c0 = 0, ld_left = live;
+  auto next_tap = [&]() {
+    ld_tap = __ffs(ld_left) - 1;
+    ld_left &= ld_left - 1;
+    ld_c0 = 0;
+  };
+
+  auto load_global = [&]() {
+    const int r = ld_tap / p.S, s = ld_tap - r * p.S;
+    const int dy = r * p.dil, dx = s * p.dil;
+    const int cc = ld_c0 + chunk * 4;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+      bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const float* src = p.x + (size_t)(a_nb[j] + iy * p.W + ix) * p.ldx + cc;
+        val = *reinterpret_cast<const f32x4*>(src);
+        if (p.in_scale) {
+          const size_t so = (size_t)a_n[j] * p.in_ss_stride + cc;
+          f32x4 sc = *reinterpret_cast<const f32x4*>(p.in_scale + so);
+          f32x4 sh = *reinterpret_cast<const f32x4*>(p.in_shift + so);
+          val = val * sc + sh;
+        }
+        if (p.in_relu) {
+          val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f);
+          val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
+        }
+      }
+      areg[j] = val;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      const float* src = p.w + ((size_t)ld_tap * p.Kpad + n0 + row0 + j * RPP) * p.C + cc;
+      breg[j] = *reinterpret_cast<const f32x4*>(src);
+    }
+    ld_c0 += BK;
+    if (ld_c0 >= p.C && ld_left) next_tap();
+  };
+
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j)
+      *reinterpret_cast<f32x4*>(&As[(buf * BM + row0 + j * RPP) * LDK + chunk * 4]) = areg[j];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j)
+      *reinterpret_cast<f32x4*>(&Bs[(buf * BN + row0 + j * RPP) * LDK + chunk * 4]) = breg[j];
+  };
+
+  if (n_it > 0) {
+    next_tap();
+    load_global();
+    store_lds(0);
+  }
+  __syncthreads();
+
+  const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
+  for (int it = 0; it < n_it; ++it) {
+    const int buf = it & 1;
+    const bool more = it + 1 < n_it;
+    if (more) load_global();
+    const float* Ab = &As[(buf * BM + wm * WTM + frag_row) * LDK + frag_k];
+    const float* Bb = &Bs[(buf * BN + wn * WTN + frag_row) * LDK + frag_k];
+#pragma unroll
+    for (int kc = 0; kc < BK / 8; ++kc) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + kc * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + kc * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  const int colq = lane & 31, rowq = 4 * (lane >> 5);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + colq;
+    if (col >= p.K) continue;
+    float osc = 1.f, osh = 0.f;
+    if (p.out_scale) { osc = p.out_scale[col]; osh = p.out_shift[col]; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
+        if (row < p.M) {
+          float val = acc[i][j][r];
+          if (p.out_scale) val = val * osc + osh;
+          if (p.res) val += p.res[(size_t)row * p.ldres + col];
+          if (p.out_relu) val = fmaxf(val, 0.f);
+          p.y[(size_t)row * p.ldy + col] = val;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+int launch_conv(MssConvArgs& p, hipStream_t stream) {
+  p.mtiles = mss_cdiv(p.M, BM);
+  p.ntiles = mss_cdiv(p.K, BN);
+  if (p.Kpad < p.ntiles * BN) return MSS_ERR_BAD_ARG;
+  const size_t smem = ((size_t)2 * (BM + BN) * (BK + 4) + 4) * sizeof(float);
+  auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN>;
+  if (smem > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles), dim3(NT), smem, stream, p);
+  return mss_launch_status();
+}
+
+// [K][C][R][S] (PyTorch) -> [R*S][Kpad][Cp], zero padded. flip=1 builds the dgrad weights:
+// a conv from K channels back to C channels with the taps rotated 180 degrees.
+__global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int K, int C,
+                                    int R, int S, int Kpad, int Cp, int flip) {
+  const size_t total = (size_t)R * S * Kpad * Cp;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int c = i % Cp;
+    int k = (i / Cp) % Kpad;
+    int t = i / ((size_t)Cp * Kpad);
+    int r = t / S, s = t % S;
+    float val = 0.f;
+    if (!flip) {
+      if (k < K && c < C) val = src[(((size_t)k * C + c) * R + r) * S + s];
+    } else {
+      // output channel index k runs over the conv's *input* channels (C of src), input index c over src's K
+      if (k < C && c < K) val = src[(((size_t)c * C + k) * R + (R - 1 - r)) * S + (S - 1 - s)];
+    }
+    dst[i] = val;
+  }
+}
+
+// [R*S][Kpad][Cp] packed gradient -> accumulate/assign into [K][C][R][S]
+__global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int K, int C,
+                                    int R, int S, int Kpad, int Cp, int accumulate) {
+  const size_t total = (size_t)K * C * R * S;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int s = i % S;
+    int r = (i / S) % R;
+    int c = (i / ((size_t)S * R)) % C;
+    int k = i / ((size_t)S * R * C);
+    float val = src[((size_t)(r * S + s) * Kpad + k) * Cp + c];
+    dst[i] = accumulate ? dst[i] + val : val;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: dWp[tap][k][c] = sum_m dy[m][k] * act(x[m_tap][c])   (reduction over output pixels)
+// MFMA rows = k (output channels), columns = c (input channels), contraction = pixels.
+// Both operands sit in LDS as [pixel][channel] (their natural NHWC order) and are read with
+// ds_read_b32: lane (i = l&31, kk = l>>5) reads row kk, column i -> 32 consecutive floats.
+// Grid: (ktiles*ctiles, taps, splits); the pixel range is split across blockIdx.z and the
+// partial sums land in the zero-initialised dWp by fp32 atomics.
+template <int BKO, int BCI, int BP>
+__global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const float* __restrict__ dy, int lddy,
+                                                        float* __restrict__ dwp, int Cp, int pix_per_split) {
+  constexpr int LDA = BKO + 1;  // dy tile  [BP][BKO]
+  constexpr int LDB = BCI + 1;  // x  tile  [BP][BCI]
+  constexpr int TM = BKO / 2 / 32, TN = BCI / 2 / 32;  // 2x2 waves
+  __shared__ float As[2][BP][LDA];
+  __shared__ float Bs[2][BP][LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ctiles = mss_cdiv(p.C, BCI);
+  const int kt = blockIdx.x / ctiles, ct = blockIdx.x % ctiles;
+  const int k0 = kt * BKO, c0 = ct * BCI;
+  const int tap = blockIdx.y;
+  const int r = tap / p.S, s = tap - r * p.S;
+  const int dyo = r * p.dil - p.pad, dxo = s * p.dil - p.pad;
+  const int mbeg = blockIdx.z * pix_per_split;
+  const int mend = min(p.M, mbeg + pix_per_split);
+  const int ohw = p.OH * p.OW;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  // staging: each thread moves float4 pieces; A tile BP x BKO, B tile BP x BCI
+  constexpr int A_CPR = BKO / 4, B_CPR = BCI / 4;
+  constexpr int A_LD = BP * A_CPR / NT, B_LD = BP * B_CPR / NT;
+  static_assert(A_LD >= 1 && B_LD >= 1, "");
+  f32x4 areg[A_LD], breg[B_LD];
+
+  auto load_global = [&](int mb) {
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      int e = tid + j * NT;
+      int pr = e / A_CPR, ch = (e % A_CPR) * 4;
+      int m = mb + pr;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (m < mend) {
+        const float* src = dy + (size_t)m * lddy + k0 + ch;
+        if (k0 + ch + 3 < p.K) val = *reinterpret_cast<const f32x4*>(src);
+        else {
+          if (k0 + ch + 0 < p.K) val.x = src[0];
+          if (k0 + ch + 1 < p.K) val.y = src[1];
+          if (k0 + ch + 2 < p.K) val.z = src[2];
+        }
+      }
+      areg[j] = val;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      int e = tid + j * NT;
+      int pr = e / B_CPR, ch = (e % B_CPR) * 4;
+      int m = mb + pr;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (m < mend && c0 + ch < p.C) {
+        int n = m / ohw, rem = m - n * ohw;
+        int oy = rem / p.OW, ox = rem - oy * p.OW;
+        int iy = oy * p.stride + dyo, ix = ox * p.stride + dxo;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+          const int cc = c0 + ch;
+          val = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(n * p.H + iy) * p.W + ix) * p.ldx + cc);
+          if (p.in_scale) {
+            const size_t so = (size_t)n * p.in_ss_stride + cc;
+            val = val * *reinterpret_cast<const f32x4*>(p.in_scale + so) +
+                  *reinterpret_cast<const f32x4*>(p.in_shift + so);
+          }
+          if (p.in_relu) {
+            val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f);
+            val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
+          }
+        }
+      }
+      breg[j] = val;
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      int e = tid + j * NT;
+      int pr = e / A_CPR, ch = (e % A_CPR) * 4;
+      As[buf][pr][ch + 0] = areg[j].x; As[buf][pr][ch + 1] = areg[j].y;
+      As[buf][pr][ch + 2] = areg[j].z; As[buf][pr][ch + 3] = areg[j].w;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      int e = tid + j * NT;
+      int pr = e / B_CPR, ch = (e % B_CPR) * 4;
+      Bs[buf][pr][ch + 0] = breg[j].x; Bs[buf][pr][ch + 1] = breg[j].y;
+      Bs[buf][pr][ch + 2] = breg[j].z; Bs[buf][pr][ch + 3] = breg[j].w;
+    }
+  };
+
+  const int n_it = mend > mbeg ? (mend - mbeg + BP - 1) / BP : 0;
+  if (n_it > 0) { load_global(mbeg); store_lds(0); }
+  __syncthreads();
+  const int fi = lane & 31, fk = lane >> 5;
+  for (int it = 0; it < n_it; ++it) {
+    const int buf = it & 1;
+    const bool more = it + 1 < n_it;
+    if (more) load_global(mbeg + (it + 1) * BP);
+#pragma unroll
+    for (int kk = 0; kk < BP; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[buf][kk + fk][wm * (BKO / 2) + i * 32 + fi];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk + fk][wn * (BCI / 2) + j * 32 + fi];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int colq = lane & 31, rowq = 4 * (lane >> 5);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = c0 + wn * (BCI / 2) + j * 32 + colq;
+    if (col >= p.C) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = k0 + wm * (BKO / 2) + i * 32 + (q & 3) + 8 * (q >> 2) + rowq;
+        if (row < p.K) atomicAdd(&dwp[((size_t)tap * p.Kpad + row) * Cp + col], acc[i][j][q]);
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
+  MssConvArgs p = *args;
+  if (!p.x || !p.w || !p.y) return MSS_ERR_BAD_ARG;
+  if (p.C % 16 || p.ldx % 4 || p.R * p.S > 9 || p.R * p.S < 1) return MSS_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.w)) & 15) return MSS_ERR_BAD_ARG;
+  if (p.in_scale && ((reinterpret_cast<uintptr_t>(p.in_scale) | reinterpret_cast<uintptr_t>(p.in_shift)) & 15))
+    return MSS_ERR_BAD_ARG;
+  p.M = p.N * p.OH * p.OW;
+  if (p.M <= 0) return MSS_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool k32 = (p.C % 32 == 0);
+  if (p.K <= 64) {
+    return k32 ? launch_conv<256, 64, 32, 4, 1>(p, s) : launch_conv<256, 64, 16, 4, 1>(p, s);
+  }
+  return k32 ? launch_conv<128, 128, 32, 2, 2>(p, s) : launch_conv<128, 128, 16, 2, 2>(p, s);
+}
+
+// Kpad the packed layout must use for a conv with K output channels (multiple of the N tile).
+int mss_conv2d_kpad(int K) { return K <= 64 ? 64 : ((K + 127) / 128) * 128; }
+
+int mss_conv2d_pack_weights_f32(const float* w, float* packed, int K, int C, int R, int S, int Kpad, int Cp,
+                                int flip, void* stream) {
+  if (!w || !packed) return MSS_ERR_BAD_ARG;
+  const size_t total = (size_t)R * S * Kpad * Cp;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                     packed, K, C, R, S, Kpad, Cp, flip);
+  return mss_launch_status();
+}
+
+int mss_conv2d_unpack_wgrad_f32(const float* packed, float* grad, int K, int C, int R, int S, int Kpad, int Cp,
+                                int accumulate, void* stream) {
+  if (!grad || !packed) return MSS_ERR_BAD_ARG;
+  const size_t total = (size_t)K * C * R * S;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), packed,
+                     grad, K, C, R, S, Kpad, Cp, accumulate);
+  return mss_launch_status();
+}
+
+// dwp must be zero on entry ([R*S][Kpad][Cp]); args describes the *forward* conv (x, geometry,
+// optional prologue on x); dy is the NHWC output gradient with pixel stride lddy.
+int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dwp, int Cp, void* stream) {
+  MssConvArgs p = *args;
+  if (!p.x || !dy || !dwp) return MSS_ERR_BAD_ARG;
+  if (p.C % 4 || p.ldx % 4 || lddy % 4 || p.R * p.S > 9) return MSS_ERR_UNSUPPORTED;
+  p.M = p.N * p.OH * p.OW;
+  if (p.M <= 0) return MSS_OK;
+  constexpr int BKO = 128, BCI = 128, BP = 16;
+  const int ktiles = mss_cdiv(p.K, BKO), ctiles = mss_cdiv(p.C, BCI), taps = p.R * p.S;
+  // enough pixel splits to give ~4 workgroups per CU
+  int base = ktiles * ctiles * taps;
+  int splits = (1024 + base - 1) / base;
+  int max_splits = mss_cdiv(p.M, BP * 8);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int pps = mss_cdiv(mss_cdiv(p.M, splits), BP) * BP;
+  splits = mss_cdiv(p.M, pps);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BKO, BCI, BP>), dim3(ktiles * ctiles, taps, splits), dim3(NT), 0,
+                     static_cast<hipStream_t>(stream), p, dy, lddy, dwp, Cp, pps);
+  return mss_launch_status();
+}
+
+}  // extern "C"

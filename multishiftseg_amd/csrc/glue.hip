@@ -1,0 +1,714 @@
+// HBM-bound pieces of the DeepWV3Plus path that sit between the MFMA convolutions:
+// layout change of the input image, BatchNorm statistics / folding / backward, max-pool,
+// global-average-pool, broadcast, bilinear (align_corners=True) resampling, Adam.
+// All activations are NHWC fp32 with an explicit pixel stride; channels are always a multiple of
+// 4 so every access is a 16-byte vector and consecutive lanes touch consecutive channels.
+#include "mss_common.h"
+#include "../../include/mss_hip.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  return v;
+}
+
+inline int grid_for(long long work_items, int block = 256, int cap = 256 * 16) {
+  long long b = (work_items + block - 1) / block;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ---------------------------------------------------------------- image NCHW -> NHWC (padded)
+__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int HW,
+                                        int Cp) {
+  const long long total = (long long)N * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / HW, p = i - n * HW;
+    const float* src = x + n * C * HW + p;
+    float* dst = y + i * Cp;
+    for (int c = 0; c < Cp; c += 4) {
+      f32x4 v;
+      v.x = c + 0 < C ? src[(long long)(c + 0) * HW] : 0.f;
+      v.y = c + 1 < C ? src[(long long)(c + 1) * HW] : 0.f;
+      v.z = c + 2 < C ? src[(long long)(c + 2) * HW] : 0.f;
+      v.w = c + 3 < C ? src[(long long)(c + 3) * HW] : 0.f;
+      st4(dst + c, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- per-channel reductions
+// Generic column reducer over an NHWC matrix [M][C]: thread (tx, ty) owns channel quad
+// q = blockIdx.x*QPB + tx and walks rows ty, ty+RPB, ... of its row range; partial sums are kept
+// in fp32 for at most 256 rows, then flushed to fp64, combined over ty through LDS and added to
+// the global fp64 accumulators with one atomic per channel per block.
+// F(row, c0, out a[4], out b[4]) produces the two quantities to be summed.
+template <typename F>
+__device__ __forceinline__ void col_reduce2(long long M, int C, double* __restrict__ accum, F f) {
+  const int C4 = C >> 2;
+  const int QPB = C4 < 32 ? C4 : 32;            // channel quads per block
+  const int RPB = blockDim.x / QPB;             // row lanes per block
+  const int tx = threadIdx.x % QPB, ty = threadIdx.x / QPB;
+  const int q = blockIdx.x * QPB + tx;
+  const bool active = q < C4 && ty < RPB;
+  const long long rows_per_block = (M + gridDim.y - 1) / gridDim.y;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  double da[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+  if (active) {
+    long long r = r0 + ty;
+    while (r < r1) {
+      float fa[4] = {0, 0, 0, 0}, fb[4] = {0, 0, 0, 0};
+      for (int it = 0; it < 256 && r < r1; ++it, r += RPB) {
+        float a[4], b[4];
+        f(r, q * 4, a, b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { fa[k] += a[k]; fb[k] += b[k]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { da[k] += fa[k]; db[k] += fb[k]; }
+    }
+  }
+  __shared__ double red[256 * 8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[threadIdx.x * 8 + k] = da[k]; red[threadIdx.x * 8 + 4 + k] = db[k]; }
+  __syncthreads();
+  if (ty == 0 && q < C4) {
+    for (int yy = 1; yy < RPB; ++yy) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        da[k] += red[(yy * QPB + tx) * 8 + k];
+        db[k] += red[(yy * QPB + tx) * 8 + 4 + k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(&accum[q * 4 + k], da[k]);
+      atomicAdd(&accum[C + q * 4 + k], db[k]);
+    }
+  }
+}
+
+inline dim3 col_reduce_grid(long long M, int C) {
+  const int C4 = C >> 2;
+  const int QPB = C4 < 32 ? C4 : 32;
+  const int gx = (C4 + QPB - 1) / QPB;
+  long long gy = 2048 / gx;
+  const long long max_gy = (M + 63) / 64;
+  if (gy > max_gy) gy = max_gy;
+  if (gy < 1) gy = 1;
+  return dim3(gx, (unsigned)gy);
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long long M, int C, int ldx,
+                                                       double* __restrict__ accum) {
+  col_reduce2(M, C, accum, [&](long long r, int c0, float* a, float* b) {
+    f32x4 v = ld4(x + r * ldx + c0);
+    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+    b[0] = v.x * v.x; b[1] = v.y * v.y; b[2] = v.z * v.z; b[3] = v.w * v.w;
+  });
+}
+
+__global__ void bn_finalize_train_kernel(const double* __restrict__ accum, long long M, int C,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                         float momentum, float* running_mean, float* running_var, float* scale,
+                                         float* shift, float* save_mean, float* save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = accum[c] / (double)M;
+  double var = accum[C + c] / (double)M - mean * mean;
+  if (var < 0) var = 0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * invstd;
+  scale[c] = sc;
+  shift[c] = b - (float)mean * sc;
+  if (save_mean) save_mean[c] = (float)mean;
+  if (save_invstd) save_invstd[c] = invstd;
+  if (running_mean) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_fold_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
+                                    float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rv[c] + eps);
+  const float sc = (gamma ? gamma[c] : 1.f) * invstd;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+
+__global__ void affine_relu_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                   long long M, int C, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, int relu) {
+  const int C4 = C >> 2;
+  const long long total = M * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    f32x4 v = ld4(x + r * ldx + c);
+    if (scale) v = v * ld4(scale + c) + ld4(shift + c);
+    if (relu) v = relu4(v);
+    st4(y + r * ldy + c, v);
+  }
+}
+
+// backward of y = relu(x*scale + shift) where (scale, shift) fold a train-mode BatchNorm
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(
+    const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx, long long M, int C,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ save_mean,
+    const float* __restrict__ save_invstd, int relu, double* __restrict__ accum) {
+  col_reduce2(M, C, accum, [&](long long r, int c0, float* a, float* b) {
+    f32x4 g = ld4(dy + r * lddy + c0);
+    f32x4 v = ld4(x + r * ldx + c0);
+    f32x4 sc = ld4(scale + c0), sh = ld4(shift + c0), mu = ld4(save_mean + c0), is = ld4(save_invstd + c0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float dz = g[k];
+      if (relu && !(v[k] * sc[k] + sh[k] > 0.f)) dz = 0.f;
+      a[k] = dz;
+      b[k] = dz * (v[k] - mu[k]) * is[k];
+    }
+  });
+}
+
+__global__ void bn_relu_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
+                                         int ldx, float* __restrict__ dx, int lddx, long long M, int C,
+                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                         const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                         int relu, const double* __restrict__ accum) {
+  const int C4 = C >> 2;
+  const long long total = M * C4;
+  const float invM = 1.f / (float)M;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    f32x4 g = ld4(dy + r * lddy + c);
+    f32x4 v = ld4(x + r * ldx + c);
+    f32x4 sc = ld4(scale + c), sh = ld4(shift + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float dz = g[k];
+      if (relu && !(v[k] * sc[k] + sh[k] > 0.f)) dz = 0.f;
+      if (accum) {
+        const float xhat = (v[k] - save_mean[c + k]) * save_invstd[c + k];
+        const float s1 = (float)accum[c + k], s2 = (float)accum[C + c + k];
+        o[k] = sc[k] * (dz - s1 * invM - xhat * s2 * invM);
+      } else {
+        o[k] = sc[k] * dz;
+      }
+    }
+    st4(dx + r * lddx + c, o);
+  }
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ accum, int C, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dbeta) dbeta[c] += (float)accum[c];
+  if (dgamma) dgamma[c] += (float)accum[C + c];
+}
+
+// ---------------------------------------------------------------- pooling / broadcast
+__global__ void maxpool3s2_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int N,
+                                  int H, int W, int C, int OH, int OW) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * OH * OW * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long p = i / C4;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int n = (int)(p / OH);
+    const float ninf = -__builtin_huge_valf();
+    f32x4 m = {ninf, ninf, ninf, ninf};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = oy * 2 - 1 + dy;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = ox * 2 - 1 + dx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        f32x4 v = ld4(x + ((long long)(n * H + iy) * W + ix) * ldx + c);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    st4(y + ((long long)(n * OH + oy) * OW + ox) * ldy + c, m);
+  }
+}
+
+// y[n][c] = mult * sum_p x[n][p][c]; grid (C/64, N), block 256 = 16 quads x 16 row lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                     int HW, int C, float mult) {
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = (blockIdx.x * 16 + tx) * 4;
+  const int n = blockIdx.y;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const float* base = x + (long long)n * HW * ldx + c;
+    for (int p = ty; p < HW; p += 16) acc += ld4(base + (long long)p * ldx);
+  }
+  __shared__ f32x4 red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    for (int yy = 1; yy < 16; ++yy) acc += red[yy * 16 + tx];
+    st4(y + (long long)n * C + c, acc * mult);
+  }
+}
+
+__global__ void broadcast_rows_kernel(const float* __restrict__ v, float* __restrict__ y, int ldy, int N, int HW,
+                                      int C, const float* __restrict__ scale, const float* __restrict__ shift,
+                                      int relu) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * HW * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const long long p = i / C4;
+    const int n = (int)(p / HW);
+    f32x4 val = ld4(v + (long long)n * C + c);
+    if (scale) val = val * ld4(scale + c) + ld4(shift + c);
+    if (relu) val = relu4(val);
+    st4(y + p * ldy + c, val);
+  }
+}
+
+// ---------------------------------------------------------------- bilinear, align_corners=True
+// Same arithmetic as ATen's upsample_bilinear2d (area_pixel_compute_source_index with
+// align_corners): src = scale*dst, i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1-l1.
+struct Tap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Tap ac_tap(int o, float scale, int in) {
+  Tap t;
+  const float src = scale * (float)o;
+  t.i0 = (int)src;
+  t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+__global__ void upsample_ac_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int N,
+                                   int IH, int IW, int OH, int OW, int C, float sh, float sw) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * OH * OW * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long p = i / C4;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int n = (int)(p / OH);
+    const Tap ty = ac_tap(oy, sh, IH), tx = ac_tap(ox, sw, IW);
+    const float* b = x + (long long)n * IH * IW * ldx + c;
+    const f32x4 v00 = ld4(b + ((long long)ty.i0 * IW + tx.i0) * ldx), v01 = ld4(b + ((long long)ty.i0 * IW + tx.i1) * ldx);
+    const f32x4 v10 = ld4(b + ((long long)ty.i1 * IW + tx.i0) * ldx), v11 = ld4(b + ((long long)ty.i1 * IW + tx.i1) * ldx);
+    const f32x4 o = ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
+    st4(y + ((long long)(n * OH + oy) * OW + ox) * ldy + c, o);
+  }
+}
+
+// candidate output range [lo, hi] whose source index can touch input cell i
+__device__ __forceinline__ void ac_range(int i, float scale, int out, int& lo, int& hi) {
+  if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+  const float inv = 1.f / scale;
+  lo = (int)floorf(((float)i - 1.f) * inv) - 1;
+  hi = (int)ceilf(((float)i + 1.f) * inv) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+__device__ __forceinline__ float ac_weight(int o, int i, float scale, int in) {
+  const Tap t = ac_tap(o, scale, in);
+  float w = 0.f;
+  if (t.i0 == i) w += t.l0;
+  if (t.i1 == i) w += t.l1;
+  return w;
+}
+
+__global__ void upsample_ac_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
+                                       int N, int IH, int IW, int OH, int OW, int C, float sh, float sw) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * IH * IW * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long p = i / C4;
+    const int ix = (int)(p % IW); p /= IW;
+    const int iy = (int)(p % IH);
+    const int n = (int)(p / IH);
+    int ylo, yhi, xlo, xhi;
+    ac_range(iy, sh, OH, ylo, yhi);
+    ac_range(ix, sw, OW, xlo, xhi);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* b = dy + (long long)n * OH * OW * lddy + c;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float wy = ac_weight(oy, iy, sh, IH);
+      if (wy == 0.f) continue;
+      f32x4 rowacc = {0.f, 0.f, 0.f, 0.f};
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float wx = ac_weight(ox, ix, sw, IW);
+        if (wx == 0.f) continue;
+        rowacc += wx * ld4(b + ((long long)oy * OW + ox) * lddy);
+      }
+      acc += wy * rowacc;
+    }
+    st4(dx + ((long long)(n * IH + iy) * IW + ix) * lddx + c, acc);
+  }
+}
+
+// ---------------------------------------------------------------- OOD-score tail
+// One thread per output pixel: 4 half-resolution neighbours, each a contiguous C-vector.
+template <int C>
+__global__ __launch_bounds__(256) void ood_score_kernel(const float* __restrict__ dec2, int ld2,
+                                                        const float* __restrict__ dec1, int ld1, int N, int IH,
+                                                        int IW, int OH, int OW, float sh, float sw,
+                                                        float* __restrict__ score, float* __restrict__ logit,
+                                                        uint8_t* __restrict__ label) {
+  const long long total = (long long)N * OH * OW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long p = i;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int n = (int)(p / OH);
+    const Tap ty = ac_tap(oy, sh, IH), tx = ac_tap(ox, sw, IW);
+    const long long nb = (long long)n * IH * IW;
+    const long long o00 = nb + (long long)ty.i0 * IW + tx.i0, o01 = nb + (long long)ty.i0 * IW + tx.i1;
+    const long long o10 = nb + (long long)ty.i1 * IW + tx.i0, o11 = nb + (long long)ty.i1 * IW + tx.i1;
+    if (score) {
+      float e[4];
+      const long long offs[4] = {o00, o01, o10, o11};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* q = dec2 + offs[k] * ld2;
+        float v[C];
+        float m = -__builtin_huge_valf();
+#pragma unroll
+        for (int c = 0; c < C; ++c) { v[c] = q[c]; m = fmaxf(m, v[c]); }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) s += expf(v[c] - m);
+        e[k] = -(m + logf(s));  // energy_func: -logsumexp (deepv3.py:251-253)
+      }
+      score[i] = ty.l0 * (tx.l0 * e[0] + tx.l1 * e[1]) + ty.l1 * (tx.l0 * e[2] + tx.l1 * e[3]);
+    }
+    if (logit || label) {
+      const float* q00 = dec1 + o00 * ld1; const float* q01 = dec1 + o01 * ld1;
+      const float* q10 = dec1 + o10 * ld1; const float* q11 = dec1 + o11 * ld1;
+      float best = -__builtin_huge_valf();
+      int arg = 0;
+      const long long plane = (long long)OH * OW;
+      float* lo = logit ? logit + (long long)n * C * plane + (long long)oy * OW + ox : nullptr;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float val = ty.l0 * (tx.l0 * q00[c] + tx.l1 * q01[c]) + ty.l1 * (tx.l0 * q10[c] + tx.l1 * q11[c]);
+        if (lo) lo[c * plane] = val;
+        if (val > best || (val != val && best == best)) { best = val; arg = c; }  // first max; NaN wins like torch
+      }
+      if (label) label[i] = (uint8_t)arg;
+    }
+  }
+}
+
+// backward of the tail: one thread per half-resolution pixel (gather form of the transpose)
+template <int C>
+__global__ __launch_bounds__(256) void ood_score_bwd_kernel(const float* __restrict__ dec2, int ld2,
+                                                            const float* __restrict__ dscore,
+                                                            const float* __restrict__ dlogit, int N, int IH,
+                                                            int IW, int OH, int OW, float sh, float sw,
+                                                            float* __restrict__ ddec2, int ldd2,
+                                                            float* __restrict__ ddec1, int ldd1) {
+  const long long total = (long long)N * IH * IW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long p = i;
+    const int ix = (int)(p % IW); p /= IW;
+    const int iy = (int)(p % IH);
+    const int n = (int)(p / IH);
+    int ylo, yhi, xlo, xhi;
+    ac_range(iy, sh, OH, ylo, yhi);
+    ac_range(ix, sw, OW, xlo, xhi);
+    const long long plane = (long long)OH * OW;
+    float gs = 0.f;
+    float gl[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) gl[c] = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float wy = ac_weight(oy, iy, sh, IH);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float w = wy * ac_weight(ox, ix, sw, IW);
+        if (w == 0.f) continue;
+        const long long o = (long long)oy * OW + ox;
+        if (dscore) gs += w * dscore[(long long)n * plane + o];
+        if (dlogit) {
+          const float* q = dlogit + (long long)n * C * plane + o;
+#pragma unroll
+          for (int c = 0; c < C; ++c) gl[c] += w * q[c * plane];
+        }
+      }
+    }
+    if (ddec1) {
+      float* o = ddec1 + i * ldd1;
+#pragma unroll
+      for (int c = 0; c < C; ++c) o[c] = gl[c];
+    }
+    if (ddec2) {
+      const float* q = dec2 + i * ld2;
+      float v[C];
+      float m = -__builtin_huge_valf();
+#pragma unroll
+      for (int c = 0; c < C; ++c) { v[c] = q[c]; m = fmaxf(m, v[c]); }
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - m); s += v[c]; }
+      const float k = -gs / s;  // d(-lse)/dx_c = -softmax_c
+      float* o = ddec2 + i * ldd2;
+#pragma unroll
+      for (int c = 0; c < C; ++c) o[c] = k * v[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- Mask2Former anomaly score
+// block = one row segment of 256 pixels of one image; class probabilities of the image's Q
+// queries live in LDS as [Q][CP] (CP = C rounded up to 4) and are read as broadcast b128.
+template <int CP>
+__global__ __launch_bounds__(256) void m2f_score_kernel(const float* __restrict__ cls, const float* __restrict__ mask,
+                                                        int Q, int C, int H, int W, int Hm, int Wm,
+                                                        float* __restrict__ score) {
+  extern __shared__ __attribute__((aligned(16))) float prob[];  // [Q][CP]
+  const int b = blockIdx.y;
+  for (int q = threadIdx.x; q < Q; q += blockDim.x) {
+    const float* row = cls + ((long long)b * Q + q) * (C + 1);
+    float m = -__builtin_huge_valf();
+    for (int c = 0; c <= C; ++c) m = fmaxf(m, row[c]);
+    float s = 0.f;
+    for (int c = 0; c <= C; ++c) s += expf(row[c] - m);
+    const float inv = 1.f / s;
+    for (int c = 0; c < CP; ++c) prob[q * CP + c] = c < C ? expf(row[c] - m) * inv : 0.f;
+  }
+  __syncthreads();
+  const long long HW = (long long)H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int h = (int)(i / W), w = (int)(i - (long long)h * W);
+    const float* mp = mask + (long long)b * Q * Hm * Wm + (long long)h * Wm + w;
+    f32x4 acc[CP / 4];
+#pragma unroll
+    for (int k = 0; k < CP / 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < Q; ++q) {
+      const float x = mp[(long long)q * Hm * Wm];
+      const float sg = 1.f / (1.f + expf(-x));
+#pragma unroll
+      for (int k = 0; k < CP / 4; ++k) acc[k] += sg * *reinterpret_cast<const f32x4*>(&prob[q * CP + 4 * k]);
+    }
+    float best = -__builtin_huge_valf();
+#pragma unroll
+    for (int k = 0; k < CP / 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * k + e < C) best = fmaxf(best, acc[k][e]);
+    score[(long long)b * HW + i] = 1.f - best;
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2_sqrt) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float grad = g[i] + wd * p[i];
+    float mi = b1 * m[i] + (1.f - b1) * grad;
+    float vi = b2 * v[i] + (1.f - b2) * grad * grad;
+    m[i] = mi; v[i] = vi;
+    // torch.optim.Adam: denom = sqrt(v)/sqrt(bias2) + eps ; p -= (lr/bias1) * m/denom
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace
+
+#define S_(x) static_cast<hipStream_t>(x)
+
+extern "C" {
+
+int mss_nchw_to_nhwc_pad_f32(const float* x, float* y, int N, int C, int H, int W, int Cp, void* stream) {
+  if (!x || !y || Cp % 4 || Cp < C) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for((long long)N * H * W)), dim3(256), 0, S_(stream), x, y,
+                     N, C, H * W, Cp);
+  return mss_launch_status();
+}
+
+int mss_bn_stats_nhwc_f32(const float* x, long long M, int C, int ldx, double* accum, void* stream) {
+  if (!x || !accum || C % 4 || ldx % 4) return MSS_ERR_BAD_ARG;
+  if (M <= 0) return MSS_OK;
+  hipLaunchKernelGGL(bn_stats_kernel, col_reduce_grid(M, C), dim3(256), 0, S_(stream), x, M, C, ldx, accum);
+  return mss_launch_status();
+}
+
+int mss_bn_finalize_train_f32(const double* accum, long long M, int C, const float* gamma, const float* beta,
+                              float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                              float* shift, float* save_mean, float* save_invstd, void* stream) {
+  if (!accum || !scale || !shift || M <= 0) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 255) / 256), dim3(256), 0, S_(stream), accum, M, C, gamma,
+                     beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
+  return mss_launch_status();
+}
+
+int mss_bn_fold_eval_f32(const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, int C, float* scale, float* shift, void* stream) {
+  if (!running_mean || !running_var || !scale || !shift) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_fold_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, S_(stream), gamma, beta,
+                     running_mean, running_var, eps, C, scale, shift);
+  return mss_launch_status();
+}
+
+int mss_affine_relu_nhwc_f32(const float* x, int ldx, float* y, int ldy, long long M, int C, const float* scale,
+                             const float* shift, int relu, void* stream) {
+  if (!x || !y || C % 4 || ldx % 4 || ldy % 4) return MSS_ERR_BAD_ARG;
+  if (M <= 0) return MSS_OK;
+  hipLaunchKernelGGL(affine_relu_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, S_(stream), x, ldx, y, ldy, M,
+                     C, scale, shift, relu);
+  return mss_launch_status();
+}
+
+int mss_bn_relu_bwd_reduce_f32(const float* dy, int lddy, const float* x, int ldx, long long M, int C,
+                               const float* scale, const float* shift, const float* save_mean,
+                               const float* save_invstd, int relu, double* accum, void* stream) {
+  if (!dy || !x || !scale || !shift || !save_mean || !save_invstd || !accum) return MSS_ERR_BAD_ARG;
+  if (C % 4 || ldx % 4 || lddy % 4) return MSS_ERR_BAD_ARG;
+  if (M <= 0) return MSS_OK;
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, col_reduce_grid(M, C), dim3(256), 0, S_(stream), dy, lddy, x, ldx,
+                     M, C, scale, shift, save_mean, save_invstd, relu, accum);
+  return mss_launch_status();
+}
+
+int mss_bn_relu_bwd_apply_f32(const float* dy, int lddy, const float* x, int ldx, float* dx, int lddx,
+                              long long M, int C, const float* gamma, const float* scale, const float* shift,
+                              const float* save_mean, const float* save_invstd, int relu, const double* accum,
+                              float* dgamma, float* dbeta, void* stream) {
+  (void)gamma;
+  if (!dy || !x || !dx || !scale || !shift) return MSS_ERR_BAD_ARG;
+  if (accum && (!save_mean || !save_invstd)) return MSS_ERR_BAD_ARG;
+  if (C % 4 || ldx % 4 || lddy % 4 || lddx % 4) return MSS_ERR_BAD_ARG;
+  if (M <= 0) return MSS_OK;
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, S_(stream), dy, lddy, x,
+                     ldx, dx, lddx, M, C, scale, shift, save_mean, save_invstd, relu, accum);
+  if (accum && (dgamma || dbeta))
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, S_(stream), accum, C, dgamma,
+                       dbeta);
+  return mss_launch_status();
+}
+
+int mss_maxpool3s2_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int OH,
+                            int OW, void* stream) {
+  if (!x || !y || C % 4 || ldx % 4 || ldy % 4) return MSS_ERR_BAD_ARG;
+  if (OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(maxpool3s2_kernel, dim3(grid_for((long long)N * OH * OW * (C / 4))), dim3(256), 0, S_(stream),
+                     x, ldx, y, ldy, N, H, W, C, OH, OW);
+  return mss_launch_status();
+}
+
+int mss_gap_nhwc_f32(const float* x, int ldx, float* y, int N, int HW, int C, void* stream) {
+  if (!x || !y || C % 4 || ldx % 4 || HW <= 0) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(colsum_kernel, dim3((C / 4 + 15) / 16, N), dim3(256), 0, S_(stream), x, ldx, y, HW, C,
+                     1.f / (float)HW);
+  return mss_launch_status();
+}
+
+int mss_colsum_nhwc_f32(const float* dy, int lddy, float* dv, int N, int HW, int C, void* stream) {
+  if (!dy || !dv || C % 4 || lddy % 4 || HW <= 0) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(colsum_kernel, dim3((C / 4 + 15) / 16, N), dim3(256), 0, S_(stream), dy, lddy, dv, HW, C, 1.f);
+  return mss_launch_status();
+}
+
+int mss_broadcast_rows_nhwc_f32(const float* v, float* y, int ldy, int N, int HW, int C, const float* scale,
+                                const float* shift, int relu, void* stream) {
+  if (!v || !y || C % 4 || ldy % 4) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3(grid_for((long long)N * HW * (C / 4))), dim3(256), 0, S_(stream),
+                     v, y, ldy, N, HW, C, scale, shift, relu);
+  return mss_launch_status();
+}
+
+int mss_upsample_ac_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N, int IH, int IW, int OH, int OW,
+                             int C, void* stream) {
+  if (!x || !y || C % 4 || ldx % 4 || ldy % 4) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(upsample_ac_kernel, dim3(grid_for((long long)N * OH * OW * (C / 4))), dim3(256), 0, S_(stream),
+                     x, ldx, y, ldy, N, IH, IW, OH, OW, C, ac_scale(IH, OH), ac_scale(IW, OW));
+  return mss_launch_status();
+}
+
+int mss_upsample_ac_nhwc_bwd_f32(const float* dy, int lddy, float* dx, int lddx, int N, int IH, int IW, int OH,
+                                 int OW, int C, void* stream) {
+  if (!dy || !dx || C % 4 || lddx % 4 || lddy % 4) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(upsample_ac_bwd_kernel, dim3(grid_for((long long)N * IH * IW * (C / 4))), dim3(256), 0,
+                     S_(stream), dy, lddy, dx, lddx, N, IH, IW, OH, OW, C, ac_scale(IH, OH), ac_scale(IW, OW));
+  return mss_launch_status();
+}
+
+int mss_ood_score_f32(const float* dec2, int ld2, const float* dec1, int ld1, int N, int IH, int IW, int C,
+                      int OH, int OW, float* score, float* logit_nchw, uint8_t* label, void* stream) {
+  if (C != 19) return MSS_ERR_UNSUPPORTED;  // Cityscapes, the only class count on the path
+  if (score && !dec2) return MSS_ERR_BAD_ARG;
+  if ((logit_nchw || label) && !dec1) return MSS_ERR_BAD_ARG;
+  if ((long long)N * OH * OW == 0) return MSS_OK;
+  hipLaunchKernelGGL(ood_score_kernel<19>, dim3(grid_for((long long)N * OH * OW, 256, 1 << 20)), dim3(256), 0,
+                     S_(stream), dec2, ld2, dec1, ld1, N, IH, IW, OH, OW, ac_scale(IH, OH), ac_scale(IW, OW), score,
+                     logit_nchw, label);
+  return mss_launch_status();
+}
+
+int mss_ood_score_bwd_f32(const float* dec2, int ld2, const float* dscore, const float* dlogit_nchw, int N,
+                          int IH, int IW, int C, int OH, int OW, float* ddec2, int ldd2, float* ddec1, int ldd1,
+                          void* stream) {
+  if (C != 19) return MSS_ERR_UNSUPPORTED;
+  if (ddec2 && !dec2) return MSS_ERR_BAD_ARG;
+  if ((long long)N * IH * IW == 0) return MSS_OK;
+  hipLaunchKernelGGL(ood_score_bwd_kernel<19>, dim3(grid_for((long long)N * IH * IW, 256, 1 << 20)), dim3(256), 0,
+                     S_(stream), dec2, ld2, ddec2 ? dscore : nullptr, ddec1 ? dlogit_nchw : nullptr, N, IH, IW, OH,
+                     OW, ac_scale(IH, OH), ac_scale(IW, OW), ddec2, ldd2, ddec1, ldd1);
+  return mss_launch_status();
+}
+
+int mss_m2f_score_f32(const float* cls, const float* mask, int B, int Q, int C, int H, int W, int Hm, int Wm,
+                      float* score, void* stream) {
+  if (!cls || !mask || !score || H > Hm || W > Wm) return MSS_ERR_BAD_ARG;
+  if (C > 20 || C < 1) return MSS_ERR_UNSUPPORTED;
+  if ((long long)B * H * W == 0) return MSS_OK;
+  constexpr int CP = 20;
+  const size_t smem = (size_t)Q * CP * sizeof(float);
+  if (smem > 65536) return MSS_ERR_UNSUPPORTED;
+  const int gx = grid_for((long long)H * W, 256, 1024);
+  hipLaunchKernelGGL(m2f_score_kernel<CP>, dim3(gx, B), dim3(256), smem, S_(stream), cls, mask, Q, C, H, W, Hm, Wm,
+                     score);
+  return mss_launch_status();
+}
+
+int mss_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return MSS_ERR_BAD_ARG;
+  if (n <= 0) return MSS_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, S_(stream), param, grad, exp_avg, exp_avg_sq, n,
+                     lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+  return mss_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,519 @@
+// Fused RelContrastiveLoss for MI355X: forward value and both gradients (dlogit, dscore) in a
+// handful of streaming passes instead of the ~25 ATen kernels + topk + host randperm of the
+// reference (lib/loss.py:34-156).
+//
+//   pass1   one read of logit/score/target: per-pixel logsumexp + CE, pixel kind, partial sums,
+//           the augmented half's CE values for the selection                (loss.py:46-60,90-96)
+//   select  exact k-th smallest CE by 4 x 8-bit radix histograms on the fp32 bit pattern
+//           (replaces torch.topk over ~4 M values, loss.py:98-102)
+//   pass2   softmax-minus-onehot gradient written once, target mutation     (loss.py:103-111)
+//   compact ordered stream compaction of the three score sets              (loss.py:122-124)
+//   pairs   hinge terms over permuted pairs + scatter of dscore             (loss.py:129-137)
+//   cin     in-distribution consistency term                                (loss.py:139-145)
+// HBM traffic: logit is read twice (pass1, pass2) and dlogit written once.
+#include "mss_common.h"
+#include "../../include/mss_hip.h"
+
+namespace {
+
+enum { CNT_SUM_CE_ORIG = 0, CNT_N_IN_ORIG, CNT_N_IN_AUG, CNT_N_OOD, CNT_SUM_CIN, CNT_N_SAME, CNT_SUM_CE_AUG_ALL,
+       CNT_SUM_SEL, CNT_N_SEL, CNT_SUM_CORIG, CNT_SUM_CAUG, CNT_N_PAIRS };
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+  uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+template <int NV>
+__device__ __forceinline__ void block_add(const float (&v)[NV], double* dst, const int* slots) {
+  __shared__ float red[4][NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    float s = mss_wave_sum(v[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (s != 0.f) atomicAdd(&dst[slots[threadIdx.x]], (double)s);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void rcl_pass1_kernel(MssRclArgs a, float* __restrict__ lse_out,
+                                                        float* __restrict__ ce_aug, uint8_t* __restrict__ kind_out,
+                                                        double* __restrict__ counters) {
+  const long long HW = (long long)a.H * a.W;
+  const long long total = (long long)a.B * HW;
+  const int h = a.B / 2;
+  const long long half = (long long)h * HW;
+  float acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / HW);
+    const long long p = i - (long long)b * HW;
+    const int64_t t = a.target[i];
+    const bool in = t < 99;                      // in_id  (loss.py:31,47)
+    const bool ood = t > 99 && t != 255;         // void_id (loss.py:32,46)
+    const float* lp = a.logit + (long long)b * a.C * HW + p;
+    float m = -__builtin_huge_valf();
+    for (int c = 0; c < a.C; ++c) m = fmaxf(m, lp[(long long)c * HW]);
+    float s = 0.f;
+    for (int c = 0; c < a.C; ++c) s += expf(lp[(long long)c * HW] - m);
+    const float lse = m + logf(s);
+    lse_out[i] = lse;
+    float ce = 0.f;
+    if (in) ce = lse - lp[(long long)t * HW];
+    kind_out[i] = in ? 1 : (ood ? 2 : 0);
+    if (b < h) {
+      acc[0] += ce;
+      acc[1] += in ? 1.f : 0.f;
+      // pair (i, i + half): in-distribution consistency term (loss.py:141-145)
+      const int64_t t2 = a.target[i + half];
+      if (in && t2 < 99) {
+        acc[4] += fmaxf(a.score[i + half] - a.score[i] - a.m2, 0.f);
+        acc[5] += 1.f;
+      }
+    } else {
+      ce_aug[i - half] = in ? ce : __builtin_huge_valf();
+      acc[2] += in ? 1.f : 0.f;
+      acc[6] += ce;
+    }
+    acc[3] += ood ? 1.f : 0.f;
+  }
+  __shared__ int slots[7];
+  if (threadIdx.x == 0) {
+    slots[0] = CNT_SUM_CE_ORIG; slots[1] = CNT_N_IN_ORIG; slots[2] = CNT_N_IN_AUG; slots[3] = CNT_N_OOD;
+    slots[4] = CNT_SUM_CIN; slots[5] = CNT_N_SAME; slots[6] = CNT_SUM_CE_AUG_ALL;
+  }
+  __syncthreads();
+  block_add<7>(acc, counters, slots);
+}
+
+// ---- radix select --------------------------------------------------------------------------
+// sel[0] prefix key, sel[1] n_less (elements with key < final threshold), sel[2] k, sel[3] need_equal,
+// sel[4] tie ticket counter, sel[5] k_remaining (internal)
+__global__ void rcl_select_init_kernel(const double* __restrict__ counters, float ratio, uint32_t* sel,
+                                       uint32_t* hist) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float n_in = (float)counters[CNT_N_IN_AUG];
+    const uint32_t k = (uint32_t)(int)(ratio * n_in);  // int(selection_ratio * total_num), float32 as in torch
+    sel[0] = 0; sel[1] = 0; sel[2] = k; sel[3] = 0; sel[4] = 0; sel[5] = k;
+  }
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void rcl_hist_kernel(const float* __restrict__ v, long long n, const uint32_t* sel,
+                                                       int shift, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t lh[256];
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t prefix = sel[0];
+  const uint32_t mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+  if (sel[2] != 0) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+      const uint32_t key = f2key(v[i]);
+      if ((key & mask) == (prefix & mask)) atomicAdd(&lh[(key >> shift) & 255], 1u);
+    }
+  }
+  __syncthreads();
+  if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+__global__ void rcl_pick_kernel(uint32_t* sel, uint32_t* hist, int shift) {
+  if (threadIdx.x == 0 && sel[2] != 0) {
+    uint32_t krem = sel[5];  // 1-based rank of the wanted element inside the current bucket
+    uint32_t less = sel[1];
+    uint32_t d = 0;
+    for (; d < 256; ++d) {
+      const uint32_t c = hist[d];
+      if (krem <= c) break;
+      krem -= c;
+      less += c;
+    }
+    if (d > 255) d = 255;
+    sel[0] |= d << shift;
+    sel[1] = less;
+    sel[5] = krem;
+    if (shift == 0) sel[3] = krem;  // how many elements equal to the threshold are taken
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+}
+
+// ---- pass 2 ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rcl_pass2_kernel(MssRclArgs a, const float* __restrict__ lse,
+                                                        const float* __restrict__ ce_aug,
+                                                        const uint8_t* __restrict__ kind, uint32_t* sel,
+                                                        double* __restrict__ counters, float grad_scale,
+                                                        float* __restrict__ dlogit) {
+  const long long HW = (long long)a.H * a.W;
+  const long long total = (long long)a.B * HW;
+  const int h = a.B / 2;
+  const long long half = (long long)h * HW;
+  const uint32_t thr = sel[0], k = sel[2], need_eq = sel[3];
+  const float g_orig = grad_scale * a.w_ce_orig / (float)half;
+  const float g_aug = a.select ? (k ? grad_scale * a.w_ce_aug / (float)k : 0.f) : grad_scale * a.w_ce_aug / (float)half;
+  float acc[2] = {0.f, 0.f};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / HW);
+    const long long p = i - (long long)b * HW;
+    const bool in = kind[i] == 1;
+    float g = 0.f;
+    if (b < h) {
+      if (in) g = g_orig;
+    } else if (!a.select) {
+      if (in) g = g_aug;
+    } else {
+      bool chosen = false;
+      if (in && k) {
+        const float ce = ce_aug[i - half];
+        const uint32_t key = f2key(ce);
+        if (key < thr) chosen = true;
+        else if (key == thr) chosen = atomicAdd(&sel[4], 1u) < need_eq;
+        if (chosen) { acc[0] += ce; acc[1] += 1.f; }
+      }
+      if (chosen) g = g_aug;
+      else a.target[i] = 255;                    // loss.py:110-111,115 (every non-selected pixel)
+    }
+    if (dlogit) {
+      float* dp = dlogit + (long long)b * a.C * HW + p;
+      if (g != 0.f) {
+        const float* lp = a.logit + (long long)b * a.C * HW + p;
+        const float l = lse[i];
+        const int t = (int)a.target[i];
+        for (int c = 0; c < a.C; ++c) {
+          float pr = expf(lp[(long long)c * HW] - l);
+          dp[(long long)c * HW] = g * (pr - (c == t ? 1.f : 0.f));
+        }
+      } else {
+        for (int c = 0; c < a.C; ++c) dp[(long long)c * HW] = 0.f;
+      }
+    }
+  }
+  __shared__ int slots[2];
+  if (threadIdx.x == 0) { slots[0] = CNT_SUM_SEL; slots[1] = CNT_N_SEL; }
+  __syncthreads();
+  block_add<2>(acc, counters, slots);
+}
+
+// ---- ordered compaction ------------------------------------------------------------------------
+constexpr int CB = 1024;  // pixels per compaction block (4 per thread)
+
+__device__ __forceinline__ int kind_class(uint8_t kind, bool first_half) {
+  if (kind == 2) return 2;
+  if (kind == 1) return first_half ? 0 : 1;
+  return -1;
+}
+
+__global__ __launch_bounds__(256) void rcl_count_kernel(const uint8_t* __restrict__ kind, long long total,
+                                                        long long half, uint32_t* __restrict__ block_counts,
+                                                        int nblocks) {
+  const long long base = (long long)blockIdx.x * CB;
+  float c[3] = {0.f, 0.f, 0.f};
+  for (int e = 0; e < 4; ++e) {
+    const long long i = base + threadIdx.x * 4 + e;
+    if (i < total) {
+      const int k = kind_class(kind[i], i < half);
+      if (k >= 0) c[k] += 1.f;
+    }
+  }
+  __shared__ float red[4][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < 3; ++k) {
+    float s = mss_wave_sum(c[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    block_counts[threadIdx.x * nblocks + blockIdx.x] =
+        (uint32_t)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// exclusive scan of each of the 3 rows of block_counts (single workgroup), totals to n_out
+__global__ __launch_bounds__(1024) void rcl_scan_kernel(uint32_t* block_counts, int nblocks, uint32_t* n_out) {
+  __shared__ uint32_t part[1024];
+  for (int k = 0; k < 3; ++k) {
+    uint32_t* row = block_counts + (size_t)k * nblocks;
+    const int per = (nblocks + 1023) / 1024;
+    const int b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
+    uint32_t s = 0;
+    for (int i = b0; i < b1; ++i) s += row[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int o = 1; o < 1024; o <<= 1) {
+      uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (int i = b0; i < b1; ++i) { uint32_t c = row[i]; row[i] = run; run += c; }
+    if (threadIdx.x == 1023) n_out[k] = part[1023];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void rcl_scatter_kernel(const uint8_t* __restrict__ kind, long long total,
+                                                          long long half, const uint32_t* __restrict__ block_offs,
+                                                          int nblocks, int32_t* __restrict__ idx0,
+                                                          int32_t* __restrict__ idx1, int32_t* __restrict__ idx2) {
+  const long long base = (long long)blockIdx.x * CB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int kc[4];
+  int cnt[3] = {0, 0, 0};
+  for (int e = 0; e < 4; ++e) {
+    const long long i = base + threadIdx.x * 4 + e;
+    kc[e] = i < total ? kind_class(kind[i], i < half) : -1;
+    if (kc[e] >= 0) cnt[kc[e]]++;
+  }
+  // exclusive prefix of cnt[k] over the 256 threads (thread order == pixel order)
+  __shared__ int wsum[4][3];
+  int pre[3];
+  for (int k = 0; k < 3; ++k) {
+    int v = cnt[k];
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    pre[k] = inc - v;
+    if (lane == 63) wsum[wave][k] = inc;
+  }
+  __syncthreads();
+  for (int k = 0; k < 3; ++k) {
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += wsum[w][k];
+    pre[k] += off + (int)block_offs[(size_t)k * nblocks + blockIdx.x];
+  }
+  int32_t* outs[3] = {idx0, idx1, idx2};
+  for (int e = 0; e < 4; ++e) {
+    if (kc[e] >= 0) {
+      outs[kc[e]][pre[kc[e]]] = (int32_t)(base + threadIdx.x * 4 + e);
+      pre[kc[e]]++;
+    }
+  }
+}
+
+// ---- pair terms -------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+// keyed bijection of [0, n): balanced Feistel network on 2*hb bits + cycle walking
+__device__ __forceinline__ uint32_t feistel_perm(uint32_t i, uint32_t n, uint32_t seed) {
+  int bits = 32 - __clz(n > 1 ? n - 1 : 1);
+  if (bits < 2) bits = 2;
+  const int hb = (bits + 1) >> 1;
+  const uint32_t hm = (1u << hb) - 1;
+  uint32_t x = i;
+  do {
+    uint32_t l = x >> hb, r = x & hm;
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+      const uint32_t f = mix32(r ^ (seed + 0x9e3779b9u * (rd + 1))) & hm;
+      const uint32_t nl = r;
+      r = l ^ f;
+      l = nl;
+    }
+    x = (l << hb) | r;
+  } while (x >= n);
+  return x;
+}
+
+template <bool FEISTEL>
+__global__ __launch_bounds__(256) void rcl_pairs_kernel(const float* __restrict__ score,
+                                                        const int32_t* __restrict__ idx_a,
+                                                        const int64_t* __restrict__ perm_a,
+                                                        const int32_t* __restrict__ idx_o,
+                                                        const int64_t* __restrict__ perm_o, long long n_host,
+                                                        const uint32_t* __restrict__ n_out, int set_a,
+                                                        long long max_samples, uint32_t seed_a, uint32_t seed_o,
+                                                        float margin, double* __restrict__ counters, int slot,
+                                                        float grad_w, float* __restrict__ dscore) {
+  long long n = n_host;
+  uint32_t na = 0, no = 0;
+  if (FEISTEL) {
+    na = n_out[set_a]; no = n_out[2];
+    n = max_samples;
+    if (n > (long long)n_out[0]) n = n_out[0];
+    if (n > (long long)n_out[1]) n = n_out[1];
+    if (n > (long long)n_out[2]) n = n_out[2];
+  }
+  const float coef = n > 0 ? grad_w / (float)n : 0.f;
+  float acc[1] = {0.f};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long ja, jo;
+    if (FEISTEL) { ja = feistel_perm((uint32_t)i, na, seed_a); jo = feistel_perm((uint32_t)i, no, seed_o); }
+    else { ja = perm_a[i]; jo = perm_o[i]; }
+    const int32_t pa = idx_a[ja], po = idx_o[jo];
+    const float v = score[pa] + margin - score[po];
+    if (v > 0.f) {
+      acc[0] += v;
+      if (dscore) { atomicAdd(&dscore[pa], coef); atomicAdd(&dscore[po], -coef); }
+    }
+  }
+  __shared__ int slots[1];
+  if (threadIdx.x == 0) slots[0] = slot;
+  __syncthreads();
+  block_add<1>(acc, counters, slots);
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[CNT_N_PAIRS] = (double)n;
+}
+
+// dscore of the consistency term; ASSIGNS every element (so it doubles as the zero fill)
+__global__ void rcl_cin_bwd_kernel(MssRclArgs a, const uint8_t* __restrict__ kind,
+                                   const double* __restrict__ counters, float grad_w, float* __restrict__ dscore) {
+  const long long HW = (long long)a.H * a.W;
+  const long long half = (long long)(a.B / 2) * HW;
+  const double ns = counters[CNT_N_SAME];
+  const float coef = ns > 0 ? grad_w / (float)ns : 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < half;
+       i += (long long)gridDim.x * blockDim.x) {
+    float g = 0.f;
+    if (kind[i] == 1 && kind[i + half] == 1 && a.score[i + half] - a.score[i] - a.m2 > 0.f) g = coef;
+    dscore[i] = -g;
+    dscore[i + half] = g;
+  }
+  // odd batch sizes leave a tail that belongs to no pair
+  const long long total = (long long)a.B * HW;
+  for (long long i = 2 * half + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x)
+    dscore[i] = 0.f;
+}
+
+// loss = w0*ce_orig + w1*ce_aug + wc*(c_orig + c_aug + c_in)   (loss.py:73-88,147)
+__global__ void rcl_finalize_kernel(MssRclArgs a, const double* __restrict__ counters, const uint32_t* sel,
+                                    float* __restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  const double half = (double)(a.B / 2) * a.H * a.W;
+  const float ce_orig = (float)(counters[CNT_SUM_CE_ORIG] / half);
+  float ce_aug;
+  if (a.select) {
+    const uint32_t k = sel[2];
+    ce_aug = k ? (float)(counters[CNT_SUM_SEL] / (double)k) : 0.f;
+  } else {
+    ce_aug = (float)(counters[CNT_SUM_CE_AUG_ALL] / half);
+  }
+  const double np = counters[CNT_N_PAIRS];
+  const float c_orig = (float)(counters[CNT_SUM_CORIG] / np);   // 0/0 -> NaN, as mean() of an empty tensor
+  const float c_aug = (float)(counters[CNT_SUM_CAUG] / np);
+  const float c_in = (float)(counters[CNT_SUM_CIN] / counters[CNT_N_SAME]);
+  out[0] = (a.w_ce_orig * ce_orig + a.w_ce_aug * ce_aug) + a.w_contras * ((c_orig + c_aug) + c_in);
+  out[1] = ce_orig; out[2] = ce_aug; out[3] = c_orig; out[4] = c_aug; out[5] = c_in;
+}
+
+inline int grid_for(long long work_items, int cap = 256 * 16) {
+  long long b = (work_items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+int rcl_check(const MssRclArgs* a) {
+  if (!a || !a->logit || !a->score || !a->target) return MSS_ERR_BAD_ARG;
+  if (a->B < 2 || a->C < 1 || a->H < 1 || a->W < 1) return MSS_ERR_BAD_ARG;
+  if ((long long)a->B * a->H * a->W >= (1ll << 31)) return MSS_ERR_UNSUPPORTED;
+  return MSS_OK;
+}
+
+}  // namespace
+
+#define S_(x) static_cast<hipStream_t>(x)
+
+extern "C" {
+
+int mss_rcl_num_compact_blocks(int B, int H, int W) { return (int)(((long long)B * H * W + CB - 1) / CB); }
+
+int mss_rcl_pass1_f32(const MssRclArgs* a, float* lse, float* ce_aug, uint8_t* kind, double* counters,
+                      void* stream) {
+  int rc = rcl_check(a);
+  if (rc) return rc;
+  if (!lse || !ce_aug || !kind || !counters) return MSS_ERR_BAD_ARG;
+  hipError_t e = hipMemsetAsync(counters, 0, 16 * sizeof(double), S_(stream));
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(rcl_pass1_kernel, dim3(grid_for((long long)a->B * a->H * a->W)), dim3(256), 0, S_(stream), *a,
+                     lse, ce_aug, kind, counters);
+  return mss_launch_status();
+}
+
+int mss_rcl_select_f32(const float* ce_aug, long long n, const double* counters, float selection_ratio,
+                       uint32_t* hist_ws, uint32_t* sel, void* stream) {
+  if (!ce_aug || !counters || !hist_ws || !sel || n <= 0) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rcl_select_init_kernel, dim3(1), dim3(256), 0, S_(stream), counters, selection_ratio, sel,
+                     hist_ws);
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hipLaunchKernelGGL(rcl_hist_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, S_(stream), ce_aug, n, sel, shift,
+                       hist_ws);
+    hipLaunchKernelGGL(rcl_pick_kernel, dim3(1), dim3(256), 0, S_(stream), sel, hist_ws, shift);
+  }
+  return mss_launch_status();
+}
+
+int mss_rcl_pass2_f32(const MssRclArgs* a, const float* lse, const float* ce_aug, const uint8_t* kind,
+                      uint32_t* sel, double* counters, float grad_scale, float* dlogit, void* stream) {
+  int rc = rcl_check(a);
+  if (rc) return rc;
+  if (!lse || !ce_aug || !kind || !sel || !counters) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rcl_pass2_kernel, dim3(grid_for((long long)a->B * a->H * a->W)), dim3(256), 0, S_(stream), *a,
+                     lse, ce_aug, kind, sel, counters, grad_scale, dlogit);
+  return mss_launch_status();
+}
+
+int mss_rcl_compact_f32(const uint8_t* kind, int B, int H, int W, int32_t* idx_orig, int32_t* idx_aug,
+                        int32_t* idx_ood, uint32_t* block_counts, uint32_t* n_out, void* stream) {
+  if (!kind || !idx_orig || !idx_aug || !idx_ood || !block_counts || !n_out) return MSS_ERR_BAD_ARG;
+  const long long total = (long long)B * H * W;
+  const long long half = (long long)(B / 2) * H * W;
+  const int nb = mss_rcl_num_compact_blocks(B, H, W);
+  hipLaunchKernelGGL(rcl_count_kernel, dim3(nb), dim3(256), 0, S_(stream), kind, total, half, block_counts, nb);
+  hipLaunchKernelGGL(rcl_scan_kernel, dim3(1), dim3(1024), 0, S_(stream), block_counts, nb, n_out);
+  hipLaunchKernelGGL(rcl_scatter_kernel, dim3(nb), dim3(256), 0, S_(stream), kind, total, half, block_counts, nb,
+                     idx_orig, idx_aug, idx_ood);
+  return mss_launch_status();
+}
+
+int mss_rcl_pairs_f32(const float* score, const int32_t* idx_a, const int64_t* perm_a, const int32_t* idx_o,
+                      const int64_t* perm_o, long long n, float margin, double* counters, int slot, float grad_w,
+                      float* dscore, void* stream) {
+  if (!score || !idx_a || !idx_o || !perm_a || !perm_o || !counters || n < 0) return MSS_ERR_BAD_ARG;
+  if (slot != 0 && slot != 1) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rcl_pairs_kernel<false>, dim3(grid_for(n > 0 ? n : 1, 2048)), dim3(256), 0, S_(stream), score,
+                     idx_a, perm_a, idx_o, perm_o, n, nullptr, 0, 0ll, 0u, 0u, margin, counters,
+                     slot == 0 ? CNT_SUM_CORIG : CNT_SUM_CAUG, grad_w, dscore);
+  return mss_launch_status();
+}
+
+int mss_rcl_pairs_device_f32(const float* score, const int32_t* idx_a, const int32_t* idx_o, const uint32_t* n_out,
+                             int set_a, long long max_samples, uint32_t seed_a, uint32_t seed_o, float margin,
+                             double* counters, int slot, float grad_w, float* dscore, void* stream) {
+  if (!score || !idx_a || !idx_o || !n_out || !counters) return MSS_ERR_BAD_ARG;
+  if ((slot != 0 && slot != 1) || (set_a != 0 && set_a != 1)) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rcl_pairs_kernel<true>, dim3(2048), dim3(256), 0, S_(stream), score, idx_a, nullptr, idx_o,
+                     nullptr, 0ll, n_out, set_a, max_samples, seed_a, seed_o, margin, counters,
+                     slot == 0 ? CNT_SUM_CORIG : CNT_SUM_CAUG, grad_w, dscore);
+  return mss_launch_status();
+}
+
+int mss_rcl_cin_bwd_f32(const MssRclArgs* a, const uint8_t* kind, const double* counters, float grad_w,
+                        float* dscore, void* stream) {
+  int rc = rcl_check(a);
+  if (rc) return rc;
+  if (!kind || !counters || !dscore) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rcl_cin_bwd_kernel, dim3(grid_for((long long)(a->B / 2) * a->H * a->W)), dim3(256), 0,
+                     S_(stream), *a, kind, counters, grad_w, dscore);
+  return mss_launch_status();
+}
+
+int mss_rcl_finalize_f32(const MssRclArgs* a, const double* counters, const uint32_t* sel, float* out,
+                         void* stream) {
+  int rc = rcl_check(a);
+  if (rc) return rc;
+  if (!counters || !sel || !out) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rcl_finalize_kernel, dim3(1), dim3(64), 0, S_(stream), *a, counters, sel, out);
+  return mss_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// Shared device/host helpers for the MI355X (gfx950) kernels of multishiftseg_amd.
+// Everything here is written for wave64 / CDNA4 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MSS_OK 0
+#define MSS_ERR_BAD_ARG 1001     // a precondition of the C-ABI entry point was violated
+#define MSS_ERR_UNSUPPORTED 1002 // shape outside what the kernels are built for
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Every launcher ends with this: kernel-launch failures are returned, never printf'd
+// (the reference only printf'd them: ms_deform_im2col_cuda.cuh:953-957).
+static inline int mss_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MSS_OK : (int)e;
+}
+
+__host__ __device__ static inline int mss_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Blocks b and b+8 share an XCD (and its L2) under round-robin dispatch. Map the hardware
+// block id to a virtual id so that every XCD walks one contiguous chunk of the tile grid.
+// Bijective for any grid size (guide: "XCD swizzle must be bijective").
+__device__ __forceinline__ int mss_xcd_remap(int bid, int nwg) {
+  int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+// DPP add across lanes, used for reductions inside 8/16/32/64-lane groups without LDS.
+template <int CTRL>
+__device__ __forceinline__ float mss_dpp_add(float v) {
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
+  return v + __int_as_float(t);
+}
+// sum over aligned groups of 8 consecutive lanes; every lane of the group gets the sum
+__device__ __forceinline__ float mss_sum8(float v) {
+  v = mss_dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = mss_dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = mss_dpp_add<0x141>(v);  // row_half_mirror: lane i <-> 7-i inside each 8-lane half row
+  return v;
+}
+// sum over the whole wave (64 lanes); every lane gets the sum
+__device__ __forceinline__ float mss_wave_sum(float v) {
+  v = mss_sum8(v);
+  v = mss_dpp_add<0x140>(v);  // row_mirror: lane i <-> 15-i inside each 16-lane row
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ double mss_wave_sum_d(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float mss_wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}

@@ -1,0 +1,105 @@
+"""Pins the CPU oracle (oracle/*.py) against vectors produced by the reference itself
+(tools/gen_golden.py -> tests/golden/*.npz). CPU only."""
+import ast
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import deepv3, loss as oloss, m2f, msda, nnops
+
+
+def test_conv_classes():
+    g = golden("ops")
+    x = g["conv_x"]
+    for tag, (stride, dil) in {"1x1": (1, 1), "3x3_d1": (1, 1), "3x3_d2": (1, 2), "3x3_d4": (1, 4), "3x3_d12": (1, 12),
+                               "3x3_d24": (1, 24), "3x3_d36": (1, 36), "3x3_s2": (2, 1), "1x1_s2": (2, 1)}.items():
+        w = g[f"conv_{tag}_w"]
+        pad = dil if w.shape[2] == 3 else 0
+        y = nnops.conv2d(x, w, stride=stride, dilation=dil, padding=pad)
+        np.testing.assert_allclose(y, g[f"conv_{tag}_y"], rtol=1e-5, atol=2e-6, err_msg=tag)
+
+
+def test_batchnorm_pool_upsample_lse():
+    g = golden("ops")
+    y, _, _ = nnops.batchnorm(g["bn_x"], g["bn_gamma"], g["bn_beta"], g["bn_rm"], g["bn_rv"], train=False)
+    np.testing.assert_allclose(y, g["bn_eval_y"], rtol=1e-5, atol=1e-6)
+    y, rm, rv = nnops.batchnorm(g["bn_x"], g["bn_gamma"], g["bn_beta"], g["bn_rm"], g["bn_rv"], train=True)
+    np.testing.assert_allclose(y, g["bn_train_y"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(rm, g["bn_train_rm"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rv, g["bn_train_rv"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(nnops.maxpool3s2(g["pool_x"]), g["pool_y"])
+    for tag in "abc":
+        y = nnops.upsample_bilinear_ac(g["up_x"], g[f"up_{tag}_y"].shape[2:])
+        np.testing.assert_allclose(y, g[f"up_{tag}_y"], rtol=1e-5, atol=1e-6)
+        gx = nnops.upsample_bilinear_ac_bwd(g[f"up_{tag}_gy"], g["up_x"].shape[2:])
+        np.testing.assert_allclose(gx, g[f"up_{tag}_gx"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(nnops.upsample_bilinear_ac(g["up1_x"], (5, 6)), g["up1_y"], rtol=0, atol=0)
+    np.testing.assert_allclose(nnops.logsumexp(g["lse_x"], 1), g["lse_y"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["eval_1x64x128", "eval_2x96x96"])
+def test_deepwv3plus_eval(tag, deeplab_params):
+    from multishiftseg_amd import synth
+    g = golden("deepwv3plus_" + tag)
+    n, h, w = (int(v) for v in g["shape"])
+    img = synth.synth_image(int(g["image_seed"]), n, h, w)
+    taps = {}
+    score, logit = deepv3.forward(deeplab_params, img, taps=taps)
+    # north_star tolerance: logits and OOD scores within 1e-3 (fp32), argmax bit-exact
+    np.testing.assert_allclose(taps["m2"][:, ::8], g["m2"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(taps["x"][:, ::64], g["x"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(taps["dec1"], g["dec1"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(taps["dec2"], g["dec2"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(logit, g["logit"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(score, g["score"], rtol=0, atol=1e-3)
+    label = logit.argmax(1)
+    clear = g["margin"] > 1e-3           # pixels whose top-2 margin exceeds the tolerance must agree exactly
+    assert clear.mean() > 0.99
+    np.testing.assert_array_equal(label[clear], g["label"][clear])
+
+
+@pytest.mark.parametrize("tag", ["testpy_f64", "testpy_f32", "d30_f64", "d32_f64", "d64_f64", "d71_f64", "m8d32_f32"])
+def test_msda(tag):
+    g = golden("msda_" + tag)
+    f64 = tag.endswith("f64")
+    out = msda.forward(g["value"], g["shapes"], g["starts"], g["loc"], g["attn"])
+    gv, gl, ga = msda.backward(g["value"], g["shapes"], g["starts"], g["loc"], g["attn"], g["grad_out"])
+    # ops/test.py:43 torch.allclose defaults for fp64; :59 rtol 1e-2 atol 1e-3 for fp32 (we hold 1e-5)
+    tol = dict(rtol=1e-9, atol=1e-12) if f64 else dict(rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out, g["out"], **tol)
+    np.testing.assert_allclose(gv, g["grad_value"], **tol)
+    np.testing.assert_allclose(gl, g["grad_loc"], **(tol if f64 else dict(rtol=1e-3, atol=1e-4)))
+    np.testing.assert_allclose(ga, g["grad_attn"], **tol)
+
+
+def test_m2f_score():
+    g = golden("m2f_score")
+    s = m2f.anomaly_score(g["cls"], g["mask"], tuple(int(v) for v in g["size"]))
+    np.testing.assert_allclose(s, g["score"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["deeplab_4x32x32", "m2f_4x32x32", "ratio1_4x16x16", "no_ood_4x16x16",
+                                 "no_in_aug_4x16x16", "deeplab_8x48x40"])
+def test_rel_contrastive_loss(tag):
+    g = golden("rcl_" + tag)
+    params = ast.literal_eval(str(g["params"]))
+    B, C, H, W = (int(v) for v in g["shape"])
+    if g["logits"].size:
+        logits = g["logits"]
+    else:
+        logits = np.random.default_rng(int(g["seed"])).standard_normal((B, C, H, W), dtype=np.float32) * 3
+    target = g["target"].astype(np.int64)
+    perms = [g[f"perm{i}"].astype(np.int64) for i in range(3)]
+    r = oloss.rel_contrastive_loss(logits, g["score"], target, params, perms)
+    if np.isnan(g["loss"]):
+        assert np.isnan(r["loss"])
+    else:
+        np.testing.assert_allclose(r["loss"], g["loss"], rtol=2e-6)
+        np.testing.assert_allclose(r["dscore"], g["dscore"], rtol=1e-5, atol=1e-9)
+        if "dlogit" in g:
+            np.testing.assert_allclose(r["dlogit"], g["dlogit"], rtol=1e-4, atol=1e-8)
+        else:
+            np.testing.assert_allclose(r["dlogit"][:, :, ::3, ::3], g["dlogit_sub"], rtol=1e-4, atol=1e-8)
+        np.testing.assert_allclose(np.abs(r["dlogit"].astype(np.float64)).sum(), g["dlogit_abs_sum"], rtol=1e-5)
+    np.testing.assert_array_equal(target.astype(np.uint8), g["target_mut"])

@@ -1,0 +1,382 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself on CPU.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box and is
+never copied): the reference modules are imported in place, fed deterministic inputs, and only
+inputs + outputs (data) are written. Weights are not stored: they come from
+multishiftseg_amd.synth (counter-based generator keyed by state-dict name), so the GPU box
+regenerates bit-identical parameters.
+
+    python tools/gen_golden.py            # all fixtures
+    python tools/gen_golden.py msda loss  # a subset
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from multishiftseg_amd import synth  # noqa: E402
+
+
+def import_reference():
+    """Import recipe from SURVEY.md 8(c): stub the import-time argparse module and the absent
+    compiled extension, nothing else."""
+    sys.path.insert(0, REF)
+    pa = types.ModuleType("lib.configs.parse_arg")
+    pa.opt = types.SimpleNamespace()
+    pa.args = types.SimpleNamespace()
+    sys.modules["lib.configs.parse_arg"] = pa
+    from lib.network.deepv3.deepv3 import DeepWV3Plus
+    import lib.loss as ref_loss
+    sys.path.insert(0, os.path.join(REF, "lib/network/mask2former/modeling/pixel_decoder"))
+    sys.modules["MultiScaleDeformableAttention"] = types.ModuleType("MultiScaleDeformableAttention")
+    from ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch
+    from ops.modules.ms_deform_attn import MSDeformAttn
+    return DeepWV3Plus, ref_loss, ms_deform_attn_core_pytorch, MSDeformAttn
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------- ops
+def gen_ops():
+    """Per-op vectors for every distinct conv class on the path + BN/pool/upsample/logsumexp."""
+    rng = np.random.default_rng(11)
+    out = {}
+    x = rng.standard_normal((2, 16, 20, 24), dtype=np.float32)
+    out["conv_x"] = x
+    for tag, (r, stride, dil) in {"1x1": (1, 1, 1), "3x3_d1": (3, 1, 1), "3x3_d2": (3, 1, 2), "3x3_d4": (3, 1, 4),
+                                  "3x3_d12": (3, 1, 12), "3x3_d24": (3, 1, 24), "3x3_d36": (3, 1, 36),
+                                  "3x3_s2": (3, 2, 1), "1x1_s2": (1, 2, 1)}.items():
+        w = rng.standard_normal((8, 16, r, r), dtype=np.float32) * 0.1
+        pad = dil if r == 3 else 0
+        y = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), stride=stride, dilation=dil, padding=pad)
+        out[f"conv_{tag}_w"] = w
+        out[f"conv_{tag}_y"] = t2n(y)
+    # BatchNorm2d train / eval
+    bx = rng.standard_normal((3, 8, 7, 9), dtype=np.float32) * 2 + 0.5
+    bn = torch.nn.BatchNorm2d(8)
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, 8).astype(np.float32)))
+        bn.bias.copy_(torch.from_numpy(rng.standard_normal(8).astype(np.float32)))
+        bn.running_mean.copy_(torch.from_numpy(rng.standard_normal(8).astype(np.float32) * 0.1))
+        bn.running_var.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, 8).astype(np.float32)))
+    out.update(bn_x=bx, bn_gamma=t2n(bn.weight), bn_beta=t2n(bn.bias), bn_rm=t2n(bn.running_mean).copy(),
+               bn_rv=t2n(bn.running_var).copy())
+    bn.eval()
+    out["bn_eval_y"] = t2n(bn(torch.from_numpy(bx)))
+    bn.train()
+    out["bn_train_y"] = t2n(bn(torch.from_numpy(bx)))
+    out["bn_train_rm"] = t2n(bn.running_mean)
+    out["bn_train_rv"] = t2n(bn.running_var)
+    # MaxPool2d(3,2,1), odd and even sizes
+    px = rng.standard_normal((2, 4, 11, 14), dtype=np.float32)
+    out["pool_x"] = px
+    out["pool_y"] = t2n(F.max_pool2d(torch.from_numpy(px), 3, stride=2, padding=1))
+    # bilinear align_corners=True: x2-ish, x4-ish (88->350 style), 1x1 -> hxw
+    ux = rng.standard_normal((2, 4, 11, 13), dtype=np.float32)
+    out["up_x"] = ux
+    for tag, size in {"a": (22, 26), "b": (41, 50), "c": (11, 13)}.items():
+        xt = torch.from_numpy(ux).requires_grad_(True)
+        y = F.interpolate(xt, size=size, mode="bilinear", align_corners=True)
+        gy = torch.from_numpy(rng.standard_normal(tuple(y.shape), dtype=np.float32))
+        y.backward(gy)
+        out[f"up_{tag}_y"] = t2n(y)
+        out[f"up_{tag}_gy"] = t2n(gy)
+        out[f"up_{tag}_gx"] = t2n(xt.grad)
+    u1 = rng.standard_normal((2, 4, 1, 1), dtype=np.float32)
+    out["up1_x"] = u1
+    out["up1_y"] = t2n(F.interpolate(torch.from_numpy(u1), size=(5, 6), mode="bilinear", align_corners=True))
+    lx = rng.standard_normal((2, 19, 5, 6), dtype=np.float32) * 4
+    out["lse_x"] = lx
+    out["lse_y"] = t2n(torch.logsumexp(torch.from_numpy(lx), dim=1))
+    save("ops", **out)
+
+
+# --------------------------------------------------------------------------------------- DeepLab
+def build_ref_model(DeepWV3Plus, seed=0):
+    torch.manual_seed(0)
+    model = DeepWV3Plus(19)
+    sd = model.state_dict()
+    shapes = synth.deepwv3plus_param_shapes(19)
+    assert list(sd.keys()) == list(shapes.keys()), "state-dict names/order differ from synth"
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), (k, v.shape, shapes[k])
+    params = synth.deepwv3plus_params(seed)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in params.items()}, strict=True)
+    return model
+
+
+def gen_deeplab(DeepWV3Plus):
+    model = build_ref_model(DeepWV3Plus)
+    model.eval()
+    for tag, (n, h, w) in {"eval_1x64x128": (1, 64, 128), "eval_2x96x96": (2, 96, 96)}.items():
+        img = synth.synth_image(1, n, h, w)
+        taps = {}
+        hooks = [
+            model.mod2.register_forward_hook(lambda m, i, o: taps.__setitem__("m2", t2n(o))),
+            model.mod7.register_forward_hook(lambda m, i, o: taps.__setitem__("x", t2n(o))),
+            model.aspp.register_forward_hook(lambda m, i, o: taps.__setitem__("aspp", t2n(o))),
+            model.final[5].register_forward_hook(lambda m, i, o: taps.__setitem__("feature", t2n(o))),
+            model.final[6].register_forward_hook(lambda m, i, o: taps.__setitem__("dec1", t2n(o))),
+            model.ood_head.register_forward_hook(lambda m, i, o: taps.__setitem__("dec2", t2n(o))),
+        ]
+        with torch.no_grad():
+            score, logit = model(torch.from_numpy(img))
+        for hk in hooks:
+            hk.remove()
+        logit_n = t2n(logit)
+        top2 = np.sort(logit_n, axis=1)[:, -2:]
+        save("deepwv3plus_" + tag, image_seed=np.int64(1), shape=np.array([n, h, w]), score=t2n(score),
+             logit=logit_n, label=logit_n.argmax(1).astype(np.uint8), margin=(top2[:, 1] - top2[:, 0]),
+             m2=taps["m2"][:, ::8], x=taps["x"][:, ::64], aspp=taps["aspp"][:, ::16],
+             feature=taps["feature"][:, ::16], dec1=taps["dec1"], dec2=taps["dec2"],
+             x_absmax=np.float32(np.abs(taps["x"]).max()), feature_absmax=np.float32(np.abs(taps["feature"]).max()))
+        print(f"   {tag}: |x|max {np.abs(taps['x']).max():.3g}  |feature|max {np.abs(taps['feature']).max():.3g} "
+              f" logit range [{logit_n.min():.3g},{logit_n.max():.3g}]  score range [{t2n(score).min():.3g},"
+              f"{t2n(score).max():.3g}]  min top-2 margin {(top2[:, 1] - top2[:, 0]).min():.3g}")
+    return model
+
+
+def gen_train_step(DeepWV3Plus, ref_loss):
+    """a-7: one optimizer step of each training stage on a (2+2)x3x96x128 batch, train-mode BN on
+    the frozen trunk, Dropout2d masks and the loss permutations recorded and stored."""
+    pairs, h, w = 2, 96, 128
+    img = synth.synth_image(2, 2 * pairs, h, w)
+    target = synth.synth_targets(2, pairs, h, w)
+    loss_params = {"ce_weights": [50, 10], "conduct_pixel_selection": True, "selection_ratio": 0.8,
+                   "inoutaug_contras_margins_tri": [10, 5, 5]}        # exps/DeepLab.yaml:30-35
+    out = dict(image_seed=np.int64(2), shape=np.array([pairs, h, w]), target=target.astype(np.uint8))
+    for stage, (names, lr) in {"stage1": (["ood_head"], 1e-4),
+                               "stage2": (["aspp", "bot_fine", "bot_aspp", "ood_head"], 1e-6)}.items():
+        model = build_ref_model(DeepWV3Plus)
+        model.uncertainty_func_init()                                   # train_deeplab.py:108-111
+        params = []
+        for name, p in model.named_parameters():                       # train_deeplab.py:124-130
+            p.requires_grad = any(s in name for s in names)
+            if p.requires_grad:
+                params.append(p)
+        opt = torch.optim.Adam(params, lr=lr, weight_decay=1e-4)       # train_deeplab.py:145-149
+        model.train()
+        # record Dropout2d masks: replace the two dropout modules' forward by an explicit mask
+        masks = {}
+        torch.manual_seed(123)
+
+        def make_drop(key, p):
+            def fwd(x):
+                m = (torch.rand(x.shape[0], x.shape[1]) >= p).float() / (1 - p)
+                masks[key] = t2n(m)
+                return x * m[:, :, None, None]
+            return fwd
+        model.mod6.block1.convs.dropout.forward = make_drop("mod6", 0.3)
+        model.mod7.block1.convs.dropout.forward = make_drop("mod7", 0.5)
+        perms = []
+        real_randperm = torch.randperm
+
+        def logging_randperm(n, *a, **k):
+            p = real_randperm(n, *a, **k)
+            perms.append(t2n(p))
+            return p
+        torch.randperm = logging_randperm
+        try:
+            crit = ref_loss.RelContrastiveLoss(loss_params)
+            tgt = torch.from_numpy(target.copy())
+            before = {n_: p.detach().clone() for n_, p in model.named_parameters() if p.requires_grad}
+            score, logit = model(torch.from_numpy(img))
+            loss = crit(logit, score, tgt).mean()
+            opt.zero_grad()
+            loss.backward()
+            grads = {n_: p.grad.detach().clone() for n_, p in model.named_parameters() if p.requires_grad}
+            opt.step()
+        finally:
+            torch.randperm = real_randperm
+        pre = stage + "_"
+        out[pre + "loss"] = t2n(loss)
+        out[pre + "score"] = t2n(score)
+        out[pre + "logit_sub"] = t2n(logit)[:, :, ::4, ::4]
+        out[pre + "target_mut"] = t2n(tgt).astype(np.uint8)
+        out[pre + "drop_mod6"] = masks["mod6"]
+        out[pre + "drop_mod7"] = masks["mod7"]
+        for i, p in enumerate(perms):
+            out[pre + f"perm{i}"] = p.astype(np.int32)
+        sd = model.state_dict()
+        for k in ("mod2.block1.bn1.0.running_mean", "mod2.block1.bn1.0.running_var",
+                  "mod7.block1.convs.bn3.0.running_mean", "mod7.block1.convs.bn3.0.running_var",
+                  "aspp.features.3.1.running_mean", "aspp.features.3.1.running_var",
+                  "aspp.img_conv.1.running_var", "final.4.running_mean", "final.4.running_var"):
+            out[pre + "rs_" + k] = t2n(sd[k])
+        for n_, g in grads.items():
+            gn = t2n(g)
+            if gn.size > 70000:   # keep a slice of the big ones + a checksum
+                flat = gn.reshape(gn.shape[0], -1)
+                out[pre + "grad_sub_" + n_] = flat[:, ::max(1, flat.shape[1] // 64)][:, :64].copy()
+                out[pre + "grad_l2_" + n_] = np.float64(np.sqrt((gn.astype(np.float64) ** 2).sum()))
+            else:
+                out[pre + "grad_" + n_] = gn
+        for n_, b in before.items():
+            delta = t2n(dict(model.named_parameters())[n_].detach() - b)
+            if delta.size <= 70000:
+                out[pre + "delta_" + n_] = delta
+        print(f"   {stage}: loss {float(loss):.6f}, {len(grads)} trainable tensors, perms {[len(p) for p in perms]}")
+    save("deepwv3plus_train_step", **out)
+
+
+# ------------------------------------------------------------------------------------------ loss
+def gen_loss(ref_loss):
+    def run(tag, B, H, W, params, seed, tmod=None, full=True):
+        rng = np.random.default_rng(seed)
+        logits = (rng.standard_normal((B, 19, H, W), dtype=np.float32) * 3)
+        score = rng.standard_normal((B, H, W), dtype=np.float32) * 4
+        target = synth.synth_targets(seed, B // 2, H, W)
+        if tmod is not None:
+            target = tmod(target)
+        perms = []
+        real_randperm = torch.randperm
+
+        def logging_randperm(n, *a, **k):
+            p = real_randperm(n, *a, **k)
+            perms.append(t2n(p))
+            return p
+        torch.randperm = logging_randperm
+        try:
+            torch.manual_seed(seed)
+            lt = torch.from_numpy(logits).requires_grad_(True)
+            st = torch.from_numpy(score).requires_grad_(True)
+            tt = torch.from_numpy(target.copy())
+            crit = ref_loss.RelContrastiveLoss(params)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                loss = crit(lt, st, tt)
+            if torch.isfinite(loss):
+                loss.backward()
+                dl, ds = t2n(lt.grad), t2n(st.grad)
+            else:
+                dl, ds = np.zeros_like(logits), np.zeros_like(score)
+        finally:
+            torch.randperm = real_randperm
+        arrays = dict(logits=logits if full else np.zeros(0, np.float32), score=score, target=target.astype(np.uint8),
+                      seed=np.int64(seed), shape=np.array([B, 19, H, W]), loss=t2n(loss), dscore=ds,
+                      target_mut=t2n(tt).astype(np.uint8), params=np.array(repr(params)))
+        arrays["dlogit" if full else "dlogit_sub"] = dl if full else dl[:, :, ::3, ::3].copy()
+        arrays["dlogit_abs_sum"] = np.float64(np.abs(dl.astype(np.float64)).sum())
+        for i, p in enumerate(perms):
+            arrays[f"perm{i}"] = p.astype(np.int32)
+        print(f"   {tag}: loss {float(loss.detach()):.6f}  perms {[len(p) for p in perms]}")
+        save("rcl_" + tag, **arrays)
+
+    deeplab = {"ce_weights": [50, 10], "conduct_pixel_selection": True, "selection_ratio": 0.8,
+               "inoutaug_contras_margins_tri": [10, 5, 5]}                       # exps/DeepLab.yaml
+    m2f = {"ce_weights": [0, 0], "conduct_pixel_selection": False, "selection_ratio": 1.0,
+           "inoutaug_contras_margins_tri": [0.7, 0.5, 0.2]}                       # exps/M2F.yaml
+    run("deeplab_4x32x32", 4, 32, 32, deeplab, 5)
+    run("deeplab_8x48x40", 8, 48, 40, deeplab, 6, full=False)
+    run("m2f_4x32x32", 4, 32, 32, m2f, 7)
+    run("ratio1_4x16x16", 4, 16, 16, dict(deeplab, selection_ratio=1.0), 8)
+    run("no_ood_4x16x16", 4, 16, 16, deeplab, 9, tmod=lambda t: np.where(t == 254, 3, t))      # NaN loss
+    def void_aug(t):                                                                            # select_num == 0
+        t = t.copy(); t[t.shape[0] // 2:] = np.where(t[t.shape[0] // 2:] < 99, 255, t[t.shape[0] // 2:]); return t
+    run("no_in_aug_4x16x16", 4, 16, 16, deeplab, 10, tmod=void_aug)
+
+
+# ------------------------------------------------------------------------------------------ MSDA
+def gen_msda(core, MSDeformAttn):
+    def case(tag, N, M, D, Lq, P, shapes, seed, dtype, loc_range=(0.0, 1.0), value_scale=0.01):
+        torch.manual_seed(seed)
+        shp = torch.as_tensor(shapes, dtype=torch.long)
+        L = len(shapes)
+        starts = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+        S = int(shp.prod(1).sum())
+        value = (torch.rand(N, S, M, D) * value_scale).to(dtype).requires_grad_(True)
+        lo, hi = loc_range
+        loc = (torch.rand(N, Lq, M, L, P, 2) * (hi - lo) + lo).to(dtype).requires_grad_(True)
+        attn = torch.rand(N, Lq, M, L, P) + 1e-5
+        attn = (attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)).to(dtype).requires_grad_(True)
+        out = core(value, shp, loc, attn)
+        gout = torch.randn(out.shape, dtype=dtype)
+        out.backward(gout)
+        save("msda_" + tag, value=t2n(value), shapes=t2n(shp), starts=t2n(starts), loc=t2n(loc), attn=t2n(attn),
+             out=t2n(out), grad_out=t2n(gout), grad_value=t2n(value.grad), grad_loc=t2n(loc.grad),
+             grad_attn=t2n(attn.grad))
+
+    # ops/test.py:24-31 recipe (N,M,D=1,2,2; Lq,L,P=2,2,2; shapes (6,4),(3,2); seed 3), fp64 and fp32
+    case("testpy_f64", 1, 2, 2, 2, 2, [(6, 4), (3, 2)], 3, torch.float64)
+    case("testpy_f32", 1, 2, 2, 2, 2, [(6, 4), (3, 2)], 3, torch.float32)
+    # the channel counts of ops/test.py:88-89 that hit each backward variant, kept small (fp64)
+    for d in (30, 32, 64, 71):
+        case(f"d{d}_f64", 1, 2, d, 3, 2, [(6, 4), (3, 2)], 3 + d, torch.float64, loc_range=(-0.15, 1.15))
+    # production geometry (M=8, D=32, L=3, P=4) scaled down, locations beyond the borders
+    case("m8d32_f32", 1, 8, 32, 100, 4, [(4, 5), (8, 10), (16, 20)], 21, torch.float32, loc_range=(-0.2, 1.2),
+         value_scale=1.0)
+    # a-10: the module around the op, generator weights
+    torch.manual_seed(31)
+    mod = MSDeformAttn(d_model=256, n_levels=3, n_heads=8, n_points=4)
+    sd = {k: synth.gen_tensor(7, "msdeformattn." + k, tuple(v.shape), gain=1.0) if v.dim() == 2
+          else t2n(v) for k, v in mod.state_dict().items()}
+    sd["sampling_offsets.bias"] = t2n(mod.state_dict()["sampling_offsets.bias"])   # the ring init, ms_deform_attn.py:66-80
+    mod.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    shapes = [(4, 5), (8, 10), (16, 20)]
+    shp = torch.as_tensor(shapes, dtype=torch.long)
+    starts = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    S = int(shp.prod(1).sum())
+    rng = np.random.default_rng(32)
+    query = rng.standard_normal((1, S, 256), dtype=np.float32)
+    src = rng.standard_normal((1, S, 256), dtype=np.float32)
+    refp = rng.random((1, S, 3, 2), dtype=np.float32)
+    with torch.no_grad():
+        y = mod(torch.from_numpy(query), torch.from_numpy(refp), torch.from_numpy(src), shp, starts)
+    # 2-D weights are regenerated by synth.gen_tensor(7, "msdeformattn."+name, ...); only the biases are stored
+    save("msda_module", query=query, src=src, refp=refp, shapes=t2n(shp), starts=t2n(starts), out=t2n(y),
+         **{"b_" + k: np.asarray(v) for k, v in sd.items() if np.asarray(v).ndim == 1})
+
+
+def gen_m2f():
+    """train_m2f.py:387-407 cannot be imported (detectron2 absent); its five lines of torch
+    arithmetic are evaluated here verbatim on random inputs."""
+    rng = np.random.default_rng(41)
+    cls = rng.standard_normal((2, 100, 20), dtype=np.float32) * 2
+    mask = rng.standard_normal((2, 100, 24, 32), dtype=np.float32) * 3
+    size = (22, 30)
+    class_probs = torch.softmax(torch.from_numpy(cls), dim=-1)[..., :-1]
+    mask_probs = torch.from_numpy(mask).sigmoid()
+    u = torch.einsum("bqc,bqhw->bchw", class_probs, mask_probs)[:, :, :size[0], :size[1]]
+    score = 1 - torch.max(u, dim=1)[0]
+    save("m2f_score", cls=cls, mask=mask, size=np.array(size), score=t2n(score))
+
+
+def main():
+    which = set(sys.argv[1:]) or {"ops", "deeplab", "train", "loss", "msda", "m2f"}
+    torch.set_num_threads(8)
+    DeepWV3Plus, ref_loss, core, MSDeformAttn = import_reference()
+    if "ops" in which:
+        print("ops"); gen_ops()
+    if "msda" in which:
+        print("msda"); gen_msda(core, MSDeformAttn)
+    if "m2f" in which:
+        print("m2f"); gen_m2f()
+    if "loss" in which:
+        print("loss"); gen_loss(ref_loss)
+    if "deeplab" in which:
+        print("deeplab"); gen_deeplab(DeepWV3Plus)
+    if "train" in which:
+        print("train"); gen_train_step(DeepWV3Plus, ref_loss)
+
+
+if __name__ == "__main__":
+    main()
