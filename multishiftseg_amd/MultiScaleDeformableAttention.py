@@ -1,0 +1,65 @@
+"""Drop-in for the reference's compiled ``MultiScaleDeformableAttention`` extension module.
+
+Same two functions, same argument order and meaning, same preconditions as
+ops/src/vision.cpp:18-21 -> ms_deform_attn.h:25-66 -> cuda/ms_deform_attn_cuda.cu:25-157, backed by
+mss_msda_{forward,backward}_{f32,f64} in libmss_hip.so. To let reference-style code
+(`import MultiScaleDeformableAttention as MSDA`) pick it up unchanged call `install()`.
+"""
+import sys
+
+import torch
+
+from ._lib import call, ptr
+
+
+def _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step, extra=()):
+    tensors = dict(value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                   sampling_loc=sampling_loc, attn_weight=attn_weight, **dict(extra))
+    for name, t in tensors.items():
+        if not t.is_contiguous():                       # ms_deform_attn_cuda.cu:33-37,98-103
+            raise RuntimeError(f"{name} tensor has to be contiguous")
+    for name, t in tensors.items():
+        if not t.is_cuda:                               # ms_deform_attn.h:43,65 / .cu:39-43
+            raise RuntimeError("Not implemented on the CPU" if name == "value" else f"{name} must be a CUDA tensor")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64")
+    if value.dtype not in (torch.float32, torch.float64):   # AT_DISPATCH_FLOATING_TYPES, .cu:69,139
+        raise RuntimeError(f"ms_deform_attn: unsupported dtype {value.dtype}")
+    for name in ("sampling_loc", "attn_weight") + tuple(k for k, _ in extra):
+        if tensors[name].dtype != value.dtype:
+            raise RuntimeError(f"{name} dtype {tensors[name].dtype} != value dtype {value.dtype}")
+    batch = value.shape[0]
+    step = min(batch, int(im2col_step))
+    if batch and batch % step != 0:                      # .cu:55-57,122-124
+        raise RuntimeError(f"batch({batch}) must divide im2col_step({step})")
+    N, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+    return N, S, M, D, L, Lq, P
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    N, S, M, D, L, Lq, P = _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    out = torch.empty((N, Lq, M * D), device=value.device, dtype=value.dtype)
+    sfx = "f32" if value.dtype == torch.float32 else "f64"
+    call(f"mss_msda_forward_{sfx}", ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(sampling_loc),
+         ptr(attn_weight), N, S, M, D, L, Lq, P, ptr(out))
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step):
+    N, S, M, D, L, Lq, P = _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step,
+                                  extra=(("grad_output", grad_output),))
+    grad_value = torch.empty_like(value)                 # zero-filled by the callee
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_attn = torch.empty_like(attn_weight)
+    sfx = "f32" if value.dtype == torch.float32 else "f64"
+    call(f"mss_msda_backward_{sfx}", ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(sampling_loc),
+         ptr(attn_weight), ptr(grad_output), N, S, M, D, L, Lq, P, ptr(grad_value), ptr(grad_loc), ptr(grad_attn))
+    return [grad_value, grad_loc, grad_attn]
+
+
+def install():
+    """Register this module under the extension's name for `import MultiScaleDeformableAttention`."""
+    sys.modules["MultiScaleDeformableAttention"] = sys.modules[__name__]

@@ -1,0 +1,349 @@
+"""DeepWV3Plus on MI355X: the reference's module contract, executed by hand-written HIP kernels.
+
+Host-side mirror of lib/network/deepv3/deepv3.py:203-285 (DeepWV3Plus, ASPP) and
+lib/network/deepv3/wider_resnet.py:64-182,267-364 (WiderResNetA2 trunk): same constructor, same
+``forward(inp) -> (anomaly_score [B,H,W], logit [B,19,H,W])``, same parameter / buffer names (the
+269 state-dict entries load unchanged), same train()/eval() behaviour of BatchNorm and Dropout2d,
+same ``uncertainty_func_init``. The nn.Conv2d / nn.BatchNorm2d children are parameter containers
+only -- their forward is never called. What runs instead (all in libmss_hip.so):
+
+  * activations live in NHWC; every conv is the fp32-MFMA implicit GEMM with BatchNorm+ReLU of the
+    producer folded into its A-operand load, the residual add folded into its epilogue, Dropout2d
+    folded into a per-sample affine, and concats written in place through channel slices;
+  * the frozen trunk (mod1..mod7, never trainable in the reference: exps/DeepLab.yaml:10-11) runs
+    without autograd; the decoder/heads run inside ONE autograd.Function whose backward is a fixed
+    sequence of dgrad/wgrad/BN-backward kernels.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .kernels import Act
+
+_STRUCTURE = [3, 3, 6, 3, 1, 1]
+_CHANNELS = [(128, 128), (256, 256), (512, 512), (512, 1024), (512, 1024, 2048), (1024, 2048, 4096)]
+_ASPP_RATES = (12, 24, 36)   # output_stride 8 doubles (6, 12, 18): deepv3.py:53-54
+
+
+def _bnrelu(c):
+    return nn.Sequential(nn.BatchNorm2d(c), nn.ReLU(inplace=True))
+
+
+class _Block(nn.Module):
+    """Parameter container with the names of IdentityResidualBlock (wider_resnet.py:64-167)."""
+
+    def __init__(self, cin, channels, stride, dilation, drop_p):
+        super().__init__()
+        self.stride, self.dilation, self.drop_p = stride, dilation, drop_p
+        self.bottleneck = len(channels) == 3
+        self.bn1 = _bnrelu(cin)
+        if not self.bottleneck:
+            layers = [("conv1", nn.Conv2d(cin, channels[0], 3, stride=stride, padding=dilation, bias=False,
+                                          dilation=dilation)),
+                      ("bn2", _bnrelu(channels[0])),
+                      ("conv2", nn.Conv2d(channels[0], channels[1], 3, padding=dilation, bias=False,
+                                          dilation=dilation))]
+            if drop_p is not None:
+                layers.insert(2, ("dropout", nn.Dropout2d(p=drop_p)))
+        else:
+            layers = [("conv1", nn.Conv2d(cin, channels[0], 1, stride=stride, bias=False)),
+                      ("bn2", _bnrelu(channels[0])),
+                      ("conv2", nn.Conv2d(channels[0], channels[1], 3, padding=dilation, bias=False,
+                                          dilation=dilation)),
+                      ("bn3", _bnrelu(channels[1])),
+                      ("conv3", nn.Conv2d(channels[1], channels[2], 1, bias=False))]
+            if drop_p is not None:
+                layers.insert(4, ("dropout", nn.Dropout2d(p=drop_p)))
+        self.convs = nn.Sequential(OrderedDict(layers))
+        if stride != 1 or cin != channels[-1]:
+            self.proj_conv = nn.Conv2d(cin, channels[-1], 1, stride=stride, bias=False)
+
+
+class _ASPP(nn.Module):
+    """Names of _AtrousSpatialPyramidPoolingModule (deepv3.py:47-82)."""
+
+    def __init__(self, in_dim=4096, red=256):
+        super().__init__()
+        feats = [nn.Sequential(nn.Conv2d(in_dim, red, 1, bias=False), nn.BatchNorm2d(red), nn.ReLU(inplace=True))]
+        for r in _ASPP_RATES:
+            feats.append(nn.Sequential(nn.Conv2d(in_dim, red, 3, dilation=r, padding=r, bias=False),
+                                       nn.BatchNorm2d(red), nn.ReLU(inplace=True)))
+        self.features = nn.ModuleList(feats)
+        self.img_pooling = nn.AdaptiveAvgPool2d(1)
+        self.img_conv = nn.Sequential(nn.Conv2d(in_dim, red, 1, bias=False), nn.BatchNorm2d(red),
+                                      nn.ReLU(inplace=True))
+
+
+class _HeadFn(torch.autograd.Function):
+    """Decoder + heads (deepv3.py:270-283) as one differentiable node."""
+
+    @staticmethod
+    def forward(ctx, model, x, m2, size, *params):
+        score, logit, saved = model._head_forward(x, m2, size, keep=True)
+        ctx.model, ctx.saved = model, saved
+        return score, logit
+
+    @staticmethod
+    def backward(ctx, dscore, dlogit):
+        grads = ctx.model._head_backward(ctx.saved, dscore, dlogit, ctx.needs_input_grad[4:])
+        ctx.saved = None
+        return (None, None, None, None) + tuple(grads)
+
+
+class DeepWV3Plus(nn.Module):
+    """Wide-ResNet-38 DeepLabV3+ with the extra OOD head (deepv3.py:203-285)."""
+
+    def __init__(self, num_classes, criterion=None, trunk="WideResnet38"):
+        super().__init__()
+        if num_classes != 19:
+            raise NotImplementedError("the HIP OOD-score tail is built for the 19 Cityscapes classes")
+        self.mod1 = nn.Sequential(OrderedDict([("conv1", nn.Conv2d(3, 64, 3, stride=1, padding=1, bias=False))]))
+        cin = 64
+        for mod_id, num in enumerate(_STRUCTURE):
+            blocks = []
+            for b in range(num):
+                dil = 2 if mod_id == 3 else (4 if mod_id > 3 else 1)        # wider_resnet.py:322-332
+                stride = 2 if (b == 0 and mod_id == 2) else 1
+                drop = 0.3 if mod_id == 4 else (0.5 if mod_id == 5 else None)  # wider_resnet.py:334-339
+                blocks.append((f"block{b + 1}", _Block(cin, _CHANNELS[mod_id], stride, dil, drop)))
+                cin = _CHANNELS[mod_id][-1]
+            setattr(self, f"mod{mod_id + 2}", nn.Sequential(OrderedDict(blocks)))
+        self.pool2 = nn.MaxPool2d(3, stride=2, padding=1)
+        self.pool3 = nn.MaxPool2d(3, stride=2, padding=1)
+        self.aspp = _ASPP(4096, 256)
+        self.bot_fine = nn.Conv2d(128, 48, kernel_size=1, bias=False)
+        self.bot_aspp = nn.Conv2d(1280, 256, kernel_size=1, bias=False)
+        self.final = nn.Sequential(
+            nn.Conv2d(256 + 48, 256, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(256),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(256, 256, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(256), nn.ReLU(inplace=True),
+            nn.Conv2d(256, num_classes, kernel_size=1, bias=False))
+        self.ood_head = nn.Conv2d(256, num_classes, kernel_size=1, bias=False)
+        self.criterion = criterion
+        self.num_classes = num_classes
+        self._heads_cache = None
+        # test hook: {"mod6": [N,1024], "mod7": [N,2048]} pre-scaled Dropout2d masks
+        self.dropout_masks = None
+
+    # ---- reference API ---------------------------------------------------------------------
+    def energy_func(self, logit):
+        """-logsumexp over classes (deepv3.py:251-253); the fused kernel computes the same thing."""
+        return -(1.0 * torch.logsumexp(logit, dim=1))
+
+    def uncertainty_func_init(self):
+        """deepv3.py:255-256."""
+        self.ood_head.weight.data = self.final[-1].weight.data.clone()
+
+    # ---- parameter bookkeeping -----------------------------------------------------------------
+    def _head_params(self):
+        names, params = [], []
+        for prefix, mod in (("aspp", self.aspp), ("bot_fine", self.bot_fine), ("bot_aspp", self.bot_aspp),
+                            ("final", self.final), ("ood_head", self.ood_head)):
+            for n, p in mod.named_parameters():
+                names.append(f"{prefix}.{n}")
+                params.append(p)
+        return names, params
+
+    def _check_trunk_frozen(self):
+        for i in range(1, 8):
+            for n, p in getattr(self, f"mod{i}").named_parameters():
+                if p.requires_grad:
+                    raise NotImplementedError(
+                        f"mod{i}.{n} requires grad: the WideResNet trunk is frozen in both training stages of the "
+                        "reference (exps/DeepLab.yaml:10-11) and has no backward kernels here")
+
+    # ---- trunk ------------------------------------------------------------------------------------
+    def _dropout_affine(self, st, blk, name, n):
+        """Dropout2d on relu(bn(x)) == per-sample affine: relu(z)*m = relu(z*m) for m >= 0."""
+        if blk.drop_p is None or not self.training:
+            return (st.scale, st.shift)
+        if self.dropout_masks is not None:
+            mask = self.dropout_masks[name].to(st.scale.device, torch.float32)
+        else:
+            keep = 1.0 - blk.drop_p
+            mask = torch.bernoulli(torch.full((n, st.scale.numel()), keep, device=st.scale.device)) / keep
+        return ((st.scale[None, :] * mask).contiguous(), (st.shift[None, :] * mask).contiguous())
+
+    def _run_block(self, blk, a, name):
+        train = self.training
+        st1 = K.bn_fold(blk.bn1[0], a, train)
+        aff1 = (st1.scale, st1.shift)
+        if hasattr(blk, "proj_conv"):
+            shortcut = K.conv2d(a, K.packed(blk.proj_conv.weight), stride=blk.stride, in_affine=aff1, in_relu=True)
+        else:
+            shortcut = a
+        d = blk.dilation
+        c = blk.convs
+        if not blk.bottleneck:
+            o = K.conv2d(a, K.packed(c.conv1.weight), stride=blk.stride, dil=d, pad=d, in_affine=aff1, in_relu=True)
+            st2 = K.bn_fold(c.bn2[0], o, train)
+            return K.conv2d(o, K.packed(c.conv2.weight), dil=d, pad=d, in_affine=self._dropout_affine(st2, blk, name, a.N),
+                            in_relu=True, res=shortcut)
+        o = K.conv2d(a, K.packed(c.conv1.weight), stride=blk.stride, in_affine=aff1, in_relu=True)
+        st2 = K.bn_fold(c.bn2[0], o, train)
+        o2 = K.conv2d(o, K.packed(c.conv2.weight), dil=d, pad=d, in_affine=(st2.scale, st2.shift), in_relu=True)
+        st3 = K.bn_fold(c.bn3[0], o2, train)
+        return K.conv2d(o2, K.packed(c.conv3.weight), in_affine=self._dropout_affine(st3, blk, name, a.N), in_relu=True,
+                        res=shortcut)
+
+    def _run_trunk(self, inp):
+        a = K.image_to_nhwc(inp, 16)
+        a = K.conv2d(a, K.packed(self.mod1.conv1.weight), pad=1)
+        m2 = None
+        for mod_id in range(6):
+            name = f"mod{mod_id + 2}"
+            if mod_id < 2:
+                a = K.maxpool3s2(a)
+            for blk in getattr(self, name):
+                a = self._run_block(blk, a, name)
+            if mod_id == 0:
+                m2 = a
+        return a, m2
+
+    # ---- decoder + heads -------------------------------------------------------------------------
+    def _heads_weight(self):
+        """final.6 and ood_head share their input: one GEMM with K = 48 (rows 0-18 / 20-38)."""
+        w1, w2 = self.final[6].weight, self.ood_head.weight
+        key = (w1._version, w1.data_ptr(), w2._version, w2.data_ptr())
+        if self._heads_cache is None or self._heads_cache[0] != key:
+            wh = torch.zeros((48, 256, 1, 1), device=w1.device, dtype=torch.float32)
+            wh[0:19] = w1.detach()
+            wh[20:39] = w2.detach()
+            self._heads_cache = (key, K.pack_weight(wh), K.pack_weight(wh, flip=True))
+        return self._heads_cache[1], self._heads_cache[2]
+
+    def _head_forward(self, x, m2, size, keep=False):
+        train = self.training
+        N, h8, w8 = x.N, x.H, x.W
+        h2, w2 = m2.H, m2.W
+        dev = x.buf.device
+        asp = self.aspp
+        if train and N == 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size "
+                             f"torch.Size([1, 256, 1, 1])")  # what F.batch_norm raises for aspp.img_conv.1
+        raw = Act.empty(N, h8, w8, 1280, dev)                      # concat [img, 1x1, d12, d24, d36], pre-BN
+        scale = torch.empty(1280, device=dev)
+        shift = torch.empty(1280, device=dev)
+        states = []
+        # image-pooling branch (deepv3.py:84-88): GAP -> 1x1 -> BN over the N samples -> broadcast
+        pooled = K.gap(x)
+        pooled_act = Act(pooled.view(N, 1, 1, 4096))
+        u0 = K.conv2d(pooled_act, K.packed(asp.img_conv[0].weight))
+        u0_rows = u0.buf.view(N, 256)
+        st = K.bn_fold(asp.img_conv[1], train=train, x_rows=u0_rows)
+        K.broadcast_rows(u0_rows, raw.slice(0, 256))
+        states.append(st)
+        for i, feat in enumerate(asp.features):
+            rate = 1 if i == 0 else _ASPP_RATES[i - 1]
+            sl = raw.slice(256 * (i + 1), 256)
+            K.conv2d(x, K.packed(feat[0].weight), dil=rate, pad=0 if i == 0 else rate, out=sl)
+            states.append(K.bn_fold(feat[1], sl, train))
+        for i, s in enumerate(states):
+            scale[256 * i:256 * (i + 1)].copy_(s.scale)
+            shift[256 * i:256 * (i + 1)].copy_(s.shift)
+        up_small = K.conv2d(raw, K.packed(self.bot_aspp.weight), in_affine=(scale, shift), in_relu=True)
+        dec0 = Act.empty(N, h2, w2, 304, dev)                      # concat [bot_fine(m2), up(bot_aspp)]
+        K.upsample_ac(up_small, h2, w2, out=dec0.slice(48, 256))
+        K.conv2d(m2, K.packed(self.bot_fine.weight), out=dec0.slice(0, 48))
+        f0 = K.conv2d(dec0, K.packed(self.final[0].weight), pad=1)
+        st_f0 = K.bn_fold(self.final[1], f0, train)
+        f1 = K.conv2d(f0, K.packed(self.final[3].weight), pad=1, in_affine=(st_f0.scale, st_f0.shift), in_relu=True)
+        st_f1 = K.bn_fold(self.final[4], f1, train)
+        wh, _ = self._heads_weight()
+        dec12 = K.conv2d(f1, wh, in_affine=(st_f1.scale, st_f1.shift), in_relu=True)
+        score, logit, _ = K.ood_score(dec12.slice(20, 19), dec12.slice(0, 19), size[0], size[1])
+        saved = None
+        if keep:
+            saved = dict(x=x, m2=m2, raw=raw, scale=scale, shift=shift, states=states, pooled_act=pooled_act,
+                         u0_rows=u0_rows, dec0=dec0, f0=f0, st_f0=st_f0, f1=f1, st_f1=st_f1, dec12=dec12, size=size)
+        return score, logit, saved
+
+    def _head_backward(self, s, dscore, dlogit, needs):
+        names, params = self._head_params()
+        need = {n: bool(f) for n, f in zip(names, needs)}
+        grads = {}
+        x, m2, raw, dec0, f0, f1, dec12 = s["x"], s["m2"], s["raw"], s["dec0"], s["f0"], s["f1"], s["dec12"]
+        N, h8, w8, h2, w2 = x.N, x.H, x.W, m2.H, m2.W
+        OH, OW = s["size"]
+        dev = x.buf.device
+        dscore = dscore.contiguous() if dscore is not None else None
+        dlogit = dlogit.contiguous() if dlogit is not None else None
+        ddec12 = Act.zeros(N, h2, w2, 48, dev)
+        K.ood_score_bwd(dec12.slice(20, 19), dscore, dlogit, ddec12.slice(20, 19) if dscore is not None else None,
+                        ddec12.slice(0, 19) if dlogit is not None else None, OH, OW)
+        aff_f1 = (s["st_f1"].scale, s["st_f1"].shift)
+        if need["ood_head.weight"]:
+            grads["ood_head.weight"] = K.conv2d_wgrad(f1, ddec12.slice(20, 19), 19, 256, 1, 1, in_affine=aff_f1,
+                                                      in_relu=True)
+        if need["final.6.weight"]:
+            grads["final.6.weight"] = K.conv2d_wgrad(f1, ddec12.slice(0, 19), 19, 256, 1, 1, in_affine=aff_f1,
+                                                     in_relu=True)
+        upstream = [n for n in names if need[n] and not n.startswith(("ood_head", "final.6"))]
+        if not upstream:
+            return [grads.get(n) for n in names]
+        _, wh_flip = self._heads_weight()
+        d_act1 = K.conv2d(ddec12, wh_flip)
+        df1, dg, db = K.bn_relu_backward(d_act1, f1, s["st_f1"], want_param_grads=need["final.4.weight"] or need["final.4.bias"])
+        grads["final.4.weight"], grads["final.4.bias"] = dg, db
+        aff_f0 = (s["st_f0"].scale, s["st_f0"].shift)
+        if need["final.3.weight"]:
+            grads["final.3.weight"] = K.conv2d_wgrad(f0, df1, 256, 256, 3, 3, pad=1, in_affine=aff_f0, in_relu=True)
+        d_act0 = K.conv2d(df1, K.packed(self.final[3].weight, flip=True), pad=1)
+        df0, dg, db = K.bn_relu_backward(d_act0, f0, s["st_f0"], want_param_grads=need["final.1.weight"] or need["final.1.bias"])
+        grads["final.1.weight"], grads["final.1.bias"] = dg, db
+        if need["final.0.weight"]:
+            grads["final.0.weight"] = K.conv2d_wgrad(dec0, df0, 256, 304, 3, 3, pad=1)
+        if not any(need[n] for n in names if n.startswith(("aspp", "bot_"))):
+            return [grads.get(n) if need[n] else None for n in names]
+        ddec0 = K.conv2d(df0, K.packed(self.final[0].weight, flip=True), pad=1)
+        if need["bot_fine.weight"]:
+            grads["bot_fine.weight"] = K.conv2d_wgrad(m2, ddec0.slice(0, 48), 48, 128, 1, 1)
+        if any(need[n] for n in names if n.startswith(("aspp", "bot_aspp"))):
+            d_up = K.upsample_ac_bwd(ddec0.slice(48, 256), h8, w8)
+            aff = (s["scale"], s["shift"])
+            if need["bot_aspp.weight"]:
+                grads["bot_aspp.weight"] = K.conv2d_wgrad(raw, d_up, 256, 1280, 1, 1, in_affine=aff, in_relu=True)
+            if any(need[n] for n in names if n.startswith("aspp")):
+                d_act = K.conv2d(d_up, K.packed(self.bot_aspp.weight, flip=True))
+                states = s["states"]
+                # image-pooling branch: the broadcast's transpose is a column sum
+                dv = K.colsum(d_act.slice(0, 256))
+                want = need["aspp.img_conv.1.weight"] or need["aspp.img_conv.1.bias"]
+                du0, dg, db = K.bn_relu_backward(None, None, states[0], want_param_grads=want, x_rows=s["u0_rows"], dy_rows=dv)
+                grads["aspp.img_conv.1.weight"], grads["aspp.img_conv.1.bias"] = dg, db
+                if need["aspp.img_conv.0.weight"]:
+                    grads["aspp.img_conv.0.weight"] = K.conv2d_wgrad(s["pooled_act"], Act(du0.view(N, 1, 1, 256)), 256,
+                                                                     4096, 1, 1)
+                for i in range(4):
+                    p = f"aspp.features.{i}"
+                    sl = raw.slice(256 * (i + 1), 256)
+                    want = need[p + ".1.weight"] or need[p + ".1.bias"]
+                    draw, dg, db = K.bn_relu_backward(d_act.slice(256 * (i + 1), 256), sl, states[i + 1], want_param_grads=want)
+                    grads[p + ".1.weight"], grads[p + ".1.bias"] = dg, db
+                    if need[p + ".0.weight"]:
+                        rate = 1 if i == 0 else _ASPP_RATES[i - 1]
+                        r = 1 if i == 0 else 3
+                        grads[p + ".0.weight"] = K.conv2d_wgrad(x, draw, 256, 4096, r, r, dil=rate,
+                                                                pad=0 if i == 0 else rate)
+        return [grads.get(n) if need[n] else None for n in names]
+
+    # ---- forward -------------------------------------------------------------------------------------
+    def forward(self, inp):
+        if not inp.is_cuda:
+            raise RuntimeError("DeepWV3Plus (multishiftseg_amd) runs on an MI355X only; there is no CPU path")
+        inp = inp.float()
+        size = (inp.shape[2], inp.shape[3])
+        names, params = self._head_params()
+        want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if torch.is_grad_enabled():
+            self._check_trunk_frozen()
+        with torch.no_grad():
+            x, m2 = self._run_trunk(inp)
+        if want_grad:
+            score, logit = _HeadFn.apply(self, x, m2, size, *params)
+        else:
+            with torch.no_grad():
+                score, logit, _ = self._head_forward(x, m2, size)
+        return score, logit

@@ -1,0 +1,306 @@
+"""Thin tensor-level wrappers over the C ABI (include/mss_hip.h).
+
+torch is used for device memory and streams only; every computation below is a HIP kernel in
+libmss_hip.so. An activation is an `Act`: a channel slice [c0, c0+C) of a contiguous NHWC buffer,
+so concats are written in place and never copied.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import MssConvArgs, call, ptr
+
+
+class Act:
+    """Channel slice of an NHWC fp32 buffer [N,H,W,ld]."""
+    __slots__ = ("buf", "N", "H", "W", "C", "ld", "c0")
+
+    def __init__(self, buf, C=None, c0=0):
+        assert buf.dim() == 4 and buf.is_contiguous() and buf.dtype == torch.float32
+        self.buf = buf
+        self.N, self.H, self.W, self.ld = buf.shape
+        self.C = self.ld - c0 if C is None else C
+        self.c0 = c0
+        assert self.c0 % 4 == 0 and self.ld % 4 == 0 and self.c0 + self.C <= self.ld
+
+    @staticmethod
+    def empty(N, H, W, C, device, ld=None):
+        return Act(torch.empty((N, H, W, ld or C), device=device, dtype=torch.float32), C)
+
+    @staticmethod
+    def zeros(N, H, W, C, device, ld=None):
+        return Act(torch.zeros((N, H, W, ld or C), device=device, dtype=torch.float32), C)
+
+    def slice(self, c0, C):
+        return Act(self.buf, C, self.c0 + c0)
+
+    @property
+    def ptr(self):
+        return ctypes.c_void_p(self.buf.data_ptr() + 4 * self.c0)
+
+    @property
+    def M(self):
+        return self.N * self.H * self.W
+
+    def nchw(self):
+        """Materialise as an NCHW torch tensor (tests / debugging only)."""
+        return self.buf[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def from_nchw(t, ld=None):
+        n, c, h, w = t.shape
+        a = Act.zeros(n, h, w, c, t.device, ld)
+        a.buf[..., :c] = t.permute(0, 2, 3, 1)
+        return a
+
+
+class PackedWeight:
+    """[R*S][Kpad][Cp] layout consumed by the MFMA kernels."""
+    __slots__ = ("t", "K", "C", "R", "S", "Kpad", "Cp")
+
+    def __init__(self, t, K, C, R, S, Kpad, Cp):
+        self.t, self.K, self.C, self.R, self.S, self.Kpad, self.Cp = t, K, C, R, S, Kpad, Cp
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def pack_weight(w, flip=False, min_c=16):
+    """nn.Conv2d.weight [K,C,R,S] -> PackedWeight. flip=True packs the data-gradient filter."""
+    K, C, R, S = w.shape
+    w = w.detach().contiguous()
+    if not flip:
+        k_out, c_in = K, C
+    else:
+        k_out, c_in = C, K
+    Kpad = _lib.value("mss_conv2d_kpad", k_out)
+    Cp = _round_up(max(c_in, min_c), 16)
+    t = torch.empty((R * S, Kpad, Cp), device=w.device, dtype=torch.float32)
+    call("mss_conv2d_pack_weights_f32", ptr(w), ptr(t), K, C, R, S, Kpad, Cp, 1 if flip else 0)
+    return PackedWeight(t, k_out, c_in, R, S, Kpad, Cp)
+
+
+_pack_cache = {}
+
+
+def packed(param, flip=False):
+    """Cached pack of an nn.Parameter; re-packed when the parameter is modified in place
+    (optimizer step, load_state_dict) -- tracked through tensor._version."""
+    key = (id(param), flip)
+    ent = _pack_cache.get(key)
+    if ent is not None and ent[0] == param._version and ent[1] == param.data_ptr():
+        return ent[2]
+    pw = pack_weight(param, flip)
+    _pack_cache[key] = (param._version, param.data_ptr(), pw)
+    return pw
+
+
+def conv_out_size(h, r, stride, dil, pad):
+    return (h + 2 * pad - dil * (r - 1) - 1) // stride + 1
+
+
+def _conv_args(x, pw, y, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res):
+    a = MssConvArgs()
+    a.x, a.w, a.y = x.ptr, ptr(pw.t), (y.ptr if y is not None else None)
+    if in_affine is not None:
+        sc, sh = in_affine
+        a.in_scale, a.in_shift = ptr(sc), ptr(sh)
+        a.in_ss_stride = sc.shape[1] if sc.dim() == 2 else 0
+        assert sc.shape[-1] >= pw.Cp and sc.is_contiguous() and sh.is_contiguous()
+    if out_affine is not None:
+        a.out_scale, a.out_shift = ptr(out_affine[0]), ptr(out_affine[1])
+    if res is not None:
+        a.res, a.ldres = res.ptr, res.ld
+    a.N, a.H, a.W, a.C, a.ldx = x.N, x.H, x.W, pw.Cp, x.ld
+    a.R, a.S, a.stride, a.dil, a.pad = pw.R, pw.S, stride, dil, pad
+    a.K, a.Kpad = pw.K, pw.Kpad
+    a.in_relu, a.out_relu = int(in_relu), int(out_relu)
+    return a
+
+
+def conv2d(x, pw, stride=1, dil=1, pad=0, in_affine=None, in_relu=False, out_affine=None, out_relu=False, res=None,
+           out=None):
+    """y = epilogue(conv(prologue(x))). x: Act with C == pw.Cp channels visible."""
+    assert x.C == pw.Cp or (x.C >= pw.C and x.C <= pw.Cp and x.c0 + pw.Cp <= x.ld), (x.C, pw.C, pw.Cp)
+    OH = conv_out_size(x.H, pw.R, stride, dil, pad)
+    OW = conv_out_size(x.W, pw.S, stride, dil, pad)
+    if out is None:
+        out = Act.empty(x.N, OH, OW, pw.K, x.buf.device, ld=_round_up(pw.K, 4))
+    assert (out.N, out.H, out.W) == (x.N, OH, OW) and out.C >= pw.K
+    a = _conv_args(x, pw, out, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res)
+    a.OH, a.OW, a.ldy = OH, OW, out.ld
+    call("mss_conv2d_forward_f32", ctypes.byref(a))
+    return out
+
+
+def conv2d_wgrad(x, dy, K, C, R, S, stride=1, dil=1, pad=0, in_affine=None, in_relu=False):
+    """Weight gradient [K,C,R,S] of y = conv(prologue(x)); dy: Act with K channels."""
+    Kpad = _round_up(K, 4)
+    Cp = _round_up(C, 4)
+    dwp = torch.zeros((R * S, Kpad, Cp), device=x.buf.device, dtype=torch.float32)
+    a = MssConvArgs()
+    a.x = x.ptr
+    if in_affine is not None:
+        sc, sh = in_affine
+        a.in_scale, a.in_shift = ptr(sc), ptr(sh)
+        a.in_ss_stride = sc.shape[1] if sc.dim() == 2 else 0
+    a.N, a.H, a.W, a.C, a.ldx = x.N, x.H, x.W, C, x.ld
+    a.OH, a.OW, a.K, a.Kpad = dy.H, dy.W, K, Kpad
+    a.R, a.S, a.stride, a.dil, a.pad = R, S, stride, dil, pad
+    a.in_relu = int(in_relu)
+    call("mss_conv2d_wgrad_f32", ctypes.byref(a), dy.ptr, dy.ld, ptr(dwp), Cp)
+    grad = torch.empty((K, C, R, S), device=x.buf.device, dtype=torch.float32)
+    call("mss_conv2d_unpack_wgrad_f32", ptr(dwp), ptr(grad), K, C, R, S, Kpad, Cp, 0)
+    return grad
+
+
+def image_to_nhwc(img, Cp=16):
+    n, c, h, w = img.shape
+    img = img.contiguous()
+    out = Act.empty(n, h, w, Cp, img.device)
+    call("mss_nchw_to_nhwc_pad_f32", ptr(img), out.ptr, n, c, h, w, Cp)
+    return out
+
+
+class BNState:
+    """Folded BatchNorm: y = x*scale + shift (+ what the backward needs in train mode)."""
+    __slots__ = ("scale", "shift", "save_mean", "save_invstd", "M", "train")
+
+
+def bn_fold(bn, x=None, train=False, M=None, x_rows=None):
+    """Fold nn.BatchNorm2d `bn` into (scale, shift). train=True computes batch statistics of the
+    NHWC activation x (Act) and updates the running buffers exactly like F.batch_norm
+    (momentum 0.1, unbiased running variance; mynn.py:8-12)."""
+    C = bn.num_features
+    dev = bn.weight.device
+    st = BNState()
+    st.train = train
+    st.scale = torch.empty(C, device=dev, dtype=torch.float32)
+    st.shift = torch.empty(C, device=dev, dtype=torch.float32)
+    st.save_mean = st.save_invstd = None
+    if not train:
+        call("mss_bn_fold_eval_f32", ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+             float(bn.eps), C, ptr(st.scale), ptr(st.shift))
+        st.M = None
+        return st
+    accum = torch.zeros(2 * C, device=dev, dtype=torch.float64)
+    if x_rows is not None:          # plain [M, C] matrix (image-pooling branch)
+        M = x_rows.shape[0]
+        call("mss_bn_stats_nhwc_f32", ptr(x_rows), M, C, x_rows.shape[1], ptr(accum))
+    else:
+        M = x.M
+        call("mss_bn_stats_nhwc_f32", x.ptr, M, C, x.ld, ptr(accum))
+    st.M = M
+    st.save_mean = torch.empty(C, device=dev, dtype=torch.float32)
+    st.save_invstd = torch.empty(C, device=dev, dtype=torch.float32)
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    track = bn.track_running_stats and bn.running_mean is not None
+    call("mss_bn_finalize_train_f32", ptr(accum), M, C, ptr(bn.weight), ptr(bn.bias), float(bn.eps), mom,
+         ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None, ptr(st.scale),
+         ptr(st.shift), ptr(st.save_mean), ptr(st.save_invstd))
+    if track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return st
+
+
+def bn_relu_backward(dy, x, st, relu=True, want_param_grads=False, x_rows=None, dy_rows=None):
+    """Backward of y = relu(x*scale+shift) with (scale, shift) = folded BN `st`.
+    Returns (dx Act or [M,C] tensor, dgamma, dbeta)."""
+    if x_rows is not None:
+        M, C = x_rows.shape
+        xp, ldx, dyp, lddy = ptr(x_rows), x_rows.shape[1], ptr(dy_rows), dy_rows.shape[1]
+        dx = torch.empty_like(x_rows)
+        dxp, lddx = ptr(dx), C
+        dev = x_rows.device
+    else:
+        M, C = x.M, x.C
+        xp, ldx, dyp, lddy = x.ptr, x.ld, dy.ptr, dy.ld
+        dx = Act.empty(x.N, x.H, x.W, C, x.buf.device)
+        dxp, lddx = dx.ptr, dx.ld
+        dev = x.buf.device
+    dgamma = dbeta = None
+    accum = None
+    if st.train:
+        accum = torch.zeros(2 * C, device=dev, dtype=torch.float64)
+        call("mss_bn_relu_bwd_reduce_f32", dyp, lddy, xp, ldx, M, C, ptr(st.scale), ptr(st.shift), ptr(st.save_mean),
+             ptr(st.save_invstd), int(relu), ptr(accum))
+        if want_param_grads:
+            dgamma = torch.zeros(C, device=dev, dtype=torch.float32)
+            dbeta = torch.zeros(C, device=dev, dtype=torch.float32)
+    elif want_param_grads:
+        raise NotImplementedError("BatchNorm affine gradients in eval mode")
+    call("mss_bn_relu_bwd_apply_f32", dyp, lddy, xp, ldx, dxp, lddx, M, C, None, ptr(st.scale), ptr(st.shift),
+         ptr(st.save_mean), ptr(st.save_invstd), int(relu), ptr(accum), ptr(dgamma), ptr(dbeta))
+    return dx, dgamma, dbeta
+
+
+def maxpool3s2(x):
+    OH, OW = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
+    y = Act.empty(x.N, OH, OW, x.C, x.buf.device)
+    call("mss_maxpool3s2_nhwc_f32", x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, OH, OW)
+    return y
+
+
+def gap(x):
+    y = torch.empty((x.N, x.C), device=x.buf.device, dtype=torch.float32)
+    call("mss_gap_nhwc_f32", x.ptr, x.ld, ptr(y), x.N, x.H * x.W, x.C)
+    return y
+
+
+def colsum(dy):
+    y = torch.empty((dy.N, dy.C), device=dy.buf.device, dtype=torch.float32)
+    call("mss_colsum_nhwc_f32", dy.ptr, dy.ld, ptr(y), dy.N, dy.H * dy.W, dy.C)
+    return y
+
+
+def broadcast_rows(v, out, scale=None, shift=None, relu=False):
+    call("mss_broadcast_rows_nhwc_f32", ptr(v), out.ptr, out.ld, out.N, out.H * out.W, out.C, ptr(scale), ptr(shift),
+         int(relu))
+    return out
+
+
+def upsample_ac(x, OH, OW, out=None):
+    if out is None:
+        out = Act.empty(x.N, OH, OW, x.C, x.buf.device)
+    call("mss_upsample_ac_nhwc_f32", x.ptr, x.ld, out.ptr, out.ld, x.N, x.H, x.W, OH, OW, x.C)
+    return out
+
+
+def upsample_ac_bwd(dy, IH, IW):
+    dx = Act.empty(dy.N, IH, IW, dy.C, dy.buf.device)
+    call("mss_upsample_ac_nhwc_bwd_f32", dy.ptr, dy.ld, dx.ptr, dx.ld, dy.N, IH, IW, dy.H, dy.W, dy.C)
+    return dx
+
+
+def ood_score(dec2, dec1, OH, OW, want_score=True, want_logit=True, want_label=False):
+    """The OOD-score tail (deepv3.py:279-283). dec2/dec1: Acts with 19 channels at half res."""
+    ref = dec2 if dec2 is not None else dec1
+    dev = ref.buf.device
+    N = ref.N
+    score = torch.empty((N, OH, OW), device=dev, dtype=torch.float32) if want_score else None
+    logit = torch.empty((N, 19, OH, OW), device=dev, dtype=torch.float32) if want_logit else None
+    label = torch.empty((N, OH, OW), device=dev, dtype=torch.uint8) if want_label else None
+    call("mss_ood_score_f32", dec2.ptr if dec2 is not None else None, dec2.ld if dec2 is not None else 0,
+         dec1.ptr if dec1 is not None else None, dec1.ld if dec1 is not None else 0, N, ref.H, ref.W, 19, OH, OW,
+         ptr(score), ptr(logit), ptr(label))
+    return score, logit, label
+
+
+def ood_score_bwd(dec2, dscore, dlogit, ddec2, ddec1, OH, OW):
+    call("mss_ood_score_bwd_f32", dec2.ptr, dec2.ld, ptr(dscore), ptr(dlogit), dec2.N, dec2.H, dec2.W, 19, OH, OW,
+         ddec2.ptr if ddec2 is not None else None, ddec2.ld if ddec2 is not None else 0,
+         ddec1.ptr if ddec1 is not None else None, ddec1.ld if ddec1 is not None else 0)
+
+
+def m2f_score(class_logits, mask_logits, size):
+    """train_m2f.py:387-407 -> [B,H,W]."""
+    B, Q, C1 = class_logits.shape
+    _, _, Hm, Wm = mask_logits.shape
+    H, W = size
+    cls = class_logits.contiguous().float()
+    mask = mask_logits.contiguous().float()
+    out = torch.empty((B, H, W), device=cls.device, dtype=torch.float32)
+    call("mss_m2f_score_f32", ptr(cls), ptr(mask), B, Q, C1 - 1, H, W, Hm, Wm, ptr(out))
+    return out

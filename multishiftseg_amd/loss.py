@@ -1,0 +1,125 @@
+"""RelContrastiveLoss on MI355X -- host side of the fused loss kernels (csrc/loss.hip).
+
+Mirrors lib/loss.py:7-156: same constructor (``param_dict`` keys), same
+``forward(logits, anomaly_score, targets) -> 0-dim tensor``, same in-place mutation of ``targets``
+(loss.py:110-111,115), NaN when a batch has no OOD pixel (mean of an empty tensor). The value and
+both gradients come out of one sequence of streaming kernels; autograd only sees one node.
+
+Pair sampling (loss.py:129-131 draws three ``torch.randperm`` on the CPU generator):
+  * ``pairing="reference"`` (default for parity): draws the same three CPU permutations, in the same
+    order, from torch's default generator -> with the same ``torch.manual_seed`` the loss equals the
+    reference's to fp32 rounding. Costs one device->host read of the three set sizes.
+  * ``pairing="device"``: keyed Feistel bijections evaluated inside the kernel; no host round trip
+    and no materialised permutation (same distribution, different sample). Used by bench.py.
+  * explicit ``perms=(orig, aug, ood)`` int64 tensors: parity tests inject the recorded ones.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import MssRclArgs, call, ptr
+
+
+class _RclFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, score, targets, mod, perms):
+        need_dl = logits.requires_grad
+        need_ds = score.requires_grad
+        out, dlogit, dscore = mod._run(logits.detach(), score.detach(), targets, need_dl, need_ds, perms)
+        ctx.dlogit, ctx.dscore = dlogit, dscore
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        dl = ctx.dlogit * g if ctx.dlogit is not None else None
+        ds = ctx.dscore * g if ctx.dscore is not None else None
+        return dl, ds, None, None, None
+
+
+class RelContrastiveLoss(nn.Module):
+    def __init__(self, param_dict, pairing="reference", seed=0):
+        super().__init__()
+        self.inoutaug_contras_margins_tri = param_dict.get("inoutaug_contras_margins_tri", None)
+        self.sample_ratio = param_dict.get("sample_ratio", 1)
+        self.conduct_pixel_selection = param_dict.get("conduct_pixel_selection", False)
+        self.selection_ratio = param_dict.get("selection_ratio", 1.0)
+        self.ce_weights = param_dict.get("ce_weights", [1, 1])
+        self.contras_weight = param_dict.get("contras_weight", 1.0)
+        self.in_id = 99
+        self.void_id = 255
+        if pairing not in ("reference", "device"):
+            raise ValueError(pairing)
+        self.pairing = pairing
+        self._step = int(seed)
+        self.last_terms = None   # device tensor [8]: loss, ce_orig, ce_aug, c_orig, c_aug, c_in
+
+    def forward(self, logits, anomaly_score, targets, perms=None):
+        if not logits.is_cuda:
+            raise RuntimeError("RelContrastiveLoss (multishiftseg_amd) runs on an MI355X only; there is no CPU path")
+        if targets.dtype != torch.int64 or not targets.is_contiguous():
+            raise RuntimeError("targets must be a contiguous int64 tensor (it is mutated in place, loss.py:110-111)")
+        return _RclFn.apply(logits, anomaly_score, targets, self, perms)
+
+    def _run(self, logits, score, targets, need_dl, need_ds, perms):
+        logits = logits.contiguous().float()
+        score = score.contiguous().float()
+        B, C, H, W = logits.shape
+        if B < 2:
+            raise RuntimeError("RelContrastiveLoss needs an (original, augmented) pair: batch >= 2")
+        dev = logits.device
+        h = B // 2
+        total, half = B * H * W, h * H * W
+        a = MssRclArgs()
+        a.logit, a.score, a.target = ptr(logits), ptr(score), ptr(targets)
+        a.B, a.C, a.H, a.W = B, C, H, W
+        a.w_ce_orig, a.w_ce_aug, a.w_contras = float(self.ce_weights[0]), float(self.ce_weights[1]), float(self.contras_weight)
+        m = self.inoutaug_contras_margins_tri
+        a.m0, a.m1, a.m2 = float(m[0]), float(m[1]), float(m[2])
+        select = bool(self.conduct_pixel_selection and 0.0 < self.selection_ratio < 1.0)
+        a.select, a.selection_ratio = int(select), float(self.selection_ratio)
+        ra = ctypes.byref(a)
+
+        lse = torch.empty(total, device=dev, dtype=torch.float32)
+        ce_aug = torch.empty(half, device=dev, dtype=torch.float32)
+        kind = torch.empty(total, device=dev, dtype=torch.uint8)
+        counters = torch.empty(16, device=dev, dtype=torch.float64)
+        sel = torch.zeros(8, device=dev, dtype=torch.int32)
+        hist = torch.empty(256, device=dev, dtype=torch.int32)
+        call("mss_rcl_pass1_f32", ra, ptr(lse), ptr(ce_aug), ptr(kind), ptr(counters))
+        if select:
+            call("mss_rcl_select_f32", ptr(ce_aug), half, ptr(counters), float(self.selection_ratio), ptr(hist), ptr(sel))
+        dlogit = torch.empty_like(logits) if need_dl else None
+        if select or need_dl:
+            call("mss_rcl_pass2_f32", ra, ptr(lse), ptr(ce_aug), ptr(kind), ptr(sel), ptr(counters), 1.0, ptr(dlogit))
+        # contrastive part
+        nb = _lib.value("mss_rcl_num_compact_blocks", B, H, W)
+        idx = torch.empty((3, total), device=dev, dtype=torch.int32)
+        block_counts = torch.empty(3 * nb, device=dev, dtype=torch.int32)
+        n_out = torch.empty(4, device=dev, dtype=torch.int32)
+        call("mss_rcl_compact_f32", ptr(kind), B, H, W, ptr(idx[0]), ptr(idx[1]), ptr(idx[2]), ptr(block_counts), ptr(n_out))
+        dscore = torch.empty_like(score) if need_ds else None
+        wc = float(self.contras_weight)
+        if need_ds:
+            call("mss_rcl_cin_bwd_f32", ra, ptr(kind), ptr(counters), wc, ptr(dscore))
+        max_samples = int(total * self.sample_ratio)
+        if perms is None and self.pairing == "device":
+            self._step += 1
+            s0 = (self._step * 0x9E3779B1) & 0xFFFFFFFF
+            for slot, (set_a, margin) in enumerate(((0, a.m0), (1, a.m1))):
+                call("mss_rcl_pairs_device_f32", ptr(score), ptr(idx[set_a]), ptr(idx[2]), ptr(n_out), set_a, max_samples,
+                     (s0 + 1 + slot) & 0xFFFFFFFF, (s0 + 7) & 0xFFFFFFFF, float(margin), ptr(counters), slot, wc, ptr(dscore))
+        else:
+            n_orig, n_aug, n_ood = (int(v) for v in n_out[:3].tolist())      # host sync, as the reference's .sum()/int()
+            n = min(max_samples, n_ood, n_orig, n_aug)                         # loss.py:149-156
+            if perms is None:
+                perms = [torch.randperm(k) for k in (n_orig, n_aug, n_ood)]    # CPU default generator, loss.py:129-131
+            p_orig, p_aug, p_ood = (p[:n].to(dev, torch.int64).contiguous() for p in perms)
+            for slot, (set_a, pa, margin) in enumerate(((0, p_orig, a.m0), (1, p_aug, a.m1))):
+                call("mss_rcl_pairs_f32", ptr(score), ptr(idx[set_a]), ptr(pa), ptr(idx[2]), ptr(p_ood), n, float(margin),
+                     ptr(counters), slot, wc, ptr(dscore))
+        out = torch.empty(8, device=dev, dtype=torch.float32)
+        call("mss_rcl_finalize_f32", ra, ptr(counters), ptr(sel), ptr(out))
+        self.last_terms = out
+        return out, dlogit, dscore

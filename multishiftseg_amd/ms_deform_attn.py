@@ -1,0 +1,103 @@
+"""Host-side mirror of the MSDeformAttn operator stack
+(lib/network/mask2former/modeling/pixel_decoder/ops/functions/ms_deform_attn_func.py:32-49 and
+ops/modules/ms_deform_attn.py:35-125): same class names, arguments and parameter names, on top of
+the HIP op. Unlike the reference module there is no ``try/except`` around the op: a failing kernel
+raises instead of silently falling back to a slow PyTorch path (ms_deform_attn.py:116-121)."""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.init import constant_, xavier_uniform_
+
+from . import MultiScaleDeformableAttention as MSDA
+
+
+class MSDeformAttnFunction(Function):
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step):
+        ctx.im2col_step = im2col_step
+        output = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                                             sampling_locations, attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                              attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, starts, loc, attn = ctx.saved_tensors
+        grad_value, grad_loc, grad_attn = MSDA.ms_deform_attn_backward(value, shapes, starts, loc, attn,
+                                                                       grad_output.contiguous(), ctx.im2col_step)
+        return grad_value, None, None, grad_loc, grad_attn, None
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or n < 0:
+        raise ValueError(f"invalid input for _is_power_of_2: {n} (type: {type(n)})")
+    return (n & (n - 1) == 0) and n != 0
+
+
+class MSDeformAttn(nn.Module):
+    """Multi-scale deformable attention module (ops/modules/ms_deform_attn.py:35-125)."""
+
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError(f"d_model must be divisible by n_heads, but got {d_model} and {n_heads}")
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("d_model // n_heads is not a power of 2: the float4 fast path of the HIP kernel needs "
+                          "a head dimension of 16, 32 or 64")
+        self.im2col_step = 128
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        # ms_deform_attn.py:66-80: zero offsets weight, a ring of directions scaled by the point index as bias
+        constant_(self.sampling_offsets.weight.data, 0.0)
+        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2)
+        grid = grid.repeat(1, self.n_levels, self.n_points, 1)
+        for i in range(self.n_points):
+            grid[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid.view(-1))
+        constant_(self.attention_weights.weight.data, 0.0)
+        constant_(self.attention_weights.bias.data, 0.0)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.0)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.0)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        weights = F.softmax(weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
+        if reference_points.shape[-1] == 2:
+            normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            locations = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            locations = reference_points[:, :, None, :, None, :2] \
+                + offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
+        output = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
+                                            locations.contiguous(), weights.contiguous(), self.im2col_step)
+        return self.output_proj(output)

@@ -1,0 +1,85 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads, and exports every
+symbol include/mss_hip.h declares; the host mirrors keep the reference's names. No compute."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from multishiftseg_amd import _lib
+    return _lib
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "mss_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|long long)\s+(mss_\w+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = header_functions()
+    assert len(names) >= 30
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (mss_\w+)", out))
+    missing = [n for n in names if n not in exported]
+    assert not missing, f"declared in mss_hip.h but not exported: {missing}"
+    unbound = [n for n in names if n not in lib.SIGNATURES]
+    assert not unbound, f"declared in mss_hip.h but not bound in _lib.py: {unbound}"
+    extra = [n for n in exported if n not in names]
+    assert not extra, f"exported but not declared in mss_hip.h: {extra}"
+    handle = lib.load()
+    assert handle.mss_abi_version() == 1
+    assert lib.value("mss_conv2d_kpad", 19) == 64 and lib.value("mss_conv2d_kpad", 304) == 384
+
+
+def test_struct_layout_matches_header(lib):
+    """sizeof(MssConvArgs)/sizeof(MssRclArgs) as the C compiler sees them."""
+    import ctypes
+    code = '#include <stdio.h>\n#include "mss_hip.h"\nint main(){printf("%zu %zu\\n", sizeof(MssConvArgs), sizeof(MssRclArgs));return 0;}'
+    exe = "/tmp/mss_sizeof"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=code.encode(), check=True)
+    a, b = (int(v) for v in subprocess.check_output([exe], text=True).split())
+    assert ctypes.sizeof(lib.MssConvArgs) == a and ctypes.sizeof(lib.MssRclArgs) == b
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    from multishiftseg_amd.loss import RelContrastiveLoss
+    from multishiftseg_amd import MultiScaleDeformableAttention as MSDA
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    crit = RelContrastiveLoss({"inoutaug_contras_margins_tri": [10, 5, 5]})
+    with pytest.raises(RuntimeError):
+        crit(torch.zeros(2, 19, 4, 4), torch.zeros(2, 4, 4), torch.zeros(2, 4, 4, dtype=torch.int64))
+    v = torch.zeros(1, 30, 2, 2)
+    with pytest.raises(RuntimeError, match="CPU"):
+        MSDA.ms_deform_attn_forward(v, torch.tensor([[6, 4], [3, 2]]), torch.tensor([0, 24]), torch.zeros(1, 2, 2, 2, 2, 2),
+                                    torch.zeros(1, 2, 2, 2, 2), 2)
+
+
+def test_no_product_import_of_oracle():
+    """The oracle is test infrastructure: nothing under multishiftseg_amd/ may import it."""
+    pkg = os.path.join(ROOT, "multishiftseg_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+            assert "/root/reference" not in src, fn
+
+
+def test_deeplab_module_names(deeplab_params):
+    import torch
+    from multishiftseg_amd.deepv3 import DeepWV3Plus
+    with torch.device("meta"):
+        m = DeepWV3Plus(19)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(deeplab_params.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(deeplab_params[k].shape), k

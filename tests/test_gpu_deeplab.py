@@ -1,0 +1,112 @@
+"""End-to-end parity of DeepWV3Plus on the GPU against outputs of the reference model itself
+(tests/golden/deepwv3plus_*.npz): logits and OOD scores within 1e-3 (fp32), argmax label map
+bit-exact wherever the reference's own top-2 margin exceeds that tolerance (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model(deeplab_params):
+    from multishiftseg_amd.deepv3 import DeepWV3Plus
+    m = DeepWV3Plus(19)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in deeplab_params.items()}, strict=True)
+    return m.cuda()
+
+
+@pytest.mark.parametrize("tag", ["eval_1x64x128", "eval_2x96x96"])
+def test_eval_forward_golden(model, tag):
+    from multishiftseg_amd import synth
+    g = golden("deepwv3plus_" + tag)
+    n, h, w = (int(v) for v in g["shape"])
+    img = torch.from_numpy(synth.synth_image(int(g["image_seed"]), n, h, w)).cuda()
+    model.eval()
+    with torch.no_grad():
+        score, logit = model(img)
+    logit, score = logit.cpu().numpy(), score.cpu().numpy()
+    assert np.abs(logit - g["logit"]).max() < 1e-3
+    assert np.abs(score - g["score"]).max() < 1e-3
+    clear = g["margin"] > 1e-3
+    np.testing.assert_array_equal(logit.argmax(1)[clear], g["label"][clear])
+
+
+def test_state_dict_contract(model, deeplab_params):
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(deeplab_params.keys())          # 269 entries, reference order
+    assert len(sd) == 269
+    names = [n for n, _ in model.named_parameters()]
+    stage2 = [n for n in names if any(s in n for s in ["aspp", "bot_fine", "bot_aspp", "ood_head"])]
+    assert sum(dict(model.named_parameters())[n].numel() for n in stage2) == 30749952
+    assert model.ood_head.weight.numel() == 4864
+
+
+@pytest.mark.parametrize("stage,names,lr", [("stage1", ["ood_head"], 1e-4),
+                                            ("stage2", ["aspp", "bot_fine", "bot_aspp", "ood_head"], 1e-6)])
+def test_train_step_golden(deeplab_params, stage, names, lr):
+    """a-7: one optimizer step with train-mode BN on the frozen trunk, the reference's Dropout2d
+    masks and loss permutations injected."""
+    from multishiftseg_amd import synth
+    from multishiftseg_amd.deepv3 import DeepWV3Plus
+    from multishiftseg_amd.loss import RelContrastiveLoss
+    g = golden("deepwv3plus_train_step")
+    pairs, h, w = (int(v) for v in g["shape"])
+    m = DeepWV3Plus(19)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in deeplab_params.items()}, strict=True)
+    m = m.cuda()
+    m.uncertainty_func_init()
+    params = []
+    for n, p in m.named_parameters():
+        p.requires_grad = any(s in n for s in names)
+        if p.requires_grad:
+            params.append(p)
+    opt = torch.optim.Adam(params, lr=lr, weight_decay=1e-4)
+    m.train()
+    pre = stage + "_"
+    m.dropout_masks = {"mod6": torch.from_numpy(g[pre + "drop_mod6"]), "mod7": torch.from_numpy(g[pre + "drop_mod7"])}
+    img = torch.from_numpy(synth.synth_image(int(g["image_seed"]), 2 * pairs, h, w)).cuda()
+    target = torch.from_numpy(g["target"].astype(np.int64)).cuda()
+    crit = RelContrastiveLoss({"ce_weights": [50, 10], "conduct_pixel_selection": True, "selection_ratio": 0.8,
+                               "inoutaug_contras_margins_tri": [10, 5, 5]})
+    perms = [torch.from_numpy(g[pre + f"perm{i}"].astype(np.int64)) for i in range(3)]
+    before = {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+    score, logit = m(img)
+    loss = crit(logit, score, target, perms=perms).mean()
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    np.testing.assert_allclose(score.detach().cpu().numpy(), g[pre + "score"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(logit.detach().cpu().numpy()[:, :, ::4, ::4], g[pre + "logit_sub"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(loss.item(), float(g[pre + "loss"]), rtol=1e-4)
+    mism = (target.cpu().numpy().astype(np.uint8) != g[pre + "target_mut"]).mean()
+    assert mism < 1e-3          # selection threshold ties / 1e-6 CE differences may move a handful of pixels
+    sd = m.state_dict()
+    for k in [k for k in g.files if k.startswith(pre + "rs_")]:
+        np.testing.assert_allclose(sd[k[len(pre) + 3:]].cpu().numpy(), g[k], rtol=1e-3, atol=1e-4, err_msg=k)
+    pd = dict(m.named_parameters())
+    for k in [k for k in g.files if k.startswith(pre + "grad_") and not k.startswith(pre + "grad_sub_")
+              and not k.startswith(pre + "grad_l2_")]:
+        name = k[len(pre) + 5:]
+        ref = g[k]
+        got = pd[name].grad.cpu().numpy()
+        scale = np.abs(ref).max() + 1e-12
+        assert np.abs(got - ref).max() / scale < 2e-3, name
+    for k in [k for k in g.files if k.startswith(pre + "grad_l2_")]:
+        name = k[len(pre) + 8:]
+        got = pd[name].grad.double().norm().item()
+        np.testing.assert_allclose(got, float(g[k]), rtol=2e-3, err_msg=name)
+        flat = pd[name].grad.cpu().numpy().reshape(pd[name].shape[0], -1)
+        sub = flat[:, ::max(1, flat.shape[1] // 64)][:, :64]
+        ref = g[pre + "grad_sub_" + name]
+        assert np.abs(sub - ref).max() / (np.abs(ref).max() + 1e-12) < 5e-3, name
+    for k in [k for k in g.files if k.startswith(pre + "delta_")]:
+        name = k[len(pre) + 6:]
+        got = (pd[name].detach() - before[name]).cpu().numpy()
+        # Adam's first step is lr*sign-like: compare where the reference moved clearly
+        ref = g[k]
+        big = np.abs(ref) > 0.5 * lr
+        assert (np.sign(got[big]) == np.sign(ref[big])).mean() > 0.999, name
+        np.testing.assert_allclose(got, ref, rtol=0, atol=0.05 * lr, err_msg=name)

@@ -1,0 +1,97 @@
+"""GPU parity of the fused RelContrastiveLoss against the reference's own outputs (golden, with the
+reference's recorded permutations injected) and against the CPU oracle at a larger size."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import loss as oloss
+
+pytestmark = pytest.mark.gpu
+
+
+def run(params, logits, score, target, perms, **kw):
+    from multishiftseg_amd.loss import RelContrastiveLoss
+    crit = RelContrastiveLoss(params, **kw)
+    lt = torch.from_numpy(logits).cuda().requires_grad_(True)
+    st = torch.from_numpy(score).cuda().requires_grad_(True)
+    tt = torch.from_numpy(target.astype(np.int64)).cuda()
+    loss = crit(lt, st, tt, perms=perms)
+    if torch.isfinite(loss):
+        loss.backward()
+    return loss, lt.grad, st.grad, tt
+
+
+@pytest.mark.parametrize("tag", ["deeplab_4x32x32", "m2f_4x32x32", "ratio1_4x16x16", "no_ood_4x16x16",
+                                 "no_in_aug_4x16x16", "deeplab_8x48x40"])
+def test_golden(tag):
+    g = golden("rcl_" + tag)
+    params = ast.literal_eval(str(g["params"]))
+    B, C, H, W = (int(v) for v in g["shape"])
+    logits = g["logits"] if g["logits"].size else \
+        np.random.default_rng(int(g["seed"])).standard_normal((B, C, H, W), dtype=np.float32) * 3
+    perms = [torch.from_numpy(g[f"perm{i}"].astype(np.int64)) for i in range(3)]
+    loss, dl, ds, tt = run(params, logits, g["score"], g["target"], perms)
+    if np.isnan(g["loss"]):
+        assert torch.isnan(loss)      # mean of an empty tensor, reproduced not "fixed"
+    else:
+        np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+        np.testing.assert_allclose(ds.cpu().numpy(), g["dscore"], rtol=1e-4, atol=1e-8)
+        d = dl.cpu().numpy()
+        if "dlogit" in g:
+            np.testing.assert_allclose(d, g["dlogit"], rtol=1e-3, atol=1e-7)
+        else:
+            np.testing.assert_allclose(d[:, :, ::3, ::3], g["dlogit_sub"], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(np.abs(d.astype(np.float64)).sum(), g["dlogit_abs_sum"], rtol=1e-4)
+    np.testing.assert_array_equal(tt.cpu().numpy().astype(np.uint8), g["target_mut"])
+
+
+def test_seeded_reference_pairing_matches_oracle():
+    """pairing='reference' draws torch.randperm on the CPU generator exactly as loss.py:129-131."""
+    from multishiftseg_amd import synth
+    rng = np.random.default_rng(77)
+    B, H, W = 4, 96, 80
+    logits = rng.standard_normal((B, 19, H, W), dtype=np.float32) * 3
+    score = rng.standard_normal((B, H, W), dtype=np.float32) * 4
+    target = synth.synth_targets(77, B // 2, H, W)
+    params = {"ce_weights": [50, 10], "conduct_pixel_selection": True, "selection_ratio": 0.8,
+              "inoutaug_contras_margins_tri": [10, 5, 5]}
+    torch.manual_seed(5)
+    loss, dl, ds, tt = run(params, logits, score, target, None)
+    # replay the same three CPU permutations for the oracle
+    t = target.copy()
+    n_orig = int((t[:B // 2] < 99).sum()); n_aug = int((t[B // 2:] < 99).sum()); n_ood = int(((t > 99) & (t != 255)).sum())
+    torch.manual_seed(5)
+    perms = [torch.randperm(k).numpy() for k in (n_orig, n_aug, n_ood)]
+    r = oloss.rel_contrastive_loss(logits, score, t, params, perms)
+    np.testing.assert_allclose(loss.item(), r["loss"], rtol=1e-5)
+    np.testing.assert_allclose(ds.cpu().numpy(), r["dscore"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(dl.cpu().numpy(), r["dlogit"], rtol=1e-3, atol=1e-7)
+    np.testing.assert_array_equal(tt.cpu().numpy(), t)
+
+
+def test_device_pairing_statistics():
+    """pairing='device' (Feistel bijections): same terms except the two randomly paired hinges,
+    which must agree with the reference pairing in expectation; every non-random term is exact."""
+    from multishiftseg_amd import synth
+    from multishiftseg_amd.loss import RelContrastiveLoss
+    rng = np.random.default_rng(78)
+    B, H, W = 4, 128, 128
+    logits = torch.from_numpy(rng.standard_normal((B, 19, H, W), dtype=np.float32) * 3).cuda()
+    score = torch.from_numpy(rng.standard_normal((B, H, W), dtype=np.float32) * 4).cuda()
+    target = torch.from_numpy(synth.synth_targets(78, B // 2, H, W)).cuda()
+    params = {"ce_weights": [50, 10], "conduct_pixel_selection": True, "selection_ratio": 0.8,
+              "inoutaug_contras_margins_tri": [10, 5, 5]}
+    a = RelContrastiveLoss(params, pairing="reference")
+    b = RelContrastiveLoss(params, pairing="device")
+    torch.manual_seed(1)
+    a(logits, score, target.clone())
+    sr = score.clone().requires_grad_(True)
+    lb = b(logits, sr, target.clone())
+    lb.backward()
+    ta, tb = a.last_terms.cpu().numpy(), b.last_terms.cpu().numpy()
+    np.testing.assert_allclose(tb[[1, 2, 5]], ta[[1, 2, 5]], rtol=1e-6)      # ce_orig, ce_aug, c_in: deterministic
+    np.testing.assert_allclose(tb[[3, 4]], ta[[3, 4]], rtol=0.05)            # c_orig, c_aug: same expectation
+    assert torch.isfinite(sr.grad).all() and abs(float(sr.grad.sum())) < 1e-3  # +coef/-coef pairs cancel

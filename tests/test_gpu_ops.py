@@ -1,0 +1,211 @@
+"""GPU parity of the per-op HIP kernels against the CPU oracle and the reference's own vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import m2f as om2f, nnops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from multishiftseg_amd import kernels
+    return kernels
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_conv(K, x, w, stride=1, dil=1, pad=0, **kw):
+    xa = K.Act.from_nchw(dev(x), ld=((x.shape[1] + 15) // 16) * 16)
+    pw = K.pack_weight(dev(w))
+    y = K.conv2d(xa, pw, stride=stride, dil=dil, pad=pad, **kw)
+    return y.nchw().cpu().numpy()
+
+
+def test_conv_classes_golden(K):
+    g = golden("ops")
+    x = g["conv_x"]
+    for tag, (stride, dil) in {"1x1": (1, 1), "3x3_d1": (1, 1), "3x3_d2": (1, 2), "3x3_d4": (1, 4), "3x3_d12": (1, 12),
+                               "3x3_d24": (1, 24), "3x3_d36": (1, 36), "3x3_s2": (2, 1), "1x1_s2": (2, 1)}.items():
+        w = g[f"conv_{tag}_w"]
+        pad = dil if w.shape[2] == 3 else 0
+        y = run_conv(K, x, w, stride, dil, pad)
+        np.testing.assert_allclose(y, g[f"conv_{tag}_y"], rtol=1e-5, atol=2e-6, err_msg=tag)
+
+
+@pytest.mark.parametrize("cin,cout,r,stride,dil,n,h,w", [
+    (64, 128, 3, 1, 1, 2, 33, 47),      # mod2-style, ragged M tile
+    (48, 48, 1, 1, 1, 1, 17, 19),       # narrow-N tile, C % 32 != 0
+    (304, 256, 3, 1, 1, 1, 24, 20),     # final.0 (C = 304 -> BK 16)
+    (256, 512, 3, 2, 1, 2, 31, 29),     # mod4.block1.conv1 stride 2, odd size
+    (128, 256, 3, 1, 12, 1, 16, 32),    # ASPP rate 12 on a small map: dead taps
+    (128, 64, 3, 1, 36, 2, 16, 16),     # rate 36: only the centre tap is live
+    (512, 19 + 29, 1, 1, 1, 2, 9, 7),   # heads-like K = 48
+])
+def test_conv_vs_oracle(K, cin, cout, r, stride, dil, n, h, w):
+    rng = np.random.default_rng(cin * 7 + cout)
+    x = rng.standard_normal((n, cin, h, w), dtype=np.float32)
+    wt = rng.standard_normal((cout, cin, r, r), dtype=np.float32) / np.sqrt(cin * r * r)
+    pad = dil if r == 3 else 0
+    ref = nnops.conv2d(x, wt, stride, dil, pad)
+    y = run_conv(K, x, wt, stride, dil, pad)
+    np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_conv_fusions(K):
+    """prologue BN+ReLU (shared and per-sample), epilogue affine + residual + ReLU."""
+    rng = np.random.default_rng(3)
+    n, c, k, h, w = 2, 64, 128, 12, 15
+    x = rng.standard_normal((n, c, h, w), dtype=np.float32)
+    wt = rng.standard_normal((k, c, 3, 3), dtype=np.float32) / 24
+    sc = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    sh = rng.standard_normal(c).astype(np.float32)
+    res = rng.standard_normal((n, k, h, w), dtype=np.float32)
+    osc = rng.uniform(0.5, 1.5, k).astype(np.float32)
+    osh = rng.standard_normal(k).astype(np.float32)
+    act = np.maximum(x * sc[None, :, None, None] + sh[None, :, None, None], 0)
+    ref = nnops.conv2d(act, wt, 1, 1, 1)
+    ref = np.maximum(ref * osc[None, :, None, None] + osh[None, :, None, None] + res, 0)
+    xa = K.Act.from_nchw(dev(x))
+    ra = K.Act.from_nchw(dev(res))
+    y = K.conv2d(xa, K.pack_weight(dev(wt)), pad=1, in_affine=(dev(sc), dev(sh)), in_relu=True,
+                 out_affine=(dev(osc), dev(osh)), out_relu=True, res=ra)
+    np.testing.assert_allclose(y.nchw().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    # per-sample affine (Dropout2d fold)
+    mask = (rng.random((n, c)) > 0.3).astype(np.float32) / 0.7
+    act = np.maximum(x * (sc[None] * mask)[:, :, None, None] + (sh[None] * mask)[:, :, None, None], 0)
+    ref = nnops.conv2d(act, wt, 1, 1, 1)
+    y = K.conv2d(xa, K.pack_weight(dev(wt)), pad=1, in_affine=(dev(sc[None] * mask), dev(sh[None] * mask)), in_relu=True)
+    np.testing.assert_allclose(y.nchw().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_conv_channel_slices(K):
+    """read from / write into slices of a wider NHWC buffer (in-place concat)."""
+    rng = np.random.default_rng(4)
+    n, h, w = 1, 10, 11
+    big = rng.standard_normal((n, 96, h, w), dtype=np.float32)
+    wt = rng.standard_normal((48, 32, 1, 1), dtype=np.float32) / 6
+    ba = K.Act.from_nchw(dev(big))
+    out = K.Act.zeros(n, h, w, 304, "cuda")
+    K.conv2d(ba.slice(32, 32), K.pack_weight(dev(wt)), out=out.slice(48, 48))
+    ref = nnops.conv2d(big[:, 32:64], wt)
+    got = out.buf.permute(0, 3, 1, 2).cpu().numpy()
+    np.testing.assert_allclose(got[:, 48:96], ref, rtol=1e-4, atol=1e-5)
+    assert np.all(got[:, :48] == 0) and np.all(got[:, 96:] == 0)
+
+
+def test_dgrad_and_wgrad(K):
+    rng = np.random.default_rng(5)
+    for (cin, cout, r, dil, n, h, w) in [(64, 128, 3, 1, 2, 14, 13), (256, 48, 1, 1, 1, 9, 8), (128, 64, 3, 12, 1, 20, 18)]:
+        pad = dil if r == 3 else 0
+        x = torch.from_numpy(rng.standard_normal((n, cin, h, w), dtype=np.float32)).requires_grad_(True)
+        wt = torch.from_numpy(rng.standard_normal((cout, cin, r, r), dtype=np.float32) / np.sqrt(cin * r * r)).requires_grad_(True)
+        y = torch.nn.functional.conv2d(x, wt, dilation=dil, padding=pad)
+        gy = torch.from_numpy(rng.standard_normal(tuple(y.shape), dtype=np.float32))
+        y.backward(gy)
+        ga = K.Act.from_nchw(gy.cuda(), ld=((cout + 15) // 16) * 16)
+        dx = K.conv2d(ga, K.pack_weight(wt.detach().cuda(), flip=True), dil=dil, pad=pad)
+        np.testing.assert_allclose(dx.nchw().cpu().numpy(), x.grad.numpy(), rtol=1e-4, atol=1e-4)
+        dw = K.conv2d_wgrad(K.Act.from_nchw(x.detach().cuda()), ga.slice(0, cout), cout, cin, r, r, dil=dil, pad=pad)
+        np.testing.assert_allclose(dw.cpu().numpy(), wt.grad.numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_batchnorm_train_eval(K):
+    g = golden("ops")
+    bn = torch.nn.BatchNorm2d(8).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(dev(g["bn_gamma"])); bn.bias.copy_(dev(g["bn_beta"]))
+        bn.running_mean.copy_(dev(g["bn_rm"])); bn.running_var.copy_(dev(g["bn_rv"]))
+    xa = K.Act.from_nchw(dev(g["bn_x"]))
+    st = K.bn_fold(bn, train=False)
+    y = torch.empty_like(xa.buf)
+    from multishiftseg_amd._lib import call, ptr
+    call("mss_affine_relu_nhwc_f32", xa.ptr, xa.ld, ptr(y), 8, xa.M, 8, ptr(st.scale), ptr(st.shift), 0)
+    np.testing.assert_allclose(y.permute(0, 3, 1, 2).cpu().numpy(), g["bn_eval_y"], rtol=1e-5, atol=1e-5)
+    st = K.bn_fold(bn, xa, train=True)
+    call("mss_affine_relu_nhwc_f32", xa.ptr, xa.ld, ptr(y), 8, xa.M, 8, ptr(st.scale), ptr(st.shift), 0)
+    np.testing.assert_allclose(y.permute(0, 3, 1, 2).cpu().numpy(), g["bn_train_y"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), g["bn_train_rm"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), g["bn_train_rv"], rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_bn_relu_backward(K):
+    rng = np.random.default_rng(8)
+    x = torch.from_numpy(rng.standard_normal((3, 16, 9, 7), dtype=np.float32) * 2 + 0.3).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(16)
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, 16).astype(np.float32)))
+        bn.bias.copy_(torch.from_numpy(rng.standard_normal(16).astype(np.float32) * 0.3))
+    y = torch.relu(bn(x))
+    gy = torch.from_numpy(rng.standard_normal(tuple(y.shape), dtype=np.float32))
+    y.backward(gy)
+    bn_g = torch.nn.BatchNorm2d(16).cuda()
+    bn_g.load_state_dict({k: v for k, v in bn.state_dict().items()})
+    with torch.no_grad():
+        bn_g.running_mean.zero_(); bn_g.running_var.fill_(1)
+    xa = K.Act.from_nchw(x.detach().cuda())
+    st = K.bn_fold(bn_g, xa, train=True)
+    dx, dg, db = K.bn_relu_backward(K.Act.from_nchw(gy.cuda()), xa, st, want_param_grads=True)
+    np.testing.assert_allclose(dx.nchw().cpu().numpy(), x.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dg.cpu().numpy(), bn.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), bn.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_pool_gap_upsample(K):
+    g = golden("ops")
+    px = np.repeat(g["pool_x"], 1, axis=1)
+    y = K.maxpool3s2(K.Act.from_nchw(dev(px)))
+    np.testing.assert_array_equal(y.nchw().cpu().numpy(), g["pool_y"])
+    ux = g["up_x"]
+    for tag in "abc":
+        oh, ow = g[f"up_{tag}_y"].shape[2:]
+        y = K.upsample_ac(K.Act.from_nchw(dev(ux)), oh, ow)
+        np.testing.assert_allclose(y.nchw().cpu().numpy(), g[f"up_{tag}_y"], rtol=1e-5, atol=1e-6)
+        gx = K.upsample_ac_bwd(K.Act.from_nchw(dev(g[f"up_{tag}_gy"])), ux.shape[2], ux.shape[3])
+        np.testing.assert_allclose(gx.nchw().cpu().numpy(), g[f"up_{tag}_gx"], rtol=1e-4, atol=1e-5)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((3, 64, 5, 9), dtype=np.float32)
+    np.testing.assert_allclose(K.gap(K.Act.from_nchw(dev(x))).cpu().numpy(), x.mean((2, 3)), rtol=1e-5, atol=1e-6)
+
+
+def test_ood_score_tail(K):
+    rng = np.random.default_rng(6)
+    n, h, w = 2, 13, 17
+    d = rng.standard_normal((n, 48, h, w), dtype=np.float32) * 3
+    da = K.Act.from_nchw(dev(d))
+    for (oh, ow) in [(26, 34), (25, 33), (13, 17)]:
+        score, logit, label = K.ood_score(da.slice(20, 19), da.slice(0, 19), oh, ow, want_label=True)
+        rs, rl = nnops.ood_score_tail(d[:, 20:39], d[:, 0:19], (oh, ow))
+        np.testing.assert_allclose(score.cpu().numpy(), rs, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(logit.cpu().numpy(), rl, rtol=1e-5, atol=1e-5)
+        got = logit.cpu().numpy()
+        np.testing.assert_array_equal(label.cpu().numpy(), got.argmax(1))   # bit-exact vs its own logits
+    # backward vs torch autograd of the same composition
+    dt = torch.from_numpy(d).requires_grad_(True)
+    lg = torch.nn.functional.interpolate(dt[:, 0:19], size=(26, 34), mode="bilinear", align_corners=True)
+    sc = torch.nn.functional.interpolate(-torch.logsumexp(dt[:, 20:39], 1, keepdim=True), size=(26, 34), mode="bilinear",
+                                         align_corners=True)[:, 0]
+    gl = torch.from_numpy(rng.standard_normal(tuple(lg.shape), dtype=np.float32))
+    gs = torch.from_numpy(rng.standard_normal(tuple(sc.shape), dtype=np.float32))
+    (lg * gl).sum().backward(retain_graph=True)
+    (sc * gs).sum().backward()
+    dd = K.Act.zeros(n, h, w, 48, "cuda")
+    K.ood_score_bwd(da.slice(20, 19), gs.cuda(), gl.cuda(), dd.slice(20, 19), dd.slice(0, 19), 26, 34)
+    np.testing.assert_allclose(dd.nchw().cpu().numpy(), dt.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_m2f_score(K):
+    g = golden("m2f_score")
+    size = tuple(int(v) for v in g["size"])
+    s = K.m2f_score(dev(g["cls"]), dev(g["mask"]), size)
+    np.testing.assert_allclose(s.cpu().numpy(), g["score"], rtol=1e-5, atol=1e-5)
+    rng = np.random.default_rng(9)
+    cls = rng.standard_normal((1, 100, 20), dtype=np.float32)
+    mask = rng.standard_normal((1, 100, 64, 96), dtype=np.float32) * 4
+    s = K.m2f_score(dev(cls), dev(mask), (64, 96))
+    np.testing.assert_allclose(s.cpu().numpy(), om2f.anomaly_score(cls, mask, (64, 96)), rtol=1e-5, atol=1e-5)
