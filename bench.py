@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DeepLabV3+/WRN38 training step (+ OOD-score throughput) on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic batch: trunk forward (train-mode BN +
+Dropout2d on the frozen trunk), decoder/heads forward, fused RelContrastiveLoss, backward
+(dgrad/wgrad/BN backward of the stage's trainable set), gradient all-reduce (N > 1), Adam step.
+Default workload = BASELINE.json's metric configuration, per GPU: one (original, augmented) pair of
+1024x2048 images (2 images), stage-2 trainable set (aspp, bot_fine, bot_aspp, ood_head). Every rank
+has the same amount of work (weak scaling); `value` is whole-job images/s. Inputs are generated on
+the device before the timed region; weights are synthetic (multishiftseg_amd.synth), fp32 throughout.
+
+One JSON line on rank 0 carries the step metric, the fp32-MFMA roofline of the dominant kernel
+(conv_igemm, timed live with HIP events on its launch stream), the OOD-score Mpix/s of the eval path,
+and -- at N=1 -- a CPU baseline (the numpy oracle, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, dense fp32 matrix
+FWD_GMAC_1024x2048 = 5827.2            # conv MACs of one forward at 1024x2048
+STAGE2_STEP_OVER_FWD = 1.287           # stage-2 step FLOPs / forward FLOPs
+
+
+def cpu_baseline(h=256, w=512):
+    """The numpy oracle (a port, not the reference) on the host cores: one eval forward of a
+    1x3xhxw image; converted to the metric's unit by the algorithmic-FLOP ratio of a stage-2 train
+    step at the benchmark resolution."""
+    from multishiftseg_amd import synth
+    from oracle import deepv3 as odeepv3
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    params = synth.deepwv3plus_params(0)
+    img = synth.synth_image(3, 1, h, w)
+    odeepv3.forward(params, synth.synth_image(3, 1, 64, 128))      # warm-up (BLAS thread pool, page-in)
+    t0 = time.time()
+    odeepv3.forward(params, img)
+    dt = time.time() - t0
+    return dict(seconds=dt, cores=int(cores), h=h, w=w, fwd_gmac=FWD_GMAC_1024x2048 * h * w / (1024 * 2048))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny"],
+                    help="c3: 1 pair of 1024x2048 per GPU; c2: 8 pairs of 768x768 (exps/DeepLab.yaml batch 8); tiny: smoke")
+    ap.add_argument("--stage", type=int, default=2, choices=[1, 2])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ood", action="store_true")
+    args = ap.parse_args()
+
+    from multishiftseg_amd import ddp, kernels as K, synth
+    from multishiftseg_amd.deepv3 import DeepWV3Plus
+    from multishiftseg_amd.loss import RelContrastiveLoss
+    from multishiftseg_amd.trainer import LOSS_PARAMS, TrainStep, ood_scores
+
+    rank, world, local_rank, device = ddp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if device.type != "cuda":
+        raise SystemExit("bench.py needs an MI355X")
+
+    pairs, H, W = {"c3": (1, 1024, 2048), "c2": (8, 768, 768), "tiny": (1, 128, 256)}[args.workload]
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    params = synth.deepwv3plus_params(0)
+    model = DeepWV3Plus(19)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in params.items()})
+    del params
+    model = model.to(device)
+    model.uncertainty_func_init()
+    crit = RelContrastiveLoss(LOSS_PARAMS, pairing="device", seed=1000 + rank)
+    step = TrainStep(model, crit, stage=args.stage)
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    img = torch.randn((2 * pairs, 3, H, W), device=device, generator=gen)
+    target0 = torch.from_numpy(synth.synth_targets(100 + rank, pairs, H, W)).to(device)
+
+    def one_step():
+        return step(img, target0.clone())      # the loss mutates its targets; a loader would hand over fresh ones
+
+    for _ in range(args.warmup):
+        one_step()
+    prof = K.ConvProfile()
+    K.set_conv_profile(prof)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    K.set_conv_profile(None)
+    loss_val = float(loss)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    images = 2 * pairs * world * args.steps
+    value = images / elapsed
+    summ = prof.summary()
+    conv = summ.get("conv_igemm", dict(launches=0, flops=0.0, ms=1.0))
+    achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["launches"] else 0.0
+    wg = summ.get("conv_wgrad")
+    step_flops_alg = 2 * FWD_GMAC_1024x2048 * 1e9 * (H * W) / (1024 * 2048) * 2 * pairs * \
+        (STAGE2_STEP_OVER_FWD if args.stage == 2 else 1.0)
+
+    out = {
+        "metric": "train images/sec (DeepLabV3+ WRN38, fwd + RelContrastiveLoss + bwd + Adam)",
+        "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {2 * pairs} images ({pairs} orig+aug pair(s)) of {H}x{W} per GPU, "
+                               f"stage-{args.stage} trainable set, train-mode BN/Dropout2d on the frozen trunk",
+                   "images_per_gpu": 2 * pairs, "height": H, "width": W, "stage": args.stage,
+                   "parallelism": f"dp{world}", "loss_pairing": "device", "loss": round(loss_val, 4)},
+        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+                     "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "launches_per_step": conv["launches"] // max(args.steps, 1),
+                     "avg_launch_ms": round(conv["ms"] / max(conv["launches"], 1), 4),
+                     "kernel_ms_per_step": round(conv["ms"] / max(args.steps, 1), 2)},
+        "step_tflops_algorithmic": round(step_flops_alg / (elapsed / args.steps) / 1e12, 2),
+    }
+    if wg:
+        out["wgrad"] = {"achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                        "kernel_ms_per_step": round(wg["ms"] / max(args.steps, 1), 2)}
+
+    if not args.no_ood:
+        # OOD-score path (test_deeplab.py:86-90): eval forward -> per-pixel anomaly score
+        e_img = img[:1].contiguous()
+        for _ in range(2):
+            ood_scores(model, e_img)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_eval = 5
+        for _ in range(n_eval):
+            score, logit = ood_scores(model, e_img)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / n_eval
+        # the fused tail kernel alone (23 B per output pixel algorithmic: SURVEY 8d)
+        dec = K.Act(torch.randn(1, H // 2, W // 2, 48, device=device))
+        for _ in range(3):
+            K.ood_score(dec.slice(20, 19), None, H, W, want_logit=False)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(20):
+            K.ood_score(dec.slice(20, 19), None, H, W, want_logit=False)
+        e.record()
+        torch.cuda.synchronize()
+        k_ms = s.elapsed_time(e) / 20
+        out["ood_score"] = {"end_to_end_mpix_s": round(H * W / dt / 1e6, 3), "end_to_end_ms": round(dt * 1e3, 2),
+                            "tail_kernel_mpix_s": round(H * W / (k_ms * 1e-3) / 1e6, 1),
+                            "tail_kernel_GBs": round(23.0 * H * W / (k_ms * 1e-3) / 1e9, 1), "hbm_peak_GBs": 8000,
+                            "image": f"1x3x{H}x{W}"}
+
+    if cpu is not None:
+        # CPU forward seconds for the sample -> train images/s at the benchmark resolution
+        t_fwd_full = cpu["seconds"] * (H * W) / (cpu["h"] * cpu["w"])
+        t_step_img = t_fwd_full * (STAGE2_STEP_OVER_FWD if args.stage == 2 else 1.0)
+        out["cpu_baseline"] = {"value": round(1.0 / t_step_img, 6), "unit": "images/s", "cores": cpu["cores"],
+                               "kind": "port",
+                               "sample": f"numpy oracle eval forward of one 1x3x{cpu['h']}x{cpu['w']} image "
+                                         f"({cpu['seconds']:.2f} s, {cpu['fwd_gmac']:.0f} GMAC), scaled by pixel count to "
+                                         f"{H}x{W} and by the stage-{args.stage} step/forward FLOP ratio"}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

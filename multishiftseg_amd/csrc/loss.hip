@@ -478,7 +478,8 @@ int mss_rcl_compact_f32(const uint8_t* kind, int B, int H, int W, int32_t* idx_o
 int mss_rcl_pairs_f32(const float* score, const int32_t* idx_a, const int64_t* perm_a, const int32_t* idx_o,
                       const int64_t* perm_o, long long n, float margin, double* counters, int slot, float grad_w,
                       float* dscore, void* stream) {
-  if (!score || !idx_a || !idx_o || !perm_a || !perm_o || !counters || n < 0) return MSS_ERR_BAD_ARG;
+  if (!score || !idx_a || !idx_o || !counters || n < 0) return MSS_ERR_BAD_ARG;
+  if (n > 0 && (!perm_a || !perm_o)) return MSS_ERR_BAD_ARG;
   if (slot != 0 && slot != 1) return MSS_ERR_BAD_ARG;
   hipLaunchKernelGGL(rcl_pairs_kernel<false>, dim3(grid_for(n > 0 ? n : 1, 2048)), dim3(256), 0, S_(stream), score,
                      idx_a, perm_a, idx_o, perm_o, n, nullptr, 0, 0ll, 0u, 0u, margin, counters,

@@ -219,8 +219,9 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
 template <typename T>
 int msda_check(const T* value, const int64_t* shapes, const int64_t* starts, const T* loc, const T* attn, int N,
                int S, int M, int D, int L, int Lq, int P) {
-  if (!value || !shapes || !starts || !loc || !attn) return MSS_ERR_BAD_ARG;
   if (N < 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq < 0 || P <= 0) return MSS_ERR_BAD_ARG;
+  if ((long long)N * Lq == 0) return MSS_OK;  // empty query set: nothing is dereferenced
+  if (!value || !shapes || !starts || !loc || !attn) return MSS_ERR_BAD_ARG;
   return MSS_OK;
 }
 
@@ -228,9 +229,10 @@ template <typename T>
 int msda_forward(const T* value, const int64_t* shapes, const int64_t* starts, const T* loc, const T* attn,
                  int N, int S, int M, int D, int L, int Lq, int P, T* out, hipStream_t stream) {
   int rc = msda_check(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P);
-  if (rc || !out) return rc ? rc : MSS_ERR_BAD_ARG;
+  if (rc) return rc;
   const long long npairs = (long long)N * Lq * M;
   if (npairs == 0) return MSS_OK;
+  if (!out) return MSS_ERR_BAD_ARG;
   const long long total = npairs * D;
   int blocks = (int)min((total + 255) / 256, (long long)256 * 32);
   hipLaunchKernelGGL(msda_fwd_generic_kernel<T>, dim3(blocks), dim3(256), 0, stream, value, shapes, starts, loc,
@@ -257,11 +259,14 @@ int msda_backward(const T* value, const int64_t* shapes, const int64_t* starts, 
                   hipStream_t stream) {
   int rc = msda_check(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P);
   if (rc) return rc;
-  if (!gout || !gvalue || !gloc || !gattn) return MSS_ERR_BAD_ARG;
-  hipError_t e = hipMemsetAsync(gvalue, 0, (size_t)N * S * M * D * sizeof(T), stream);
-  if (e != hipSuccess) return (int)e;
+  if (!gvalue && N > 0) return MSS_ERR_BAD_ARG;
+  if (N > 0) {
+    hipError_t e = hipMemsetAsync(gvalue, 0, (size_t)N * S * M * D * sizeof(T), stream);
+    if (e != hipSuccess) return (int)e;
+  }
   const long long npairs = (long long)N * Lq * M;
   if (npairs == 0) return MSS_OK;
+  if (!gout || !gloc || !gattn) return MSS_ERR_BAD_ARG;
   if (D <= 32) {
     const long long nblocks = (npairs + 7) / 8;
     hipLaunchKernelGGL((msda_bwd_kernel<T, 32>), dim3((unsigned)nblocks), dim3(256), 0, stream, value, shapes,
@@ -285,8 +290,9 @@ int mss_msda_forward_f32(const float* value, const int64_t* spatial_shapes, cons
                          int Lq, int P, float* out, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = msda_check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L, Lq, P);
-  if (rc || !out) return rc ? rc : MSS_ERR_BAD_ARG;
+  if (rc) return rc;
   if ((long long)N * Lq * M == 0) return MSS_OK;
+  if (!out) return MSS_ERR_BAD_ARG;
   const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   const size_t smem_per_lp = (size_t)4 * 3 * sizeof(float) * L * P;
   if (aligned && D == 32 && smem_per_lp * 8 <= 65536)

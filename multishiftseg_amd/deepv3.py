@@ -124,6 +124,9 @@ class DeepWV3Plus(nn.Module):
         self.criterion = criterion
         self.num_classes = num_classes
         self._heads_cache = None
+        # data-parallel hook: callable(name, grad_tensor) invoked inside the backward as soon as a
+        # parameter gradient has been produced (multishiftseg_amd/ddp.py launches its all-reduce there)
+        self.grad_sink = None
         # test hook: {"mod6": [N,1024], "mod7": [N,2048]} pre-scaled Dropout2d masks
         self.dropout_masks = None
 
@@ -263,7 +266,21 @@ class DeepWV3Plus(nn.Module):
     def _head_backward(self, s, dscore, dlogit, needs):
         names, params = self._head_params()
         need = {n: bool(f) for n, f in zip(names, needs)}
-        grads = {}
+        sink = self.grad_sink
+
+        class _Grads(dict):
+            def __setitem__(self, k, v):
+                dict.__setitem__(self, k, v)
+                if sink is not None and v is not None and need.get(k):
+                    sink(k, v)
+        grads = _Grads()
+        try:
+            return self._head_backward_impl(s, dscore, dlogit, names, need, grads)
+        finally:
+            if sink is not None and hasattr(sink, "backward_done"):
+                sink.backward_done()
+
+    def _head_backward_impl(self, s, dscore, dlogit, names, need, grads):
         x, m2, raw, dec0, f0, f1, dec12 = s["x"], s["m2"], s["raw"], s["dec0"], s["f0"], s["f1"], s["dec12"]
         N, h8, w8, h2, w2 = x.N, x.H, x.W, m2.H, m2.W
         OH, OW = s["size"]

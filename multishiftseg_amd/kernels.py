@@ -70,6 +70,8 @@ def _round_up(v, m):
 def pack_weight(w, flip=False, min_c=16):
     """nn.Conv2d.weight [K,C,R,S] -> PackedWeight. flip=True packs the data-gradient filter."""
     K, C, R, S = w.shape
+    if w.dtype != torch.float32 or not w.is_cuda:
+        raise TypeError(f"pack_weight needs a float32 CUDA tensor, got {w.dtype} on {w.device}")
     w = w.detach().contiguous()
     if not flip:
         k_out, c_in = K, C
@@ -95,6 +97,51 @@ def packed(param, flip=False):
     pw = pack_weight(param, flip)
     _pack_cache[key] = (param._version, param.data_ptr(), pw)
     return pw
+
+
+class ConvProfile:
+    """Optional live timing of every MFMA conv launch (bench.py's roofline leg): a pair of HIP events
+    on the launch stream around each launch plus the launch's algorithmic FLOPs (dense 2*MAC)."""
+
+    def __init__(self):
+        self.records = []   # (kind, flops, start_event, stop_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, flops, s, e in self.records:
+            ms = s.elapsed_time(e)
+            d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += ms
+        return out
+
+
+_profile = None
+
+
+def set_conv_profile(prof):
+    global _profile
+    _profile = prof
+
+
+class _Timed:
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if _profile is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if _profile is not None:
+            self.e.record()
+            _profile.records.append((self.kind, self.flops, self.s, self.e))
+        return False
 
 
 def conv_out_size(h, r, stride, dil, pad):
@@ -131,7 +178,8 @@ def conv2d(x, pw, stride=1, dil=1, pad=0, in_affine=None, in_relu=False, out_aff
     assert (out.N, out.H, out.W) == (x.N, OH, OW) and out.C >= pw.K
     a = _conv_args(x, pw, out, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res)
     a.OH, a.OW, a.ldy = OH, OW, out.ld
-    call("mss_conv2d_forward_f32", ctypes.byref(a))
+    with _Timed("conv_igemm", 2.0 * x.N * OH * OW * pw.K * pw.C * pw.R * pw.S):
+        call("mss_conv2d_forward_f32", ctypes.byref(a))
     return out
 
 
@@ -150,7 +198,8 @@ def conv2d_wgrad(x, dy, K, C, R, S, stride=1, dil=1, pad=0, in_affine=None, in_r
     a.OH, a.OW, a.K, a.Kpad = dy.H, dy.W, K, Kpad
     a.R, a.S, a.stride, a.dil, a.pad = R, S, stride, dil, pad
     a.in_relu = int(in_relu)
-    call("mss_conv2d_wgrad_f32", ctypes.byref(a), dy.ptr, dy.ld, ptr(dwp), Cp)
+    with _Timed("conv_wgrad", 2.0 * x.N * dy.H * dy.W * K * C * R * S):
+        call("mss_conv2d_wgrad_f32", ctypes.byref(a), dy.ptr, dy.ld, ptr(dwp), Cp)
     grad = torch.empty((K, C, R, S), device=x.buf.device, dtype=torch.float32)
     call("mss_conv2d_unpack_wgrad_f32", ptr(dwp), ptr(grad), K, C, R, S, Kpad, Cp, 0)
     return grad

@@ -1,0 +1,82 @@
+"""Training / evaluation loop semantics of the reference harness, for the build's own drivers.
+
+Mirrors what matters on the hot path of train_deeplab.py:113-216 and test_deeplab.py:74-117:
+  * trainable set chosen by substring match on parameter names (train_deeplab.py:124-130), stage 1
+    = ["ood_head"], stage 2 = ["aspp", "bot_fine", "bot_aspp", "ood_head"] (exps/DeepLab.yaml:10-11);
+  * Adam(lr 1e-4 -> 1e-6, weight_decay 1e-4) rebuilt from scratch at the stage switch (:151-166);
+  * model.train() with the frozen trunk in batch-statistics mode (:182);
+  * batch = cat([img, div_img]), cat([target, div_target]) (:194-195); loss.mean(); zero_grad /
+    backward / step (:198-204);
+  * per-rank data parallelism instead of nn.DataParallel (multishiftseg_amd/ddp.py).
+Datasets, logging, checkpoint policy and metrics are the reference's harness and stay out of scope.
+"""
+import torch
+
+from . import ddp
+from .optim import Adam
+
+STAGE_TRAINABLE = {1: ["ood_head"], 2: ["aspp", "bot_fine", "bot_aspp", "ood_head"]}   # exps/DeepLab.yaml:10-11
+STAGE_LR = {1: 1.0e-4, 2: 1.0e-6}                                                       # exps/DeepLab.yaml:21-22
+WEIGHT_DECAY = 1.0e-4                                                                    # exps/DeepLab.yaml:24
+LOSS_PARAMS = {"ce_weights": [50, 10], "conduct_pixel_selection": True, "selection_ratio": 0.8,
+               "inoutaug_contras_margins_tri": [10, 5, 5]}                               # exps/DeepLab.yaml:28-35
+
+# order in which DeepWV3Plus._head_backward produces gradients (heads first, ASPP last)
+BACKWARD_ORDER = ["ood_head.weight", "final.6.weight", "final.4.weight", "final.4.bias", "final.3.weight",
+                  "final.1.weight", "final.1.bias", "final.0.weight", "bot_fine.weight", "bot_aspp.weight",
+                  "aspp.img_conv.1.weight", "aspp.img_conv.1.bias", "aspp.img_conv.0.weight"] + \
+    [f"aspp.features.{i}.{s}" for i in range(4) for s in ("1.weight", "1.bias", "0.weight")]
+
+
+def configure_trainable_params(model, patterns):
+    """train_deeplab.py:113-132: requires_grad by substring, returns (params, names)."""
+    params, names = [], []
+    for name, p in model.named_parameters():
+        if any(s in name for s in patterns):
+            p.requires_grad = True
+            params.append(p)
+            names.append(name)
+        else:
+            p.requires_grad = False
+    return params, names
+
+
+class TrainStep:
+    """One optimisation step of either stage on this rank's pairs."""
+
+    def __init__(self, model, criterion, stage=2, bucket_bytes=64 << 20):
+        self.model, self.criterion = model, criterion
+        self.set_stage(stage, bucket_bytes)
+
+    def set_stage(self, stage, bucket_bytes=64 << 20):
+        """update_trainable_params (train_deeplab.py:151-166): new trainable set, new Adam."""
+        self.stage = stage
+        params, names = configure_trainable_params(self.model, STAGE_TRAINABLE[stage])
+        self.optimizer = Adam(params, lr=STAGE_LR[stage], weight_decay=WEIGHT_DECAY)
+        self.names = names
+        named = dict(zip(names, params))
+        order = [(n, named[n]) for n in BACKWARD_ORDER if n in named]
+        assert len(order) == len(named), sorted(set(named) - set(n for n, _ in order))
+        self.sync = ddp.GradAllReduce(order, bucket_bytes) if torch.distributed.is_initialized() else None
+        self.model.grad_sink = self.sync
+        self.model.train()
+
+    def __call__(self, img, target):
+        """img [2p,3,H,W] laid out [orig...; aug...], target int64 [2p,H,W] (mutated by the loss)."""
+        score, logit = self.model(img)
+        loss = self.criterion(logit, score, target).mean()
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+
+@torch.no_grad()
+def ood_scores(model, img):
+    """test_deeplab.py:86-90: eval-mode forward -> (anomaly_score, logit)."""
+    was = model.training
+    model.eval()
+    try:
+        return model(img)
+    finally:
+        model.train(was)

@@ -49,7 +49,7 @@ def test_conv_classes_golden(K):
 def test_conv_vs_oracle(K, cin, cout, r, stride, dil, n, h, w):
     rng = np.random.default_rng(cin * 7 + cout)
     x = rng.standard_normal((n, cin, h, w), dtype=np.float32)
-    wt = rng.standard_normal((cout, cin, r, r), dtype=np.float32) / np.sqrt(cin * r * r)
+    wt = (rng.standard_normal((cout, cin, r, r), dtype=np.float32) / np.sqrt(cin * r * r)).astype(np.float32)
     pad = dil if r == 3 else 0
     ref = nnops.conv2d(x, wt, stride, dil, pad)
     y = run_conv(K, x, wt, stride, dil, pad)
@@ -103,7 +103,7 @@ def test_dgrad_and_wgrad(K):
     for (cin, cout, r, dil, n, h, w) in [(64, 128, 3, 1, 2, 14, 13), (256, 48, 1, 1, 1, 9, 8), (128, 64, 3, 12, 1, 20, 18)]:
         pad = dil if r == 3 else 0
         x = torch.from_numpy(rng.standard_normal((n, cin, h, w), dtype=np.float32)).requires_grad_(True)
-        wt = torch.from_numpy(rng.standard_normal((cout, cin, r, r), dtype=np.float32) / np.sqrt(cin * r * r)).requires_grad_(True)
+        wt = torch.from_numpy((rng.standard_normal((cout, cin, r, r), dtype=np.float32) / np.sqrt(cin * r * r)).astype(np.float32)).requires_grad_(True)
         y = torch.nn.functional.conv2d(x, wt, dilation=dil, padding=pad)
         gy = torch.from_numpy(rng.standard_normal(tuple(y.shape), dtype=np.float32))
         y.backward(gy)
@@ -165,7 +165,7 @@ def test_pool_gap_upsample(K):
     for tag in "abc":
         oh, ow = g[f"up_{tag}_y"].shape[2:]
         y = K.upsample_ac(K.Act.from_nchw(dev(ux)), oh, ow)
-        np.testing.assert_allclose(y.nchw().cpu().numpy(), g[f"up_{tag}_y"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(y.nchw().cpu().numpy(), g[f"up_{tag}_y"], rtol=1e-5, atol=5e-6)
         gx = K.upsample_ac_bwd(K.Act.from_nchw(dev(g[f"up_{tag}_gy"])), ux.shape[2], ux.shape[3])
         np.testing.assert_allclose(gx.nchw().cpu().numpy(), g[f"up_{tag}_gx"], rtol=1e-4, atol=1e-5)
     rng = np.random.default_rng(2)
