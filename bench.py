@@ -116,7 +116,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     K.set_conv_profile(None)
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
