@@ -25,7 +25,7 @@ namespace {
 
 constexpr int NT = 256;
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, bool PER_SAMPLE>
 __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
   constexpr int LDK = BK + 4;            // +4 floats: ds_read_b128 of 16 distinct rows is conflict-free
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -93,54 +93,91 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 areg[A_LD], breg[B_LD];
-
-  // iteration state of the *loader* (runs one step ahead of the MFMA loop)
+  // ---- loader: runs one K-step ahead of the MFMA loop, split "issue early / write late":
+  // issue_loads() only issues global loads (no wait, no branch: rows that fall in the zero padding
+  // read a dummy valid address and are zeroed later); finish_store() runs AFTER the MFMA block of
+  // the current step, applies the fused BatchNorm+ReLU prologue and writes the LDS tile. The loads'
+  // latency is therefore covered by 64 MFMAs instead of stalling the wave 4x per step.
+  constexpr int S_LD = PER_SAMPLE ? A_LD : 1;   // one affine per staged row only for the Dropout2d fold
+  f32x4 areg[A_LD], breg[B_LD], sreg[S_LD], hreg[S_LD];
+  const float* a_ptr[A_LD];
+  const float* b_ptr[B_LD];
+  const float* s_ptr[S_LD];
+  const float* h_ptr[S_LD];
+  unsigned a_ok = 0;       // bit j: row j of this thread is inside the image for the current tap
+  unsigned ld_ok = 0;      // a_ok of the step whose data sits in the staging registers
   int ld_tap = -1, ld_c0 = 0, ld_left = live;
+  const bool has_affine = p.in_scale != nullptr;
+
   auto next_tap = [&]() {
     ld_tap = __ffs(ld_left) - 1;
     ld_left &= ld_left - 1;
     ld_c0 = 0;
-  };
-
-  auto load_global = [&]() {
     const int r = ld_tap / p.S, s = ld_tap - r * p.S;
     const int dy = r * p.dil, dx = s * p.dil;
-    const int cc = ld_c0 + chunk * 4;
+    a_ok = 0;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
-      bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const float* src = p.x + (size_t)(a_nb[j] + iy * p.W + ix) * p.ldx + cc;
-        val = *reinterpret_cast<const f32x4*>(src);
-        if (p.in_scale) {
-          const size_t so = (size_t)a_n[j] * p.in_ss_stride + cc;
-          f32x4 sc = *reinterpret_cast<const f32x4*>(p.in_scale + so);
-          f32x4 sh = *reinterpret_cast<const f32x4*>(p.in_shift + so);
-          val = val * sc + sh;
-        }
-        if (p.in_relu) {
-          val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f);
-          val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
-        }
-      }
-      areg[j] = val;
+      const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      a_ok |= (ok ? 1u : 0u) << j;
+      a_ptr[j] = ok ? p.x + (size_t)(a_nb[j] + iy * p.W + ix) * p.ldx + chunk * 4 : p.x;
     }
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) {
-      const float* src = p.w + ((size_t)ld_tap * p.Kpad + n0 + row0 + j * RPP) * p.C + cc;
-      breg[j] = *reinterpret_cast<const f32x4*>(src);
+    for (int j = 0; j < B_LD; ++j)
+      b_ptr[j] = p.w + ((size_t)ld_tap * p.Kpad + n0 + row0 + j * RPP) * p.C + chunk * 4;
+    if (has_affine) {
+#pragma unroll
+      for (int j = 0; j < S_LD; ++j) {
+        const size_t so = (PER_SAMPLE ? (size_t)a_n[j] * p.in_ss_stride : 0) + chunk * 4;
+        s_ptr[j] = p.in_scale + so;
+        h_ptr[j] = p.in_shift + so;
+      }
     }
-    ld_c0 += BK;
-    if (ld_c0 >= p.C && ld_left) next_tap();
   };
 
-  auto store_lds = [&](int buf) {
+  auto issue_loads = [&]() {
 #pragma unroll
-    for (int j = 0; j < A_LD; ++j)
-      *reinterpret_cast<f32x4*>(&As[(buf * BM + row0 + j * RPP) * LDK + chunk * 4]) = areg[j];
+    for (int j = 0; j < A_LD; ++j) areg[j] = *reinterpret_cast<const f32x4*>(a_ptr[j]);
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) breg[j] = *reinterpret_cast<const f32x4*>(b_ptr[j]);
+    if (has_affine) {
+#pragma unroll
+      for (int j = 0; j < S_LD; ++j) {
+        sreg[j] = *reinterpret_cast<const f32x4*>(s_ptr[j]);
+        hreg[j] = *reinterpret_cast<const f32x4*>(h_ptr[j]);
+      }
+    }
+    ld_ok = a_ok;
+    // advance to the next K-step
+    ld_c0 += BK;
+    if (ld_c0 >= p.C) {
+      if (ld_left) next_tap();
+    } else {
+#pragma unroll
+      for (int j = 0; j < A_LD; ++j)
+        if ((a_ok >> j) & 1) a_ptr[j] += BK;
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j) b_ptr[j] += BK;
+      if (has_affine) {
+#pragma unroll
+        for (int j = 0; j < S_LD; ++j) { s_ptr[j] += BK; h_ptr[j] += BK; }
+      }
+    }
+  };
+
+  auto finish_store = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      f32x4 val = areg[j];
+      if (has_affine) val = val * sreg[PER_SAMPLE ? j : 0] + hreg[PER_SAMPLE ? j : 0];
+      if (p.in_relu) {
+        val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f);
+        val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
+      }
+      if (!((ld_ok >> j) & 1)) val = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&As[(buf * BM + row0 + j * RPP) * LDK + chunk * 4]) = val;
+    }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j)
       *reinterpret_cast<f32x4*>(&Bs[(buf * BN + row0 + j * RPP) * LDK + chunk * 4]) = breg[j];
@@ -148,35 +185,56 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
 
   if (n_it > 0) {
     next_tap();
-    load_global();
-    store_lds(0);
+    issue_loads();
+    finish_store(0);
   }
   __syncthreads();
 
+  // ---- main loop, software pipelined inside the wave -------------------------------------------
+  // A K-step is NKC chunks of 8 k (= 4 MFMA k-steps x TM x TN tiles). The A/B fragments of chunk
+  // kc+1 are read from LDS while chunk kc multiplies (two fragment register sets); the staging
+  // registers are written to the other LDS buffer before the second-to-last chunk, the single
+  // workgroup barrier sits before the last chunk, and the first fragments of the NEXT K-step are
+  // read right after it -- so neither the global-load latency, nor the LDS round trip, nor the
+  // barrier skew is ever exposed without MFMAs in flight.
+  constexpr int NKC = BK / 8;
   const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
+  const float* Abase = &As[(wm * WTM + frag_row) * LDK + frag_k];
+  const float* Bbase = &Bs[(wn * WTN + frag_row) * LDK + frag_k];
+  f32x4 fa[2][TM], fb[2][TN];
+  auto load_frags = [&](int set, int buf, int kc) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      fa[set][i] = *reinterpret_cast<const f32x4*>(Abase + (buf * BM + i * 32) * LDK + kc * 8);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      fb[set][j] = *reinterpret_cast<const f32x4*>(Bbase + (buf * BN + j * 32) * LDK + kc * 8);
+  };
+  auto mfma_chunk = [&](int set) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][s], fb[set][j][s], acc[i][j], 0, 0, 0);
+  };
+
+  if (n_it > 0) load_frags(0, 0, 0);
   for (int it = 0; it < n_it; ++it) {
     const int buf = it & 1;
     const bool more = it + 1 < n_it;
-    if (more) load_global();
-    const float* Ab = &As[(buf * BM + wm * WTM + frag_row) * LDK + frag_k];
-    const float* Bb = &Bs[(buf * BN + wn * WTN + frag_row) * LDK + frag_k];
+    if (more) issue_loads();
 #pragma unroll
-    for (int kc = 0; kc < BK / 8; ++kc) {
-      f32x4 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + kc * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + kc * 8);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    for (int kc = 0; kc < NKC; ++kc) {
+      if (kc + 1 < NKC) load_frags((kc + 1) & 1, buf, kc + 1);
+      if (kc == NKC - 2 && more) finish_store(buf ^ 1);
+      if (kc == NKC - 1) {
+        __syncthreads();
+        if (more) load_frags(NKC & 1, buf ^ 1, 0);
+      }
+      mfma_chunk(kc & 1);
     }
-    if (more) store_lds(buf ^ 1);
-    __syncthreads();
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
@@ -204,13 +262,22 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
   }
 }
 
+template <int BM, int BN, int BK, int WM, int WN, bool PS>
+int launch_conv_t(MssConvArgs& p, hipStream_t stream);
+
 template <int BM, int BN, int BK, int WM, int WN>
 int launch_conv(MssConvArgs& p, hipStream_t stream) {
+  if (p.in_scale && p.in_ss_stride) return launch_conv_t<BM, BN, BK, WM, WN, true>(p, stream);
+  return launch_conv_t<BM, BN, BK, WM, WN, false>(p, stream);
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool PS>
+int launch_conv_t(MssConvArgs& p, hipStream_t stream) {
   p.mtiles = mss_cdiv(p.M, BM);
   p.ntiles = mss_cdiv(p.K, BN);
   if (p.Kpad < p.ntiles * BN) return MSS_ERR_BAD_ARG;
   const size_t smem = ((size_t)2 * (BM + BN) * (BK + 4) + 4) * sizeof(float);
-  auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN>;
+  auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, PS>;
   if (smem > 65536) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -417,7 +484,8 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool k32 = (p.C % 32 == 0);
   if (p.K <= 64) {
-    return k32 ? launch_conv<256, 64, 32, 4, 1>(p, s) : launch_conv<256, 64, 16, 4, 1>(p, s);
+    (void)k32;
+    return launch_conv<256, 64, 16, 4, 1>(p, s);
   }
   return k32 ? launch_conv<128, 128, 32, 2, 2>(p, s) : launch_conv<128, 128, 16, 2, 2>(p, s);
 }
