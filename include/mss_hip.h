@@ -218,6 +218,12 @@ int mss_rcl_finalize_f32(const MssRclArgs* a, const double* counters, const uint
 int mss_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* Calibration kernels (bench.py: achievable peaks of this device next to the datasheet ones).
+ * mss_peak_mfma_f32: blocks x 4 waves x iters x 16 back-to-back v_mfma_f32_32x32x2_f32 (4096 FLOP
+ * each), out >= blocks*256 floats. mss_peak_stream_f32: float4 copy of n floats (8*n bytes moved). */
+int mss_peak_mfma_f32(float* out, int blocks, int iters, void* stream);
+int mss_peak_stream_f32(const float* src, float* dst, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

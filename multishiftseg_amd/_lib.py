@@ -90,6 +90,8 @@ SIGNATURES = {
     "mss_rcl_pairs_device_f32": [P, P, P, P, I, L, U, U, F, P, I, F, P, P],
     "mss_rcl_finalize_f32": [POINTER(MssRclArgs), P, P, P, P],
     "mss_adam_step_f32": [P, P, P, P, L, F, F, F, F, F, I, P],
+    "mss_peak_mfma_f32": [P, I, I, P],
+    "mss_peak_stream_f32": [P, P, L, P],
 }
 # entry points that return a plain value rather than a status code
 _VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_rcl_num_compact_blocks"}

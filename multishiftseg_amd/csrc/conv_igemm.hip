@@ -98,7 +98,10 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
   // read a dummy valid address and are zeroed later); finish_store() runs AFTER the MFMA block of
   // the current step, applies the fused BatchNorm+ReLU prologue and writes the LDS tile. The loads'
   // latency is therefore covered by 64 MFMAs instead of stalling the wave 4x per step.
-  constexpr int S_LD = PER_SAMPLE ? A_LD : 1;   // one affine per staged row only for the Dropout2d fold
+  // PER_SAMPLE: the prologue affine differs per image (Dropout2d fold) AND a tile may straddle two
+  // images; then each staged row looks its affine up at LDS-write time. Otherwise one affine per
+  // tile (offset by the tile's image when in_ss_stride != 0) rides along with the early loads.
+  constexpr int S_LD = 1;
   f32x4 areg[A_LD], breg[B_LD], sreg[S_LD], hreg[S_LD];
   const float* a_ptr[A_LD];
   const float* b_ptr[B_LD];
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
   const float* h_ptr[S_LD];
   unsigned a_ok = 0;       // bit j: row j of this thread is inside the image for the current tap
   unsigned ld_ok = 0;      // a_ok of the step whose data sits in the staging registers
+  int ld_cc = 0;           // its first channel (per-sample lookup at write time)
   int ld_tap = -1, ld_c0 = 0, ld_left = live;
   const bool has_affine = p.in_scale != nullptr;
 
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
     if (has_affine) {
 #pragma unroll
       for (int j = 0; j < S_LD; ++j) {
-        const size_t so = (PER_SAMPLE ? (size_t)a_n[j] * p.in_ss_stride : 0) + chunk * 4;
+        const size_t so = (size_t)(m0 / ohw) * p.in_ss_stride + chunk * 4;   // image of the tile's first row
         s_ptr[j] = p.in_scale + so;
         h_ptr[j] = p.in_shift + so;
       }
@@ -148,6 +152,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
         hreg[j] = *reinterpret_cast<const f32x4*>(h_ptr[j]);
       }
     }
+    ld_cc = ld_c0 + chunk * 4;
     ld_ok = a_ok;
     // advance to the next K-step
     ld_c0 += BK;
@@ -170,7 +175,14 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       f32x4 val = areg[j];
-      if (has_affine) val = val * sreg[PER_SAMPLE ? j : 0] + hreg[PER_SAMPLE ? j : 0];
+      if (has_affine) {
+        if (PER_SAMPLE) {
+          const size_t so = (size_t)a_n[j] * p.in_ss_stride + ld_cc;
+          val = val * *reinterpret_cast<const f32x4*>(p.in_scale + so) + *reinterpret_cast<const f32x4*>(p.in_shift + so);
+        } else {
+          val = val * sreg[0] + hreg[0];
+        }
+      }
       if (p.in_relu) {
         val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f);
         val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
@@ -267,7 +279,8 @@ int launch_conv_t(MssConvArgs& p, hipStream_t stream);
 
 template <int BM, int BN, int BK, int WM, int WN>
 int launch_conv(MssConvArgs& p, hipStream_t stream) {
-  if (p.in_scale && p.in_ss_stride) return launch_conv_t<BM, BN, BK, WM, WN, true>(p, stream);
+  // a tile can only straddle two images when the image's pixel count is not a multiple of BM
+  if (p.in_scale && p.in_ss_stride && (p.OH * p.OW) % BM != 0) return launch_conv_t<BM, BN, BK, WM, WN, true>(p, stream);
   return launch_conv_t<BM, BN, BK, WM, WN, false>(p, stream);
 }
 
@@ -328,17 +341,26 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __rest
 // wgrad: dWp[tap][k][c] = sum_m dy[m][k] * act(x[m_tap][c])   (reduction over output pixels)
 // MFMA rows = k (output channels), columns = c (input channels), contraction = pixels.
 // Both operands sit in LDS as [pixel][channel] (their natural NHWC order) and are read with
-// ds_read_b32: lane (i = l&31, kk = l>>5) reads row kk, column i -> 32 consecutive floats.
+// ds_read_b32: lane (i = l&31, kk = l>>5) reads row kk, column i -> 32 consecutive floats, so any
+// row stride is conflict-free; the stride is a multiple of 4 floats so staging uses ds_write_b128.
+// Same in-wave pipeline as the forward kernel: loads for pixel block t+1 issued first, written to
+// LDS before the second-to-last chunk, one barrier before the last chunk.
 // Grid: (ktiles*ctiles, taps, splits); the pixel range is split across blockIdx.z and the
 // partial sums land in the zero-initialised dWp by fp32 atomics.
-template <int BKO, int BCI, int BP>
+template <int BKO, int BCI, int BP, bool LATE>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const float* __restrict__ dy, int lddy,
                                                         float* __restrict__ dwp, int Cp, int pix_per_split) {
-  constexpr int LDA = BKO + 1;  // dy tile  [BP][BKO]
-  constexpr int LDB = BCI + 1;  // x  tile  [BP][BCI]
+  constexpr int LDA = BKO + 4;  // dy tile  [BP][BKO]
+  constexpr int LDB = BCI + 4;  // x  tile  [BP][BCI]
   constexpr int TM = BKO / 2 / 32, TN = BCI / 2 / 32;  // 2x2 waves
-  __shared__ float As[2][BP][LDA];
-  __shared__ float Bs[2][BP][LDB];
+  constexpr int A_CPR = BKO / 4, B_CPR = BCI / 4;
+  constexpr int A_LD = BP * A_CPR / NT, B_LD = BP * B_CPR / NT;
+  constexpr int A_RPP = NT / A_CPR, B_RPP = NT / B_CPR;   // pixel rows covered per staging pass
+  constexpr int NKC = BP / 8;                             // chunks of 8 pixels = 4 MFMA k-steps
+  static_assert(A_LD >= 1 && B_LD >= 1 && NKC >= 2, "");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                    // [2][BP][LDA]
+  float* Bs = smem + 2 * BP * LDA;     // [2][BP][LDB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -360,97 +382,143 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  // staging: each thread moves float4 pieces; A tile BP x BKO, B tile BP x BCI
-  constexpr int A_CPR = BKO / 4, B_CPR = BCI / 4;
-  constexpr int A_LD = BP * A_CPR / NT, B_LD = BP * B_CPR / NT;
-  static_assert(A_LD >= 1 && B_LD >= 1, "");
-  f32x4 areg[A_LD], breg[B_LD];
+  // ---- per-thread staging descriptors: pointers advance by BP pixels per step; the pixel -> (n, y, x)
+  // decode (two integer divisions) is only redone when a row of this thread wraps to the next image row
+  const int a_ch = (tid % A_CPR) * 4, a_pr0 = tid / A_CPR;
+  const int b_ch = (tid % B_CPR) * 4, b_pr0 = tid / B_CPR;
+  const bool a_full = k0 + a_ch + 3 < p.K;          // whole float4 of output channels exists
+  const bool b_in = c0 + b_ch < p.C;
+  const float* a_ptr[A_LD];
+#pragma unroll
+  for (int j = 0; j < A_LD; ++j) a_ptr[j] = dy + (size_t)(mbeg + a_pr0 + j * A_RPP) * lddy + k0 + a_ch;
+  const size_t a_step = (size_t)BP * lddy;
+  const float* b_ptr[B_LD];
+  int b_n[B_LD], b_oy[B_LD], b_ox[B_LD], b_ix[B_LD];
+  unsigned b_rowok = 0;
+  auto place_row = [&](int j) {   // (n, oy, ox) -> source pointer / validity of the image row
+    const int iy = b_oy[j] * p.stride + dyo;
+    b_ix[j] = b_ox[j] * p.stride + dxo;
+    const bool ok = b_in && b_n[j] < p.N && (unsigned)iy < (unsigned)p.H;
+    b_rowok = (b_rowok & ~(1u << j)) | ((ok ? 1u : 0u) << j);
+    b_ptr[j] = ok ? p.x + ((size_t)(b_n[j] * p.H + iy) * p.W) * p.ldx + c0 + b_ch : p.x;
+  };
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int m = mbeg + b_pr0 + j * B_RPP;
+    const int n = m / ohw, rem = m - n * ohw;
+    b_n[j] = n; b_oy[j] = rem / p.OW; b_ox[j] = rem - b_oy[j] * p.OW;
+    place_row(j);
+  }
+  const bool has_affine = p.in_scale != nullptr;
+  f32x4 areg[A_LD], breg[B_LD], sreg[B_LD], hreg[B_LD];
+  unsigned ld_ok = 0;
+  int ld_m = mbeg;    // first pixel of the block the loader fetches next
 
-  auto load_global = [&](int mb) {
+  auto issue_loads = [&]() {
+    const bool tail = ld_m + BP > mend;   // block-uniform: only the last step of a split can be ragged
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      int e = tid + j * NT;
-      int pr = e / A_CPR, ch = (e % A_CPR) * 4;
-      int m = mb + pr;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (m < mend) {
-        const float* src = dy + (size_t)m * lddy + k0 + ch;
-        if (k0 + ch + 3 < p.K) val = *reinterpret_cast<const f32x4*>(src);
-        else {
-          if (k0 + ch + 0 < p.K) val.x = src[0];
-          if (k0 + ch + 1 < p.K) val.y = src[1];
-          if (k0 + ch + 2 < p.K) val.z = src[2];
-        }
+      const bool ok = !tail || ld_m + a_pr0 + j * A_RPP < mend;
+      const float* src = ok ? a_ptr[j] : dy;
+      f32x4 val;
+      if (a_full) val = *reinterpret_cast<const f32x4*>(src);
+      else {
+        val.x = k0 + a_ch + 0 < p.K ? src[0] : 0.f;
+        val.y = k0 + a_ch + 1 < p.K ? src[1] : 0.f;
+        val.z = k0 + a_ch + 2 < p.K ? src[2] : 0.f;
+        val.w = 0.f;
       }
-      areg[j] = val;
+      areg[j] = ok ? val : f32x4{0.f, 0.f, 0.f, 0.f};
+      a_ptr[j] += a_step;
     }
+    ld_ok = 0;
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
-      int e = tid + j * NT;
-      int pr = e / B_CPR, ch = (e % B_CPR) * 4;
-      int m = mb + pr;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (m < mend && c0 + ch < p.C) {
-        int n = m / ohw, rem = m - n * ohw;
-        int oy = rem / p.OW, ox = rem - oy * p.OW;
-        int iy = oy * p.stride + dyo, ix = ox * p.stride + dxo;
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-          const int cc = c0 + ch;
-          val = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(n * p.H + iy) * p.W + ix) * p.ldx + cc);
-          if (p.in_scale) {
-            const size_t so = (size_t)n * p.in_ss_stride + cc;
-            val = val * *reinterpret_cast<const f32x4*>(p.in_scale + so) +
-                  *reinterpret_cast<const f32x4*>(p.in_shift + so);
-          }
-          if (p.in_relu) {
-            val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f);
-            val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
-          }
-        }
+      const bool ok = ((b_rowok >> j) & 1) && (unsigned)b_ix[j] < (unsigned)p.W &&
+                      (!tail || ld_m + b_pr0 + j * B_RPP < mend);
+      ld_ok |= (ok ? 1u : 0u) << j;
+      const float* src = ok ? b_ptr[j] + (size_t)b_ix[j] * p.ldx : p.x;
+      breg[j] = *reinterpret_cast<const f32x4*>(src);
+      if (has_affine) {
+        const size_t so = (ok ? (size_t)b_n[j] * p.in_ss_stride + c0 + b_ch : 0);
+        sreg[j] = *reinterpret_cast<const f32x4*>(p.in_scale + so);
+        hreg[j] = *reinterpret_cast<const f32x4*>(p.in_shift + so);
       }
-      breg[j] = val;
+      // advance this row's pixel by BP for the next step
+      b_ox[j] += BP;
+      b_ix[j] += BP * p.stride;
+      if (b_ox[j] >= p.OW) {
+        do { b_ox[j] -= p.OW; b_oy[j] += 1; } while (b_ox[j] >= p.OW);
+        while (b_oy[j] >= p.OH) { b_oy[j] -= p.OH; b_n[j] += 1; }
+        place_row(j);
+      }
     }
+    ld_m += BP;
   };
-  auto store_lds = [&](int buf) {
+  auto finish_store = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < A_LD; ++j) {
-      int e = tid + j * NT;
-      int pr = e / A_CPR, ch = (e % A_CPR) * 4;
-      As[buf][pr][ch + 0] = areg[j].x; As[buf][pr][ch + 1] = areg[j].y;
-      As[buf][pr][ch + 2] = areg[j].z; As[buf][pr][ch + 3] = areg[j].w;
-    }
+    for (int j = 0; j < A_LD; ++j)
+      *reinterpret_cast<f32x4*>(&As[(buf * BP + a_pr0 + j * A_RPP) * LDA + a_ch]) = areg[j];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
-      int e = tid + j * NT;
-      int pr = e / B_CPR, ch = (e % B_CPR) * 4;
-      Bs[buf][pr][ch + 0] = breg[j].x; Bs[buf][pr][ch + 1] = breg[j].y;
-      Bs[buf][pr][ch + 2] = breg[j].z; Bs[buf][pr][ch + 3] = breg[j].w;
+      f32x4 val = breg[j];
+      if (has_affine) val = val * sreg[j] + hreg[j];
+      if (p.in_relu) {
+        val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f);
+        val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
+      }
+      if (!((ld_ok >> j) & 1)) val = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&Bs[(buf * BP + b_pr0 + j * B_RPP) * LDB + b_ch]) = val;
     }
   };
 
-  const int n_it = mend > mbeg ? (mend - mbeg + BP - 1) / BP : 0;
-  if (n_it > 0) { load_global(mbeg); store_lds(0); }
-  __syncthreads();
   const int fi = lane & 31, fk = lane >> 5;
-  for (int it = 0; it < n_it; ++it) {
-    const int buf = it & 1;
-    const bool more = it + 1 < n_it;
-    if (more) load_global(mbeg + (it + 1) * BP);
+  float fa[2][4][TM], fb[2][4][TN];
+  auto load_frags = [&](int set, int buf, int kc) {
 #pragma unroll
-    for (int kk = 0; kk < BP; kk += 2) {
-      float a[TM], b[TN];
+    for (int ks = 0; ks < 4; ++ks) {
+      const int row = buf * BP + kc * 8 + ks * 2 + fk;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[buf][kk + fk][wm * (BKO / 2) + i * 32 + fi];
+      for (int i = 0; i < TM; ++i) fa[set][ks][i] = As[row * LDA + wm * (BKO / 2) + i * 32 + fi];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk + fk][wn * (BCI / 2) + j * 32 + fi];
+      for (int j = 0; j < TN; ++j) fb[set][ks][j] = Bs[row * LDB + wn * (BCI / 2) + j * 32 + fi];
+    }
+  };
+  auto mfma_chunk = [&](int set) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][ks][i], fb[set][ks][j], acc[i][j], 0, 0, 0);
+  };
+
+  const int n_it = mend > mbeg ? (mend - mbeg + BP - 1) / BP : 0;
+  if (n_it > 0) { issue_loads(); finish_store(0); }
+  __syncthreads();
+  if (n_it > 0) load_frags(0, 0, 0);
+  for (int it = 0; it < n_it; ++it) {
+    const int buf = it & 1;
+    const bool more = it + 1 < n_it;
+    if (more) issue_loads();
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      if (kc + 1 < NKC) load_frags((kc + 1) & 1, buf, kc + 1);
+      if (!LATE) {
+        if (kc == NKC - 2 && more) finish_store(buf ^ 1);
+        if (kc == NKC - 1) {
+          __syncthreads();
+          if (more) load_frags(NKC & 1, buf ^ 1, 0);
+        }
+      }
+      mfma_chunk(kc & 1);
     }
-    if (more) store_lds(buf ^ 1);
-    __syncthreads();
+    if (LATE) {   // maximum global-load latency tolerance: stage after the whole MFMA block
+      if (more) finish_store(buf ^ 1);
+      __syncthreads();
+      if (more) load_frags(0, buf ^ 1, 0);
+    }
   }
 
   const int colq = lane & 31, rowq = 4 * (lane >> 5);
@@ -521,18 +589,36 @@ int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dw
   if (p.C % 4 || p.ldx % 4 || lddy % 4 || p.R * p.S > 9) return MSS_ERR_UNSUPPORTED;
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return MSS_OK;
-  constexpr int BKO = 128, BCI = 128, BP = 16;
+  constexpr int BKO = 128, BCI = 128, BP = 32;
   const int ktiles = mss_cdiv(p.K, BKO), ctiles = mss_cdiv(p.C, BCI), taps = p.R * p.S;
-  // enough pixel splits to give ~4 workgroups per CU
-  int base = ktiles * ctiles * taps;
-  int splits = (1024 + base - 1) / base;
+  // Pixel splits: 2 workgroups fit a CU (LDS), i.e. 512 run at once. Pick the smallest split count
+  // whose grid fills its last round of 512 to >= 95 % (a 1152-block grid runs 3 rounds for 2.25
+  // rounds of work); more splits only add atomic traffic on the [R*S][K][C] slab.
+  const int base = ktiles * ctiles * taps;
+  const int slots = 512;
   int max_splits = mss_cdiv(p.M, BP * 8);
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
+  if (max_splits > 64) max_splits = 64;
+  if (max_splits < 1) max_splits = 1;
+  int splits = 1;
+  double best = 0.0;
+  for (int sp = 1; sp <= max_splits; ++sp) {
+    const long long total = (long long)base * sp;
+    const double eff = (double)total / (double)(((total + slots - 1) / slots) * slots);
+    if (eff > best + 1e-9) { best = eff; splits = sp; }
+    if (eff >= 0.95 && total >= slots) break;
+  }
   int pps = mss_cdiv(mss_cdiv(p.M, splits), BP) * BP;
   splits = mss_cdiv(p.M, pps);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BKO, BCI, BP>), dim3(ktiles * ctiles, taps, splits), dim3(NT), 0,
-                     static_cast<hipStream_t>(stream), p, dy, lddy, dwp, Cp, pps);
+  const size_t smem = (size_t)2 * BP * (BKO + 4 + BCI + 4) * sizeof(float);
+  // LATE=true (stage after the whole MFMA block) and BP=16 were measured: within 1-4 % slower
+  auto kern = conv_wgrad_kernel<BKO, BCI, BP, false>;
+  if (smem > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3(ktiles * ctiles, taps, splits), dim3(NT), smem, static_cast<hipStream_t>(stream), p,
+                     dy, lddy, dwp, Cp, pps);
   return mss_launch_status();
 }
 

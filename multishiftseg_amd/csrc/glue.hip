@@ -250,24 +250,43 @@ __global__ void maxpool3s2_kernel(const float* __restrict__ x, int ldx, float* _
   }
 }
 
-// y[n][c] = mult * sum_p x[n][p][c]; grid (C/64, N), block 256 = 16 quads x 16 row lanes
+// y[n][c] += mult * sum_{p in split} x[n][p][c]; grid (C/64, N, splits), block 256 = 16 channel
+// quads x 16 row lanes; y is zeroed by the launcher and the splits combine with fp32 atomics, so a
+// [2,32768,4096] reduction runs on 4096 workgroups instead of 128.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
-                                                     int HW, int C, float mult) {
+                                                     int HW, int C, float mult, int rows_per_split) {
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = (blockIdx.x * 16 + tx) * 4;
   const int n = blockIdx.y;
+  const int p0 = blockIdx.z * rows_per_split, p1 = min(HW, p0 + rows_per_split);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (c < C) {
     const float* base = x + (long long)n * HW * ldx + c;
-    for (int p = ty; p < HW; p += 16) acc += ld4(base + (long long)p * ldx);
+    for (int p = p0 + ty; p < p1; p += 16) acc += ld4(base + (long long)p * ldx);
   }
   __shared__ f32x4 red[256];
   red[threadIdx.x] = acc;
   __syncthreads();
   if (ty == 0 && c < C) {
     for (int yy = 1; yy < 16; ++yy) acc += red[yy * 16 + tx];
-    st4(y + (long long)n * C + c, acc * mult);
+    float* o = y + (long long)n * C + c;
+    atomicAdd(o + 0, acc.x * mult); atomicAdd(o + 1, acc.y * mult);
+    atomicAdd(o + 2, acc.z * mult); atomicAdd(o + 3, acc.w * mult);
   }
+}
+
+inline int launch_colsum(const float* x, int ldx, float* y, int N, int HW, int C, float mult, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(y, 0, (size_t)N * C * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  const int gx = (C / 4 + 15) / 16;
+  int splits = 2048 / (gx * N > 0 ? gx * N : 1);
+  const int max_splits = (HW + 127) / 128;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int rps = (HW + splits - 1) / splits;
+  splits = (HW + rps - 1) / rps;
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, N, splits), dim3(256), 0, st, x, ldx, y, HW, C, mult, rps);
+  return mss_launch_status();
 }
 
 __global__ void broadcast_rows_kernel(const float* __restrict__ v, float* __restrict__ y, int ldy, int N, int HW,
@@ -420,6 +439,85 @@ __global__ __launch_bounds__(256) void ood_score_kernel(const float* __restrict_
         if (val > best || (val != val && best == best)) { best = val; arg = c; }  // first max; NaN wins like torch
       }
       if (label) label[i] = (uint8_t)arg;
+    }
+  }
+}
+
+// Tiled version for the up-sampling case (the only one on the path: x2): a workgroup owns a
+// TH x TW block of output pixels, stages the few half-resolution rows it needs in LDS with coalesced
+// loads (each source value is read from HBM/L2 once per tile instead of ~4x19 scattered 4-byte
+// loads per output pixel), computes -logsumexp once per SOURCE pixel, then interpolates from LDS and
+// writes score / NCHW logits / labels with 128 consecutive pixels per store instruction.
+template <int C, int TH, int TW>
+__global__ __launch_bounds__(256) void ood_score_tiled_kernel(const float* __restrict__ dec2, int ld2,
+                                                              const float* __restrict__ dec1, int ld1, int IH,
+                                                              int IW, int OH, int OW, float sh, float sw, int SRmax,
+                                                              int SCmax, float* __restrict__ score,
+                                                              float* __restrict__ logit, uint8_t* __restrict__ label) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* en = lds;                       // [SRmax*SCmax] energies
+  float* dv = lds + SRmax * SCmax;       // [SRmax*SCmax][C] staged channel vectors
+  const int n = blockIdx.z;
+  const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+  const int oy1 = min(oy0 + TH, OH) - 1, ox1 = min(ox0 + TW, OW) - 1;
+  const int r0 = ac_tap(oy0, sh, IH).i0, r1 = ac_tap(oy1, sh, IH).i1;
+  const int c0 = ac_tap(ox0, sw, IW).i0, c1 = ac_tap(ox1, sw, IW).i1;
+  const int SR = r1 - r0 + 1, SC = c1 - c0 + 1;   // <= SRmax, SCmax by construction
+  const int npix = SR * SC;
+  const long long nb = (long long)n * IH * IW;
+  auto stage = [&](const float* __restrict__ src, int ld) {
+    for (int idx = threadIdx.x; idx < npix * C; idx += 256) {
+      const int pix = idx / C, c = idx - pix * C;
+      const int rr = pix / SC, cc = pix - rr * SC;
+      dv[idx] = src[(nb + (long long)(r0 + rr) * IW + (c0 + cc)) * ld + c];
+    }
+  };
+  if (score) {
+    stage(dec2, ld2);
+    __syncthreads();
+    for (int pix = threadIdx.x; pix < npix; pix += 256) {
+      const float* q = dv + pix * C;
+      float m = -__builtin_huge_valf();
+#pragma unroll
+      for (int c = 0; c < C; ++c) m = fmaxf(m, q[c]);
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) s += expf(q[c] - m);
+      en[pix] = -(m + logf(s));
+    }
+    __syncthreads();
+  }
+  if (logit || label) {
+    stage(dec1, ld1);
+    __syncthreads();
+  }
+  const int tx = threadIdx.x % TW;
+  const int ox = ox0 + tx;
+  if (ox > ox1) return;
+  const Tap tapx = ac_tap(ox, sw, IW);
+  const int x0 = tapx.i0 - c0, x1 = tapx.i1 - c0;
+  const long long plane = (long long)OH * OW;
+  for (int ty = threadIdx.x / TW; ty < TH; ty += 256 / TW) {
+    const int oy = oy0 + ty;
+    if (oy > oy1) break;
+    const Tap tapy = ac_tap(oy, sh, IH);
+    const int p00 = (tapy.i0 - r0) * SC + x0, p01 = (tapy.i0 - r0) * SC + x1;
+    const int p10 = (tapy.i1 - r0) * SC + x0, p11 = (tapy.i1 - r0) * SC + x1;
+    const long long o = (long long)n * plane + (long long)oy * OW + ox;
+    if (score)
+      score[o] = tapy.l0 * (tapx.l0 * en[p00] + tapx.l1 * en[p01]) + tapy.l1 * (tapx.l0 * en[p10] + tapx.l1 * en[p11]);
+    if (logit || label) {
+      float best = -__builtin_huge_valf();
+      int arg = 0;
+      float* lo = logit ? logit + (long long)n * C * plane + (long long)oy * OW + ox : nullptr;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float val = tapy.l0 * (tapx.l0 * dv[p00 * C + c] + tapx.l1 * dv[p01 * C + c]) +
+                          tapy.l1 * (tapx.l0 * dv[p10 * C + c] + tapx.l1 * dv[p11 * C + c]);
+        if (lo) lo[c * plane] = val;
+        if (val > best || (val != val && best == best)) { best = val; arg = c; }
+      }
+      if (label) label[o] = (uint8_t)arg;
     }
   }
 }
@@ -627,15 +725,12 @@ int mss_maxpool3s2_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N, i
 
 int mss_gap_nhwc_f32(const float* x, int ldx, float* y, int N, int HW, int C, void* stream) {
   if (!x || !y || C % 4 || ldx % 4 || HW <= 0) return MSS_ERR_BAD_ARG;
-  hipLaunchKernelGGL(colsum_kernel, dim3((C / 4 + 15) / 16, N), dim3(256), 0, S_(stream), x, ldx, y, HW, C,
-                     1.f / (float)HW);
-  return mss_launch_status();
+  return launch_colsum(x, ldx, y, N, HW, C, 1.f / (float)HW, S_(stream));
 }
 
 int mss_colsum_nhwc_f32(const float* dy, int lddy, float* dv, int N, int HW, int C, void* stream) {
   if (!dy || !dv || C % 4 || lddy % 4 || HW <= 0) return MSS_ERR_BAD_ARG;
-  hipLaunchKernelGGL(colsum_kernel, dim3((C / 4 + 15) / 16, N), dim3(256), 0, S_(stream), dy, lddy, dv, HW, C, 1.f);
-  return mss_launch_status();
+  return launch_colsum(dy, lddy, dv, N, HW, C, 1.f, S_(stream));
 }
 
 int mss_broadcast_rows_nhwc_f32(const float* v, float* y, int ldy, int N, int HW, int C, const float* scale,
@@ -668,6 +763,18 @@ int mss_ood_score_f32(const float* dec2, int ld2, const float* dec1, int ld1, in
   if (score && !dec2) return MSS_ERR_BAD_ARG;
   if ((logit_nchw || label) && !dec1) return MSS_ERR_BAD_ARG;
   if ((long long)N * OH * OW == 0) return MSS_OK;
+  {
+    constexpr int TH = 8, TW = 128;
+    const float sh = ac_scale(IH, OH), sw = ac_scale(IW, OW);
+    const int SRmax = (int)((TH - 1) * sh) + 3, SCmax = (int)((TW - 1) * sw) + 3;
+    const size_t smem = (size_t)SRmax * SCmax * (19 + 1) * sizeof(float);
+    if (smem <= 48 * 1024 && N <= 65535) {   // up-sampling: the source footprint of a tile is small
+      hipLaunchKernelGGL((ood_score_tiled_kernel<19, TH, TW>), dim3((OW + TW - 1) / TW, (OH + TH - 1) / TH, N),
+                         dim3(256), smem, S_(stream), dec2, ld2, dec1, ld1, IH, IW, OH, OW, sh, sw, SRmax, SCmax, score,
+                         logit_nchw, label);
+      return mss_launch_status();
+    }
+  }
   hipLaunchKernelGGL(ood_score_kernel<19>, dim3(grid_for((long long)N * OH * OW, 256, 1 << 20)), dim3(256), 0,
                      S_(stream), dec2, ld2, dec1, ld1, N, IH, IW, OH, OW, ac_scale(IH, OH), ac_scale(IW, OW), score,
                      logit_nchw, label);

@@ -1,0 +1,55 @@
+// Calibration kernels: what THIS device sustains for the two rooflines the path is priced against.
+//   mss_peak_mfma_f32  : back-to-back v_mfma_f32_32x32x2_f32 on 4 independent accumulators, operands
+//                        in registers, one or two waves per SIMD -> achievable fp32 matrix rate
+//   mss_peak_stream_f32: float4 copy of a large buffer -> achievable HBM bandwidth
+// bench.py reports them next to the datasheet peaks (157.3 TFLOP/s, 8 TB/s).
+#include "mss_common.h"
+#include "../../include/mss_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void peak_mfma_kernel(float* __restrict__ out, int iters, float seed) {
+  f32x16 acc0, acc1, acc2, acc3;
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+  float a0 = seed + threadIdx.x * 1e-3f, a1 = a0 * 0.5f, b0 = seed - threadIdx.x * 1e-3f, b1 = b0 * 0.25f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc2, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc3, 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r] + acc2[r] + acc3[r];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void peak_stream_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst,
+                                                          long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+// out: at least blocks*256 floats. FLOPs performed = blocks * 4 waves * iters * 16 MFMAs * 4096.
+int mss_peak_mfma_f32(float* out, int blocks, int iters, void* stream) {
+  if (!out || blocks <= 0 || iters <= 0) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(peak_mfma_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), out, iters, 1.0f);
+  return mss_launch_status();
+}
+
+// copies n floats (n % 4 == 0); bytes moved = 8 * n.
+int mss_peak_stream_f32(const float* src, float* dst, long long n, void* stream) {
+  if (!src || !dst || n <= 0 || n % 4) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(peak_stream_kernel, dim3(256 * 8), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst), n / 4);
+  return mss_launch_status();
+}
+
+}  // extern "C"

@@ -105,6 +105,7 @@ class ConvProfile:
 
     def __init__(self):
         self.records = []   # (kind, flops, start_event, stop_event)
+        self.tags = []
 
     def summary(self):
         torch.cuda.synchronize()
@@ -117,6 +118,15 @@ class ConvProfile:
             d["ms"] += ms
         return out
 
+    def per_launch(self):
+        """[(kind, tag, ms, TFLOP/s)] in launch order (debugging aid: tools/layer_table.py)."""
+        torch.cuda.synchronize()
+        rows = []
+        for (kind, flops, s, e), tag in zip(self.records, self.tags):
+            ms = s.elapsed_time(e)
+            rows.append((kind, tag, ms, flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0))
+        return rows
+
 
 _profile = None
 
@@ -127,8 +137,8 @@ def set_conv_profile(prof):
 
 
 class _Timed:
-    def __init__(self, kind, flops):
-        self.kind, self.flops = kind, flops
+    def __init__(self, kind, flops, tag=None):
+        self.kind, self.flops, self.tag = kind, flops, tag
 
     def __enter__(self):
         if _profile is not None:
@@ -141,6 +151,7 @@ class _Timed:
         if _profile is not None:
             self.e.record()
             _profile.records.append((self.kind, self.flops, self.s, self.e))
+            _profile.tags.append(self.tag)
         return False
 
 
@@ -178,7 +189,8 @@ def conv2d(x, pw, stride=1, dil=1, pad=0, in_affine=None, in_relu=False, out_aff
     assert (out.N, out.H, out.W) == (x.N, OH, OW) and out.C >= pw.K
     a = _conv_args(x, pw, out, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res)
     a.OH, a.OW, a.ldy = OH, OW, out.ld
-    with _Timed("conv_igemm", 2.0 * x.N * OH * OW * pw.K * pw.C * pw.R * pw.S):
+    with _Timed("conv_igemm", 2.0 * x.N * OH * OW * pw.K * pw.C * pw.R * pw.S,
+                (x.N, x.H, x.W, pw.C, pw.K, pw.R, stride, dil)):
         call("mss_conv2d_forward_f32", ctypes.byref(a))
     return out
 
@@ -198,7 +210,7 @@ def conv2d_wgrad(x, dy, K, C, R, S, stride=1, dil=1, pad=0, in_affine=None, in_r
     a.OH, a.OW, a.K, a.Kpad = dy.H, dy.W, K, Kpad
     a.R, a.S, a.stride, a.dil, a.pad = R, S, stride, dil, pad
     a.in_relu = int(in_relu)
-    with _Timed("conv_wgrad", 2.0 * x.N * dy.H * dy.W * K * C * R * S):
+    with _Timed("conv_wgrad", 2.0 * x.N * dy.H * dy.W * K * C * R * S, (x.N, x.H, x.W, C, K, R, stride, dil)):
         call("mss_conv2d_wgrad_f32", ctypes.byref(a), dy.ptr, dy.ld, ptr(dwp), Cp)
     grad = torch.empty((K, C, R, S), device=x.buf.device, dtype=torch.float32)
     call("mss_conv2d_unpack_wgrad_f32", ptr(dwp), ptr(grad), K, C, R, S, Kpad, Cp, 0)

@@ -75,11 +75,18 @@ def test_conv_fusions(K):
     y = K.conv2d(xa, K.pack_weight(dev(wt)), pad=1, in_affine=(dev(sc), dev(sh)), in_relu=True,
                  out_affine=(dev(osc), dev(osh)), out_relu=True, res=ra)
     np.testing.assert_allclose(y.nchw().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
-    # per-sample affine (Dropout2d fold)
+    # per-sample affine (Dropout2d fold); 12x15 tiles straddle images, the 16x16 case below does not
     mask = (rng.random((n, c)) > 0.3).astype(np.float32) / 0.7
     act = np.maximum(x * (sc[None] * mask)[:, :, None, None] + (sh[None] * mask)[:, :, None, None], 0)
     ref = nnops.conv2d(act, wt, 1, 1, 1)
     y = K.conv2d(xa, K.pack_weight(dev(wt)), pad=1, in_affine=(dev(sc[None] * mask), dev(sh[None] * mask)), in_relu=True)
+    np.testing.assert_allclose(y.nchw().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    x2 = rng.standard_normal((3, c, 16, 16), dtype=np.float32)
+    mask2 = (rng.random((3, c)) > 0.5).astype(np.float32) / 0.5
+    act = np.maximum(x2 * (sc[None] * mask2)[:, :, None, None] + (sh[None] * mask2)[:, :, None, None], 0)
+    ref = nnops.conv2d(act, wt, 1, 1, 1)
+    y = K.conv2d(K.Act.from_nchw(dev(x2)), K.pack_weight(dev(wt)), pad=1,
+                 in_affine=(dev(sc[None] * mask2), dev(sh[None] * mask2)), in_relu=True)
     np.testing.assert_allclose(y.nchw().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
 
 
@@ -178,7 +185,7 @@ def test_ood_score_tail(K):
     n, h, w = 2, 13, 17
     d = rng.standard_normal((n, 48, h, w), dtype=np.float32) * 3
     da = K.Act.from_nchw(dev(d))
-    for (oh, ow) in [(26, 34), (25, 33), (13, 17)]:
+    for (oh, ow) in [(26, 34), (25, 33), (13, 17), (300, 270)]:   # tiled x2 path, odd sizes, identity (fallback), big ratio
         score, logit, label = K.ood_score(da.slice(20, 19), da.slice(0, 19), oh, ow, want_label=True)
         rs, rl = nnops.ood_score_tail(d[:, 20:39], d[:, 0:19], (oh, ow))
         np.testing.assert_allclose(score.cpu().numpy(), rs, rtol=1e-5, atol=1e-5)

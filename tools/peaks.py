@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Achievable fp32-MFMA and HBM-stream rates of the device (calibration for the rooflines)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multishiftseg_amd._lib import call, ptr
+
+
+def measure():
+    out = torch.empty(256 * 8 * 256, device="cuda")
+    res = {}
+    for waves_per_simd in (1, 2):
+        blocks, iters = 256 * waves_per_simd, 20000
+        call("mss_peak_mfma_f32", ptr(out), blocks, 200)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        call("mss_peak_mfma_f32", ptr(out), blocks, iters)
+        e.record()
+        torch.cuda.synchronize()
+        res[f"mfma_f32_tflops_{waves_per_simd}w"] = blocks * 4 * iters * 16 * 4096 / (s.elapsed_time(e) * 1e-3) / 1e12
+    n = 1 << 28   # 1 GiB source, 1 GiB destination: far beyond the 256 MiB Infinity Cache
+    a = torch.empty(n, device="cuda").normal_()
+    b = torch.empty(n, device="cuda")
+    call("mss_peak_stream_f32", ptr(a), ptr(b), n)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(5):
+        call("mss_peak_stream_f32", ptr(a), ptr(b), n)
+    e.record()
+    torch.cuda.synchronize()
+    res["stream_copy_GBs"] = 5 * 8.0 * n / (s.elapsed_time(e) * 1e-3) / 1e9
+    return res
+
+
+if __name__ == "__main__":
+    print(measure())
