@@ -20,12 +20,13 @@
 // for dilation 12/24/36 on /8 maps) are skipped with a block-uniform decision.
 #include "mss_common.h"
 #include "../../include/mss_hip.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int NT = 256;
 
-template <int BM, int BN, int BK, int WM, int WN, bool PER_SAMPLE>
+template <int BM, int BN, int BK, int WM, int WN, bool PER_SAMPLE, bool AFFINE>
 __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
   constexpr int LDK = BK + 4;            // +4 floats: ds_read_b128 of 16 distinct rows is conflict-free
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
   unsigned ld_ok = 0;      // a_ok of the step whose data sits in the staging registers
   int ld_cc = 0;           // its first channel (per-sample lookup at write time)
   int ld_tap = -1, ld_c0 = 0, ld_left = live;
-  const bool has_affine = p.in_scale != nullptr;
+  constexpr bool has_affine = AFFINE;
+  const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
 
   auto next_tap = [&]() {
     ld_tap = __ffs(ld_left) - 1;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
     }
   };
 
-  auto issue_loads = [&]() {
+  auto issue_loads = [&]() {   // straight-line: every pointer is always a valid address
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) areg[j] = *reinterpret_cast<const f32x4*>(a_ptr[j]);
 #pragma unroll
@@ -154,11 +156,12 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
     }
     ld_cc = ld_c0 + chunk * 4;
     ld_ok = a_ok;
-    // advance to the next K-step
-    ld_c0 += BK;
-    if (ld_c0 >= p.C) {
+  };
+  auto advance = [&]() {       // move the loader to the next K-step (stays put after the last one)
+    if (ld_c0 + BK >= p.C) {
       if (ld_left) next_tap();
     } else {
+      ld_c0 += BK;
 #pragma unroll
       for (int j = 0; j < A_LD; ++j)
         if ((a_ok >> j) & 1) a_ptr[j] += BK;
@@ -183,10 +186,8 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
           val = val * sreg[0] + hreg[0];
         }
       }
-      if (p.in_relu) {
-        val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f);
-        val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
-      }
+      val.x = fmaxf(val.x, relu_floor); val.y = fmaxf(val.y, relu_floor);
+      val.z = fmaxf(val.z, relu_floor); val.w = fmaxf(val.w, relu_floor);
       if (!((ld_ok >> j) & 1)) val = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(&As[(buf * BM + row0 + j * RPP) * LDK + chunk * 4]) = val;
     }
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
     next_tap();
     issue_loads();
     finish_store(0);
+    advance();
   }
   __syncthreads();
 
@@ -235,18 +237,21 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
   if (n_it > 0) load_frags(0, 0, 0);
   for (int it = 0; it < n_it; ++it) {
     const int buf = it & 1;
-    const bool more = it + 1 < n_it;
-    if (more) issue_loads();
+    // The body is branch-free so the scheduler may interleave loads, LDS traffic, prologue math and
+    // MFMAs freely: in the last step the loader re-reads its (still valid) last tile and stages it
+    // into the buffer nobody reads any more.
+    issue_loads();
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
       if (kc + 1 < NKC) load_frags((kc + 1) & 1, buf, kc + 1);
-      if (kc == NKC - 2 && more) finish_store(buf ^ 1);
+      if (kc == NKC - 2) finish_store(buf ^ 1);
       if (kc == NKC - 1) {
         __syncthreads();
-        if (more) load_frags(NKC & 1, buf ^ 1, 0);
+        load_frags(NKC & 1, buf ^ 1, 0);
       }
       mfma_chunk(kc & 1);
     }
+    advance();
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
@@ -274,23 +279,24 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool PS>
+template <int BM, int BN, int BK, int WM, int WN, bool PS, bool AFF>
 int launch_conv_t(MssConvArgs& p, hipStream_t stream);
 
 template <int BM, int BN, int BK, int WM, int WN>
 int launch_conv(MssConvArgs& p, hipStream_t stream) {
+  if (!p.in_scale) return launch_conv_t<BM, BN, BK, WM, WN, false, false>(p, stream);
   // a tile can only straddle two images when the image's pixel count is not a multiple of BM
-  if (p.in_scale && p.in_ss_stride && (p.OH * p.OW) % BM != 0) return launch_conv_t<BM, BN, BK, WM, WN, true>(p, stream);
-  return launch_conv_t<BM, BN, BK, WM, WN, false>(p, stream);
+  if (p.in_ss_stride && (p.OH * p.OW) % BM != 0) return launch_conv_t<BM, BN, BK, WM, WN, true, true>(p, stream);
+  return launch_conv_t<BM, BN, BK, WM, WN, false, true>(p, stream);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool PS>
+template <int BM, int BN, int BK, int WM, int WN, bool PS, bool AFF>
 int launch_conv_t(MssConvArgs& p, hipStream_t stream) {
   p.mtiles = mss_cdiv(p.M, BM);
   p.ntiles = mss_cdiv(p.K, BN);
   if (p.Kpad < p.ntiles * BN) return MSS_ERR_BAD_ARG;
   const size_t smem = ((size_t)2 * (BM + BN) * (BK + 4) + 4) * sizeof(float);
-  auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, PS>;
+  auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, PS, AFF>;
   if (smem > 65536) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -550,7 +556,12 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return MSS_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool k32 = (p.C % 32 == 0);
+  static int force_bk = -1;
+  if (force_bk < 0) { const char* e = getenv("MSS_CONV_BK"); force_bk = e ? atoi(e) : 0; }
+  // K-step: 16 (41 KB LDS, 144 registers -> 3 workgroups/CU, 3 waves/SIMD) is the faster choice except
+  // for the ASPP shape (4096 input channels, 256 output channels), where the 32-deep step wins
+  // (measured: 128 vs 119 TFLOP/s); MSS_CONV_BK=16|32 overrides for experiments.
+  const bool k32 = (p.C % 32 == 0) && (force_bk == 32 || (force_bk != 16 && p.C >= 2048 && p.K <= 256));
   if (p.K <= 64) {
     (void)k32;
     return launch_conv<256, 64, 16, 4, 1>(p, s);
