@@ -154,6 +154,23 @@ def main():
                      "kernel_ms_per_step": round(conv["ms"] / max(args.steps, 1), 2)},
         "step_tflops_algorithmic": round(step_flops_alg / (elapsed / args.steps) / 1e12, 2),
     }
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+    # they cannot be collected from inside this process); the summary of the last such run is kept in profiles/
+    tpath = os.path.join(ROOT, "profiles", "conv_traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            out["roofline"]["traffic"] = round(tj["hbm_bytes_per_launch"])
+            out["roofline"]["traffic_note"] = ("bytes per launch, L2-memory-side (Infinity-Cache hits included), from "
+                                               "profiles/conv_traffic_latest.json: " + tj["correction"])
+        except Exception:
+            pass
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import peaks
+        out["measured_peaks"] = {k: round(v, 1) for k, v in peaks.measure().items()}
+    except Exception as exc:   # calibration is informative only
+        out["measured_peaks"] = {"error": str(exc)}
     if wg:
         out["wgrad"] = {"achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                         "kernel_ms_per_step": round(wg["ms"] / max(args.steps, 1), 2)}

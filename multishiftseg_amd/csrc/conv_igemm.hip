@@ -353,7 +353,7 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __rest
 // LDS before the second-to-last chunk, one barrier before the last chunk.
 // Grid: (ktiles*ctiles, taps, splits); the pixel range is split across blockIdx.z and the
 // partial sums land in the zero-initialised dWp by fp32 atomics.
-template <int BKO, int BCI, int BP, bool LATE>
+template <int BKO, int BCI, int BP>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const float* __restrict__ dy, int lddy,
                                                         float* __restrict__ dwp, int Cp, int pix_per_split) {
   constexpr int LDA = BKO + 4;  // dy tile  [BP][BKO]
@@ -416,6 +416,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
     place_row(j);
   }
   const bool has_affine = p.in_scale != nullptr;
+  const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
   f32x4 areg[A_LD], breg[B_LD], sreg[B_LD], hreg[B_LD];
   unsigned ld_ok = 0;
   int ld_m = mbeg;    // first pixel of the block the loader fetches next
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       const bool ok = !tail || ld_m + a_pr0 + j * A_RPP < mend;
-      const float* src = ok ? a_ptr[j] : dy;
+      const float* src = ok ? a_ptr[j] : dy + k0 + a_ch;
       f32x4 val;
       if (a_full) val = *reinterpret_cast<const f32x4*>(src);
       else {
@@ -469,10 +470,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
     for (int j = 0; j < B_LD; ++j) {
       f32x4 val = breg[j];
       if (has_affine) val = val * sreg[j] + hreg[j];
-      if (p.in_relu) {
-        val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f);
-        val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
-      }
+      val.x = fmaxf(val.x, relu_floor); val.y = fmaxf(val.y, relu_floor);
+      val.z = fmaxf(val.z, relu_floor); val.w = fmaxf(val.w, relu_floor);
       if (!((ld_ok >> j) & 1)) val = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(&Bs[(buf * BP + b_pr0 + j * B_RPP) * LDB + b_ch]) = val;
     }
@@ -506,24 +505,18 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
   if (n_it > 0) load_frags(0, 0, 0);
   for (int it = 0; it < n_it; ++it) {
     const int buf = it & 1;
-    const bool more = it + 1 < n_it;
-    if (more) issue_loads();
+    // branch-free body (see the forward kernel): in the last step the loader runs past the split's
+    // end, where every row is masked to a dummy address, and stages zeros nobody reads
+    issue_loads();
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
       if (kc + 1 < NKC) load_frags((kc + 1) & 1, buf, kc + 1);
-      if (!LATE) {
-        if (kc == NKC - 2 && more) finish_store(buf ^ 1);
-        if (kc == NKC - 1) {
-          __syncthreads();
-          if (more) load_frags(NKC & 1, buf ^ 1, 0);
-        }
+      if (kc == NKC - 2) finish_store(buf ^ 1);
+      if (kc == NKC - 1) {
+        __syncthreads();
+        load_frags(NKC & 1, buf ^ 1, 0);
       }
       mfma_chunk(kc & 1);
-    }
-    if (LATE) {   // maximum global-load latency tolerance: stage after the whole MFMA block
-      if (more) finish_store(buf ^ 1);
-      __syncthreads();
-      if (more) load_frags(0, buf ^ 1, 0);
     }
   }
 
@@ -621,8 +614,8 @@ int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dw
   int pps = mss_cdiv(mss_cdiv(p.M, splits), BP) * BP;
   splits = mss_cdiv(p.M, pps);
   const size_t smem = (size_t)2 * BP * (BKO + 4 + BCI + 4) * sizeof(float);
-  // LATE=true (stage after the whole MFMA block) and BP=16 were measured: within 1-4 % slower
-  auto kern = conv_wgrad_kernel<BKO, BCI, BP, false>;
+  // staging after the whole MFMA block, and BP=16, were measured: within 1-4 % slower
+  auto kern = conv_wgrad_kernel<BKO, BCI, BP>;
   if (smem > 65536) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -56,11 +56,13 @@ class Act:
 
 
 class PackedWeight:
-    """[R*S][Kpad][Cp] layout consumed by the MFMA kernels."""
-    __slots__ = ("t", "K", "C", "R", "S", "Kpad", "Cp")
+    """[R*S][Kpad][Cp] layout consumed by the MFMA kernels. When the output-channel count leaves a
+    narrow last 128-wide tile (e.g. 304 = 2*128 + 48, the data gradient of final.0), `tail` holds
+    those channels as a separate pack that runs on the 64-wide tile instead of wasting 2/3 of a tile."""
+    __slots__ = ("t", "K", "C", "R", "S", "Kpad", "Cp", "tail")
 
-    def __init__(self, t, K, C, R, S, Kpad, Cp):
-        self.t, self.K, self.C, self.R, self.S, self.Kpad, self.Cp = t, K, C, R, S, Kpad, Cp
+    def __init__(self, t, K, C, R, S, Kpad, Cp, tail=None):
+        self.t, self.K, self.C, self.R, self.S, self.Kpad, self.Cp, self.tail = t, K, C, R, S, Kpad, Cp, tail
 
 
 def _round_up(v, m):
@@ -77,6 +79,15 @@ def pack_weight(w, flip=False, min_c=16):
         k_out, c_in = K, C
     else:
         k_out, c_in = C, K
+    rem = k_out % 128
+    if k_out > 128 and 0 < rem <= 64:
+        split = k_out - rem
+        if not flip:
+            main, tail = pack_weight(w[:split], flip, min_c), pack_weight(w[split:], flip, min_c)
+        else:
+            main, tail = pack_weight(w[:, :split], flip, min_c), pack_weight(w[:, split:], flip, min_c)
+        main.tail = tail
+        return main
     Kpad = _lib.value("mss_conv2d_kpad", k_out)
     Cp = _round_up(max(c_in, min_c), 16)
     t = torch.empty((R * S, Kpad, Cp), device=w.device, dtype=torch.float32)
@@ -184,15 +195,31 @@ def conv2d(x, pw, stride=1, dil=1, pad=0, in_affine=None, in_relu=False, out_aff
     assert x.C == pw.Cp or (x.C >= pw.C and x.C <= pw.Cp and x.c0 + pw.Cp <= x.ld), (x.C, pw.C, pw.Cp)
     OH = conv_out_size(x.H, pw.R, stride, dil, pad)
     OW = conv_out_size(x.W, pw.S, stride, dil, pad)
+    k_total = pw.K + (pw.tail.K if pw.tail is not None else 0)
     if out is None:
-        out = Act.empty(x.N, OH, OW, pw.K, x.buf.device, ld=_round_up(pw.K, 4))
-    assert (out.N, out.H, out.W) == (x.N, OH, OW) and out.C >= pw.K
+        out = Act.empty(x.N, OH, OW, k_total, x.buf.device, ld=_round_up(k_total, 4))
+    assert (out.N, out.H, out.W) == (x.N, OH, OW) and out.C >= k_total
+    if pw.tail is not None:
+        def sub(t, lo, n):
+            return None if t is None else t[lo:lo + n]
+        conv2d(x, pw.tail, stride, dil, pad, in_affine, in_relu,
+               None if out_affine is None else (sub(out_affine[0], pw.K, pw.tail.K), sub(out_affine[1], pw.K, pw.tail.K)),
+               out_relu, None if res is None else res.slice(pw.K, pw.tail.K), out=out.slice(pw.K, pw.tail.K))
+        out_affine = None if out_affine is None else (sub(out_affine[0], 0, pw.K), sub(out_affine[1], 0, pw.K))
+        res = None if res is None else res.slice(0, pw.K)
+        out_main = out.slice(0, pw.K)
+        _conv_launch(x, pw, out_main, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res)
+        return out
+    _conv_launch(x, pw, out, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res)
+    return out
+
+
+def _conv_launch(x, pw, out, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res):
     a = _conv_args(x, pw, out, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res)
     a.OH, a.OW, a.ldy = OH, OW, out.ld
     with _Timed("conv_igemm", 2.0 * x.N * OH * OW * pw.K * pw.C * pw.R * pw.S,
                 (x.N, x.H, x.W, pw.C, pw.K, pw.R, stride, dil)):
         call("mss_conv2d_forward_f32", ctypes.byref(a))
-    return out
 
 
 def conv2d_wgrad(x, dy, K, C, R, S, stride=1, dil=1, pad=0, in_affine=None, in_relu=False):

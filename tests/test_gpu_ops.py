@@ -45,6 +45,7 @@ def test_conv_classes_golden(K):
     (128, 256, 3, 1, 12, 1, 16, 32),    # ASPP rate 12 on a small map: dead taps
     (128, 64, 3, 1, 36, 2, 16, 16),     # rate 36: only the centre tap is live
     (512, 19 + 29, 1, 1, 1, 2, 9, 7),   # heads-like K = 48
+    (64, 304, 3, 1, 1, 1, 12, 10),      # K = 2*128 + 48: main + narrow tail launch
 ])
 def test_conv_vs_oracle(K, cin, cout, r, stride, dil, n, h, w):
     rng = np.random.default_rng(cin * 7 + cout)
