@@ -593,13 +593,13 @@ int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dw
   if (p.C % 4 || p.ldx % 4 || lddy % 4 || p.R * p.S > 9) return MSS_ERR_UNSUPPORTED;
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return MSS_OK;
-  constexpr int BKO = 128, BCI = 128, BP = 32;
+  constexpr int BKO = 128, BCI = 128, BP = 16;
   const int ktiles = mss_cdiv(p.K, BKO), ctiles = mss_cdiv(p.C, BCI), taps = p.R * p.S;
   // Pixel splits: 2 workgroups fit a CU (LDS), i.e. 512 run at once. Pick the smallest split count
   // whose grid fills its last round of 512 to >= 95 % (a 1152-block grid runs 3 rounds for 2.25
   // rounds of work); more splits only add atomic traffic on the [R*S][K][C] slab.
   const int base = ktiles * ctiles * taps;
-  const int slots = 512;
+  const int slots = 768;   // 3 workgroups per CU (34 KB LDS, 154 registers)
   int max_splits = mss_cdiv(p.M, BP * 8);
   if (max_splits > 64) max_splits = 64;
   if (max_splits < 1) max_splits = 1;
