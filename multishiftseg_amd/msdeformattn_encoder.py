@@ -1,0 +1,136 @@
+"""The callers of the MSDeformAttn op inside Mask2Former's pixel decoder.
+
+Host-side mirror of ``MSDeformAttnTransformerEncoderOnly`` / ``...EncoderLayer`` / ``...Encoder``
+(lib/network/mask2former/modeling/pixel_decoder/msdeformattn.py:21-153) and of
+``PositionEmbeddingSine`` (modeling/transformer_decoder/position_encoding.py:13-52): same class and
+parameter names (``encoder.layers.N.self_attn.sampling_offsets.weight``, ``level_embed`` ...), so the
+encoder slice of a Mask2Former checkpoint loads unchanged, and the same op inputs: level order as
+given (res5 -> res3 in the decoder, msdeformattn.py:319), ``spatial_shapes`` int64 [L,2],
+``level_start_index``, reference points at pixel centres. The detectron2-dependent shell around it
+(``MSDeformAttnPixelDecoder``: input_proj convs + GroupNorm, FPN) is out of scope.
+
+The attention itself is the HIP op (multishiftseg_amd.ms_deform_attn.MSDeformAttn); LayerNorm and the
+FFN Linears are library ops. Masks are all-False in the reference (msdeformattn.py:62), so valid
+ratios are 1 and are folded away here.
+"""
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .ms_deform_attn import MSDeformAttn
+
+
+class PositionEmbeddingSine(nn.Module):
+    """Sine/cosine position code over a [N,C,H,W] map (position_encoding.py:13-52), mask-free."""
+
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        super().__init__()
+        if scale is not None and normalize is False:
+            raise ValueError("normalize should be True if scale is passed")
+        self.num_pos_feats, self.temperature, self.normalize = num_pos_feats, temperature, normalize
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def forward(self, x, mask=None):
+        n, _, h, w = x.shape
+        ys = torch.arange(1, h + 1, dtype=torch.float32, device=x.device)
+        xs = torch.arange(1, w + 1, dtype=torch.float32, device=x.device)
+        if self.normalize:
+            eps = 1e-6
+            ys = ys / (ys[-1] + eps) * self.scale
+            xs = xs / (xs[-1] + eps) * self.scale
+        i = torch.arange(self.num_pos_feats, dtype=torch.float32, device=x.device)
+        dim_t = self.temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / self.num_pos_feats)
+
+        def code(v):                              # [len] -> [len, num_pos_feats], sin on even / cos on odd slots
+            p = v[:, None] / dim_t
+            return torch.stack((p[:, 0::2].sin(), p[:, 1::2].cos()), dim=2).flatten(1)
+        py = code(ys)[:, None, :].expand(h, w, -1)
+        px = code(xs)[None, :, :].expand(h, w, -1)
+        return torch.cat((py, px), dim=2).permute(2, 0, 1)[None].expand(n, -1, -1, -1).contiguous()
+
+
+class MSDeformAttnTransformerEncoderLayer(nn.Module):
+    """self-attention (deformable) + FFN, post-norm (msdeformattn.py:92-131)."""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = {"relu": F.relu, "gelu": F.gelu, "glu": F.glu}[activation]
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        q = src if pos is None else src + pos
+        src = self.norm1(src + self.dropout1(
+            self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)))
+        ffn = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        return self.norm2(src + self.dropout3(ffn))
+
+
+class MSDeformAttnTransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        """Pixel centres ((x+0.5)/W, (y+0.5)/H) of every query's own level, shared by all target
+        levels (msdeformattn.py:140-153) -> [N, sum(HW), L, 2]."""
+        pts = []
+        for lvl, (h, w) in enumerate(spatial_shapes.tolist()):
+            ys = (torch.arange(h, dtype=torch.float32, device=device) + 0.5)
+            xs = (torch.arange(w, dtype=torch.float32, device=device) + 0.5)
+            gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+            ry = gy.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * h)
+            rx = gx.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * w)
+            pts.append(torch.stack((rx, ry), -1))
+        ref = torch.cat(pts, 1)
+        return ref[:, :, None] * valid_ratios[:, None]
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None):
+        ref = self.get_reference_points(spatial_shapes, valid_ratios, src.device)
+        out = src
+        for layer in self.layers:
+            out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask)
+        return out
+
+
+class MSDeformAttnTransformerEncoderOnly(nn.Module):
+    """Flattens the multi-scale maps, builds the op's index tensors and runs the encoder
+    (msdeformattn.py:21-89)."""
+
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, dim_feedforward=1024, dropout=0.1,
+                 activation="relu", num_feature_levels=4, enc_n_points=4):
+        super().__init__()
+        self.d_model, self.nhead = d_model, nhead
+        layer = MSDeformAttnTransformerEncoderLayer(d_model, dim_feedforward, dropout, activation,
+                                                    num_feature_levels, nhead, enc_n_points)
+        self.encoder = MSDeformAttnTransformerEncoder(layer, num_encoder_layers)
+        self.level_embed = nn.Parameter(torch.empty(num_feature_levels, d_model))
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        nn.init.normal_(self.level_embed)
+
+    def forward(self, srcs, pos_embeds):
+        shapes = [(s.shape[2], s.shape[3]) for s in srcs]
+        src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
+                         for lvl, p in enumerate(pos_embeds)], 1)
+        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src.device)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        valid_ratios = torch.ones((src.shape[0], len(shapes), 2), dtype=torch.float32, device=src.device)
+        memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, None)
+        return memory, spatial_shapes, level_start_index

@@ -346,6 +346,57 @@ def gen_msda(core, MSDeformAttn):
          **{"b_" + k: np.asarray(v) for k, v in sd.items() if np.asarray(v).ndim == 1})
 
 
+def import_reference_encoder():
+    """msdeformattn.py imports detectron2 / fvcore (absent, un-vendored) at module level only for the
+    pixel-decoder shell below the encoder classes. Stub those third-party names (never the reference)
+    and load the file through a synthetic package whose __path__ points at the real directories, so
+    the reference's own __init__ chains (which need detectron2 everywhere) are not executed."""
+    import importlib
+    base = os.path.join(REF, "lib/network/mask2former/modeling")
+    for name, attrs in {
+        "fvcore": {}, "fvcore.nn": {}, "fvcore.nn.weight_init": {},
+        "detectron2": {}, "detectron2.config": {"configurable": lambda f=None, **k: f if f is not None else (lambda g: g)},
+        "detectron2.layers": {"Conv2d": torch.nn.Conv2d, "ShapeSpec": object, "get_norm": lambda *a, **k: None},
+        "detectron2.modeling": {"SEM_SEG_HEADS_REGISTRY": types.SimpleNamespace(register=lambda: (lambda c: c))},
+    }.items():
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            sys.modules[name] = m
+    for name, sub in {"m2fref": "", "m2fref.pixel_decoder": "pixel_decoder", "m2fref.transformer_decoder": "transformer_decoder"}.items():
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(base, sub)]
+        sys.modules[name] = m
+    mod = importlib.import_module("m2fref.pixel_decoder.msdeformattn")
+    pe = importlib.import_module("m2fref.transformer_decoder.position_encoding")
+    return mod.MSDeformAttnTransformerEncoderOnly, pe.PositionEmbeddingSine
+
+
+def gen_encoder():
+    """a-11: the reference's encoder-only transformer (2 layers) on 3 levels, CPU, eval mode."""
+    Enc, PE = import_reference_encoder()
+    torch.manual_seed(51)
+    enc = Enc(d_model=256, nhead=8, num_encoder_layers=2, dim_feedforward=1024, dropout=0.0, activation="relu",
+              num_feature_levels=3, enc_n_points=4).eval()
+    sd = {}
+    for k, v in enc.state_dict().items():
+        if k.endswith("sampling_offsets.bias"):
+            sd[k] = v.clone()                                   # keep the ring initialisation
+        else:
+            sd[k] = torch.from_numpy(synth.gen_tensor(9, "m2fenc." + k, tuple(v.shape), gain=1.0))
+    enc.load_state_dict(sd)
+    rng = np.random.default_rng(52)
+    shapes = [(4, 5), (8, 10), (16, 20)]
+    srcs = [rng.standard_normal((1, 256, h, w), dtype=np.float32) for h, w in shapes]
+    pe = PE(128, normalize=True)
+    pos = [pe(torch.from_numpy(s)) for s in srcs]
+    with torch.no_grad():
+        memory, spatial_shapes, starts = enc([torch.from_numpy(s) for s in srcs], pos)
+    save("m2f_encoder", memory=t2n(memory), spatial_shapes=t2n(spatial_shapes), starts=t2n(starts),
+         pos0=t2n(pos[0]), pos2_sub=t2n(pos[2])[:, ::16], seed=np.int64(52),
+         names=np.array(list(sd.keys())), offsets_bias=t2n(sd["encoder.layers.0.self_attn.sampling_offsets.bias"]))
+
+
 def gen_m2f():
     """train_m2f.py:387-407 cannot be imported (detectron2 absent); its five lines of torch
     arithmetic are evaluated here verbatim on random inputs."""
@@ -361,7 +412,7 @@ def gen_m2f():
 
 
 def main():
-    which = set(sys.argv[1:]) or {"ops", "deeplab", "train", "loss", "msda", "m2f"}
+    which = set(sys.argv[1:]) or {"ops", "deeplab", "train", "loss", "msda", "m2f", "encoder"}
     torch.set_num_threads(8)
     DeepWV3Plus, ref_loss, core, MSDeformAttn = import_reference()
     if "ops" in which:
@@ -370,6 +421,8 @@ def main():
         print("msda"); gen_msda(core, MSDeformAttn)
     if "m2f" in which:
         print("m2f"); gen_m2f()
+    if "encoder" in which:
+        print("encoder"); gen_encoder()
     if "loss" in which:
         print("loss"); gen_loss(ref_loss)
     if "deeplab" in which:

@@ -65,5 +65,26 @@ def main():
                               fwd_GBs=round(byt / ms_f / 1e6, 1))), flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def encoder_bench():
+    """C4: the 6-layer MSDeformAttn encoder of the pixel decoder (msdeformattn.py:21-153), 704^2 crops."""
+    from multishiftseg_amd.msdeformattn_encoder import MSDeformAttnTransformerEncoderOnly, PositionEmbeddingSine
+    enc = MSDeformAttnTransformerEncoderOnly(256, 8, 6, 1024, 0.0, "relu", 3, 4).cuda()
+    pe = PositionEmbeddingSine(128, normalize=True)
+    for N in (1, 16):
+        srcs = [torch.randn(N, 256, h, w, device="cuda", requires_grad=True) for h, w in ((22, 22), (44, 44), (88, 88))]
+        pos = [pe(s) for s in srcs]
+        with torch.no_grad():
+            ms_f = timeit(lambda: enc(srcs, pos), iters=5, warm=2)
+        def fb():
+            m, _, _ = enc(srcs, pos)
+            m.sum().backward()
+        ms_fb = timeit(fb, iters=5, warm=2)
+        print(json.dumps(dict(kernel="msda_encoder_6layers", N=N, fwd_ms=round(ms_f, 3), fwd_bwd_ms=round(ms_fb, 3))), flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "encoder":
+    encoder_bench()

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""HBM-bound kernels of the path at their BASELINE sizes: achieved GB/s of algorithmic bytes."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multishiftseg_amd import kernels as K, synth
+from multishiftseg_amd.loss import RelContrastiveLoss
+from multishiftseg_amd.trainer import LOSS_PARAMS
+from tools.microbench import timeit
+
+
+def row(name, ms, nbytes, note=""):
+    print(json.dumps(dict(kernel=name, ms=round(ms, 4), alg_MB=round(nbytes / 1e6, 1), GBs=round(nbytes / ms / 1e6, 1), note=note)), flush=True)
+
+
+def main():
+    dev = "cuda"
+    # OOD-score tail at 2x1024x2048 (train) : dec 48-wide half-res -> score + logits
+    for n, H, W in ((1, 1024, 2048), (2, 1024, 2048)):
+        dec = K.Act(torch.randn(n, H // 2, W // 2, 48, device=dev))
+        ms = timeit(lambda: K.ood_score(dec.slice(20, 19), dec.slice(0, 19), H, W))
+        row(f"ood_score score+logit {n}x{H}x{W}", ms, n * H * W * (2 * 19 * 4 / 4 + 4 + 19 * 4))
+        ms = timeit(lambda: K.ood_score(dec.slice(20, 19), None, H, W, want_logit=False))
+        row(f"ood_score score only {n}x{H}x{W}", ms, n * H * W * 23.0, "23 B/px")
+    # M2F score, C5: cls [1,100,20], mask [1,100,1024,2048]
+    cls = torch.randn(1, 100, 20, device=dev)
+    mask = torch.randn(1, 100, 1024, 2048, device=dev)
+    ms = timeit(lambda: K.m2f_score(cls, mask, (1024, 2048)), iters=5)
+    row("m2f_score 1x100x1024x2048", ms, 1024 * 2048 * 404.0, "404 B/px")
+    del mask
+    # fused loss fwd+bwd at C3 (2x1024x2048) and C2 (16x768x768)
+    for B, H, W in ((2, 1024, 2048), (16, 768, 768)):
+        logits = (torch.randn(B, 19, H, W, device=dev) * 3).requires_grad_(True)
+        score = (torch.randn(B, H, W, device=dev) * 4).requires_grad_(True)
+        tgt = torch.from_numpy(synth.synth_targets(3, B // 2, H, W)).to(dev)
+        crit = RelContrastiveLoss(LOSS_PARAMS, pairing="device")
+        def f():
+            crit(logits, score, tgt.clone())
+        ms = timeit(f, iters=5)
+        row(f"rel_contrastive_loss value+grads {B}x19x{H}x{W}", ms, B * H * W * 168.0, "168 B/px minimum")
+    # BN statistics + maxpool + upsample at train sizes
+    x = K.Act(torch.randn(2, 512, 1024, 128, device=dev))
+    acc = torch.zeros(256, device=dev, dtype=torch.float64)
+    from multishiftseg_amd._lib import call, ptr
+    ms = timeit(lambda: call("mss_bn_stats_nhwc_f32", x.ptr, x.M, 128, x.ld, ptr(acc)))
+    row("bn_stats 2x512x1024x128", ms, x.M * 128 * 4.0)
+    x1 = K.Act(torch.randn(2, 1024, 2048, 64, device=dev))
+    ms = timeit(lambda: K.maxpool3s2(x1))
+    row("maxpool3s2 2x1024x2048x64", ms, x1.M * 64 * 4.0 * 1.25)
+    u = K.Act(torch.randn(2, 128, 256, 256, device=dev))
+    ms = timeit(lambda: K.upsample_ac(u, 512, 1024))
+    row("upsample_ac 2x128x256x256 -> 512x1024", ms, 2 * 512 * 1024 * 256 * 4.0 * (1 + 1 / 16))
+    g = K.Act(torch.randn(2, 512, 1024, 256, device=dev))
+    ms = timeit(lambda: K.upsample_ac_bwd(g, 128, 256))
+    row("upsample_ac_bwd 2x512x1024x256 -> 128x256", ms, 2 * 512 * 1024 * 256 * 4.0 * (1 + 1 / 16))
+    xx = K.Act(torch.randn(2, 128, 256, 4096, device=dev))
+    ms = timeit(lambda: K.gap(xx))
+    row("gap 2x128x256x4096", ms, xx.M * 4096 * 4.0)
+
+
+if __name__ == "__main__":
+    main()
