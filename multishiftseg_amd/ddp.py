@@ -103,12 +103,14 @@ def init_from_env():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(local_rank % ndev)
+        device = torch.device("cuda", local_rank % ndev)
         backend = "nccl"
     else:
         device = torch.device("cpu")
         backend = "gloo"
+    backend = os.environ.get("MSS_DIST_BACKEND", backend)   # tests: gloo with several ranks on one GPU
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
