@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_float, c_int, c_longlong, c_uint32, c_v
 import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so libmss_hip.so binds to the same runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmss_hip.so")
+LIB_PATH = os.environ.get("MSS_LIB", os.path.join(_HERE, "libmss_hip.so"))   # MSS_LIB: A/B experiments only
 
 MSS_ERR_BAD_ARG = 1001
 MSS_ERR_UNSUPPORTED = 1002
