@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny"],
                     help="c3: 1 pair of 1024x2048 per GPU; c2: 8 pairs of 768x768 (exps/DeepLab.yaml batch 8); tiny: smoke")
     ap.add_argument("--stage", type=int, default=2, choices=[1, 2])
+    ap.add_argument("--loss-sync", default="local", choices=["local", "global"],
+                    help="local: per-rank loss (no loss collectives); global: reference semantics over all ranks' pairs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ood", action="store_true")
     args = ap.parse_args()
@@ -90,7 +92,8 @@ def main():
     del params
     model = model.to(device)
     model.uncertainty_func_init()
-    crit = RelContrastiveLoss(LOSS_PARAMS, pairing="device", seed=1000 + rank)
+    crit = RelContrastiveLoss(LOSS_PARAMS, pairing="device", seed=1000 + (rank if args.loss_sync == "local" else 0),
+                              sync=args.loss_sync)
     step = TrainStep(model, crit, stage=args.stage)
 
     gen = torch.Generator(device=device)
@@ -145,7 +148,7 @@ def main():
         "config": {"workload": f"{args.workload}: {2 * pairs} images ({pairs} orig+aug pair(s)) of {H}x{W} per GPU, "
                                f"stage-{args.stage} trainable set, train-mode BN/Dropout2d on the frozen trunk",
                    "images_per_gpu": 2 * pairs, "height": H, "width": W, "stage": args.stage,
-                   "parallelism": f"dp{world}", "loss_pairing": "device", "loss": round(loss_val, 4)},
+                   "parallelism": f"dp{world}", "loss_pairing": "device", "loss_sync": args.loss_sync, "loss": round(loss_val, 4)},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32)",
                      "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,

@@ -185,6 +185,13 @@ int mss_rcl_pass1_f32(const MssRclArgs* a, float* lse, float* ce_aug, uint8_t* k
  * = {threshold key, n_less, k, n_equal_to_take, tie tickets, ...}. */
 int mss_rcl_select_f32(const float* ce_aug, long long n, const double* counters, float selection_ratio,
                        uint32_t* hist_ws, uint32_t* sel, void* stream);
+/* the same selection one radix pass at a time (shift = 24, 16, 8, 0): a data-parallel caller
+ * all-reduces the 256-bin histogram between hist and pick -> exact GLOBAL k-th smallest. */
+int mss_rcl_select_init_f32(const double* counters, float selection_ratio, uint32_t* hist_ws, uint32_t* sel,
+                            void* stream);
+int mss_rcl_select_hist_f32(const float* ce_aug, long long n, const uint32_t* sel, int shift, uint32_t* hist_ws,
+                            void* stream);
+int mss_rcl_select_pick_f32(uint32_t* sel, uint32_t* hist_ws, int shift, void* stream);
 /* pass2: dlogit (NCHW, assigned; may be NULL) = grad_scale * d loss / d logit, target mutation,
  * counters[7..8]. */
 int mss_rcl_pass2_f32(const MssRclArgs* a, const float* lse, const float* ce_aug, const uint8_t* kind,
@@ -210,6 +217,16 @@ int mss_rcl_pairs_f32(const float* score, const int32_t* idx_a, const int64_t* p
 int mss_rcl_pairs_device_f32(const float* score, const int32_t* idx_a, const int32_t* idx_o, const uint32_t* n_out,
                              int set_a, long long max_samples, uint32_t seed_a, uint32_t seed_o, float margin,
                              double* counters, int slot, float grad_w, float* dscore, void* stream);
+/* data-parallel pairing over the rank-major concatenation of all ranks' sets: this rank owns the
+ * slice [a_off, a_off+a_cnt_local) of global set A (a_cnt_global elements); ood_all is the
+ * all-gathered [W][cap] OOD score vector with exclusive global offsets ood_off[W+1]; gradients w.r.t.
+ * OOD scores are accumulated into g_ood [W][cap] (the caller all-reduces it and scatters its row). */
+int mss_rcl_pairs_global_f32(const float* score, const int32_t* idx_a, uint32_t a_off, uint32_t a_cnt_local,
+                             uint32_t a_cnt_global, const float* ood_all, const uint32_t* ood_off, int W,
+                             uint32_t cap, uint32_t n_pairs, uint32_t seed_a, uint32_t seed_o, float margin,
+                             double* counters, int slot, float coef, float* dscore, float* g_ood, void* stream);
+int mss_rcl_gather_f32(const float* src, const int32_t* idx, uint32_t n, float* dst, void* stream);
+int mss_rcl_scatter_add_f32(const float* g, const int32_t* idx, uint32_t n, float* dst, void* stream);
 /* out: float[8] = {loss, ce_orig, ce_aug, c_orig, c_aug, c_in, -, -} (loss.py:73-88,147). */
 int mss_rcl_finalize_f32(const MssRclArgs* a, const double* counters, const uint32_t* sel, float* out,
                          void* stream);

@@ -89,6 +89,12 @@ SIGNATURES = {
     "mss_rcl_pairs_f32": [P, P, P, P, P, L, F, P, I, F, P, P],
     "mss_rcl_pairs_device_f32": [P, P, P, P, I, L, U, U, F, P, I, F, P, P],
     "mss_rcl_finalize_f32": [POINTER(MssRclArgs), P, P, P, P],
+    "mss_rcl_select_init_f32": [P, F, P, P, P],
+    "mss_rcl_select_hist_f32": [P, L, P, I, P, P],
+    "mss_rcl_select_pick_f32": [P, P, I, P],
+    "mss_rcl_pairs_global_f32": [P, P, U, U, U, P, P, I, U, U, U, U, F, P, I, F, P, P, P],
+    "mss_rcl_gather_f32": [P, P, U, P, P],
+    "mss_rcl_scatter_add_f32": [P, P, U, P, P],
     "mss_adam_step_f32": [P, P, P, P, L, F, F, F, F, F, I, P],
     "mss_peak_mfma_f32": [P, I, I, P],
     "mss_peak_stream_f32": [P, P, L, P],

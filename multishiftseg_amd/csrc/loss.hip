@@ -365,6 +365,49 @@ __global__ __launch_bounds__(256) void rcl_pairs_kernel(const float* __restrict_
   if (blockIdx.x == 0 && threadIdx.x == 0) counters[CNT_N_PAIRS] = (double)n;
 }
 
+// ---- data-parallel ("global") pairing ------------------------------------------------------------
+// The three score sets are the rank-major concatenation of every rank's compaction. Pair i couples
+// element perm_a(i) of the global set A with element perm_o(i) of the global OOD set (keyed Feistel
+// bijections shared by all ranks). Every rank walks all n pairs and keeps those whose A element it
+// owns; the OOD score comes from the all-gathered [W][cap] vector and its gradient goes into a
+// [W][cap] buffer that the host all-reduces and scatters back into the owner's dscore.
+__global__ __launch_bounds__(256) void rcl_pairs_global_kernel(
+    const float* __restrict__ score, const int32_t* __restrict__ idx_a, uint32_t a_off, uint32_t a_cnt_local,
+    uint32_t a_cnt_global, const float* __restrict__ ood_all, const uint32_t* __restrict__ ood_off, int W, uint32_t cap,
+    uint32_t n_pairs, uint32_t seed_a, uint32_t seed_o, float margin, double* __restrict__ counters, int slot,
+    float coef, float* __restrict__ dscore, float* __restrict__ g_ood) {
+  const uint32_t n_ood = ood_off[W];
+  float acc[1] = {0.f};
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += gridDim.x * blockDim.x) {
+    const uint32_t ja = feistel_perm(i, a_cnt_global, seed_a);
+    if (ja < a_off || ja >= a_off + a_cnt_local) continue;
+    const uint32_t jo = feistel_perm(i, n_ood, seed_o);
+    int r = 0;
+    while (r + 1 < W && jo >= ood_off[r + 1]) ++r;
+    const size_t slot_o = (size_t)r * cap + (jo - ood_off[r]);
+    const int32_t pa = idx_a[ja - a_off];
+    const float v = score[pa] + margin - ood_all[slot_o];
+    if (v > 0.f) {
+      acc[0] += v;
+      if (dscore) { atomicAdd(&dscore[pa], coef); atomicAdd(&g_ood[slot_o], -coef); }
+    }
+  }
+  __shared__ int slots[1];
+  if (threadIdx.x == 0) slots[0] = slot;
+  __syncthreads();
+  block_add<1>(acc, counters, slots);
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[CNT_N_PAIRS] = (double)n_pairs;
+}
+
+__global__ void rcl_gather_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, uint32_t n,
+                                  float* __restrict__ dst) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+__global__ void rcl_scatter_add_kernel(const float* __restrict__ g, const int32_t* __restrict__ idx, uint32_t n,
+                                       float* __restrict__ dst) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[idx[i]] += g[i];
+}
+
 // dscore of the consistency term; ASSIGNS every element (so it doubles as the zero fill)
 __global__ void rcl_cin_bwd_kernel(MssRclArgs a, const uint8_t* __restrict__ kind,
                                    const double* __restrict__ counters, float grad_w, float* __restrict__ dscore) {
@@ -449,6 +492,54 @@ int mss_rcl_select_f32(const float* ce_aug, long long n, const double* counters,
                        hist_ws);
     hipLaunchKernelGGL(rcl_pick_kernel, dim3(1), dim3(256), 0, S_(stream), sel, hist_ws, shift);
   }
+  return mss_launch_status();
+}
+
+// The same selection, one radix pass at a time, so a data-parallel caller can all-reduce the 256-bin
+// histogram between hist and pick (4 all-reduces of 1 KB give the exact global k-th smallest).
+int mss_rcl_select_init_f32(const double* counters, float selection_ratio, uint32_t* hist_ws, uint32_t* sel,
+                            void* stream) {
+  if (!counters || !hist_ws || !sel) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rcl_select_init_kernel, dim3(1), dim3(256), 0, S_(stream), counters, selection_ratio, sel,
+                     hist_ws);
+  return mss_launch_status();
+}
+int mss_rcl_select_hist_f32(const float* ce_aug, long long n, const uint32_t* sel, int shift, uint32_t* hist_ws,
+                            void* stream) {
+  if (!ce_aug || !sel || !hist_ws || n <= 0 || shift < 0 || shift > 24 || shift % 8) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rcl_hist_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, S_(stream), ce_aug, n, sel, shift,
+                     hist_ws);
+  return mss_launch_status();
+}
+int mss_rcl_select_pick_f32(uint32_t* sel, uint32_t* hist_ws, int shift, void* stream) {
+  if (!sel || !hist_ws || shift < 0 || shift > 24 || shift % 8) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rcl_pick_kernel, dim3(1), dim3(256), 0, S_(stream), sel, hist_ws, shift);
+  return mss_launch_status();
+}
+
+int mss_rcl_pairs_global_f32(const float* score, const int32_t* idx_a, uint32_t a_off, uint32_t a_cnt_local,
+                             uint32_t a_cnt_global, const float* ood_all, const uint32_t* ood_off, int W,
+                             uint32_t cap, uint32_t n_pairs, uint32_t seed_a, uint32_t seed_o, float margin,
+                             double* counters, int slot, float coef, float* dscore, float* g_ood, void* stream) {
+  if (!score || !idx_a || !ood_all || !ood_off || !counters || W < 1) return MSS_ERR_BAD_ARG;
+  if (slot != 0 && slot != 1) return MSS_ERR_BAD_ARG;
+  if (dscore && !g_ood) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rcl_pairs_global_kernel, dim3(grid_for(n_pairs > 0 ? n_pairs : 1, 2048)), dim3(256), 0,
+                     S_(stream), score, idx_a, a_off, a_cnt_local, a_cnt_global, ood_all, ood_off, W, cap, n_pairs,
+                     seed_a, seed_o, margin, counters, slot == 0 ? CNT_SUM_CORIG : CNT_SUM_CAUG, coef, dscore, g_ood);
+  return mss_launch_status();
+}
+
+int mss_rcl_gather_f32(const float* src, const int32_t* idx, uint32_t n, float* dst, void* stream) {
+  if (n == 0) return MSS_OK;
+  if (!src || !idx || !dst) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rcl_gather_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, S_(stream), src, idx, n, dst);
+  return mss_launch_status();
+}
+int mss_rcl_scatter_add_f32(const float* g, const int32_t* idx, uint32_t n, float* dst, void* stream) {
+  if (n == 0) return MSS_OK;
+  if (!g || !idx || !dst) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rcl_scatter_add_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, S_(stream), g, idx, n, dst);
   return mss_launch_status();
 }
 

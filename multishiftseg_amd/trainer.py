@@ -45,6 +45,9 @@ class TrainStep:
     """One optimisation step of either stage on this rank's pairs."""
 
     def __init__(self, model, criterion, stage=2, bucket_bytes=64 << 20):
+        """criterion: RelContrastiveLoss; with sync="global" it reproduces the reference's gathered-batch
+        loss across ranks (its gradients come pre-multiplied by the world size, which the averaging
+        all-reduce of ddp.GradAllReduce undoes); sync="local" needs no loss communication."""
         self.model, self.criterion = model, criterion
         self.set_stage(stage, bucket_bytes)
 
