@@ -73,6 +73,8 @@ typedef struct MssConvArgs {
   int in_relu, out_relu;   /* ReLU after the prologue affine / at the very end of the epilogue   */
   int ldres;
   int M, mtiles, ntiles;   /* filled in by the launcher                                          */
+  int batch;               /* > 1: that many independent GEMMs in one launch (1x1 only, no res);  */
+  long long x_bs, w_bs, y_bs; /* element strides between their x / w / y (Winograd positions)    */
 } MssConvArgs;
 
 int mss_conv2d_forward_f32(MssConvArgs* args, void* stream);
@@ -88,6 +90,18 @@ int mss_conv2d_pack_weights_f32(const float* w, float* packed, int K, int C, int
 int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dwp, int Cp, void* stream);
 int mss_conv2d_unpack_wgrad_f32(const float* packed, float* grad, int K, int C, int R, int S, int Kpad,
                                 int Cp, int accumulate, void* stream);
+
+/* Winograd F(2x2,3x3) path for stride-1 3x3 convolutions with many channels (csrc/winograd.hip):
+ * weights [K][C][3][3] -> U [16][Kpad][Cp]; x -> X' [16][T][C] (T = mss_wino_num_tiles, BatchNorm/ReLU
+ * prologue and zero padding fused); then ONE mss_conv2d_forward_f32 call in batched 1x1 mode
+ * (batch = 16, x_bs = T*C, w_bs = Kpad*Cp, y_bs = T*K) gives Y' [16][T][K]; Y' -> NHWC y (+ residual).
+ * Dilation is exact (per-residue sub-grids). */
+long long mss_wino_num_tiles(int N, int H, int W, int dil);
+int mss_wino_pack_weights_f32(const float* w, float* u, int K, int C, int Kpad, int Cp, void* stream);
+int mss_wino_input_transform_f32(const float* x, int ldx, int N, int H, int W, int C, int dil, const float* scale,
+                                 const float* shift, int relu, float* xt, void* stream);
+int mss_wino_output_transform_f32(const float* yt, int N, int H, int W, int K, int dil, const float* res, int ldres,
+                                  float* y, int ldy, void* stream);
 
 /* image NCHW [N,C,H,W] -> NHWC [N,H,W,Cp] with channels C..Cp-1 zero (feeds mod1.conv1). */
 int mss_nchw_to_nhwc_pad_f32(const float* x, float* y, int N, int C, int H, int W, int Cp, void* stream);

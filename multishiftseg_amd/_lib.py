@@ -33,6 +33,7 @@ class MssConvArgs(Structure):
         ("in_ss_stride", c_int), ("in_relu", c_int), ("out_relu", c_int),
         ("ldres", c_int),
         ("M", c_int), ("mtiles", c_int), ("ntiles", c_int),
+        ("batch", c_int), ("x_bs", c_longlong), ("w_bs", c_longlong), ("y_bs", c_longlong),
     ]
 
 
@@ -96,11 +97,15 @@ SIGNATURES = {
     "mss_rcl_gather_f32": [P, P, U, P, P],
     "mss_rcl_scatter_add_f32": [P, P, U, P, P],
     "mss_adam_step_f32": [P, P, P, P, L, F, F, F, F, F, I, P],
+    "mss_wino_num_tiles": [I, I, I, I],
+    "mss_wino_pack_weights_f32": [P, P, I, I, I, I, P],
+    "mss_wino_input_transform_f32": [P, I, I, I, I, I, I, P, P, I, P, P],
+    "mss_wino_output_transform_f32": [P, I, I, I, I, I, P, I, P, I, P],
     "mss_peak_mfma_f32": [P, I, I, P],
     "mss_peak_stream_f32": [P, P, L, P],
 }
 # entry points that return a plain value rather than a status code
-_VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_rcl_num_compact_blocks"}
+_VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles"}
 
 _lib = None
 
@@ -118,7 +123,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_longlong if name == "mss_wino_num_tiles" else c_int
     _lib = lib
     return lib
 

@@ -48,6 +48,10 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
 
+  // batched mode (Winograd: 16 independent GEMMs in one launch): blockIdx.y picks the operand set
+  p.x += (size_t)blockIdx.y * p.x_bs;
+  p.w += (size_t)blockIdx.y * p.w_bs;
+  p.y += (size_t)blockIdx.y * p.y_bs;
   const int v = mss_xcd_remap(blockIdx.x, gridDim.x);
   const int mt = v / p.ntiles, nt = v % p.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -302,7 +306,7 @@ int launch_conv_t(MssConvArgs& p, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles), dim3(NT), smem, stream, p);
+  hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, p.batch > 1 ? p.batch : 1), dim3(NT), smem, stream, p);
   return mss_launch_status();
 }
 
@@ -546,6 +550,7 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
   if ((reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.w)) & 15) return MSS_ERR_BAD_ARG;
   if (p.in_scale && ((reinterpret_cast<uintptr_t>(p.in_scale) | reinterpret_cast<uintptr_t>(p.in_shift)) & 15))
     return MSS_ERR_BAD_ARG;
+  if (p.batch > 1 && (p.res || p.x_bs % 4 || p.w_bs % 4 || p.batch > 65535)) return MSS_ERR_BAD_ARG;
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return MSS_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -180,13 +180,13 @@ class DeepWV3Plus(nn.Module):
         d = blk.dilation
         c = blk.convs
         if not blk.bottleneck:
-            o = K.conv2d(a, K.packed(c.conv1.weight), stride=blk.stride, dil=d, pad=d, in_affine=aff1, in_relu=True)
+            o = K.conv3x3(a, c.conv1.weight, dil=d, stride=blk.stride, in_affine=aff1, in_relu=True)
             st2 = K.bn_fold(c.bn2[0], o, train)
-            return K.conv2d(o, K.packed(c.conv2.weight), dil=d, pad=d, in_affine=self._dropout_affine(st2, blk, name, a.N),
-                            in_relu=True, res=shortcut)
+            return K.conv3x3(o, c.conv2.weight, dil=d, in_affine=self._dropout_affine(st2, blk, name, a.N), in_relu=True,
+                             res=shortcut)
         o = K.conv2d(a, K.packed(c.conv1.weight), stride=blk.stride, in_affine=aff1, in_relu=True)
         st2 = K.bn_fold(c.bn2[0], o, train)
-        o2 = K.conv2d(o, K.packed(c.conv2.weight), dil=d, pad=d, in_affine=(st2.scale, st2.shift), in_relu=True)
+        o2 = K.conv3x3(o, c.conv2.weight, dil=d, in_affine=(st2.scale, st2.shift), in_relu=True)
         st3 = K.bn_fold(c.bn3[0], o2, train)
         return K.conv2d(o2, K.packed(c.conv3.weight), in_affine=self._dropout_affine(st3, blk, name, a.N), in_relu=True,
                         res=shortcut)
@@ -241,7 +241,10 @@ class DeepWV3Plus(nn.Module):
         for i, feat in enumerate(asp.features):
             rate = 1 if i == 0 else _ASPP_RATES[i - 1]
             sl = raw.slice(256 * (i + 1), 256)
-            K.conv2d(x, K.packed(feat[0].weight), dil=rate, pad=0 if i == 0 else rate, out=sl)
+            if i == 0:
+                K.conv2d(x, K.packed(feat[0].weight), out=sl)
+            else:
+                K.conv3x3(x, feat[0].weight, dil=rate, out=sl)
             states.append(K.bn_fold(feat[1], sl, train))
         for i, s in enumerate(states):
             scale[256 * i:256 * (i + 1)].copy_(s.scale)
@@ -250,9 +253,9 @@ class DeepWV3Plus(nn.Module):
         dec0 = Act.empty(N, h2, w2, 304, dev)                      # concat [bot_fine(m2), up(bot_aspp)]
         K.upsample_ac(up_small, h2, w2, out=dec0.slice(48, 256))
         K.conv2d(m2, K.packed(self.bot_fine.weight), out=dec0.slice(0, 48))
-        f0 = K.conv2d(dec0, K.packed(self.final[0].weight), pad=1)
+        f0 = K.conv3x3(dec0, self.final[0].weight)
         st_f0 = K.bn_fold(self.final[1], f0, train)
-        f1 = K.conv2d(f0, K.packed(self.final[3].weight), pad=1, in_affine=(st_f0.scale, st_f0.shift), in_relu=True)
+        f1 = K.conv3x3(f0, self.final[3].weight, in_affine=(st_f0.scale, st_f0.shift), in_relu=True)
         st_f1 = K.bn_fold(self.final[4], f1, train)
         wh, _ = self._heads_weight()
         dec12 = K.conv2d(f1, wh, in_affine=(st_f1.scale, st_f1.shift), in_relu=True)
@@ -307,14 +310,14 @@ class DeepWV3Plus(nn.Module):
         aff_f0 = (s["st_f0"].scale, s["st_f0"].shift)
         if need["final.3.weight"]:
             grads["final.3.weight"] = K.conv2d_wgrad(f0, df1, 256, 256, 3, 3, pad=1, in_affine=aff_f0, in_relu=True)
-        d_act0 = K.conv2d(df1, K.packed(self.final[3].weight, flip=True), pad=1)
+        d_act0 = K.conv3x3(df1, self.final[3].weight, flip=True)
         df0, dg, db = K.bn_relu_backward(d_act0, f0, s["st_f0"], want_param_grads=need["final.1.weight"] or need["final.1.bias"])
         grads["final.1.weight"], grads["final.1.bias"] = dg, db
         if need["final.0.weight"]:
             grads["final.0.weight"] = K.conv2d_wgrad(dec0, df0, 256, 304, 3, 3, pad=1)
         if not any(need[n] for n in names if n.startswith(("aspp", "bot_"))):
             return [grads.get(n) if need[n] else None for n in names]
-        ddec0 = K.conv2d(df0, K.packed(self.final[0].weight, flip=True), pad=1)
+        ddec0 = K.conv3x3(df0, self.final[0].weight, flip=True)
         if need["bot_fine.weight"]:
             grads["bot_fine.weight"] = K.conv2d_wgrad(m2, ddec0.slice(0, 48), 48, 128, 1, 1)
         if any(need[n] for n in names if n.startswith(("aspp", "bot_aspp"))):

@@ -244,6 +244,92 @@ def conv2d_wgrad(x, dy, K, C, R, S, stride=1, dil=1, pad=0, in_affine=None, in_r
     return grad
 
 
+class WinoWeight:
+    """Winograd-domain filter U [16][Kpad][Cp] of a 3x3 weight."""
+    __slots__ = ("t", "K", "C", "Kpad", "Cp")
+
+    def __init__(self, t, K, C, Kpad, Cp):
+        self.t, self.K, self.C, self.Kpad, self.Cp = t, K, C, Kpad, Cp
+
+
+def pack_weight_wino(w, flip=False):
+    """flip=True: the data-gradient filter (K<->C swapped, taps rotated 180 degrees), as pack_weight."""
+    if flip:
+        w = w.detach().flip(2, 3).transpose(0, 1)
+    K, C, R, S = w.shape
+    assert R == 3 and S == 3 and C % 16 == 0 and K % 4 == 0
+    if w.dtype != torch.float32 or not w.is_cuda:
+        raise TypeError("pack_weight_wino needs a float32 CUDA tensor")
+    w = w.detach().contiguous()
+    Kpad = _lib.value("mss_conv2d_kpad", K)
+    t = torch.empty((16, Kpad, C), device=w.device, dtype=torch.float32)
+    call("mss_wino_pack_weights_f32", ptr(w), ptr(t), K, C, Kpad, C)
+    return WinoWeight(t, K, C, Kpad, C)
+
+
+def packed_wino(param, flip=False):
+    key = (id(param), "wino", flip)
+    ent = _pack_cache.get(key)
+    if ent is not None and ent[0] == param._version and ent[1] == param.data_ptr():
+        return ent[2]
+    ww = pack_weight_wino(param, flip)
+    _pack_cache[key] = (param._version, param.data_ptr(), ww)
+    return ww
+
+
+WINOGRAD_MIN_CHANNELS = 256     # measured on MI355X: 1.24-1.28x at 256 channels, 1.7-2.1x at >= 512, 0.87x at 128
+
+
+def use_winograd(c_in, k_out, stride, in_affine=None):
+    """Policy: 3x3 stride-1 layers whose channel counts make the two HBM-bound transforms cheaper than the
+    MFMA work they remove. MSS_WINOGRAD=0 forces the direct implicit GEMM everywhere."""
+    import os
+    if os.environ.get("MSS_WINOGRAD", "1") == "0" or stride != 1:
+        return False
+    if in_affine is not None and in_affine[0].dim() != 1:
+        return False
+    return c_in >= WINOGRAD_MIN_CHANNELS and k_out >= WINOGRAD_MIN_CHANNELS and c_in % 16 == 0 and k_out % 4 == 0
+
+
+def conv3x3(x, weight, dil=1, stride=1, in_affine=None, in_relu=False, res=None, out=None, flip=False):
+    """3x3 convolution with padding = dilation on nn.Conv2d-layout `weight` (flip=True: its data gradient),
+    through Winograd when the policy says so, else through the direct implicit GEMM."""
+    k_out, c_in = (weight.shape[1], weight.shape[0]) if flip else (weight.shape[0], weight.shape[1])
+    if use_winograd(c_in, k_out, stride, in_affine):
+        return conv2d_winograd(x, packed_wino(weight, flip), dil=dil, in_affine=in_affine, in_relu=in_relu, res=res, out=out)
+    return conv2d(x, packed(weight, flip), stride=stride, dil=dil, pad=dil, in_affine=in_affine, in_relu=in_relu, res=res,
+                  out=out)
+
+
+def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=None):
+    """3x3 / stride 1 / padding = dilation convolution through Winograd F(2x2,3x3): input transform (with
+    the fused BatchNorm+ReLU prologue) -> 16 batched MFMA GEMMs -> output transform (+ residual)."""
+    assert x.C == ww.C
+    N, H, W, C, K = x.N, x.H, x.W, ww.C, ww.K
+    dev = x.buf.device
+    if out is None:
+        out = Act.empty(N, H, W, K, dev)
+    T = _lib.value("mss_wino_num_tiles", N, H, W, dil)
+    with _Timed("conv_winograd", 2.0 * N * H * W * K * C * 9, (N, H, W, C, K, 3, 1, dil)):
+        xt = torch.empty((16, T, C), device=dev, dtype=torch.float32)
+        sc, sh = in_affine if in_affine is not None else (None, None)
+        assert sc is None or sc.dim() == 1
+        call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
+        yt = torch.empty((16, T, K), device=dev, dtype=torch.float32)
+        a = MssConvArgs()
+        a.x, a.w, a.y = ptr(xt), ptr(ww.t), ptr(yt)
+        a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
+        a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, K, ww.Kpad, K
+        a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+        a.batch, a.x_bs, a.w_bs, a.y_bs = 16, T * C, ww.Kpad * ww.Cp, T * K
+        with _Timed("conv_igemm", 2.0 * 16 * T * C * K, (16, 1, T, C, K, 1, 1, 1)):   # the MFMA work actually executed
+            call("mss_conv2d_forward_f32", ctypes.byref(a))
+        del xt
+        call("mss_wino_output_transform_f32", ptr(yt), N, H, W, K, dil, res.ptr if res is not None else None,
+             res.ld if res is not None else 0, out.ptr, out.ld)
+    return out
+
+
 def image_to_nhwc(img, Cp=16):
     n, c, h, w = img.shape
     img = img.contiguous()

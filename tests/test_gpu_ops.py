@@ -217,3 +217,24 @@ def test_m2f_score(K):
     mask = rng.standard_normal((1, 100, 64, 96), dtype=np.float32) * 4
     s = K.m2f_score(dev(cls), dev(mask), (64, 96))
     np.testing.assert_allclose(s.cpu().numpy(), om2f.anomaly_score(cls, mask, (64, 96)), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("cin,cout,dil,n,h,w", [(32, 64, 1, 2, 12, 14), (64, 32, 2, 1, 13, 17), (32, 128, 4, 2, 16, 22),
+                                                 (48, 64, 1, 1, 7, 9), (64, 64, 4, 1, 5, 6)])
+def test_winograd_conv_vs_oracle(K, cin, cout, dil, n, h, w):
+    """Winograd F(2x2,3x3) path: dilation handled through residue sub-grids, ragged tiles, fused
+    BatchNorm+ReLU prologue and residual epilogue."""
+    rng = np.random.default_rng(cin + cout + dil)
+    x = rng.standard_normal((n, cin, h, w), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) / np.sqrt(cin * 9)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+    sh = rng.standard_normal(cin).astype(np.float32)
+    res = rng.standard_normal((n, cout, h, w), dtype=np.float32)
+    act = np.maximum(x * sc[None, :, None, None] + sh[None, :, None, None], 0)
+    ref = nnops.conv2d(act, wt, 1, dil, dil) + res
+    xa = K.Act.from_nchw(dev(x))
+    y = K.conv2d_winograd(xa, K.pack_weight_wino(dev(wt)), dil=dil, in_affine=(dev(sc), dev(sh)), in_relu=True,
+                          res=K.Act.from_nchw(dev(res)))
+    np.testing.assert_allclose(y.nchw().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    y2 = K.conv2d_winograd(xa, K.pack_weight_wino(dev(wt)), dil=dil)        # no prologue / residual
+    np.testing.assert_allclose(y2.nchw().cpu().numpy(), nnops.conv2d(x, wt, 1, dil, dil), rtol=1e-4, atol=1e-4)
