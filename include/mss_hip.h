@@ -103,6 +103,13 @@ int mss_wino_input_transform_f32(const float* x, int ldx, int N, int H, int W, i
 int mss_wino_output_transform_f32(const float* yt, int N, int H, int W, int K, int dil, const float* res, int ldres,
                                   float* y, int ldy, void* stream);
 
+/* weight gradient in the Winograd domain: dY' = A dY A^T per tile, then ONE mss_conv2d_wgrad_f32 call in
+ * batched mode (batch = 16, R = S = 1, x = X', x_bs = T*C, dy = dY', y_bs = T*K) accumulates
+ * dU [16][Kpad][Cp], and dg = G^T dU G gives the [K][C][3][3] gradient. */
+int mss_wino_grad_output_transform_f32(const float* dy, int lddy, int N, int H, int W, int K, int dil, float* dyt,
+                                       void* stream);
+int mss_wino_weight_grad_transform_f32(const float* du, float* dw, int K, int C, int Kpad, int Cp, void* stream);
+
 /* image NCHW [N,C,H,W] -> NHWC [N,H,W,Cp] with channels C..Cp-1 zero (feeds mod1.conv1). */
 int mss_nchw_to_nhwc_pad_f32(const float* x, float* y, int N, int C, int H, int W, int Cp, void* stream);
 

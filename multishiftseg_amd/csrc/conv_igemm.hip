@@ -377,8 +377,14 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
   const int ctiles = mss_cdiv(p.C, BCI);
   const int kt = blockIdx.x / ctiles, ct = blockIdx.x % ctiles;
   const int k0 = kt * BKO, c0 = ct * BCI;
-  const int tap = blockIdx.y;
-  const int r = tap / p.S, s = tap - r * p.S;
+  const int tap = blockIdx.y;           // output slab index: a filter tap, or (batched mode) a Winograd position
+  int geo_tap = tap;
+  if (p.batch > 1) {                    // 16 independent [K x T] x [T x C] products (Winograd weight gradient)
+    p.x += (size_t)tap * p.x_bs;
+    dy += (size_t)tap * p.y_bs;
+    geo_tap = 0;
+  }
+  const int r = geo_tap / p.S, s = geo_tap - r * p.S;
   const int dyo = r * p.dil - p.pad, dxo = s * p.dil - p.pad;
   const int mbeg = blockIdx.z * pix_per_split;
   const int mend = min(p.M, mbeg + pix_per_split);
@@ -599,7 +605,8 @@ int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dw
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return MSS_OK;
   constexpr int BKO = 128, BCI = 128, BP = 16;
-  const int ktiles = mss_cdiv(p.K, BKO), ctiles = mss_cdiv(p.C, BCI), taps = p.R * p.S;
+  if (p.batch > 1 && (p.R * p.S != 1 || p.batch > 65535)) return MSS_ERR_BAD_ARG;
+  const int ktiles = mss_cdiv(p.K, BKO), ctiles = mss_cdiv(p.C, BCI), taps = p.batch > 1 ? p.batch : p.R * p.S;
   // Pixel splits: 2 workgroups fit a CU (LDS), i.e. 512 run at once. Pick the smallest split count
   // whose grid fills its last round of 512 to >= 95 % (a 1152-block grid runs 3 rounds for 2.25
   // rounds of work); more splits only add atomic traffic on the [R*S][K][C] slab.

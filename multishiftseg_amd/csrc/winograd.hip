@@ -171,6 +171,84 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float*
   }
 }
 
+// dy (NHWC) -> dY' [16][T][K] = A dY A^T per 2x2 tile (zero outside the image), A = (A^T)^T
+__global__ __launch_bounds__(256) void wino_grad_output_transform_kernel(const float* __restrict__ dy, int lddy,
+                                                                         WinoGeom g, int K, float* __restrict__ dyt) {
+  const int K4 = K >> 2;
+  const long long total = g.T * K4;
+  const size_t ps = (size_t)g.T * K;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K4) * 4;
+    long long t = i / K4;
+    const long long tile = t;
+    const int tx = (int)(t % g.tW); t /= g.tW;
+    const int ty = (int)(t % g.tH); t /= g.tH;
+    const int b = (int)(t % g.d); t /= g.d;
+    const int a = (int)(t % g.d);
+    const int n = (int)(t / g.d);
+    f32x4 d[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int oy = (2 * ty + u) * g.d + a;
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int ox = (2 * tx + v) * g.d + b;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (2 * ty + u < g.Hs && oy < g.H && 2 * tx + v < g.Ws && ox < g.W)
+          val = ld4(dy + ((size_t)(n * g.H + oy) * g.W + ox) * lddy + k);
+        d[u][v] = val;
+      }
+    }
+    f32x4 tt[4][2];   // A dY : rows [d0, d0+d1, d0-d1, -d1]
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      tt[0][v] = d[0][v];
+      tt[1][v] = d[0][v] + d[1][v];
+      tt[2][v] = d[0][v] - d[1][v];
+      tt[3][v] = -d[1][v];
+    }
+    float* o = dyt + (size_t)tile * K + k;
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      st4(o + (size_t)(xi * 4 + 0) * ps, tt[xi][0]);
+      st4(o + (size_t)(xi * 4 + 1) * ps, tt[xi][0] + tt[xi][1]);
+      st4(o + (size_t)(xi * 4 + 2) * ps, tt[xi][0] - tt[xi][1]);
+      st4(o + (size_t)(xi * 4 + 3) * ps, -tt[xi][1]);
+    }
+  }
+}
+
+// dU [16][Kpad][Cp] -> dg [K][C][3][3] = G^T dU G
+__global__ void wino_weight_grad_transform_kernel(const float* __restrict__ du, float* __restrict__ dw, int K, int C,
+                                                  int Kpad, int Cp) {
+  const long long total = (long long)K * C;
+  const size_t ps = (size_t)Kpad * Cp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C), k = (int)(i / C);
+    float u[4][4];
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) u[xi][nu] = du[(size_t)(xi * 4 + nu) * ps + (size_t)k * Cp + c];
+    float t[3][4];   // G^T dU
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      t[0][nu] = u[0][nu] + 0.5f * (u[1][nu] + u[2][nu]);
+      t[1][nu] = 0.5f * (u[1][nu] - u[2][nu]);
+      t[2][nu] = 0.5f * (u[1][nu] + u[2][nu]) + u[3][nu];
+    }
+    float* o = dw + ((size_t)k * C + c) * 9;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      o[r * 3 + 0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+      o[r * 3 + 1] = 0.5f * (t[r][1] - t[r][2]);
+      o[r * 3 + 2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+    }
+  }
+}
+
 inline int grid_for(long long work_items) {
   long long b = (work_items + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 256 * 32 ? 256 * 32 : b));
@@ -209,6 +287,23 @@ int mss_wino_output_transform_f32(const float* yt, int N, int H, int W, int K, i
   if (g.T == 0) return MSS_OK;
   hipLaunchKernelGGL(wino_output_transform_kernel, dim3(grid_for(g.T * (K / 4))), dim3(256), 0, S_(stream), yt, g, K, res,
                      ldres, y, ldy);
+  return mss_launch_status();
+}
+
+int mss_wino_grad_output_transform_f32(const float* dy, int lddy, int N, int H, int W, int K, int dil, float* dyt,
+                                       void* stream) {
+  if (!dy || !dyt || K % 4 || lddy % 4 || dil < 1) return MSS_ERR_BAD_ARG;
+  const WinoGeom g = wino_geom(N, H, W, dil);
+  if (g.T == 0) return MSS_OK;
+  hipLaunchKernelGGL(wino_grad_output_transform_kernel, dim3(grid_for(g.T * (K / 4))), dim3(256), 0, S_(stream), dy,
+                     lddy, g, K, dyt);
+  return mss_launch_status();
+}
+
+int mss_wino_weight_grad_transform_f32(const float* du, float* dw, int K, int C, int Kpad, int Cp, void* stream) {
+  if (!du || !dw || Kpad < K || Cp < C) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(wino_weight_grad_transform_kernel, dim3(grid_for((long long)K * C)), dim3(256), 0, S_(stream), du,
+                     dw, K, C, Kpad, Cp);
   return mss_launch_status();
 }
 

@@ -309,12 +309,12 @@ class DeepWV3Plus(nn.Module):
         grads["final.4.weight"], grads["final.4.bias"] = dg, db
         aff_f0 = (s["st_f0"].scale, s["st_f0"].shift)
         if need["final.3.weight"]:
-            grads["final.3.weight"] = K.conv2d_wgrad(f0, df1, 256, 256, 3, 3, pad=1, in_affine=aff_f0, in_relu=True)
+            grads["final.3.weight"] = K.conv3x3_wgrad(f0, df1, 256, 256, in_affine=aff_f0, in_relu=True)
         d_act0 = K.conv3x3(df1, self.final[3].weight, flip=True)
         df0, dg, db = K.bn_relu_backward(d_act0, f0, s["st_f0"], want_param_grads=need["final.1.weight"] or need["final.1.bias"])
         grads["final.1.weight"], grads["final.1.bias"] = dg, db
         if need["final.0.weight"]:
-            grads["final.0.weight"] = K.conv2d_wgrad(dec0, df0, 256, 304, 3, 3, pad=1)
+            grads["final.0.weight"] = K.conv3x3_wgrad(dec0, df0, 256, 304)
         if not any(need[n] for n in names if n.startswith(("aspp", "bot_"))):
             return [grads.get(n) if need[n] else None for n in names]
         ddec0 = K.conv3x3(df0, self.final[0].weight, flip=True)
@@ -343,10 +343,10 @@ class DeepWV3Plus(nn.Module):
                     draw, dg, db = K.bn_relu_backward(d_act.slice(256 * (i + 1), 256), sl, states[i + 1], want_param_grads=want)
                     grads[p + ".1.weight"], grads[p + ".1.bias"] = dg, db
                     if need[p + ".0.weight"]:
-                        rate = 1 if i == 0 else _ASPP_RATES[i - 1]
-                        r = 1 if i == 0 else 3
-                        grads[p + ".0.weight"] = K.conv2d_wgrad(x, draw, 256, 4096, r, r, dil=rate,
-                                                                pad=0 if i == 0 else rate)
+                        if i == 0:
+                            grads[p + ".0.weight"] = K.conv2d_wgrad(x, draw, 256, 4096, 1, 1)
+                        else:
+                            grads[p + ".0.weight"] = K.conv3x3_wgrad(x, draw, 256, 4096, dil=_ASPP_RATES[i - 1])
         return [grads.get(n) if need[n] else None for n in names]
 
     # ---- forward -------------------------------------------------------------------------------------

@@ -330,6 +330,39 @@ def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=N
     return out
 
 
+def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False):
+    """[K,C,3,3] weight gradient of a 3x3 / stride-1 / padding = dilation conv in the Winograd domain:
+    dU[p] = dY'[p]^T X'[p] (16 batched MFMA products over tiles, 2.25x fewer FLOPs than the 9-tap form)."""
+    N, H, W = x.N, x.H, x.W
+    dev = x.buf.device
+    T = _lib.value("mss_wino_num_tiles", N, H, W, dil)
+    Kpad, Cp = _round_up(K, 4), _round_up(C, 4)
+    with _Timed("wgrad_winograd", 2.0 * N * H * W * K * C * 9, (N, H, W, C, K, 3, 1, dil)):
+        xt = torch.empty((16, T, C), device=dev, dtype=torch.float32)
+        sc, sh = in_affine if in_affine is not None else (None, None)
+        call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
+        dyt = torch.empty((16, T, K), device=dev, dtype=torch.float32)
+        call("mss_wino_grad_output_transform_f32", dy.ptr, dy.ld, N, H, W, K, dil, ptr(dyt))
+        du = torch.zeros((16, Kpad, Cp), device=dev, dtype=torch.float32)
+        a = MssConvArgs()
+        a.x = ptr(xt)
+        a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
+        a.OH, a.OW, a.K, a.Kpad = 1, T, K, Kpad
+        a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+        a.batch, a.x_bs, a.y_bs = 16, T * C, T * K
+        with _Timed("conv_wgrad", 2.0 * 16 * T * K * C, (16, 1, T, C, K, 1, 1, 1)):
+            call("mss_conv2d_wgrad_f32", ctypes.byref(a), ptr(dyt), K, ptr(du), Cp)
+        grad = torch.empty((K, C, 3, 3), device=dev, dtype=torch.float32)
+        call("mss_wino_weight_grad_transform_f32", ptr(du), ptr(grad), K, C, Kpad, Cp)
+    return grad
+
+
+def conv3x3_wgrad(x, dy, K, C, dil=1, in_affine=None, in_relu=False):
+    if use_winograd(C, K, 1, in_affine):
+        return conv2d_wgrad_winograd(x, dy, K, C, dil, in_affine, in_relu)
+    return conv2d_wgrad(x, dy, K, C, 3, 3, dil=dil, pad=dil, in_affine=in_affine, in_relu=in_relu)
+
+
 def image_to_nhwc(img, Cp=16):
     n, c, h, w = img.shape
     img = img.contiguous()

@@ -238,3 +238,25 @@ def test_winograd_conv_vs_oracle(K, cin, cout, dil, n, h, w):
     np.testing.assert_allclose(y.nchw().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
     y2 = K.conv2d_winograd(xa, K.pack_weight_wino(dev(wt)), dil=dil)        # no prologue / residual
     np.testing.assert_allclose(y2.nchw().cpu().numpy(), nnops.conv2d(x, wt, 1, dil, dil), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,dil,n,h,w", [(32, 64, 1, 2, 12, 14), (64, 32, 2, 1, 13, 17), (48, 36, 12, 2, 16, 22)])
+def test_winograd_wgrad_vs_autograd(K, cin, cout, dil, n, h, w):
+    rng = np.random.default_rng(cin * 3 + cout + dil)
+    x = torch.from_numpy(rng.standard_normal((n, cin, h, w), dtype=np.float32))
+    wt = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) / np.sqrt(cin * 9)).astype(np.float32)).requires_grad_(True)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cin).astype(np.float32))
+    sh = torch.from_numpy(rng.standard_normal(cin).astype(np.float32))
+    act = torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None])
+    y = torch.nn.functional.conv2d(act, wt, dilation=dil, padding=dil)
+    gy = torch.from_numpy(rng.standard_normal(tuple(y.shape), dtype=np.float32))
+    y.backward(gy)
+    dw = K.conv2d_wgrad_winograd(K.Act.from_nchw(x.cuda()), K.Act.from_nchw(gy.cuda()), cout, cin, dil=dil,
+                                 in_affine=(sc.cuda(), sh.cuda()), in_relu=True)
+    np.testing.assert_allclose(dw.cpu().numpy(), wt.grad.numpy(), rtol=1e-3, atol=1e-3)
+    # data gradient through the flipped Winograd filter
+    xg = torch.from_numpy(rng.standard_normal((n, cin, h, w), dtype=np.float32)).requires_grad_(True)
+    torch.nn.functional.conv2d(xg, wt.detach(), dilation=dil, padding=dil).backward(gy)
+    if cout % 16 == 0:
+        dx = K.conv2d_winograd(K.Act.from_nchw(gy.cuda()), K.pack_weight_wino(wt.detach().cuda(), flip=True), dil=dil)
+        np.testing.assert_allclose(dx.nchw().cpu().numpy(), xg.grad.numpy(), rtol=1e-4, atol=1e-4)
