@@ -322,8 +322,17 @@ def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=N
         a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, K, ww.Kpad, K
         a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
         a.batch, a.x_bs, a.w_bs, a.y_bs = 16, T * C, ww.Kpad * ww.Cp, T * K
+        rem = K % 128
+        split = K - rem if (K > 128 and 0 < rem <= 64) else 0     # e.g. 304 = 256 + 48: narrow tail on the 64-wide tile
+        if split:
+            a.K = split
         with _Timed("conv_igemm", 2.0 * 16 * T * C * K, (16, 1, T, C, K, 1, 1, 1)):   # the MFMA work actually executed
             call("mss_conv2d_forward_f32", ctypes.byref(a))
+            if split:
+                a.K, a.Kpad = rem, ww.Kpad - split
+                a.w = ctypes.c_void_p(ww.t.data_ptr() + 4 * split * ww.Cp)
+                a.y = ctypes.c_void_p(yt.data_ptr() + 4 * split)
+                call("mss_conv2d_forward_f32", ctypes.byref(a))
         del xt
         call("mss_wino_output_transform_f32", ptr(yt), N, H, W, K, dil, res.ptr if res is not None else None,
              res.ld if res is not None else 0, out.ptr, out.ld)
