@@ -230,6 +230,7 @@ class DeepWV3Plus(nn.Module):
         scale = torch.empty(1280, device=dev)
         shift = torch.empty(1280, device=dev)
         states = []
+        aspp_xt = {}
         # image-pooling branch (deepv3.py:84-88): GAP -> 1x1 -> BN over the N samples -> broadcast
         pooled = K.gap(x)
         pooled_act = Act(pooled.view(N, 1, 1, 4096))
@@ -244,7 +245,11 @@ class DeepWV3Plus(nn.Module):
             if i == 0:
                 K.conv2d(x, K.packed(feat[0].weight), out=sl)
             else:
-                K.conv3x3(x, feat[0].weight, dil=rate, out=sl)
+                # keep the Winograd-domain input for this layer's weight gradient when the three of them
+                # (16 positions x ~1.3*M/4 tiles x 4096 floats each, i.e. ~21*M*4096 bytes) fit comfortably: 15 GB at 2x1024x2048
+                kx = {} if (keep and feat[0].weight.requires_grad and 3 * 21 * x.M * 4096 < (40 << 30)) else None
+                K.conv3x3(x, feat[0].weight, dil=rate, out=sl, keep_xt=kx)
+                aspp_xt[i] = kx.get("xt") if kx else None
             states.append(K.bn_fold(feat[1], sl, train))
         for i, s in enumerate(states):
             scale[256 * i:256 * (i + 1)].copy_(s.scale)
@@ -262,7 +267,7 @@ class DeepWV3Plus(nn.Module):
         score, logit, _ = K.ood_score(dec12.slice(20, 19), dec12.slice(0, 19), size[0], size[1])
         saved = None
         if keep:
-            saved = dict(x=x, m2=m2, raw=raw, scale=scale, shift=shift, states=states, pooled_act=pooled_act,
+            saved = dict(aspp_xt=aspp_xt, x=x, m2=m2, raw=raw, scale=scale, shift=shift, states=states, pooled_act=pooled_act,
                          u0_rows=u0_rows, dec0=dec0, f0=f0, st_f0=st_f0, f1=f1, st_f1=st_f1, dec12=dec12, size=size)
         return score, logit, saved
 
@@ -346,7 +351,8 @@ class DeepWV3Plus(nn.Module):
                         if i == 0:
                             grads[p + ".0.weight"] = K.conv2d_wgrad(x, draw, 256, 4096, 1, 1)
                         else:
-                            grads[p + ".0.weight"] = K.conv3x3_wgrad(x, draw, 256, 4096, dil=_ASPP_RATES[i - 1])
+                            grads[p + ".0.weight"] = K.conv3x3_wgrad(x, draw, 256, 4096, dil=_ASPP_RATES[i - 1],
+                                                                     xt=s["aspp_xt"].pop(i, None))
         return [grads.get(n) if need[n] else None for n in names]
 
     # ---- forward -------------------------------------------------------------------------------------

@@ -291,19 +291,22 @@ def use_winograd(c_in, k_out, stride, in_affine=None):
     return c_in >= WINOGRAD_MIN_CHANNELS and k_out >= WINOGRAD_MIN_CHANNELS and c_in % 16 == 0 and k_out % 4 == 0
 
 
-def conv3x3(x, weight, dil=1, stride=1, in_affine=None, in_relu=False, res=None, out=None, flip=False):
+def conv3x3(x, weight, dil=1, stride=1, in_affine=None, in_relu=False, res=None, out=None, flip=False, keep_xt=None):
     """3x3 convolution with padding = dilation on nn.Conv2d-layout `weight` (flip=True: its data gradient),
     through Winograd when the policy says so, else through the direct implicit GEMM."""
     k_out, c_in = (weight.shape[1], weight.shape[0]) if flip else (weight.shape[0], weight.shape[1])
     if use_winograd(c_in, k_out, stride, in_affine):
-        return conv2d_winograd(x, packed_wino(weight, flip), dil=dil, in_affine=in_affine, in_relu=in_relu, res=res, out=out)
+        return conv2d_winograd(x, packed_wino(weight, flip), dil=dil, in_affine=in_affine, in_relu=in_relu, res=res, out=out,
+                               keep_xt=keep_xt)
     return conv2d(x, packed(weight, flip), stride=stride, dil=dil, pad=dil, in_affine=in_affine, in_relu=in_relu, res=res,
                   out=out)
 
 
-def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=None):
+def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=None, keep_xt=None):
     """3x3 / stride 1 / padding = dilation convolution through Winograd F(2x2,3x3): input transform (with
-    the fused BatchNorm+ReLU prologue) -> 16 batched MFMA GEMMs -> output transform (+ residual)."""
+    the fused BatchNorm+ReLU prologue) -> 16 batched MFMA GEMMs -> output transform (+ residual).
+    keep_xt: a dict; the transformed input X' is stored under keep_xt["xt"] so that the weight gradient of
+    the same layer (conv2d_wgrad_winograd(..., xt=...)) does not have to transform x again."""
     assert x.C == ww.C
     N, H, W, C, K = x.N, x.H, x.W, ww.C, ww.K
     dev = x.buf.device
@@ -333,13 +336,15 @@ def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=N
                 a.w = ctypes.c_void_p(ww.t.data_ptr() + 4 * split * ww.Cp)
                 a.y = ctypes.c_void_p(yt.data_ptr() + 4 * split)
                 call("mss_conv2d_forward_f32", ctypes.byref(a))
+        if keep_xt is not None:
+            keep_xt["xt"] = xt
         del xt
         call("mss_wino_output_transform_f32", ptr(yt), N, H, W, K, dil, res.ptr if res is not None else None,
              res.ld if res is not None else 0, out.ptr, out.ld)
     return out
 
 
-def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False):
+def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=None):
     """[K,C,3,3] weight gradient of a 3x3 / stride-1 / padding = dilation conv in the Winograd domain:
     dU[p] = dY'[p]^T X'[p] (16 batched MFMA products over tiles, 2.25x fewer FLOPs than the 9-tap form)."""
     N, H, W = x.N, x.H, x.W
@@ -347,9 +352,11 @@ def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False):
     T = _lib.value("mss_wino_num_tiles", N, H, W, dil)
     Kpad, Cp = _round_up(K, 4), _round_up(C, 4)
     with _Timed("wgrad_winograd", 2.0 * N * H * W * K * C * 9, (N, H, W, C, K, 3, 1, dil)):
-        xt = torch.empty((16, T, C), device=dev, dtype=torch.float32)
-        sc, sh = in_affine if in_affine is not None else (None, None)
-        call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
+        if xt is None:
+            xt = torch.empty((16, T, C), device=dev, dtype=torch.float32)
+            sc, sh = in_affine if in_affine is not None else (None, None)
+            call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
+        assert tuple(xt.shape) == (16, T, C)
         dyt = torch.empty((16, T, K), device=dev, dtype=torch.float32)
         call("mss_wino_grad_output_transform_f32", dy.ptr, dy.ld, N, H, W, K, dil, ptr(dyt))
         du = torch.zeros((16, Kpad, Cp), device=dev, dtype=torch.float32)
@@ -366,9 +373,9 @@ def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False):
     return grad
 
 
-def conv3x3_wgrad(x, dy, K, C, dil=1, in_affine=None, in_relu=False):
+def conv3x3_wgrad(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=None):
     if use_winograd(C, K, 1, in_affine):
-        return conv2d_wgrad_winograd(x, dy, K, C, dil, in_affine, in_relu)
+        return conv2d_wgrad_winograd(x, dy, K, C, dil, in_affine, in_relu, xt=xt)
     return conv2d_wgrad(x, dy, K, C, 3, 3, dil=dil, pad=dil, in_affine=in_affine, in_relu=in_relu)
 
 
