@@ -91,24 +91,26 @@ int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dw
 int mss_conv2d_unpack_wgrad_f32(const float* packed, float* grad, int K, int C, int R, int S, int Kpad,
                                 int Cp, int accumulate, void* stream);
 
-/* Winograd F(2x2,3x3) path for stride-1 3x3 convolutions with many channels (csrc/winograd.hip):
- * weights [K][C][3][3] -> U [16][Kpad][Cp]; x -> X' [16][T][C] (T = mss_wino_num_tiles, BatchNorm/ReLU
- * prologue and zero padding fused); then ONE mss_conv2d_forward_f32 call in batched 1x1 mode
- * (batch = 16, x_bs = T*C, w_bs = Kpad*Cp, y_bs = T*K) gives Y' [16][T][K]; Y' -> NHWC y (+ residual).
- * Dilation is exact (per-residue sub-grids). */
-long long mss_wino_num_tiles(int N, int H, int W, int dil);
-int mss_wino_pack_weights_f32(const float* w, float* u, int K, int C, int Kpad, int Cp, void* stream);
-int mss_wino_input_transform_f32(const float* x, int ldx, int N, int H, int W, int C, int dil, const float* scale,
-                                 const float* shift, int relu, float* xt, void* stream);
-int mss_wino_output_transform_f32(const float* yt, int N, int H, int W, int K, int dil, const float* res, int ldres,
-                                  float* y, int ldy, void* stream);
+/* Winograd F(m x m, 3x3) path, m = `tile` = 2 or 4, P = (m+2)^2 positions, for stride-1 3x3 convolutions with
+ * many channels (csrc/winograd.hip): weights [K][C][3][3] -> U [P][Kpad][Cp]; x -> X' [P][T][C]
+ * (T = mss_wino_num_tiles, BatchNorm/ReLU prologue and zero padding fused); then ONE mss_conv2d_forward_f32
+ * call in batched 1x1 mode (batch = P, x_bs = T*C, w_bs = Kpad*Cp, y_bs = T*K) gives Y' [P][T][K];
+ * Y' -> NHWC y (+ residual). Dilation is exact (per-residue sub-grids). MFMA work is 9*m^2/P = 2.25x (m = 2)
+ * or 4x (m = 4) below the direct form; fp32 rounding error ~1e-6 (m = 2) / ~1e-5 (m = 4) relative per layer. */
+long long mss_wino_num_tiles(int N, int H, int W, int dil, int tile);
+int mss_wino_pack_weights_f32(const float* w, float* u, int K, int C, int Kpad, int Cp, int tile, void* stream);
+int mss_wino_input_transform_f32(const float* x, int ldx, int N, int H, int W, int C, int dil, int tile,
+                                 const float* scale, const float* shift, int relu, float* xt, void* stream);
+int mss_wino_output_transform_f32(const float* yt, int N, int H, int W, int K, int dil, int tile, const float* res,
+                                  int ldres, float* y, int ldy, void* stream);
 
 /* weight gradient in the Winograd domain: dY' = A dY A^T per tile, then ONE mss_conv2d_wgrad_f32 call in
- * batched mode (batch = 16, R = S = 1, x = X', x_bs = T*C, dy = dY', y_bs = T*K) accumulates
- * dU [16][Kpad][Cp], and dg = G^T dU G gives the [K][C][3][3] gradient. */
-int mss_wino_grad_output_transform_f32(const float* dy, int lddy, int N, int H, int W, int K, int dil, float* dyt,
+ * batched mode (batch = P, R = S = 1, x = X', x_bs = T*C, dy = dY', y_bs = T*K) accumulates
+ * dU [P][Kpad][Cp], and dg = G^T dU G gives the [K][C][3][3] gradient. */
+int mss_wino_grad_output_transform_f32(const float* dy, int lddy, int N, int H, int W, int K, int dil, int tile,
+                                       float* dyt, void* stream);
+int mss_wino_weight_grad_transform_f32(const float* du, float* dw, int K, int C, int Kpad, int Cp, int tile,
                                        void* stream);
-int mss_wino_weight_grad_transform_f32(const float* du, float* dw, int K, int C, int Kpad, int Cp, void* stream);
 
 /* image NCHW [N,C,H,W] -> NHWC [N,H,W,Cp] with channels C..Cp-1 zero (feeds mod1.conv1). */
 int mss_nchw_to_nhwc_pad_f32(const float* x, float* y, int N, int C, int H, int W, int Cp, void* stream);

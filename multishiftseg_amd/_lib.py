@@ -97,12 +97,12 @@ SIGNATURES = {
     "mss_rcl_gather_f32": [P, P, U, P, P],
     "mss_rcl_scatter_add_f32": [P, P, U, P, P],
     "mss_adam_step_f32": [P, P, P, P, L, F, F, F, F, F, I, P],
-    "mss_wino_num_tiles": [I, I, I, I],
-    "mss_wino_pack_weights_f32": [P, P, I, I, I, I, P],
-    "mss_wino_input_transform_f32": [P, I, I, I, I, I, I, P, P, I, P, P],
-    "mss_wino_output_transform_f32": [P, I, I, I, I, I, P, I, P, I, P],
-    "mss_wino_grad_output_transform_f32": [P, I, I, I, I, I, I, P, P],
-    "mss_wino_weight_grad_transform_f32": [P, P, I, I, I, I, P],
+    "mss_wino_num_tiles": [I, I, I, I, I],
+    "mss_wino_pack_weights_f32": [P, P, I, I, I, I, I, P],
+    "mss_wino_input_transform_f32": [P, I, I, I, I, I, I, I, P, P, I, P, P],
+    "mss_wino_output_transform_f32": [P, I, I, I, I, I, I, P, I, P, I, P],
+    "mss_wino_grad_output_transform_f32": [P, I, I, I, I, I, I, I, P, P],
+    "mss_wino_weight_grad_transform_f32": [P, P, I, I, I, I, I, P],
     "mss_peak_mfma_f32": [P, I, I, P],
     "mss_peak_stream_f32": [P, P, L, P],
 }

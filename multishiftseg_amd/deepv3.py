@@ -239,15 +239,16 @@ class DeepWV3Plus(nn.Module):
         st = K.bn_fold(asp.img_conv[1], train=train, x_rows=u0_rows)
         K.broadcast_rows(u0_rows, raw.slice(0, 256))
         states.append(st)
+        xt_bytes = sum(K.wino_xt_bytes(N, h8, w8, 4096, r) for r in _ASPP_RATES)
         for i, feat in enumerate(asp.features):
             rate = 1 if i == 0 else _ASPP_RATES[i - 1]
             sl = raw.slice(256 * (i + 1), 256)
             if i == 0:
                 K.conv2d(x, K.packed(feat[0].weight), out=sl)
             else:
-                # keep the Winograd-domain input for this layer's weight gradient when the three of them
-                # (16 positions x ~1.3*M/4 tiles x 4096 floats each, i.e. ~21*M*4096 bytes) fit comfortably: 15 GB at 2x1024x2048
-                kx = {} if (keep and feat[0].weight.requires_grad and 3 * 21 * x.M * 4096 < (40 << 30)) else None
+                # keep the Winograd-domain input X' for this layer's weight gradient when the three of them fit
+                # comfortably (2.25-4x the 4096-channel map each: 10.6 GB in all at 2x1024x2048)
+                kx = {} if (keep and feat[0].weight.requires_grad and xt_bytes < (40 << 30)) else None
                 K.conv3x3(x, feat[0].weight, dil=rate, out=sl, keep_xt=kx)
                 aspp_xt[i] = kx.get("xt") if kx else None
             states.append(K.bn_fold(feat[1], sl, train))

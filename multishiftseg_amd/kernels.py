@@ -5,6 +5,7 @@ libmss_hip.so. An activation is an `Act`: a channel slice [c0, c0+C) of a contig
 so concats are written in place and never copied.
 """
 import ctypes
+import os
 
 import torch
 
@@ -95,19 +96,23 @@ def pack_weight(w, flip=False, min_c=16):
     return PackedWeight(t, k_out, c_in, R, S, Kpad, Cp)
 
 
-_pack_cache = {}
+def _cached_pack(param, key, make):
+    """Packed forms live on the parameter object itself and die with it. (A module-level dict keyed by
+    id(param) can hand a new parameter the packed weights of a dead one when Python recycles the id and the
+    allocator recycles the storage address -- same-shaped layers of two successive models.) Re-packed when the
+    parameter is modified in place (optimizer step, load_state_dict: tensor._version) or moved (data_ptr)."""
+    cache = param.__dict__.setdefault("_mss_packed", {})
+    ent = cache.get(key)
+    if ent is not None and ent[0] == param._version and ent[1] == param.data_ptr():
+        return ent[2]
+    val = make()
+    cache[key] = (param._version, param.data_ptr(), val)
+    return val
 
 
 def packed(param, flip=False):
-    """Cached pack of an nn.Parameter; re-packed when the parameter is modified in place
-    (optimizer step, load_state_dict) -- tracked through tensor._version."""
-    key = (id(param), flip)
-    ent = _pack_cache.get(key)
-    if ent is not None and ent[0] == param._version and ent[1] == param.data_ptr():
-        return ent[2]
-    pw = pack_weight(param, flip)
-    _pack_cache[key] = (param._version, param.data_ptr(), pw)
-    return pw
+    """Cached pack_weight of an nn.Parameter."""
+    return _cached_pack(param, ("direct", flip), lambda: pack_weight(param, flip))
 
 
 class ConvProfile:
@@ -245,91 +250,108 @@ def conv2d_wgrad(x, dy, K, C, R, S, stride=1, dil=1, pad=0, in_affine=None, in_r
 
 
 class WinoWeight:
-    """Winograd-domain filter U [16][Kpad][Cp] of a 3x3 weight."""
-    __slots__ = ("t", "K", "C", "Kpad", "Cp")
+    """Winograd-domain filter U [(tile+2)^2][Kpad][Cp] of a 3x3 weight."""
+    __slots__ = ("t", "K", "C", "Kpad", "Cp", "tile")
 
-    def __init__(self, t, K, C, Kpad, Cp):
-        self.t, self.K, self.C, self.Kpad, self.Cp = t, K, C, Kpad, Cp
+    def __init__(self, t, K, C, Kpad, Cp, tile):
+        self.t, self.K, self.C, self.Kpad, self.Cp, self.tile = t, K, C, Kpad, Cp, tile
 
 
-def pack_weight_wino(w, flip=False):
+def pack_weight_wino(w, flip=False, tile=2):
     """flip=True: the data-gradient filter (K<->C swapped, taps rotated 180 degrees), as pack_weight."""
     if flip:
         w = w.detach().flip(2, 3).transpose(0, 1)
     K, C, R, S = w.shape
-    assert R == 3 and S == 3 and C % 16 == 0 and K % 4 == 0
+    assert R == 3 and S == 3 and C % 16 == 0 and K % 4 == 0 and tile in (2, 4)
     if w.dtype != torch.float32 or not w.is_cuda:
         raise TypeError("pack_weight_wino needs a float32 CUDA tensor")
     w = w.detach().contiguous()
     Kpad = _lib.value("mss_conv2d_kpad", K)
-    t = torch.empty((16, Kpad, C), device=w.device, dtype=torch.float32)
-    call("mss_wino_pack_weights_f32", ptr(w), ptr(t), K, C, Kpad, C)
-    return WinoWeight(t, K, C, Kpad, C)
+    t = torch.empty(((tile + 2) ** 2, Kpad, C), device=w.device, dtype=torch.float32)
+    call("mss_wino_pack_weights_f32", ptr(w), ptr(t), K, C, Kpad, C, tile)
+    return WinoWeight(t, K, C, Kpad, C, tile)
 
 
-def packed_wino(param, flip=False):
-    key = (id(param), "wino", flip)
-    ent = _pack_cache.get(key)
-    if ent is not None and ent[0] == param._version and ent[1] == param.data_ptr():
-        return ent[2]
-    ww = pack_weight_wino(param, flip)
-    _pack_cache[key] = (param._version, param.data_ptr(), ww)
-    return ww
+def packed_wino(param, flip=False, tile=2):
+    return _cached_pack(param, ("wino", flip, tile), lambda: pack_weight_wino(param, flip, tile))
 
 
-WINOGRAD_MIN_CHANNELS = 256     # measured on MI355X: 1.24-1.28x at 256 channels, 1.7-2.1x at >= 512, 0.87x at 128
+# measured on MI355X (tools/bench_wino.py): F(2x2) 0.87x at 128 channels, 1.24-1.28x at 256, 1.7-2.1x at >= 512;
+# F(4x4) 1.29x at 128 channels, 2.0x at 256, 2.4-3.4x at >= 512
+WINOGRAD_MIN_CHANNELS = {2: 256, 4: 128}
 
 
-def use_winograd(c_in, k_out, stride, in_affine=None):
+def use_winograd(c_in, k_out, stride, in_affine=None, tile=2):
     """Policy: 3x3 stride-1 layers whose channel counts make the two HBM-bound transforms cheaper than the
     MFMA work they remove. MSS_WINOGRAD=0 forces the direct implicit GEMM everywhere."""
-    import os
     if os.environ.get("MSS_WINOGRAD", "1") == "0" or stride != 1:
         return False
     if in_affine is not None and in_affine[0].dim() != 1:
         return False
-    return c_in >= WINOGRAD_MIN_CHANNELS and k_out >= WINOGRAD_MIN_CHANNELS and c_in % 16 == 0 and k_out % 4 == 0
+    lo = WINOGRAD_MIN_CHANNELS[tile]
+    return c_in >= lo and k_out >= lo and c_in % 16 == 0 and k_out % 4 == 0
+
+
+def wino_tile(H, W, dil):
+    """Output-tile edge m of F(m x m, 3x3) for a layer: the one with fewer Winograd-domain elements
+    (tiles x (m+2)^2), which decides both the MFMA work and the transform traffic: 2.25 per output pixel
+    for m = 4 against 4 for m = 2, unless the dilation sub-grid is so small that 4x4 tiles are mostly padding
+    (e.g. a 12x16 map at dilation 12). MSS_WINO_TILE=2|4 forces one."""
+    forced = os.environ.get("MSS_WINO_TILE")
+    if forced:
+        return int(forced)
+    hs, ws = -(-H // dil), -(-W // dil)
+    cost = {m: (-(-hs // m)) * (-(-ws // m)) * (m + 2) ** 2 for m in (2, 4)}
+    return 4 if cost[4] < cost[2] else 2
+
+
+def wino_xt_bytes(N, H, W, C, dil):
+    """Size of the Winograd-domain input X' of one layer under the tile policy."""
+    ts = wino_tile(H, W, dil)
+    return (ts + 2) ** 2 * _lib.value("mss_wino_num_tiles", N, H, W, dil, ts) * C * 4
 
 
 def conv3x3(x, weight, dil=1, stride=1, in_affine=None, in_relu=False, res=None, out=None, flip=False, keep_xt=None):
     """3x3 convolution with padding = dilation on nn.Conv2d-layout `weight` (flip=True: its data gradient),
     through Winograd when the policy says so, else through the direct implicit GEMM."""
     k_out, c_in = (weight.shape[1], weight.shape[0]) if flip else (weight.shape[0], weight.shape[1])
-    if use_winograd(c_in, k_out, stride, in_affine):
-        return conv2d_winograd(x, packed_wino(weight, flip), dil=dil, in_affine=in_affine, in_relu=in_relu, res=res, out=out,
-                               keep_xt=keep_xt)
+    tile = wino_tile(x.H, x.W, dil)
+    if use_winograd(c_in, k_out, stride, in_affine, tile):
+        return conv2d_winograd(x, packed_wino(weight, flip, tile), dil=dil, in_affine=in_affine,
+                               in_relu=in_relu, res=res, out=out, keep_xt=keep_xt)
     return conv2d(x, packed(weight, flip), stride=stride, dil=dil, pad=dil, in_affine=in_affine, in_relu=in_relu, res=res,
                   out=out)
 
 
 def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=None, keep_xt=None):
-    """3x3 / stride 1 / padding = dilation convolution through Winograd F(2x2,3x3): input transform (with
-    the fused BatchNorm+ReLU prologue) -> 16 batched MFMA GEMMs -> output transform (+ residual).
-    keep_xt: a dict; the transformed input X' is stored under keep_xt["xt"] so that the weight gradient of
-    the same layer (conv2d_wgrad_winograd(..., xt=...)) does not have to transform x again."""
+    """3x3 / stride 1 / padding = dilation convolution through Winograd F(m x m,3x3), m = ww.tile: input
+    transform (with the fused BatchNorm+ReLU prologue) -> (m+2)^2 batched MFMA GEMMs -> output transform
+    (+ residual). keep_xt: a dict; the transformed input X' is stored under keep_xt["xt"] so that the weight
+    gradient of the same layer (conv2d_wgrad_winograd(..., xt=...)) does not have to transform x again."""
     assert x.C == ww.C
-    N, H, W, C, K = x.N, x.H, x.W, ww.C, ww.K
+    N, H, W, C, K, ts = x.N, x.H, x.W, ww.C, ww.K, ww.tile
+    P = (ts + 2) ** 2
     dev = x.buf.device
     if out is None:
         out = Act.empty(N, H, W, K, dev)
-    T = _lib.value("mss_wino_num_tiles", N, H, W, dil)
+    T = _lib.value("mss_wino_num_tiles", N, H, W, dil, ts)
     with _Timed("conv_winograd", 2.0 * N * H * W * K * C * 9, (N, H, W, C, K, 3, 1, dil)):
-        xt = torch.empty((16, T, C), device=dev, dtype=torch.float32)
+        xt = torch.empty((P, T, C), device=dev, dtype=torch.float32)
         sc, sh = in_affine if in_affine is not None else (None, None)
         assert sc is None or sc.dim() == 1
-        call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
-        yt = torch.empty((16, T, K), device=dev, dtype=torch.float32)
+        call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ts, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
+        yt = torch.empty((P, T, K), device=dev, dtype=torch.float32)
         a = MssConvArgs()
         a.x, a.w, a.y = ptr(xt), ptr(ww.t), ptr(yt)
         a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
         a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, K, ww.Kpad, K
         a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
-        a.batch, a.x_bs, a.w_bs, a.y_bs = 16, T * C, ww.Kpad * ww.Cp, T * K
+        a.batch, a.x_bs, a.w_bs, a.y_bs = P, T * C, ww.Kpad * ww.Cp, T * K
         rem = K % 128
         split = K - rem if (K > 128 and 0 < rem <= 64) else 0     # e.g. 304 = 256 + 48: narrow tail on the 64-wide tile
         if split:
             a.K = split
-        with _Timed("conv_igemm", 2.0 * 16 * T * C * K, (16, 1, T, C, K, 1, 1, 1)):   # the MFMA work actually executed
+        with _Timed("conv_igemm", 2.0 * P * T * C * K, (P, 1, T, C, K, 1, 1, 1)):   # the MFMA work actually executed
             call("mss_conv2d_forward_f32", ctypes.byref(a))
             if split:
                 a.K, a.Kpad = rem, ww.Kpad - split
@@ -339,43 +361,50 @@ def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=N
         if keep_xt is not None:
             keep_xt["xt"] = xt
         del xt
-        call("mss_wino_output_transform_f32", ptr(yt), N, H, W, K, dil, res.ptr if res is not None else None,
+        call("mss_wino_output_transform_f32", ptr(yt), N, H, W, K, dil, ts, res.ptr if res is not None else None,
              res.ld if res is not None else 0, out.ptr, out.ld)
     return out
 
 
-def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=None):
+def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=None, tile=None):
     """[K,C,3,3] weight gradient of a 3x3 / stride-1 / padding = dilation conv in the Winograd domain:
-    dU[p] = dY'[p]^T X'[p] (16 batched MFMA products over tiles, 2.25x fewer FLOPs than the 9-tap form)."""
+    dU[p] = dY'[p]^T X'[p] ((m+2)^2 batched MFMA products over tiles, 2.25x / 4x fewer FLOPs than the 9-tap
+    form). xt: the X' kept by the forward (its leading dimension tells the tile size)."""
     N, H, W = x.N, x.H, x.W
     dev = x.buf.device
-    T = _lib.value("mss_wino_num_tiles", N, H, W, dil)
+    if xt is not None:
+        ts = {16: 2, 36: 4}[xt.shape[0]]
+    else:
+        ts = tile or wino_tile(H, W, dil)
+    P = (ts + 2) ** 2
+    T = _lib.value("mss_wino_num_tiles", N, H, W, dil, ts)
     Kpad, Cp = _round_up(K, 4), _round_up(C, 4)
     with _Timed("wgrad_winograd", 2.0 * N * H * W * K * C * 9, (N, H, W, C, K, 3, 1, dil)):
         if xt is None:
-            xt = torch.empty((16, T, C), device=dev, dtype=torch.float32)
+            xt = torch.empty((P, T, C), device=dev, dtype=torch.float32)
             sc, sh = in_affine if in_affine is not None else (None, None)
-            call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
-        assert tuple(xt.shape) == (16, T, C)
-        dyt = torch.empty((16, T, K), device=dev, dtype=torch.float32)
-        call("mss_wino_grad_output_transform_f32", dy.ptr, dy.ld, N, H, W, K, dil, ptr(dyt))
-        du = torch.zeros((16, Kpad, Cp), device=dev, dtype=torch.float32)
+            call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ts, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
+        assert tuple(xt.shape) == (P, T, C)
+        dyt = torch.empty((P, T, K), device=dev, dtype=torch.float32)
+        call("mss_wino_grad_output_transform_f32", dy.ptr, dy.ld, N, H, W, K, dil, ts, ptr(dyt))
+        du = torch.zeros((P, Kpad, Cp), device=dev, dtype=torch.float32)
         a = MssConvArgs()
         a.x = ptr(xt)
         a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
         a.OH, a.OW, a.K, a.Kpad = 1, T, K, Kpad
         a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
-        a.batch, a.x_bs, a.y_bs = 16, T * C, T * K
-        with _Timed("conv_wgrad", 2.0 * 16 * T * K * C, (16, 1, T, C, K, 1, 1, 1)):
+        a.batch, a.x_bs, a.y_bs = P, T * C, T * K
+        with _Timed("conv_wgrad", 2.0 * P * T * K * C, (P, 1, T, C, K, 1, 1, 1)):
             call("mss_conv2d_wgrad_f32", ctypes.byref(a), ptr(dyt), K, ptr(du), Cp)
         grad = torch.empty((K, C, 3, 3), device=dev, dtype=torch.float32)
-        call("mss_wino_weight_grad_transform_f32", ptr(du), ptr(grad), K, C, Kpad, Cp)
+        call("mss_wino_weight_grad_transform_f32", ptr(du), ptr(grad), K, C, Kpad, Cp, ts)
     return grad
 
 
 def conv3x3_wgrad(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=None):
-    if use_winograd(C, K, 1, in_affine):
-        return conv2d_wgrad_winograd(x, dy, K, C, dil, in_affine, in_relu, xt=xt)
+    tile = {16: 2, 36: 4}[xt.shape[0]] if xt is not None else wino_tile(x.H, x.W, dil)
+    if use_winograd(C, K, 1, in_affine, tile):
+        return conv2d_wgrad_winograd(x, dy, K, C, dil, in_affine, in_relu, xt=xt, tile=tile)
     return conv2d_wgrad(x, dy, K, C, 3, 3, dil=dil, pad=dil, in_affine=in_affine, in_relu=in_relu)
 
 

@@ -219,11 +219,12 @@ def test_m2f_score(K):
     np.testing.assert_allclose(s.cpu().numpy(), om2f.anomaly_score(cls, mask, (64, 96)), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("tile", [2, 4])
 @pytest.mark.parametrize("cin,cout,dil,n,h,w", [(32, 64, 1, 2, 12, 14), (64, 32, 2, 1, 13, 17), (32, 128, 4, 2, 16, 22),
                                                  (48, 64, 1, 1, 7, 9), (64, 64, 4, 1, 5, 6)])
-def test_winograd_conv_vs_oracle(K, cin, cout, dil, n, h, w):
-    """Winograd F(2x2,3x3) path: dilation handled through residue sub-grids, ragged tiles, fused
-    BatchNorm+ReLU prologue and residual epilogue."""
+def test_winograd_conv_vs_oracle(K, cin, cout, dil, n, h, w, tile):
+    """Winograd F(2x2,3x3) / F(4x4,3x3) path: dilation handled through residue sub-grids, ragged tiles,
+    fused BatchNorm+ReLU prologue and residual epilogue."""
     rng = np.random.default_rng(cin + cout + dil)
     x = rng.standard_normal((n, cin, h, w), dtype=np.float32)
     wt = (rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) / np.sqrt(cin * 9)).astype(np.float32)
@@ -233,15 +234,16 @@ def test_winograd_conv_vs_oracle(K, cin, cout, dil, n, h, w):
     act = np.maximum(x * sc[None, :, None, None] + sh[None, :, None, None], 0)
     ref = nnops.conv2d(act, wt, 1, dil, dil) + res
     xa = K.Act.from_nchw(dev(x))
-    y = K.conv2d_winograd(xa, K.pack_weight_wino(dev(wt)), dil=dil, in_affine=(dev(sc), dev(sh)), in_relu=True,
+    y = K.conv2d_winograd(xa, K.pack_weight_wino(dev(wt), tile=tile), dil=dil, in_affine=(dev(sc), dev(sh)), in_relu=True,
                           res=K.Act.from_nchw(dev(res)))
     np.testing.assert_allclose(y.nchw().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
-    y2 = K.conv2d_winograd(xa, K.pack_weight_wino(dev(wt)), dil=dil)        # no prologue / residual
+    y2 = K.conv2d_winograd(xa, K.pack_weight_wino(dev(wt), tile=tile), dil=dil)        # no prologue / residual
     np.testing.assert_allclose(y2.nchw().cpu().numpy(), nnops.conv2d(x, wt, 1, dil, dil), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("tile", [2, 4])
 @pytest.mark.parametrize("cin,cout,dil,n,h,w", [(32, 64, 1, 2, 12, 14), (64, 32, 2, 1, 13, 17), (48, 36, 12, 2, 16, 22)])
-def test_winograd_wgrad_vs_autograd(K, cin, cout, dil, n, h, w):
+def test_winograd_wgrad_vs_autograd(K, cin, cout, dil, n, h, w, tile):
     rng = np.random.default_rng(cin * 3 + cout + dil)
     x = torch.from_numpy(rng.standard_normal((n, cin, h, w), dtype=np.float32))
     wt = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) / np.sqrt(cin * 9)).astype(np.float32)).requires_grad_(True)
@@ -252,11 +254,27 @@ def test_winograd_wgrad_vs_autograd(K, cin, cout, dil, n, h, w):
     gy = torch.from_numpy(rng.standard_normal(tuple(y.shape), dtype=np.float32))
     y.backward(gy)
     dw = K.conv2d_wgrad_winograd(K.Act.from_nchw(x.cuda()), K.Act.from_nchw(gy.cuda()), cout, cin, dil=dil,
-                                 in_affine=(sc.cuda(), sh.cuda()), in_relu=True)
+                                 in_affine=(sc.cuda(), sh.cuda()), in_relu=True, tile=tile)
     np.testing.assert_allclose(dw.cpu().numpy(), wt.grad.numpy(), rtol=1e-3, atol=1e-3)
     # data gradient through the flipped Winograd filter
     xg = torch.from_numpy(rng.standard_normal((n, cin, h, w), dtype=np.float32)).requires_grad_(True)
     torch.nn.functional.conv2d(xg, wt.detach(), dilation=dil, padding=dil).backward(gy)
     if cout % 16 == 0:
-        dx = K.conv2d_winograd(K.Act.from_nchw(gy.cuda()), K.pack_weight_wino(wt.detach().cuda(), flip=True), dil=dil)
+        dx = K.conv2d_winograd(K.Act.from_nchw(gy.cuda()), K.pack_weight_wino(wt.detach().cuda(), flip=True, tile=tile), dil=dil)
         np.testing.assert_allclose(dx.nchw().cpu().numpy(), xg.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_pack_cache_dies_with_parameter(K):
+    """Successive same-shaped parameters (recycled id() and storage address) must never see each other's packs."""
+    for tile in (0, 2, 4):
+        for seed in range(6):
+            w = torch.nn.Parameter(torch.full((32, 16, 3, 3), float(seed + 1), device="cuda"))
+            pw = K.packed(w) if tile == 0 else K.packed_wino(w, tile=tile)
+            assert pw is (K.packed(w) if tile == 0 else K.packed_wino(w, tile=tile))       # cached
+            ref = K.pack_weight(w.detach()) if tile == 0 else K.pack_weight_wino(w.detach(), tile=tile)
+            assert torch.equal(pw.t, ref.t)
+            with torch.no_grad():
+                w.mul_(2.0)                                                                 # in-place update -> re-pack
+            pw2 = K.packed(w) if tile == 0 else K.packed_wino(w, tile=tile)
+            assert pw2 is not pw and torch.allclose(pw2.t, 2 * ref.t)
+            del w, pw, pw2, ref

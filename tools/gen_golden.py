@@ -233,6 +233,32 @@ def gen_train_step(DeepWV3Plus, ref_loss):
             delta = t2n(dict(model.named_parameters())[n_].detach() - b)
             if delta.size <= 70000:
                 out[pre + "delta_" + n_] = delta
+        if stage == "stage2":
+            # conditioning of the small gradients: the same step of the reference in float64 (same masks, same
+            # permutations). rel-L2(fp32 reference, fp64 reference) per tensor is the noise floor a parity test
+            # can ask of any fp32 implementation; stored as gradnoise_<name>.
+            model64 = build_ref_model(DeepWV3Plus).double()
+            model64.uncertainty_func_init()
+            model64.ood_head.double()
+            for name, p in model64.named_parameters():
+                p.requires_grad = any(s in name for s in names)
+            model64.train()
+            model64.mod6.block1.convs.dropout.forward = lambda x: x * torch.from_numpy(masks["mod6"]).double()[:, :, None, None]
+            model64.mod7.block1.convs.dropout.forward = lambda x: x * torch.from_numpy(masks["mod7"]).double()[:, :, None, None]
+            replay = [torch.from_numpy(p_.astype(np.int64)) for p_ in perms]
+            torch.randperm = lambda n, *a, **k: replay.pop(0)
+            try:
+                score64, logit64 = model64(torch.from_numpy(img).double())
+                loss64 = ref_loss.RelContrastiveLoss(loss_params)(logit64, score64, torch.from_numpy(target.copy())).mean()
+                loss64.backward()
+            finally:
+                torch.randperm = real_randperm
+            for n_, p in model64.named_parameters():
+                if p.requires_grad and n_ in grads and grads[n_].numel() <= 70000:
+                    g32, g64 = grads[n_].double().numpy(), p.grad.numpy()
+                    out[pre + "gradnoise_" + n_] = np.float64(np.sqrt(((g32 - g64) ** 2).sum()) / (np.sqrt((g64 ** 2).sum()) + 1e-300))
+            noisy = sorted(((float(v), k) for k, v in out.items() if k.startswith(pre + "gradnoise_")), reverse=True)[:5]
+            print(f"   stage2 float64 replay: loss {float(loss64):.6f}; largest fp32-vs-fp64 gradient rel-L2: {noisy}")
         print(f"   {stage}: loss {float(loss):.6f}, {len(grads)} trainable tensors, perms {[len(p) for p in perms]}")
     save("deepwv3plus_train_step", **out)
 
