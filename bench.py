@@ -137,6 +137,12 @@ def main():
     conv = summ.get("conv_igemm", dict(launches=0, flops=0.0, ms=1.0))
     achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["launches"] else 0.0
     wg = summ.get("conv_wgrad")
+    # algorithmic HBM bytes of a conv_igemm launch: input once + output once + weights once (fp32)
+    alg_bytes = 0.0
+    for (kind, _f, _s, _e), tag in zip(prof.records, prof.tags):
+        if kind == "conv_igemm":
+            n, h, w, c, k, r, st, _d = tag
+            alg_bytes += 4.0 * (n * h * w * c + n * (-(-h // st)) * (-(-w // st)) * k + r * r * c * k * (n if h == 1 else 1))
     step_flops_alg = 2 * FWD_GMAC_1024x2048 * 1e9 * (H * W) / (1024 * 2048) * 2 * pairs * \
         (STAGE2_STEP_OVER_FWD if args.stage == 2 else 1.0)
 
@@ -152,6 +158,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32)",
                      "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": round(alg_bytes / max(conv["launches"], 1)),
                      "launches_per_step": conv["launches"] // max(args.steps, 1),
                      "avg_launch_ms": round(conv["ms"] / max(conv["launches"], 1), 4),
                      "kernel_ms_per_step": round(conv["ms"] / max(args.steps, 1), 2)},
