@@ -258,6 +258,26 @@ int mss_rcl_finalize_f32(const MssRclArgs* a, const double* counters, const uint
 int mss_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* Pixel-level OOD metrics on the device (csrc/metric.hip): exact AUROC / average precision / FPR at `recall_level`
+ * over all pixels with label id_out (positives) and id_in (negatives). Replaces eval_ood_measure, get_measures and
+ * fpr_and_fdr_at_recall (lib/utils/metric.py:170-180, 130-153, 87-127; callers test_deeplab.py:94-102,
+ * train_deeplab.py:236-241), which run sklearn on host copies of every score map.
+ *   compact:  one pass over a batch of n pixels: order-preserving u32 keys of the id_in pixels' scores packed
+ *             at the front of keys[0..n), those of the id_out pixels at the back; counts (device u64[2], zero on
+ *             entry) = {#id_in, #id_out}. No host synchronisation per batch.
+ *   sort:     ascending key sort (rocPRIM radix sort), temp sized by mss_oodm_sort_temp_bytes
+ *   measures: out[0..2] = {AUROC, AUPRC, FPR@recall_level} (device f64[3]); u2_part / ap_part: device scratch of
+ *             mss_oodm_rank_blocks(P) elements each. P, N >= 1 (the host mirror returns None otherwise, as
+ *             metric.py:176-180 does). */
+int mss_oodm_compact_f32(const float* score, const long long* label, long long n, long long id_in, long long id_out,
+                         unsigned int* keys, unsigned long long* counts, void* stream);
+long long mss_oodm_sort_temp_bytes(long long n);
+int mss_oodm_sort_u32(const unsigned int* keys_in, unsigned int* keys_out, long long n, void* temp, long long temp_bytes,
+                      void* stream);
+int mss_oodm_rank_blocks(long long P);
+int mss_oodm_measures_f64(const unsigned int* pos_sorted, long long P, const unsigned int* neg_sorted, long long N,
+                          double recall_level, unsigned long long* u2_part, double* ap_part, double* out, void* stream);
+
 /* Calibration kernels (bench.py: achievable peaks of this device next to the datasheet ones).
  * mss_peak_mfma_f32: blocks x 4 waves x iters x 16 back-to-back v_mfma_f32_32x32x2_f32 (4096 FLOP
  * each), out >= blocks*256 floats. mss_peak_stream_f32: float4 copy of n floats (8*n bytes moved). */

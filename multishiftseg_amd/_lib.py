@@ -6,7 +6,7 @@ bare ``except``: ops/modules/ms_deform_attn.py:116-121).
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_float, c_int, c_longlong, c_uint32, c_void_p
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_longlong, c_uint32, c_void_p
 
 import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so libmss_hip.so binds to the same runtime)
 
@@ -103,11 +103,18 @@ SIGNATURES = {
     "mss_wino_output_transform_f32": [P, I, I, I, I, I, I, P, I, P, I, P],
     "mss_wino_grad_output_transform_f32": [P, I, I, I, I, I, I, I, P, P],
     "mss_wino_weight_grad_transform_f32": [P, P, I, I, I, I, I, P],
+    "mss_oodm_compact_f32": [P, P, L, L, L, P, P, P],
+    "mss_oodm_sort_temp_bytes": [L],
+    "mss_oodm_sort_u32": [P, P, L, P, L, P],
+    "mss_oodm_rank_blocks": [L],
+    "mss_oodm_measures_f64": [P, L, P, L, c_double, P, P, P, P],
     "mss_peak_mfma_f32": [P, I, I, P],
     "mss_peak_stream_f32": [P, P, L, P],
 }
 # entry points that return a plain value rather than a status code
-_VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles"}
+_VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
+                    "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks"}
+_RETURNS_LONGLONG = {"mss_wino_num_tiles", "mss_oodm_sort_temp_bytes"}
 
 _lib = None
 
@@ -125,7 +132,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
-        fn.restype = c_longlong if name == "mss_wino_num_tiles" else c_int
+        fn.restype = c_longlong if name in _RETURNS_LONGLONG else c_int
     _lib = lib
     return lib
 

@@ -103,3 +103,16 @@ def test_rel_contrastive_loss(tag):
             np.testing.assert_allclose(r["dlogit"][:, :, ::3, ::3], g["dlogit_sub"], rtol=1e-4, atol=1e-8)
         np.testing.assert_allclose(np.abs(r["dlogit"].astype(np.float64)).sum(), g["dlogit_abs_sum"], rtol=1e-5)
     np.testing.assert_array_equal(target.astype(np.uint8), g["target_mut"])
+
+
+def test_ood_metrics_oracle_vs_reference():
+    """8f-1: oracle/metric.py against the reference's eval_ood_measure (sklearn inside) on the golden maps."""
+    from oracle import metric as ometric
+    g = golden("ood_metrics")
+    tags = sorted(k[:-len("_measures")] for k in g.files if k.endswith("_measures"))
+    assert len(tags) == 6
+    for tag in tags:
+        got = ometric.eval_ood_measure(g[tag + "_score"], g[tag + "_label"].astype(np.int64))
+        np.testing.assert_allclose(got, g[tag + "_measures"], rtol=0, atol=1e-12, err_msg=tag)
+    assert ometric.eval_ood_measure(np.zeros((1, 4, 4), np.float32), np.zeros((1, 4, 4), np.int64)) is None
+    assert ometric.eval_ood_measure(np.zeros((1, 4, 4), np.float32), np.ones((1, 4, 4), np.int64)) is None

@@ -437,8 +437,37 @@ def gen_m2f():
     save("m2f_score", cls=cls, mask=mask, size=np.array(size), score=t2n(score))
 
 
+def gen_metric():
+    """8f-1: lib/utils/metric.py eval_ood_measure (loaded by file path: the package __init__ needs wget/h5py) on
+    small score/label maps -- continuous scores, heavily tied scores, signed zeros, a recall level that falls
+    between thresholds, tiny positive sets."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_metric", os.path.join(REF, "lib", "utils", "metric.py"))
+    rm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rm)
+    rng = np.random.default_rng(77)
+    out = {}
+    cases = {"cont": (3, 40, 56, None, 0.25), "ties16": (2, 48, 64, 16, 0.2), "ties2": (1, 32, 32, 2, 0.5),
+             "fewpos": (1, 64, 64, None, 0.002), "fewneg": (1, 24, 40, 8, 0.97), "zeros": (1, 16, 16, 1, 0.4)}
+    for tag, (b, h, w, q, ppos) in cases.items():
+        r = rng.random((b, h, w))
+        label = np.where(r < ppos, 1, np.where(r < ppos + (1 - ppos) * 0.85, 0, 255)).astype(np.int64)
+        score = (rng.standard_normal((b, h, w)) + 0.9 * (label == 1)).astype(np.float32)
+        if q:
+            score = (np.round(score * q) / q).astype(np.float32)
+        if tag == "zeros":
+            score[score == 0] = np.where(rng.random((score == 0).sum()) < 0.5, np.float32(-0.0), np.float32(0.0))
+        res = rm.eval_ood_measure(score.copy(), label.copy())
+        out[tag + "_score"], out[tag + "_label"] = score, label.astype(np.uint8)
+        out[tag + "_measures"] = np.array(res, dtype=np.float64)
+        print(f"   {tag}: P={int((label == 1).sum())} N={int((label == 0).sum())} auroc/aupr/fpr {res}")
+    lab = np.zeros((1, 8, 8), np.int64)
+    assert rm.eval_ood_measure(np.zeros((1, 8, 8), np.float32), lab) is None          # no OOD pixel -> None
+    save("ood_metrics", **out)
+
+
 def main():
-    which = set(sys.argv[1:]) or {"ops", "deeplab", "train", "loss", "msda", "m2f", "encoder"}
+    which = set(sys.argv[1:]) or {"ops", "deeplab", "train", "loss", "msda", "m2f", "encoder", "metric"}
     torch.set_num_threads(8)
     DeepWV3Plus, ref_loss, core, MSDeformAttn = import_reference()
     if "ops" in which:
@@ -451,6 +480,8 @@ def main():
         print("encoder"); gen_encoder()
     if "loss" in which:
         print("loss"); gen_loss(ref_loss)
+    if "metric" in which:
+        print("metric"); gen_metric()
     if "deeplab" in which:
         print("deeplab"); gen_deeplab(DeepWV3Plus)
     if "train" in which:
