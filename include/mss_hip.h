@@ -258,6 +258,14 @@ int mss_rcl_finalize_f32(const MssRclArgs* a, const double* counters, const uint
 int mss_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* Mask2Former anomaly score fused with the mask upsample (csrc/m2f.hip): logit = pixel-major
+ * low-resolution mask logits [B, hm, wm, ldq] (queries contiguous; produced by mss_conv2d_forward_f32 in batched 1x1
+ * mode from mask_features and mask_embed = einsum("bqc,bchw->bqhw"), mask2former_transformer_decoder.py:544-548);
+ * the kernel applies F.interpolate(size=(Hi,Wi), bilinear, align_corners=False) (maskformer_model.py:264-277), the
+ * sigmoid, the class mix and 1 - max (train_m2f.py:387-407) and writes the crop [B,H,W]. Q % 4 == 0, C <= 20. */
+int mss_m2f_fused_score_f32(const float* cls, const float* logit, int B, int Q, int C, int hm, int wm, int ldq, int Hi,
+                            int Wi, int H, int W, float* score, void* stream);
+
 /* Pixel-level OOD metrics on the device (csrc/metric.hip): exact AUROC / average precision / FPR at `recall_level`
  * over all pixels with label id_out (positives) and id_in (negatives). Replaces eval_ood_measure, get_measures and
  * fpr_and_fdr_at_recall (lib/utils/metric.py:170-180, 130-153, 87-127; callers test_deeplab.py:94-102,

@@ -103,6 +103,7 @@ SIGNATURES = {
     "mss_wino_output_transform_f32": [P, I, I, I, I, I, I, P, I, P, I, P],
     "mss_wino_grad_output_transform_f32": [P, I, I, I, I, I, I, I, P, P],
     "mss_wino_weight_grad_transform_f32": [P, P, I, I, I, I, I, P],
+    "mss_m2f_fused_score_f32": [P, P, I, I, I, I, I, I, I, I, I, I, P, P],
     "mss_oodm_compact_f32": [P, P, L, L, L, P, P, P],
     "mss_oodm_sort_temp_bytes": [L],
     "mss_oodm_sort_u32": [P, P, L, P, L, P],

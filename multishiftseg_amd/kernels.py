@@ -556,3 +556,40 @@ def m2f_score(class_logits, mask_logits, size):
     out = torch.empty((B, H, W), device=cls.device, dtype=torch.float32)
     call("mss_m2f_score_f32", ptr(cls), ptr(mask), B, Q, C1 - 1, H, W, Hm, Wm, ptr(out))
     return out
+
+
+def m2f_mask_logits(mask_embed, mask_features):
+    """einsum("bqc,bchw->bqhw", mask_embed, mask_features) (mask2former_transformer_decoder.py:544-548) as ONE batched
+    MFMA GEMM, written pixel-major: returns [B, h, w, Q] (queries contiguous), the layout m2f_score_fused reads."""
+    B, Q, C = mask_embed.shape
+    Bf, Cf, h, w = mask_features.shape
+    if (B, C) != (Bf, Cf):
+        raise ValueError(f"mask_embed {tuple(mask_embed.shape)} does not match mask_features {tuple(mask_features.shape)}")
+    x = Act.from_nchw(mask_features.float())
+    Kpad = _lib.value("mss_conv2d_kpad", Q)
+    wp = torch.zeros((B, Kpad, C), device=x.buf.device, dtype=torch.float32)
+    wp[:, :Q] = mask_embed.detach().float()
+    out = torch.empty((B, h, w, Q), device=x.buf.device, dtype=torch.float32)
+    a = MssConvArgs()
+    a.x, a.w, a.y = x.ptr, ptr(wp), ptr(out)
+    a.N, a.H, a.W, a.C, a.ldx = 1, 1, h * w, C, x.ld
+    a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, h * w, Q, Kpad, Q
+    a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+    a.batch, a.x_bs, a.w_bs, a.y_bs = B, h * w * x.ld, Kpad * C, h * w * Q
+    with _Timed("conv_igemm", 2.0 * B * h * w * C * Q, (B, 1, h * w, C, Q, 1, 1, 1)):
+        call("mss_conv2d_forward_f32", ctypes.byref(a))
+    return out
+
+
+def m2f_score_fused(class_logits, mask_logits_nhwc, image_size, size=None):
+    """Anomaly score from LOW-resolution pixel-major mask logits [B,hm,wm,Q]: bilinear upsample to `image_size`
+    (align_corners=False, maskformer_model.py:264-277) + train_m2f.py:387-407, cropped to `size` -> [B,H,W]."""
+    B, Q, C1 = class_logits.shape
+    Bm, hm, wm, ldq = mask_logits_nhwc.shape
+    Hi, Wi = image_size
+    H, W = size if size is not None else image_size
+    cls = class_logits.contiguous().float()
+    lg = mask_logits_nhwc.contiguous()
+    out = torch.empty((B, H, W), device=cls.device, dtype=torch.float32)
+    call("mss_m2f_fused_score_f32", ptr(cls), ptr(lg), B, Q, C1 - 1, hm, wm, ldq, Hi, Wi, H, W, ptr(out))
+    return out

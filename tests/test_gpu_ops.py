@@ -278,3 +278,33 @@ def test_pack_cache_dies_with_parameter(K):
             pw2 = K.packed(w) if tile == 0 else K.packed_wino(w, tile=tile)
             assert pw2 is not pw and torch.allclose(pw2.t, 2 * ref.t)
             del w, pw, pw2, ref
+
+
+@pytest.mark.parametrize("tag", ["x4", "ragged"])
+def test_m2f_fused_score_golden(K, tag):
+    """8f-2: batched-GEMM mask prediction + fused upsample/sigmoid/class-mix/max against the reference's op chain."""
+    g = golden("m2f_fused")
+    image, crop = tuple(int(v) for v in g[tag + "_image"]), tuple(int(v) for v in g[tag + "_crop"])
+    lg = K.m2f_mask_logits(dev(g[tag + "_embed"]), dev(g[tag + "_features"]))                 # [B,h,w,Q]
+    np.testing.assert_allclose(lg.permute(0, 3, 1, 2).cpu().numpy()[:, ::7], g[tag + "_masks_sub"], rtol=1e-5, atol=1e-5)
+    s = K.m2f_score_fused(dev(g[tag + "_cls"]), lg, image, crop)
+    np.testing.assert_allclose(s.cpu().numpy(), g[tag + "_score"], rtol=1e-5, atol=1e-5)
+    s_full = K.m2f_score_fused(dev(g[tag + "_cls"]), lg, image)                               # no crop
+    want = om2f.anomaly_score_from_features(g[tag + "_cls"], g[tag + "_embed"], g[tag + "_features"], image, image)
+    np.testing.assert_allclose(s_full.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+
+
+def test_m2f_fused_equals_unfused_at_full_size(K):
+    """BASELINE C5 size (1x100x256x512 -> 1024x2048): the fused kernel equals the unfused chain (explicit upsample,
+    then the full-resolution score kernel) and never materialises the 839 MB tensor."""
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    emb = torch.randn(1, 100, 256, device="cuda", generator=gen) * 0.2
+    feat = torch.randn(1, 256, 256, 512, device="cuda", generator=gen)
+    cls = torch.randn(1, 100, 20, device="cuda", generator=gen) * 2
+    lg = K.m2f_mask_logits(emb, feat)
+    ref_lg = torch.einsum("bqc,bchw->bqhw", emb, feat)
+    assert (lg.permute(0, 3, 1, 2) - ref_lg).abs().max().item() < 2e-4 * ref_lg.abs().max().item()
+    fused = K.m2f_score_fused(cls, lg, (1024, 2048))
+    up = torch.nn.functional.interpolate(lg.permute(0, 3, 1, 2).contiguous(), size=(1024, 2048), mode="bilinear", align_corners=False)
+    unfused = K.m2f_score(cls, up, (1024, 2048))
+    assert (fused - unfused).abs().max().item() < 2e-5

@@ -116,3 +116,16 @@ def test_ood_metrics_oracle_vs_reference():
         np.testing.assert_allclose(got, g[tag + "_measures"], rtol=0, atol=1e-12, err_msg=tag)
     assert ometric.eval_ood_measure(np.zeros((1, 4, 4), np.float32), np.zeros((1, 4, 4), np.int64)) is None
     assert ometric.eval_ood_measure(np.zeros((1, 4, 4), np.float32), np.ones((1, 4, 4), np.int64)) is None
+
+
+def test_m2f_fused_chain_oracle_vs_reference_ops():
+    """8f-2: mask prediction einsum -> F.interpolate(bilinear, align_corners=False) -> anomaly score."""
+    g = golden("m2f_fused")
+    for tag in ("x4", "ragged"):
+        masks = m2f.mask_logits(g[tag + "_embed"], g[tag + "_features"])
+        np.testing.assert_allclose(masks[:, ::7], g[tag + "_masks_sub"], rtol=1e-5, atol=1e-5)
+        image, crop = tuple(int(v) for v in g[tag + "_image"]), tuple(int(v) for v in g[tag + "_crop"])
+        up = m2f.upsample_bilinear(masks, image)
+        np.testing.assert_allclose(up[:, ::9, ::3, ::3], g[tag + "_up_sub"], rtol=1e-5, atol=1e-5)
+        s = m2f.anomaly_score_from_features(g[tag + "_cls"], g[tag + "_embed"], g[tag + "_features"], image, crop)
+        np.testing.assert_allclose(s, g[tag + "_score"], rtol=1e-5, atol=1e-5)

@@ -435,6 +435,22 @@ def gen_m2f():
     u = torch.einsum("bqc,bqhw->bchw", class_probs, mask_probs)[:, :, :size[0], :size[1]]
     score = 1 - torch.max(u, dim=1)[0]
     save("m2f_score", cls=cls, mask=mask, size=np.array(size), score=t2n(score))
+    # 8f-2: the chain in front of it -- mask prediction (mask2former_transformer_decoder.py:544-548), the x4 upsample
+    # of maskformer_model.py:264-277 and the score -- evaluated with the same torch ops on random inputs
+    out = {}
+    for tag, (b, c, hm, wm, image, crop) in {"x4": (2, 64, 24, 32, (96, 128), (90, 120)),
+                                             "ragged": (1, 32, 13, 17, (50, 70), (50, 70))}.items():
+        emb = (rng.standard_normal((b, 100, c), dtype=np.float32) / np.sqrt(c) * 3).astype(np.float32)
+        feat = rng.standard_normal((b, c, hm, wm), dtype=np.float32)
+        cl = rng.standard_normal((b, 100, 20), dtype=np.float32) * 2
+        masks = torch.einsum("bqc,bchw->bqhw", torch.from_numpy(emb), torch.from_numpy(feat))
+        up = torch.nn.functional.interpolate(masks, size=image, mode="bilinear", align_corners=False)
+        probs = torch.softmax(torch.from_numpy(cl), dim=-1)[..., :-1]
+        u = torch.einsum("bqc,bqhw->bchw", probs, up.sigmoid())[:, :, :crop[0], :crop[1]]
+        out.update({tag + "_embed": emb, tag + "_features": feat, tag + "_cls": cl, tag + "_image": np.array(image),
+                    tag + "_crop": np.array(crop), tag + "_masks_sub": t2n(masks)[:, ::7], tag + "_up_sub": t2n(up)[:, ::9, ::3, ::3],
+                    tag + "_score": t2n(1 - torch.max(u, dim=1)[0])})
+    save("m2f_fused", **out)
 
 
 def gen_metric():
