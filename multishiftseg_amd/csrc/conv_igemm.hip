@@ -18,9 +18,10 @@
 //
 // Taps that are dead for the whole 128-pixel tile (all rows fall in the zero padding, common
 // for dilation 12/24/36 on /8 maps) are skipped with a block-uniform decision.
-#include "mss_common.h"
-#include "../../include/mss_hip.h"
+#include "mss_epilogue.h"
 #include <stdlib.h>
+
+int mss_gemm_nt_dispatch(MssConvArgs p, void* stream);   // gemm.hip: persistent GEMM for the 1x1 / stride-1 shapes
 
 namespace {
 
@@ -258,29 +259,8 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
     advance();
   }
 
-  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-  const int colq = lane & 31, rowq = 4 * (lane >> 5);
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * WTN + j * 32 + colq;
-    if (col >= p.K) continue;
-    float osc = 1.f, osh = 0.f;
-    if (p.out_scale) { osc = p.out_scale[col]; osh = p.out_shift[col]; }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + rowq;
-        if (row < p.M) {
-          float val = acc[i][j][r];
-          if (p.out_scale) val = val * osc + osh;
-          if (p.res) val += p.res[(size_t)row * p.ldres + col];
-          if (p.out_relu) val = fmaxf(val, 0.f);
-          p.y[(size_t)row * p.ldy + col] = val;
-        }
-      }
-    }
-  }
+  // ---- epilogue (mss_epilogue.h): affine / residual / ReLU, stores never serialised on a memory round trip ----
+  mss_epilogue_store<TM, TN>(acc, p, p.y, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool PS, bool AFF>
@@ -560,8 +540,13 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return MSS_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  static int force_bk = -1;
+  static int force_bk = -1, use_gemm = -1;
   if (force_bk < 0) { const char* e = getenv("MSS_CONV_BK"); force_bk = e ? atoi(e) : 0; }
+  if (use_gemm < 0) { const char* e = getenv("MSS_GEMM"); use_gemm = e ? atoi(e) : 1; }   // MSS_GEMM=0: A/B experiments
+  if (use_gemm && p.R * p.S == 1 && p.stride == 1 && p.pad == 0 && p.H == p.OH && p.W == p.OW) {
+    const int rc = mss_gemm_nt_dispatch(p, stream);
+    if (rc >= 0) return rc;
+  }
   // K-step: 16 (41 KB LDS, 144 registers -> 3 workgroups/CU, 3 waves/SIMD) is the faster choice except
   // for the ASPP shape (4096 input channels, 256 output channels), where the 32-deep step wins
   // (measured: 128 vs 119 TFLOP/s); MSS_CONV_BK=16|32 overrides for experiments.

@@ -1,0 +1,227 @@
+// Persistent NT GEMM on the fp32 matrix cores: Y[b][m][n] = sum_c act(X[b][m][c]) * W[b][n][c]  (+ epilogue).
+//
+// This is the 1x1 / stride-1 / padding-0 case of conv_igemm.hip without the implicit-GEMM machinery (no taps, no
+// pixel decode, no dead-tap mask): the batched Winograd-domain products (winograd.hip; 36 GEMMs of
+// [tiles x C] x [C x K] per layer), mask prediction of the M2F head, and the pre-activation 1x1 convolutions of the
+// WideResNet trunk (wider_resnet.py:121-131,157) and the heads (deepv3.py:66,235-252).
+//
+// The inner loop is conv_igemm's (128x128x16 tile, 4 waves of 64x64, LDS double buffer with +4-float row padding,
+// fragments double-buffered in registers, one barrier per K-step). What is new is the schedule around it: a
+// workgroup is PERSISTENT and walks tiles t, t + grid, t + 2 grid, ...; the loader runs one K-step ahead ACROSS tile
+// boundaries, so while the last K-step of a tile multiplies, the first K-step of the next tile is already on its way
+// from HBM and lands in the other LDS buffer; the epilogue's stores are issued and the MFMAs of the next tile start
+// right behind them. With short reductions (C = 128..512, i.e. 8..32 K-steps per tile) the start-up/drain of every
+// tile was ~5 K-steps' worth of time in the one-tile-per-workgroup kernel.
+//
+// Tile order is n-fastest and an XCD owns a contiguous run of tiles, so the n-tiles that share an X tile hit in the
+// same L2.
+#include "mss_epilogue.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int NT = 256, BM = 128, BN = 128, BK = 16;
+constexpr int LDK = BK + 4;            // +4 floats: ds_read_b128 of 16 distinct rows is conflict-free
+constexpr int WTM = 64, WTN = 64, TM = 2, TN = 2;
+constexpr int CPR = BK / 4;            // float4 chunks per tile row
+constexpr int RPP = NT / CPR;          // rows staged per pass
+constexpr int A_LD = BM / RPP, B_LD = BN / RPP;
+constexpr int NKC = BK / 8;
+static_assert(NKC == 2, "the step body below is written for two 8-k chunks");
+
+template <bool AFFINE>
+__global__ __launch_bounds__(NT, 3) void gemm_nt_kernel(MssConvArgs p, long long total_tiles, int tiles_per_batch) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                       // [2][BM][LDK]
+  float* Bs = As + 2 * BM * LDK;          // [2][BN][LDK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int chunk = tid % CPR, row0 = tid / CPR;
+  const int n_it = p.C / BK;
+  const long long stride = gridDim.x;
+  const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
+
+  // ---- loader state: the K-step the next issue_loads() fetches ----
+  const float* a_ptr[A_LD];
+  const float* b_ptr[B_LD];
+  const float* s_ptr = p.in_scale;
+  const float* h_ptr = p.in_shift;
+  long long ld_tile = mss_xcd_remap(blockIdx.x, gridDim.x);
+  int ld_k = 0;
+  auto setup = [&](long long t) {
+    const int b = (int)(t / tiles_per_batch);
+    const int v = (int)(t - (long long)b * tiles_per_batch);
+    const int mt = v / p.ntiles, nt = v - mt * p.ntiles;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      int row = mt * BM + row0 + j * RPP;
+      row = row < p.M ? row : p.M - 1;                  // rows past the end re-read the last row; never stored
+      a_ptr[j] = p.x + (size_t)b * p.x_bs + (size_t)row * p.ldx + chunk * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j)
+      b_ptr[j] = p.w + (size_t)b * p.w_bs + (size_t)(nt * BN + row0 + j * RPP) * p.C + chunk * 4;
+    if (AFFINE) {
+      // one affine per tile: per-sample affines (Dropout2d fold) are only routed here when tiles cannot straddle images
+      const size_t so = (size_t)((mt * BM) / p.H) * p.in_ss_stride + chunk * 4;     // p.H = rows per image in this mode
+      s_ptr = p.in_scale + so;
+      h_ptr = p.in_shift + so;
+    }
+  };
+  f32x4 areg[A_LD], breg[B_LD], sreg, hreg;
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) areg[j] = *reinterpret_cast<const f32x4*>(a_ptr[j]);
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) breg[j] = *reinterpret_cast<const f32x4*>(b_ptr[j]);
+    if (AFFINE) {
+      sreg = *reinterpret_cast<const f32x4*>(s_ptr);
+      hreg = *reinterpret_cast<const f32x4*>(h_ptr);
+    }
+  };
+  auto advance = [&]() {                 // next K-step of this tile, else first K-step of this workgroup's next tile
+    if (++ld_k < n_it) {
+#pragma unroll
+      for (int j = 0; j < A_LD; ++j) a_ptr[j] += BK;
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j) b_ptr[j] += BK;
+      if (AFFINE) { s_ptr += BK; h_ptr += BK; }
+    } else {
+      ld_k = 0;
+      ld_tile += stride;
+      setup(ld_tile < total_tiles ? ld_tile : ld_tile - stride);   // past the end: re-read the last tile, never used
+    }
+  };
+  auto finish_store = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      f32x4 val = areg[j];
+      if (AFFINE) {
+        val = val * sreg + hreg;
+        val.x = fmaxf(val.x, relu_floor); val.y = fmaxf(val.y, relu_floor);
+        val.z = fmaxf(val.z, relu_floor); val.w = fmaxf(val.w, relu_floor);
+      }
+      *reinterpret_cast<f32x4*>(&As[(buf * BM + row0 + j * RPP) * LDK + chunk * 4]) = val;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j)
+      *reinterpret_cast<f32x4*>(&Bs[(buf * BN + row0 + j * RPP) * LDK + chunk * 4]) = breg[j];
+  };
+
+  const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
+  const float* Abase = &As[(wm * WTM + frag_row) * LDK + frag_k];
+  const float* Bbase = &Bs[(wn * WTN + frag_row) * LDK + frag_k];
+  f32x4 fa[2][TM], fb[2][TN];
+  auto load_frags = [&](int set, int buf, int kc) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      fa[set][i] = *reinterpret_cast<const f32x4*>(Abase + (buf * BM + i * 32) * LDK + kc * 8);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      fb[set][j] = *reinterpret_cast<const f32x4*>(Bbase + (buf * BN + j * 32) * LDK + kc * 8);
+  };
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  auto mfma_chunk = [&](int set) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][s], fb[set][j][s], acc[i][j], 0, 0, 0);
+  };
+  auto epilogue = [&](long long t) {
+    const int b = (int)(t / tiles_per_batch);
+    const int v = (int)(t - (long long)b * tiles_per_batch);
+    const int mt = v / p.ntiles, nt = v - mt * p.ntiles;
+    mss_epilogue_store<TM, TN>(acc, p, p.y + (size_t)b * p.y_bs, mt * BM + wm * WTM, nt * BN + wn * WTN, lane);
+  };
+
+  long long cur = ld_tile;               // tile being multiplied (the launch guarantees cur < total_tiles)
+  setup(ld_tile);
+  issue_loads();
+  finish_store(0);
+  advance();
+  zero_acc();
+  __syncthreads();
+  load_frags(0, 0, 0);
+  int buf = 0, k = 0;
+  while (true) {
+    issue_loads();                       // K-step k+1 of this tile, or K-step 0 of the next one
+    load_frags(1, buf, 1);
+    finish_store(buf ^ 1);
+    mfma_chunk(0);
+    __syncthreads();
+    load_frags(0, buf ^ 1, 0);
+    mfma_chunk(1);
+    advance();
+    buf ^= 1;
+    if (++k == n_it) {
+      epilogue(cur);
+      cur += stride;
+      if (cur >= total_tiles) break;
+      zero_acc();
+      k = 0;
+    }
+  }
+}
+
+template <bool AFFINE>
+int launch_gemm(const MssConvArgs& p, hipStream_t stream) {
+  const int batch = p.batch > 1 ? p.batch : 1;
+  const int tiles_per_batch = p.mtiles * p.ntiles;
+  const long long total = (long long)tiles_per_batch * batch;
+  const size_t smem = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+  static int per_cu_max = 0, cus = 256;  // resident workgroups per CU (4: 40 KB LDS, <= 128 registers)
+  if (per_cu_max == 0) {
+    int dev = 0, n = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<AFFINE>, NT, smem) != hipSuccess || n < 1) n = 3;
+    const char* e = getenv("MSS_GEMM_WG_PER_CU");
+    if (e && atoi(e) > 0 && atoi(e) < n) n = atoi(e);
+    per_cu_max = n;
+  }
+  // Every workgroup walks ceil(total / grid) tiles: pick the residency (per_cu_max or one less) whose last round is
+  // fuller, e.g. 4608 tiles = 6 full rounds of 768 but 4.5 rounds of 1024.
+  int grid = 0;
+  double best = -1.0;
+  for (int per_cu = per_cu_max; per_cu >= (per_cu_max > 1 ? per_cu_max - 1 : 1); --per_cu) {
+    const long long slots = (long long)per_cu * cus;
+    const long long g = total < slots ? total : slots;
+    const long long rounds = (total + g - 1) / g;
+    const double eff = (double)total / (double)(rounds * g);
+    if (eff > best + 0.02) { best = eff; grid = (int)g; }
+  }
+  hipLaunchKernelGGL(gemm_nt_kernel<AFFINE>, dim3(grid), dim3(NT), smem, stream, p, total, tiles_per_batch);
+  return mss_launch_status();
+}
+
+}  // namespace
+
+// Called by mss_conv2d_forward_f32 (conv_igemm.hip) for eligible shapes; p.M is set, R = S = 1, stride 1, pad 0.
+// Returns -1 when the shape is not handled here (the implicit-GEMM kernel takes it).
+int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
+  if (p.K <= 64 || p.C % BK || p.C < 2 * BK) return -1;          // narrow outputs stay on the 256x64 tile
+  if (p.in_relu && !p.in_scale) return -1;                        // ReLU without affine: not a shape this path sees
+  if (p.in_scale && p.in_ss_stride) {
+    const int rows_per_image = p.OH * p.OW;                         // per-sample affine: tiles must not straddle images
+    if (rows_per_image % BM) return -1;
+    p.H = rows_per_image;
+  } else {
+    p.H = p.M > 0 ? p.M : 1;
+  }
+  p.mtiles = mss_cdiv(p.M, BM);
+  p.ntiles = mss_cdiv(p.K, BN);
+  if (p.Kpad < p.ntiles * BN) return MSS_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return p.in_scale ? launch_gemm<true>(p, s) : launch_gemm<false>(p, s);
+}
