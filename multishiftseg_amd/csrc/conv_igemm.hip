@@ -337,23 +337,26 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __rest
 // LDS before the second-to-last chunk, one barrier before the last chunk.
 // Grid: (ktiles*ctiles, taps, splits); the pixel range is split across blockIdx.z and the
 // partial sums land in the zero-initialised dWp by fp32 atomics.
-template <int BKO, int BCI, int BP>
+template <int BKO, int BCI, int BP, int WK>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const float* __restrict__ dy, int lddy,
                                                         float* __restrict__ dwp, int Cp, int pix_per_split) {
   constexpr int LDA = BKO + 4;  // dy tile  [BP][BKO]
   constexpr int LDB = BCI + 4;  // x  tile  [BP][BCI]
-  constexpr int TM = BKO / 2 / 32, TN = BCI / 2 / 32;  // 2x2 waves
+  constexpr int WC = 4 / WK;    // waves along K x waves along C (2x2; 1x4 for the 32-row tile of the 19-channel heads)
+  constexpr int WTK = BKO / WK, WTC = BCI / WC;
+  constexpr int TM = WTK / 32, TN = WTC / 32;
   constexpr int A_CPR = BKO / 4, B_CPR = BCI / 4;
-  constexpr int A_LD = BP * A_CPR / NT, B_LD = BP * B_CPR / NT;
+  constexpr bool A_PART = BP * A_CPR < NT;                // dy tile smaller than one float4 per thread: upper threads idle
+  constexpr int A_LD = A_PART ? 1 : BP * A_CPR / NT, B_LD = BP * B_CPR / NT;
   constexpr int A_RPP = NT / A_CPR, B_RPP = NT / B_CPR;   // pixel rows covered per staging pass
   constexpr int NKC = BP / 8;                             // chunks of 8 pixels = 4 MFMA k-steps
-  static_assert(A_LD >= 1 && B_LD >= 1 && NKC >= 2, "");
+  static_assert(TM >= 1 && TN >= 1 && B_LD >= 1 && NKC >= 2, "");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                    // [2][BP][LDA]
   float* Bs = smem + 2 * BP * LDA;     // [2][BP][LDB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WC, wn = wave % WC;
   const int ctiles = mss_cdiv(p.C, BCI);
   const int kt = blockIdx.x / ctiles, ct = blockIdx.x % ctiles;
   const int k0 = kt * BKO, c0 = ct * BCI;
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
   const int a_ch = (tid % A_CPR) * 4, a_pr0 = tid / A_CPR;
   const int b_ch = (tid % B_CPR) * 4, b_pr0 = tid / B_CPR;
   const bool a_full = k0 + a_ch + 3 < p.K;          // whole float4 of output channels exists
+  const bool a_act = !A_PART || a_pr0 < BP;
   const bool b_in = c0 + b_ch < p.C;
   const float* a_ptr[A_LD];
 #pragma unroll
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
     const bool tail = ld_m + BP > mend;   // block-uniform: only the last step of a split can be ragged
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      const bool ok = !tail || ld_m + a_pr0 + j * A_RPP < mend;
+      const bool ok = a_act && (!tail || ld_m + a_pr0 + j * A_RPP < mend);
       const float* src = ok ? a_ptr[j] : dy + k0 + a_ch;
       f32x4 val;
       if (a_full) val = *reinterpret_cast<const f32x4*>(src);
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
   auto finish_store = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < A_LD; ++j)
-      *reinterpret_cast<f32x4*>(&As[(buf * BP + a_pr0 + j * A_RPP) * LDA + a_ch]) = areg[j];
+      if (a_act) *reinterpret_cast<f32x4*>(&As[(buf * BP + a_pr0 + j * A_RPP) * LDA + a_ch]) = areg[j];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
       f32x4 val = breg[j];
@@ -474,9 +478,9 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
     for (int ks = 0; ks < 4; ++ks) {
       const int row = buf * BP + kc * 8 + ks * 2 + fk;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[set][ks][i] = As[row * LDA + wm * (BKO / 2) + i * 32 + fi];
+      for (int i = 0; i < TM; ++i) fa[set][ks][i] = As[row * LDA + wm * WTK + i * 32 + fi];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[set][ks][j] = Bs[row * LDB + wn * (BCI / 2) + j * 32 + fi];
+      for (int j = 0; j < TN; ++j) fb[set][ks][j] = Bs[row * LDB + wn * WTC + j * 32 + fi];
     }
   };
   auto mfma_chunk = [&](int set) {
@@ -513,16 +517,44 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
   const int colq = lane & 31, rowq = 4 * (lane >> 5);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int col = c0 + wn * (BCI / 2) + j * 32 + colq;
+    const int col = c0 + wn * WTC + j * 32 + colq;
     if (col >= p.C) continue;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int row = k0 + wm * (BKO / 2) + i * 32 + (q & 3) + 8 * (q >> 2) + rowq;
+        const int row = k0 + wm * WTK + i * 32 + (q & 3) + 8 * (q >> 2) + rowq;
         if (row < p.K) atomicAdd(&dwp[((size_t)tap * p.Kpad + row) * Cp + col], acc[i][j][q]);
       }
   }
+}
+
+template <int BKO, int BCI, int BP, int WK>
+int launch_wgrad(MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, hipStream_t stream) {
+  const int ktiles = mss_cdiv(p.K, BKO), ctiles = mss_cdiv(p.C, BCI), taps = p.batch > 1 ? p.batch : p.R * p.S;
+  // Pixel splits: pick the smallest split count whose grid fills its last round of resident workgroups to >= 95 %
+  // (a 1152-block grid on 768 slots runs 2 rounds for 1.5 rounds of work); more splits only add atomic traffic on
+  // the [R*S][K][C] slab. Small slabs (the 19 x 256 head gradient: 2 tiles) need hundreds of splits to fill the chip.
+  const int base = ktiles * ctiles * taps;
+  const int slots = 768;   // 3 workgroups per CU (34 KB LDS, 154 registers)
+  int max_splits = mss_cdiv(p.M, BP * 8);
+  if (max_splits > 1024) max_splits = 1024;
+  if (max_splits < 1) max_splits = 1;
+  int splits = 1;
+  double best = 0.0;
+  for (int sp = 1; sp <= max_splits; ++sp) {
+    const long long total = (long long)base * sp;
+    const double eff = (double)total / (double)(((total + slots - 1) / slots) * slots);
+    if (eff > best + 1e-9) { best = eff; splits = sp; }
+    if (eff >= 0.95 && total >= slots) break;
+  }
+  int pps = mss_cdiv(mss_cdiv(p.M, splits), BP) * BP;
+  splits = mss_cdiv(p.M, pps);
+  const size_t smem = (size_t)2 * BP * (BKO + 4 + BCI + 4) * sizeof(float);
+  // staging after the whole MFMA block, and BP=32, were measured: within 1-4 % slower
+  auto kern = conv_wgrad_kernel<BKO, BCI, BP, WK>;
+  hipLaunchKernelGGL(kern, dim3(ktiles * ctiles, taps, splits), dim3(NT), smem, stream, p, dy, lddy, dwp, Cp, pps);
+  return mss_launch_status();
 }
 
 }  // namespace
@@ -589,38 +621,12 @@ int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dw
   if (p.C % 4 || p.ldx % 4 || lddy % 4 || p.R * p.S > 9) return MSS_ERR_UNSUPPORTED;
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return MSS_OK;
-  constexpr int BKO = 128, BCI = 128, BP = 16;
   if (p.batch > 1 && (p.R * p.S != 1 || p.batch > 65535)) return MSS_ERR_BAD_ARG;
-  const int ktiles = mss_cdiv(p.K, BKO), ctiles = mss_cdiv(p.C, BCI), taps = p.batch > 1 ? p.batch : p.R * p.S;
-  // Pixel splits: 2 workgroups fit a CU (LDS), i.e. 512 run at once. Pick the smallest split count
-  // whose grid fills its last round of 512 to >= 95 % (a 1152-block grid runs 3 rounds for 2.25
-  // rounds of work); more splits only add atomic traffic on the [R*S][K][C] slab.
-  const int base = ktiles * ctiles * taps;
-  const int slots = 768;   // 3 workgroups per CU (34 KB LDS, 154 registers)
-  int max_splits = mss_cdiv(p.M, BP * 8);
-  if (max_splits > 64) max_splits = 64;
-  if (max_splits < 1) max_splits = 1;
-  int splits = 1;
-  double best = 0.0;
-  for (int sp = 1; sp <= max_splits; ++sp) {
-    const long long total = (long long)base * sp;
-    const double eff = (double)total / (double)(((total + slots - 1) / slots) * slots);
-    if (eff > best + 1e-9) { best = eff; splits = sp; }
-    if (eff >= 0.95 && total >= slots) break;
-  }
-  int pps = mss_cdiv(mss_cdiv(p.M, splits), BP) * BP;
-  splits = mss_cdiv(p.M, pps);
-  const size_t smem = (size_t)2 * BP * (BKO + 4 + BCI + 4) * sizeof(float);
-  // staging after the whole MFMA block, and BP=16, were measured: within 1-4 % slower
-  auto kern = conv_wgrad_kernel<BKO, BCI, BP>;
-  if (smem > 65536) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-  }
-  hipLaunchKernelGGL(kern, dim3(ktiles * ctiles, taps, splits), dim3(NT), smem, static_cast<hipStream_t>(stream), p,
-                     dy, lddy, dwp, Cp, pps);
-  return mss_launch_status();
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // output-channel tile: 32 rows (1x4 waves) for the 19-channel heads, 64 for bot_fine's 48, else 128
+  if (p.K <= 32) return launch_wgrad<32, 128, 16, 1>(p, dy, lddy, dwp, Cp, s);
+  if (p.K <= 64) return launch_wgrad<64, 128, 16, 2>(p, dy, lddy, dwp, Cp, s);
+  return launch_wgrad<128, 128, 16, 2>(p, dy, lddy, dwp, Cp, s);
 }
 
 }  // extern "C"
