@@ -62,6 +62,7 @@ SIGNATURES = {
     "mss_msda_backward_f64": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P],
     "mss_conv2d_forward_f32": [POINTER(MssConvArgs), P],
     "mss_conv2d_kpad": [I],
+    "mss_conv2d_forward_route": [POINTER(MssConvArgs)],
     "mss_conv2d_pack_weights_f32": [P, P, I, I, I, I, I, I, I, P],
     "mss_conv2d_wgrad_f32": [POINTER(MssConvArgs), P, I, P, I, P],
     "mss_conv2d_unpack_wgrad_f32": [P, P, I, I, I, I, I, I, I, P],
@@ -113,7 +114,7 @@ SIGNATURES = {
     "mss_peak_stream_f32": [P, P, L, P],
 }
 # entry points that return a plain value rather than a status code
-_VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
+_VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
                     "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks"}
 _RETURNS_LONGLONG = {"mss_wino_num_tiles", "mss_oodm_sort_temp_bytes"}
 

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 int mss_gemm_nt_dispatch(MssConvArgs p, void* stream);   // gemm.hip: persistent GEMM for the 1x1 / stride-1 shapes
+bool mss_gemm_nt_eligible(const MssConvArgs& p);
 
 namespace {
 
@@ -575,7 +576,7 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
   static int force_bk = -1, use_gemm = -1;
   if (force_bk < 0) { const char* e = getenv("MSS_CONV_BK"); force_bk = e ? atoi(e) : 0; }
   if (use_gemm < 0) { const char* e = getenv("MSS_GEMM"); use_gemm = e ? atoi(e) : 1; }   // MSS_GEMM=0: A/B experiments
-  if (use_gemm && p.R * p.S == 1 && p.stride == 1 && p.pad == 0 && p.H == p.OH && p.W == p.OW) {
+  if (use_gemm) {
     const int rc = mss_gemm_nt_dispatch(p, stream);
     if (rc >= 0) return rc;
   }
@@ -588,6 +589,14 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
     return launch_conv<256, 64, 16, 4, 1>(p, s);
   }
   return k32 ? launch_conv<128, 128, 32, 2, 2>(p, s) : launch_conv<128, 128, 16, 2, 2>(p, s);
+}
+
+// Which kernel mss_conv2d_forward_f32 runs for these arguments: 1 = gemm_nt_kernel (gemm.hip), 0 = conv_igemm_kernel.
+int mss_conv2d_forward_route(const MssConvArgs* args) {
+  MssConvArgs p = *args;
+  p.M = p.N * p.OH * p.OW;
+  const char* e = getenv("MSS_GEMM");
+  return (!e || atoi(e)) && mss_gemm_nt_eligible(p) ? 1 : 0;
 }
 
 // Kpad the packed layout must use for a conv with K output channels (multiple of the N tile).

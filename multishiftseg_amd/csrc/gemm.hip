@@ -207,18 +207,19 @@ int launch_gemm(const MssConvArgs& p, hipStream_t stream) {
 
 }  // namespace
 
-// Called by mss_conv2d_forward_f32 (conv_igemm.hip) for eligible shapes; p.M is set, R = S = 1, stride 1, pad 0.
+// Shapes this kernel takes from mss_conv2d_forward_f32 (conv_igemm.hip); p.M is set.
+bool mss_gemm_nt_eligible(const MssConvArgs& p) {
+  if (p.R * p.S != 1 || p.stride != 1 || p.pad != 0 || p.H != p.OH || p.W != p.OW) return false;
+  if (p.K <= 64 || p.C % BK || p.C < 2 * BK) return false;        // narrow outputs stay on the 256x64 tile
+  if (p.in_relu && !p.in_scale) return false;                      // ReLU without affine: not a shape this path sees
+  if (p.in_scale && p.in_ss_stride && (p.OH * p.OW) % BM) return false;   // per-sample affine: tiles must not straddle images
+  return true;
+}
+
 // Returns -1 when the shape is not handled here (the implicit-GEMM kernel takes it).
 int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
-  if (p.K <= 64 || p.C % BK || p.C < 2 * BK) return -1;          // narrow outputs stay on the 256x64 tile
-  if (p.in_relu && !p.in_scale) return -1;                        // ReLU without affine: not a shape this path sees
-  if (p.in_scale && p.in_ss_stride) {
-    const int rows_per_image = p.OH * p.OW;                         // per-sample affine: tiles must not straddle images
-    if (rows_per_image % BM) return -1;
-    p.H = rows_per_image;
-  } else {
-    p.H = p.M > 0 ? p.M : 1;
-  }
+  if (!mss_gemm_nt_eligible(p)) return -1;
+  p.H = (p.in_scale && p.in_ss_stride) ? p.OH * p.OW : (p.M > 0 ? p.M : 1);   // rows per affine group
   p.mtiles = mss_cdiv(p.M, BM);
   p.ntiles = mss_cdiv(p.K, BN);
   if (p.Kpad < p.ntiles * BN) return MSS_ERR_BAD_ARG;

@@ -171,6 +171,13 @@ class _Timed:
         return False
 
 
+def _fwd_kind(a):
+    """Profiling label of a forward launch: which of the two MFMA kernels the C side picks."""
+    if _profile is None:
+        return "conv_igemm"
+    return "gemm_nt" if _lib.value("mss_conv2d_forward_route", ctypes.byref(a)) else "conv_igemm"
+
+
 def conv_out_size(h, r, stride, dil, pad):
     return (h + 2 * pad - dil * (r - 1) - 1) // stride + 1
 
@@ -222,7 +229,7 @@ def conv2d(x, pw, stride=1, dil=1, pad=0, in_affine=None, in_relu=False, out_aff
 def _conv_launch(x, pw, out, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res):
     a = _conv_args(x, pw, out, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res)
     a.OH, a.OW, a.ldy = OH, OW, out.ld
-    with _Timed("conv_igemm", 2.0 * x.N * OH * OW * pw.K * pw.C * pw.R * pw.S,
+    with _Timed(_fwd_kind(a), 2.0 * x.N * OH * OW * pw.K * pw.C * pw.R * pw.S,
                 (x.N, x.H, x.W, pw.C, pw.K, pw.R, stride, dil)):
         call("mss_conv2d_forward_f32", ctypes.byref(a))
 
@@ -351,7 +358,7 @@ def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=N
         split = K - rem if (K > 128 and 0 < rem <= 64) else 0     # e.g. 304 = 256 + 48: narrow tail on the 64-wide tile
         if split:
             a.K = split
-        with _Timed("conv_igemm", 2.0 * P * T * C * K, (P, 1, T, C, K, 1, 1, 1)):   # the MFMA work actually executed
+        with _Timed(_fwd_kind(a), 2.0 * P * T * C * K, (P, 1, T, C, K, 1, 1, 1)):   # the MFMA work actually executed
             call("mss_conv2d_forward_f32", ctypes.byref(a))
             if split:
                 a.K, a.Kpad = rem, ww.Kpad - split
@@ -576,7 +583,7 @@ def m2f_mask_logits(mask_embed, mask_features):
     a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, h * w, Q, Kpad, Q
     a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
     a.batch, a.x_bs, a.w_bs, a.y_bs = B, h * w * x.ld, Kpad * C, h * w * Q
-    with _Timed("conv_igemm", 2.0 * B * h * w * C * Q, (B, 1, h * w, C, Q, 1, 1, 1)):
+    with _Timed(_fwd_kind(a), 2.0 * B * h * w * C * Q, (B, 1, h * w, C, Q, 1, 1, 1)):
         call("mss_conv2d_forward_f32", ctypes.byref(a))
     return out
 

@@ -9,7 +9,7 @@ bench.py prints as roofline.traffic."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
-FAMILIES = ["conv_igemm_kernel", "conv_wgrad_kernel", "wino_input_transform", "wino_output_transform",
+FAMILIES = ["gemm_nt_kernel", "conv_igemm_kernel", "conv_wgrad_kernel", "wino_input_transform", "wino_output_transform",
             "wino_grad_output_transform", "bn_stats", "ood_score"]
 
 
@@ -38,8 +38,9 @@ def main():
             f_kb, w_kb = fe[k][1] / fe[k][0], wr[k][1] / wr[k][0]
             fams[k] = {"launches": fe[k][0], "fetch_size_avg_KB": f_kb, "write_size_avg_KB": w_kb,
                        "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024}
-    c = fams["conv_igemm_kernel"]
-    out = {"kernel": "conv_igemm_kernel",
+    dom = max((k for k in ("gemm_nt_kernel", "conv_igemm_kernel") if k in fams), key=lambda k: fams[k]["launches"] * fams[k]["hbm_bytes_per_launch"])
+    c = fams[dom]
+    out = {"kernel": dom,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1 "
                      "--no-cpu-baseline --no-ood`, summarised by tools/pmc_traffic.py",
            "launches": c["launches"], "fetch_size_avg_KB": c["fetch_size_avg_KB"], "write_size_avg_KB": c["write_size_avg_KB"],
