@@ -75,6 +75,9 @@ typedef struct MssConvArgs {
   int M, mtiles, ntiles;   /* filled in by the launcher                                          */
   int batch;               /* > 1: that many independent GEMMs in one launch (1x1 only, no res);  */
   long long x_bs, w_bs, y_bs; /* element strides between their x / w / y (Winograd positions)    */
+  float* stats;            /* optional: per-channel partial sums of the OUTPUT for the next layer's train-mode    */
+                           /*   BatchNorm, [ceil(M/64)][2][K] floats (row group g: sum, sum of squares of rows      */
+                           /*   64g..64g+63); reduce with mss_bn_stats_partials_f32. Not with batch > 1.            */
 } MssConvArgs;
 
 int mss_conv2d_forward_f32(MssConvArgs* args, void* stream);
@@ -105,7 +108,9 @@ int mss_wino_pack_weights_f32(const float* w, float* u, int K, int C, int Kpad, 
 int mss_wino_input_transform_f32(const float* x, int ldx, int N, int H, int W, int C, int dil, int tile,
                                  const float* scale, const float* shift, int relu, float* xt, void* stream);
 int mss_wino_output_transform_f32(const float* yt, int N, int H, int W, int K, int dil, int tile, const float* res,
-                                  int ldres, float* y, int ldy, void* stream);
+                                  int ldres, float* y, int ldy, float* stats, void* stream);
+/* stats (optional): [mss_wino_output_stats_parts(...)][2][K] partial sums / sums of squares of y, as MssConvArgs.stats */
+int mss_wino_output_stats_parts(int N, int H, int W, int K, int dil, int tile);
 
 /* weight gradient in the Winograd domain: dY' = A dY A^T per tile, then ONE mss_conv2d_wgrad_f32 call in
  * batched mode (batch = P, R = S = 1, x = X', x_bs = T*C, dy = dY', y_bs = T*K) accumulates
@@ -121,6 +126,9 @@ int mss_nchw_to_nhwc_pad_f32(const float* x, float* y, int N, int C, int H, int 
 /* BatchNorm2d pieces (mynn.py:8-12 Norm2d = nn.BatchNorm2d, eps 1e-5, momentum 0.1).
  * stats: per-channel batch mean and biased variance of an NHWC tensor (M pixels); `accum` is a
  * zero-initialised double[2*C] workspace. */
+/* accum += column sums of a partial-sum matrix [nparts][2][C] written by a producer (MssConvArgs.stats,
+ * mss_wino_output_transform_f32): the statistics pass then never re-reads the activation. */
+int mss_bn_stats_partials_f32(const float* partials, long long nparts, int C, double* accum, void* stream);
 int mss_bn_stats_nhwc_f32(const float* x, long long M, int C, int ldx, double* accum, void* stream);
 /* finalise: from accum -> (mean, var) -> scale = gamma*rsqrt(var+eps), shift = beta-mean*scale;
  * if running_mean != NULL also running = (1-mom)*running + mom*{mean, var*M/(M-1)}.

@@ -34,6 +34,7 @@ class MssConvArgs(Structure):
         ("ldres", c_int),
         ("M", c_int), ("mtiles", c_int), ("ntiles", c_int),
         ("batch", c_int), ("x_bs", c_longlong), ("w_bs", c_longlong), ("y_bs", c_longlong),
+        ("stats", c_void_p),
     ]
 
 
@@ -101,7 +102,9 @@ SIGNATURES = {
     "mss_wino_num_tiles": [I, I, I, I, I],
     "mss_wino_pack_weights_f32": [P, P, I, I, I, I, I, P],
     "mss_wino_input_transform_f32": [P, I, I, I, I, I, I, I, P, P, I, P, P],
-    "mss_wino_output_transform_f32": [P, I, I, I, I, I, I, P, I, P, I, P],
+    "mss_wino_output_transform_f32": [P, I, I, I, I, I, I, P, I, P, I, P, P],
+    "mss_wino_output_stats_parts": [I, I, I, I, I, I],
+    "mss_bn_stats_partials_f32": [P, L, I, P, P],
     "mss_wino_grad_output_transform_f32": [P, I, I, I, I, I, I, I, P, P],
     "mss_wino_weight_grad_transform_f32": [P, P, I, I, I, I, I, P],
     "mss_m2f_fused_score_f32": [P, P, I, I, I, I, I, I, I, I, I, I, P, P],
@@ -115,7 +118,7 @@ SIGNATURES = {
 }
 # entry points that return a plain value rather than a status code
 _VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
-                    "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks"}
+                    "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts"}
 _RETURNS_LONGLONG = {"mss_wino_num_tiles", "mss_oodm_sort_temp_bytes"}
 
 _lib = None

@@ -112,6 +112,16 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   });
 }
 
+// column sums of a producer's partial-sum matrix [nparts][2][C] (sum | sum of squares) into accum[2C]
+__global__ __launch_bounds__(256) void bn_stats_partials_kernel(const float* __restrict__ part, long long nparts, int C,
+                                                                double* __restrict__ accum) {
+  col_reduce2(nparts, C, accum, [&](long long r, int c0, float* a, float* b) {
+    const f32x4 u = ld4(part + r * 2 * C + c0), v = ld4(part + r * 2 * C + C + c0);
+    a[0] = u.x; a[1] = u.y; a[2] = u.z; a[3] = u.w;
+    b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
+  });
+}
+
 __global__ void bn_finalize_train_kernel(const double* __restrict__ accum, long long M, int C,
                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                          float momentum, float* running_mean, float* running_var, float* scale,
@@ -657,6 +667,14 @@ int mss_bn_stats_nhwc_f32(const float* x, long long M, int C, int ldx, double* a
   if (!x || !accum || C % 4 || ldx % 4) return MSS_ERR_BAD_ARG;
   if (M <= 0) return MSS_OK;
   hipLaunchKernelGGL(bn_stats_kernel, col_reduce_grid(M, C), dim3(256), 0, S_(stream), x, M, C, ldx, accum);
+  return mss_launch_status();
+}
+
+int mss_bn_stats_partials_f32(const float* partials, long long nparts, int C, double* accum, void* stream) {
+  if (!partials || !accum || C % 4) return MSS_ERR_BAD_ARG;
+  if (nparts <= 0) return MSS_OK;
+  hipLaunchKernelGGL(bn_stats_partials_kernel, col_reduce_grid(nparts, C), dim3(256), 0, S_(stream), partials, nparts, C,
+                     accum);
   return mss_launch_status();
 }
 

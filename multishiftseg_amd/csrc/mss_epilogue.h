@@ -10,12 +10,17 @@
 #include "mss_common.h"
 #include "../../include/mss_hip.h"
 
+//  * p.stats: the wave also reduces its 64 rows per column (sum, sum of squares of the stored values) and writes them
+//    to row group row_base/64 of the partial-sum matrix -- the next layer's train-mode BatchNorm statistics without
+//    re-reading the activation (TM * 32 == 64 in every instantiation).
 template <int TM, int TN>
 __device__ __forceinline__ void mss_epilogue_store(const f32x16 (&acc)[TM][TN], const MssConvArgs& p, float* __restrict__ y,
                                                    int row_base, int col_base, int lane) {
+  static_assert(TM * 32 == 64, "statistics row groups are 64 rows");
   const int colq = lane & 31, rowq = 4 * (lane >> 5);
   const bool full_rows = row_base + TM * 32 <= p.M;                       // wave-uniform
-  const bool plain = !p.out_scale && !p.res && !p.out_relu;               // kernel-uniform
+  const bool plain = !p.out_scale && !p.res && !p.out_relu && !p.stats;   // kernel-uniform
+  float* stats_row = (p.stats && row_base < p.M) ? p.stats + (size_t)(row_base >> 6) * 2 * p.K : nullptr;
   const size_t ldy = (size_t)p.ldy;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -32,6 +37,7 @@ __device__ __forceinline__ void mss_epilogue_store(const f32x16 (&acc)[TM][TN], 
         float osc = 1.f, osh = 0.f;
         if (p.out_scale) { osc = p.out_scale[col]; osh = p.out_shift[col]; }
         const float floor_v = p.out_relu ? 0.f : -__builtin_huge_valf();
+        float ssum = 0.f, ssq = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int row0 = row_base + i * 32 + rowq;
@@ -49,16 +55,24 @@ __device__ __forceinline__ void mss_epilogue_store(const f32x16 (&acc)[TM][TN], 
           if (full_rows) {                     // no per-element guard: the 16 stores go out back to back
             float* yp = y + (size_t)row0 * ldy + col;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              yp[(size_t)((r & 3) + 8 * (r >> 2)) * ldy] = fmaxf(acc[i][j][r] * osc + osh + rv[r], floor_v);
+            for (int r = 0; r < 16; ++r) {
+              const float val = fmaxf(acc[i][j][r] * osc + osh + rv[r], floor_v);
+              yp[(size_t)((r & 3) + 8 * (r >> 2)) * ldy] = val;
+              ssum += val; ssq += val * val;
+            }
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int row = row0 + (r & 3) + 8 * (r >> 2);
               const float val = fmaxf(acc[i][j][r] * osc + osh + rv[r], floor_v);
-              if (row < p.M) y[(size_t)row * ldy + col] = val;
+              if (row < p.M) { y[(size_t)row * ldy + col] = val; ssum += val; ssq += val * val; }
             }
           }
+        }
+        if (stats_row) {                       // lanes l and l + 32 hold the two halves of this column's 64 rows
+          ssum += __shfl_xor(ssum, 32);
+          ssq += __shfl_xor(ssq, 32);
+          if (lane < 32) { stats_row[col] = ssum; stats_row[p.K + col] = ssq; }
         }
       }
     }

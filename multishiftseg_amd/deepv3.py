@@ -180,16 +180,17 @@ class DeepWV3Plus(nn.Module):
         d = blk.dilation
         c = blk.convs
         if not blk.bottleneck:
-            o = K.conv3x3(a, c.conv1.weight, dil=d, stride=blk.stride, in_affine=aff1, in_relu=True)
+            # want_stats: the producing kernel leaves the batch statistics the next train-mode BatchNorm needs
+            o = K.conv3x3(a, c.conv1.weight, dil=d, stride=blk.stride, in_affine=aff1, in_relu=True, want_stats=train)
             st2 = K.bn_fold(c.bn2[0], o, train)
             return K.conv3x3(o, c.conv2.weight, dil=d, in_affine=self._dropout_affine(st2, blk, name, a.N), in_relu=True,
-                             res=shortcut)
-        o = K.conv2d(a, K.packed(c.conv1.weight), stride=blk.stride, in_affine=aff1, in_relu=True)
+                             res=shortcut, want_stats=train)
+        o = K.conv2d(a, K.packed(c.conv1.weight), stride=blk.stride, in_affine=aff1, in_relu=True, want_stats=train)
         st2 = K.bn_fold(c.bn2[0], o, train)
-        o2 = K.conv3x3(o, c.conv2.weight, dil=d, in_affine=(st2.scale, st2.shift), in_relu=True)
+        o2 = K.conv3x3(o, c.conv2.weight, dil=d, in_affine=(st2.scale, st2.shift), in_relu=True, want_stats=train)
         st3 = K.bn_fold(c.bn3[0], o2, train)
         return K.conv2d(o2, K.packed(c.conv3.weight), in_affine=self._dropout_affine(st3, blk, name, a.N), in_relu=True,
-                        res=shortcut)
+                        res=shortcut, want_stats=train)
 
     def _run_trunk(self, inp):
         a = K.image_to_nhwc(inp, 16)
@@ -244,12 +245,12 @@ class DeepWV3Plus(nn.Module):
             rate = 1 if i == 0 else _ASPP_RATES[i - 1]
             sl = raw.slice(256 * (i + 1), 256)
             if i == 0:
-                K.conv2d(x, K.packed(feat[0].weight), out=sl)
+                K.conv2d(x, K.packed(feat[0].weight), out=sl, want_stats=train)
             else:
                 # keep the Winograd-domain input X' for this layer's weight gradient when the three of them fit
                 # comfortably (2.25-4x the 4096-channel map each: 10.6 GB in all at 2x1024x2048)
                 kx = {} if (keep and feat[0].weight.requires_grad and xt_bytes < (40 << 30)) else None
-                K.conv3x3(x, feat[0].weight, dil=rate, out=sl, keep_xt=kx)
+                K.conv3x3(x, feat[0].weight, dil=rate, out=sl, keep_xt=kx, want_stats=train)
                 aspp_xt[i] = kx.get("xt") if kx else None
             states.append(K.bn_fold(feat[1], sl, train))
         for i, s in enumerate(states):
@@ -259,9 +260,9 @@ class DeepWV3Plus(nn.Module):
         dec0 = Act.empty(N, h2, w2, 304, dev)                      # concat [bot_fine(m2), up(bot_aspp)]
         K.upsample_ac(up_small, h2, w2, out=dec0.slice(48, 256))
         K.conv2d(m2, K.packed(self.bot_fine.weight), out=dec0.slice(0, 48))
-        f0 = K.conv3x3(dec0, self.final[0].weight)
+        f0 = K.conv3x3(dec0, self.final[0].weight, want_stats=train)
         st_f0 = K.bn_fold(self.final[1], f0, train)
-        f1 = K.conv3x3(f0, self.final[3].weight, in_affine=(st_f0.scale, st_f0.shift), in_relu=True)
+        f1 = K.conv3x3(f0, self.final[3].weight, in_affine=(st_f0.scale, st_f0.shift), in_relu=True, want_stats=train)
         st_f1 = K.bn_fold(self.final[4], f1, train)
         wh, _ = self._heads_weight()
         dec12 = K.conv2d(f1, wh, in_affine=(st_f1.scale, st_f1.shift), in_relu=True)

@@ -14,12 +14,14 @@ from ._lib import MssConvArgs, call, ptr
 
 
 class Act:
-    """Channel slice of an NHWC fp32 buffer [N,H,W,ld]."""
-    __slots__ = ("buf", "N", "H", "W", "C", "ld", "c0")
+    """Channel slice of an NHWC fp32 buffer [N,H,W,ld]. `stats`: per-channel partial sums [parts,2,C] left by the
+    kernel that produced this slice (conv epilogue / Winograd output transform), consumed by bn_fold(train=True)."""
+    __slots__ = ("buf", "N", "H", "W", "C", "ld", "c0", "stats")
 
     def __init__(self, buf, C=None, c0=0):
         assert buf.dim() == 4 and buf.is_contiguous() and buf.dtype == torch.float32
         self.buf = buf
+        self.stats = None
         self.N, self.H, self.W, self.ld = buf.shape
         self.C = self.ld - c0 if C is None else C
         self.c0 = c0
@@ -202,8 +204,9 @@ def _conv_args(x, pw, y, stride, dil, pad, in_affine, in_relu, out_affine, out_r
 
 
 def conv2d(x, pw, stride=1, dil=1, pad=0, in_affine=None, in_relu=False, out_affine=None, out_relu=False, res=None,
-           out=None):
-    """y = epilogue(conv(prologue(x))). x: Act with C == pw.Cp channels visible."""
+           out=None, want_stats=False):
+    """y = epilogue(conv(prologue(x))). x: Act with C == pw.Cp channels visible. want_stats: the epilogue also leaves
+    the per-channel partial sums of y on the returned Act (for the next layer's train-mode BatchNorm)."""
     assert x.C == pw.Cp or (x.C >= pw.C and x.C <= pw.Cp and x.c0 + pw.Cp <= x.ld), (x.C, pw.C, pw.Cp)
     OH = conv_out_size(x.H, pw.R, stride, dil, pad)
     OW = conv_out_size(x.W, pw.S, stride, dil, pad)
@@ -222,13 +225,17 @@ def conv2d(x, pw, stride=1, dil=1, pad=0, in_affine=None, in_relu=False, out_aff
         out_main = out.slice(0, pw.K)
         _conv_launch(x, pw, out_main, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res)
         return out
-    _conv_launch(x, pw, out, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res)
+    _conv_launch(x, pw, out, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res, want_stats)
     return out
 
 
-def _conv_launch(x, pw, out, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res):
+def _conv_launch(x, pw, out, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res, want_stats=False):
     a = _conv_args(x, pw, out, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res)
     a.OH, a.OW, a.ldy = OH, OW, out.ld
+    out.stats = None
+    if want_stats and out.C == pw.K:
+        out.stats = torch.empty((-(-(x.N * OH * OW) // 64), 2, pw.K), device=x.buf.device, dtype=torch.float32)
+        a.stats = ptr(out.stats)
     with _Timed(_fwd_kind(a), 2.0 * x.N * OH * OW * pw.K * pw.C * pw.R * pw.S,
                 (x.N, x.H, x.W, pw.C, pw.K, pw.R, stride, dil)):
         call("mss_conv2d_forward_f32", ctypes.byref(a))
@@ -318,19 +325,20 @@ def wino_xt_bytes(N, H, W, C, dil):
     return (ts + 2) ** 2 * _lib.value("mss_wino_num_tiles", N, H, W, dil, ts) * C * 4
 
 
-def conv3x3(x, weight, dil=1, stride=1, in_affine=None, in_relu=False, res=None, out=None, flip=False, keep_xt=None):
+def conv3x3(x, weight, dil=1, stride=1, in_affine=None, in_relu=False, res=None, out=None, flip=False, keep_xt=None,
+            want_stats=False):
     """3x3 convolution with padding = dilation on nn.Conv2d-layout `weight` (flip=True: its data gradient),
     through Winograd when the policy says so, else through the direct implicit GEMM."""
     k_out, c_in = (weight.shape[1], weight.shape[0]) if flip else (weight.shape[0], weight.shape[1])
     tile = wino_tile(x.H, x.W, dil)
     if use_winograd(c_in, k_out, stride, in_affine, tile):
         return conv2d_winograd(x, packed_wino(weight, flip, tile), dil=dil, in_affine=in_affine,
-                               in_relu=in_relu, res=res, out=out, keep_xt=keep_xt)
+                               in_relu=in_relu, res=res, out=out, keep_xt=keep_xt, want_stats=want_stats)
     return conv2d(x, packed(weight, flip), stride=stride, dil=dil, pad=dil, in_affine=in_affine, in_relu=in_relu, res=res,
-                  out=out)
+                  out=out, want_stats=want_stats)
 
 
-def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=None, keep_xt=None):
+def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=None, keep_xt=None, want_stats=False):
     """3x3 / stride 1 / padding = dilation convolution through Winograd F(m x m,3x3), m = ww.tile: input
     transform (with the fused BatchNorm+ReLU prologue) -> (m+2)^2 batched MFMA GEMMs -> output transform
     (+ residual). keep_xt: a dict; the transformed input X' is stored under keep_xt["xt"] so that the weight
@@ -368,8 +376,12 @@ def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=N
         if keep_xt is not None:
             keep_xt["xt"] = xt
         del xt
+        out.stats = None
+        if want_stats and out.C == K:
+            out.stats = torch.empty((_lib.value("mss_wino_output_stats_parts", N, H, W, K, dil, ts), 2, K), device=dev,
+                                    dtype=torch.float32)
         call("mss_wino_output_transform_f32", ptr(yt), N, H, W, K, dil, ts, res.ptr if res is not None else None,
-             res.ld if res is not None else 0, out.ptr, out.ld)
+             res.ld if res is not None else 0, out.ptr, out.ld, ptr(out.stats))
     return out
 
 
@@ -448,6 +460,10 @@ def bn_fold(bn, x=None, train=False, M=None, x_rows=None):
     if x_rows is not None:          # plain [M, C] matrix (image-pooling branch)
         M = x_rows.shape[0]
         call("mss_bn_stats_nhwc_f32", ptr(x_rows), M, C, x_rows.shape[1], ptr(accum))
+    elif x.stats is not None and x.stats.shape[2] == C and x.C == C:   # left by the producing kernel: no re-read of x
+        M = x.M
+        call("mss_bn_stats_partials_f32", ptr(x.stats), x.stats.shape[0], C, ptr(accum))
+        x.stats = None
     else:
         M = x.M
         call("mss_bn_stats_nhwc_f32", x.ptr, M, C, x.ld, ptr(accum))

@@ -308,3 +308,40 @@ def test_m2f_fused_equals_unfused_at_full_size(K):
     up = torch.nn.functional.interpolate(lg.permute(0, 3, 1, 2).contiguous(), size=(1024, 2048), mode="bilinear", align_corners=False)
     unfused = K.m2f_score(cls, up, (1024, 2048))
     assert (fused - unfused).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,r,stride,dil,n,h,w,wino", [
+    (64, 128, 1, 1, 1, 2, 16, 24, False),      # persistent GEMM kernel
+    (32, 128, 1, 1, 1, 1, 9, 7, False),        # ragged rows (63 pixels: one partial row group)
+    (32, 96, 3, 1, 2, 2, 11, 13, False),       # implicit GEMM, 128x128 tile
+    (32, 48, 3, 2, 1, 2, 17, 19, False),       # 256x64 tile (K <= 64), stride 2
+    (32, 64, 3, 1, 1, 2, 12, 14, True),        # Winograd F(4x4): statistics from the output transform
+    (64, 32, 3, 1, 4, 1, 13, 17, True),
+])
+def test_batchnorm_statistics_from_the_producing_kernel(K, cin, cout, r, stride, dil, n, h, w, wino):
+    """want_stats: the conv epilogue / Winograd output transform leaves per-channel partial sums; bn_fold(train=True)
+    built from them must equal bn_fold on a statistics pass over the stored activation (residual included)."""
+    rng = np.random.default_rng(cin + cout + r + dil)
+    x = K.Act.from_nchw(dev(rng.standard_normal((n, cin, h, w), dtype=np.float32)))
+    wt = dev((rng.standard_normal((cout, cin, r, r), dtype=np.float32) / np.sqrt(cin * r * r)).astype(np.float32))
+    pad = dil if r == 3 else 0
+    oh, ow = K.conv_out_size(h, r, stride, dil, pad), K.conv_out_size(w, r, stride, dil, pad)
+    res = K.Act.from_nchw(dev(rng.standard_normal((n, cout, oh, ow), dtype=np.float32)))
+    if wino:
+        y = K.conv2d_winograd(x, K.pack_weight_wino(wt, tile=4), dil=dil, res=res, want_stats=True)
+    else:
+        y = K.conv2d(x, K.pack_weight(wt), stride=stride, dil=dil, pad=pad, res=res, want_stats=True)
+    assert y.stats is not None
+    bn_a, bn_b = torch.nn.BatchNorm2d(cout).cuda(), torch.nn.BatchNorm2d(cout).cuda()
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5); bn_a.bias.normal_()
+        bn_b.load_state_dict(bn_a.state_dict())
+    st_a = K.bn_fold(bn_a, y, train=True)
+    assert y.stats is None                       # consumed
+    st_b = K.bn_fold(bn_b, y, train=True)
+    for a, b in ((st_a.scale, st_b.scale), (st_a.shift, st_b.shift), (st_a.save_mean, st_b.save_mean),
+                 (st_a.save_invstd, st_b.save_invstd), (bn_a.running_mean, bn_b.running_mean), (bn_a.running_var, bn_b.running_var)):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    ref = torch.nn.functional.batch_norm(y.nchw(), None, None, bn_a.weight, bn_a.bias, training=True, eps=bn_a.eps)
+    got = y.nchw() * st_a.scale[None, :, None, None] + st_a.shift[None, :, None, None]
+    np.testing.assert_allclose(got.cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)

@@ -257,6 +257,36 @@ def gen_train_step(DeepWV3Plus, ref_loss):
                 if p.requires_grad and n_ in grads and grads[n_].numel() <= 70000:
                     g32, g64 = grads[n_].double().numpy(), p.grad.numpy()
                     out[pre + "gradnoise_" + n_] = np.float64(np.sqrt(((g32 - g64) ** 2).sum()) / (np.sqrt((g64 ** 2).sum()) + 1e-300))
+            # sensitivity of the same gradients to forward rounding: the fp32 reference again, with the two tensors
+            # the decoder consumes (mod7 and mod2 outputs) multiplied by (1 + 4e-6 * N(0,1)) -- the size of one
+            # Winograd F(4x4,3x3) layer's fp32 error. rel-L2 change per tensor = gradsens_<name>.
+            model_p = build_ref_model(DeepWV3Plus)
+            model_p.uncertainty_func_init()
+            for name, p in model_p.named_parameters():
+                p.requires_grad = any(s in name for s in names)
+            model_p.train()
+            model_p.mod6.block1.convs.dropout.forward = lambda x: x * torch.from_numpy(masks["mod6"])[:, :, None, None]
+            model_p.mod7.block1.convs.dropout.forward = lambda x: x * torch.from_numpy(masks["mod7"])[:, :, None, None]
+            gen_p = torch.Generator().manual_seed(99)
+            jitter = lambda m, i, o: o * (1 + 4e-6 * torch.randn(o.shape, generator=gen_p))
+            hooks = [model_p.mod7.register_forward_hook(jitter), model_p.mod2.register_forward_hook(jitter)]
+            replay = [torch.from_numpy(p_.astype(np.int64)) for p_ in perms]
+            torch.randperm = lambda n, *a, **k: replay.pop(0)
+            try:
+                score_p, logit_p = model_p(torch.from_numpy(img))
+                ref_loss.RelContrastiveLoss(loss_params)(logit_p, score_p, torch.from_numpy(target.copy())).mean().backward()
+            finally:
+                torch.randperm = real_randperm
+                for hk in hooks:
+                    hk.remove()
+            for n_, p in model_p.named_parameters():
+                if p.requires_grad and n_ in grads:
+                    g0, g1 = grads[n_].double().numpy(), p.grad.double().numpy()
+                    if g0.size > 70000:      # the same slice the gradient itself is stored as
+                        g0, g1 = (g.reshape(g.shape[0], -1)[:, ::max(1, g[0].size // 64)][:, :64] for g in (g0, g1))
+                    out[pre + "gradsens_" + n_] = np.float64(np.sqrt(((g0 - g1) ** 2).sum()) / (np.sqrt((g0 ** 2).sum()) + 1e-300))
+            sens = sorted(((float(v), k) for k, v in out.items() if k.startswith(pre + "gradsens_")), reverse=True)[:6]
+            print(f"   stage2 jittered replay (4e-6 relative noise on mod7/mod2 outputs): largest gradient rel-L2 change: {sens}")
             noisy = sorted(((float(v), k) for k, v in out.items() if k.startswith(pre + "gradnoise_")), reverse=True)[:5]
             print(f"   stage2 float64 replay: loss {float(loss64):.6f}; largest fp32-vs-fp64 gradient rel-L2: {noisy}")
         print(f"   {stage}: loss {float(loss):.6f}, {len(grads)} trainable tensors, perms {[len(p) for p in perms]}")
