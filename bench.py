@@ -60,8 +60,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny"],
-                    help="c3: 1 pair of 1024x2048 per GPU; c2: 8 pairs of 768x768 (exps/DeepLab.yaml batch 8); tiny: smoke")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2_700", "tiny"],
+                    help="c3: 1 pair of 1024x2048 per GPU; c2: 8 pairs of 768x768 (BASELINE's wording of exps/DeepLab.yaml batch 8); "
+                         "c2_700: 8 pairs of 700x700 (the crop size exps/DeepLab.yaml actually uses); tiny: smoke")
     ap.add_argument("--stage", type=int, default=2, choices=[1, 2])
     ap.add_argument("--loss-sync", default="local", choices=["local", "global"],
                     help="local: per-rank loss (no loss collectives); global: reference semantics over all ranks' pairs")
@@ -80,7 +81,7 @@ def main():
     if device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X")
 
-    pairs, H, W = {"c3": (1, 1024, 2048), "c2": (8, 768, 768), "tiny": (1, 128, 256)}[args.workload]
+    pairs, H, W = {"c3": (1, 1024, 2048), "c2": (8, 768, 768), "c2_700": (8, 700, 700), "tiny": (1, 128, 256)}[args.workload]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
