@@ -16,6 +16,7 @@
 //    rate); grad_loc / grad_attn are reduced over the pair's lanes with DPP/shuffles and written
 //    with plain stores (no LDS round trip, no serial thread-0 loop, no zero-init needed).
 #include "mss_common.h"
+#include <stdlib.h>
 #include "../../include/mss_hip.h"
 
 namespace {
@@ -150,7 +151,7 @@ __device__ __forceinline__ T pair_reduce(T v) {
   return v;
 }
 
-template <typename T, int LPP>
+template <typename T, int LPP, bool VALUE_GRAD>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(
     const T* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
     const T* __restrict__ loc, const T* __restrict__ attn, const T* __restrict__ gout, long long npairs, int S,
@@ -190,10 +191,10 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
           const T tg = go[d];
           const T tgv = aw * tg;
           T v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-          if (ok1) { v1 = value[o1 + d]; atomicAdd(gvalue + o1 + d, w1 * tgv); }
-          if (ok2) { v2 = value[o2 + d]; atomicAdd(gvalue + o2 + d, w2 * tgv); }
-          if (ok3) { v3 = value[o3 + d]; atomicAdd(gvalue + o3 + d, w3 * tgv); }
-          if (ok4) { v4 = value[o4 + d]; atomicAdd(gvalue + o4 + d, w4 * tgv); }
+          if (ok1) { v1 = value[o1 + d]; if (VALUE_GRAD) atomicAdd(gvalue + o1 + d, w1 * tgv); }
+          if (ok2) { v2 = value[o2 + d]; if (VALUE_GRAD) atomicAdd(gvalue + o2 + d, w2 * tgv); }
+          if (ok3) { v3 = value[o3 + d]; if (VALUE_GRAD) atomicAdd(gvalue + o3 + d, w3 * tgv); }
+          if (ok4) { v4 = value[o4 + d]; if (VALUE_GRAD) atomicAdd(gvalue + o4 + d, w4 * tgv); }
           const T val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
           const T gw = -hh * v1 + hh * v2 - lh * v3 + lh * v4;
           const T gh = -hw * v1 - lw * v2 + hw * v3 + lw * v4;
@@ -213,6 +214,247 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
         gloc[(pair * L * P + sidx) * 2 + 1] = s_h;
       }
     }
+  }
+}
+
+// grad_sampling_loc / grad_attn_weight without touching grad_value (fp32, D = 32): the forward kernel's layout -- a wave
+// holds 8 (query, head) pairs x 8 channel quads, loc/attn staged in LDS -- so the four corner rows of a sample are
+// float4 gathers and the per-sample work is 4 dot products over 32 channels (4 FMAs + a 3-step DPP sum in each 8-lane
+// group): everything the two gradients need is linear in p_c = <value_corner_c, grad_out>. Results overwrite the
+// staged loc/attn in LDS and leave with coalesced stores.
+__global__ __launch_bounds__(256) void msda_bwd_gather_fast_kernel(
+    const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
+    const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ gout, long long npairs, int S,
+    int M, int L, int Lq, int P, float* __restrict__ gloc, float* __restrict__ gattn) {
+  constexpr int LPH = 8, D = 32, HPW = 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LP = L * P;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* sloc = smem + wave * (HPW * LP * 3);  // [HPW][LP][2]
+  float* sattn = sloc + HPW * LP * 2;          // [HPW][LP]
+  const long long pair0 = ((long long)blockIdx.x * 4 + wave) * HPW;
+  if (pair0 >= npairs) return;  // whole wave leaves together (no block barrier below)
+  const int npw = (int)min((long long)HPW, npairs - pair0);
+  {
+    const float* gl = loc + pair0 * LP * 2;
+    const float* ga = attn + pair0 * LP;
+    for (int i = lane; i < npw * LP * 2; i += 64) sloc[i] = gl[i];
+    for (int i = lane; i < npw * LP; i += 64) sattn[i] = ga[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  const int g = lane / LPH, j = lane % LPH;
+  const bool live = g < npw;                                   // idle groups run along on pair0 (DPP sums stay in-group)
+  const long long pair = pair0 + (live ? g : 0);
+  const int m = (int)(pair % M);
+  const int n = (int)(pair / M / Lq);
+  float* myloc = sloc + (live ? g : 0) * LP * 2;
+  float* myattn = sattn + (live ? g : 0) * LP;
+  const size_t row_stride = (size_t)M * D;
+  const float* vbase = value + (size_t)n * S * row_stride + (size_t)m * D + 4 * j;
+  const f32x4 go4 = *reinterpret_cast<const f32x4*>(gout + pair * D + 4 * j);
+  auto dot8 = [&](f32x4 v) { return mss_sum8(v.x * go4.x + v.y * go4.y + v.z * go4.z + v.w * go4.w); };
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const float* vl = vbase + (size_t)starts[l] * row_stride;
+#pragma unroll 2
+    for (int pt = 0; pt < P; ++pt) {
+      const int sidx = l * P + pt;
+      const float lx = myloc[sidx * 2], ly = myloc[sidx * 2 + 1];
+      const float aw = myattn[sidx];
+      const float w_im = lx * W - 0.5f, h_im = ly * H - 0.5f;
+      const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const int h0 = (int)hf, w0 = (int)wf;
+      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+      const bool okh0 = inside && h0 >= 0, okh1 = inside && h0 + 1 <= H - 1;
+      const bool okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
+      const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h0 + 1, 0), H - 1);
+      const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w0 + 1, 0), W - 1);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      f32x4 v1 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h0c * W + w0c) * row_stride);
+      f32x4 v2 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h0c * W + w1c) * row_stride);
+      f32x4 v3 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h1c * W + w0c) * row_stride);
+      f32x4 v4 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h1c * W + w1c) * row_stride);
+      v1 = (okh0 && okw0) ? v1 : z;
+      v2 = (okh0 && okw1) ? v2 : z;
+      v3 = (okh1 && okw0) ? v3 : z;
+      v4 = (okh1 && okw1) ? v4 : z;
+      const float p1 = dot8(v1), p2 = dot8(v2), p3 = dot8(v3), p4 = dot8(v4);
+      const float s_attn = hh * hw * p1 + hh * lw * p2 + lh * hw * p3 + lh * lw * p4;
+      const float s_w = aw * (float)W * (-hh * p1 + hh * p2 - lh * p3 + lh * p4);
+      const float s_h = aw * (float)H * (-hw * p1 - lw * p2 + hw * p3 + lw * p4);
+      if (live && j == 0) { myloc[sidx * 2] = s_w; myloc[sidx * 2 + 1] = s_h; myattn[sidx] = s_attn; }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  {
+    float* gl = gloc + pair0 * LP * 2;
+    float* ga = gattn + pair0 * LP;
+    for (int i = lane; i < npw * LP * 2; i += 64) gl[i] = sloc[i];
+    for (int i = lane; i < npw * LP; i += 64) ga[i] = sattn[i];
+  }
+}
+
+// grad_value without global atomics (fp32, D = 32). The scatter-add formulation above is bound by memory-side
+// atomics (~1.3 TB/s of added bytes: 6 ms for the 8 GB of a 16-image C4 call). Here a workgroup OWNS a tile of
+// grad_value -- (image n, head m, level l, a band of rows x columns with at most 256 positions) -- scans the level's
+// Lq*P sampling locations of (n, m) (L2-resident, a few hundred KB), and for the samples whose bilinear footprint
+// touches its tile accumulates w_corner * attn * grad_out in LDS; the finished tile is written with plain stores.
+// Every grad_value element belongs to exactly one tile, so there is no memset and no global atomic. Passing samples
+// are compacted with a wave ballot and handled two at a time (32 channels each), four pairs in flight.
+//
+// The LDS accumulators are 64-bit FIXED POINT: ds_add_f32 runs at 0.33 lane-operations per clock per CU on gfx950
+// (measured, tools/hipbench/lds_atomic_rate.hip), ds_add_u64 at 9.2. A pre-pass finds max|grad_out| and max|attn|;
+// with 2^e >= their product every contribution is scaled by 2^(40-e), so |c| <= 2^40, 2^22 of them cannot overflow
+// and the resolution is 2^-40 of the largest possible contribution (fp32 atomics resolve 2^-24 of each partial sum).
+// The result does not depend on the order of the additions.
+constexpr int MSDA_TILE_CELLS = 256;   // x 32 channels x 8 B = 64 KB -> two workgroups per CU
+constexpr int MSDA_TILE_W = 16;
+constexpr int MSDA_FIXED_BITS = 40;
+
+__global__ __launch_bounds__(256) void msda_absmax_kernel(const float* __restrict__ a, long long na,
+                                                          const float* __restrict__ b, long long nb,
+                                                          unsigned* __restrict__ out) {
+  float ma = 0.f, mb = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < na; i += (long long)gridDim.x * 256) ma = fmaxf(ma, fabsf(a[i]));
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (long long)gridDim.x * 256) mb = fmaxf(mb, fabsf(b[i]));
+  ma = mss_wave_max(ma);
+  mb = mss_wave_max(mb);
+  if ((threadIdx.x & 63) == 0) {       // non-negative floats order like their bit patterns
+    atomicMax(out, __float_as_uint(ma));
+    atomicMax(out + 1, __float_as_uint(mb));
+  }
+}
+
+struct MsdaTile { int l, H, W, r0, r1, c0, c1; long long start; bool valid; };
+__device__ __forceinline__ MsdaTile msda_find_tile(const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
+                                                   int L, int t) {
+  MsdaTile k;
+  k.valid = false;
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    // ~16 x 16 positions (a bilinear footprint straddles a tile edge with probability ~1/16 per axis; row bands would
+    // duplicate half of the samples); thin levels get wider / taller tiles so that a tile still holds ~256 positions
+    const int BH0 = H < MSDA_TILE_W ? H : MSDA_TILE_W;
+    const int BW = min(W, MSDA_TILE_CELLS / BH0);
+    const int BH = min(H, MSDA_TILE_CELLS / BW);
+    const int nr = (H + BH - 1) / BH, nc = (W + BW - 1) / BW;
+    if (t < nr * nc) {
+      const int br = t / nc, bc = t - br * nc;
+      k.l = l; k.H = H; k.W = W; k.start = starts[l];
+      k.r0 = br * BH; k.r1 = min(H, k.r0 + BH);
+      k.c0 = bc * BW; k.c1 = min(W, k.c0 + BW);
+      k.valid = true;
+      return k;
+    }
+    t -= nr * nc;
+  }
+  return k;
+}
+
+constexpr int MSDA_LDS_NT = 1024;      // 16 waves: the gout gathers are latency-bound, two such workgroups per CU
+__global__ __launch_bounds__(MSDA_LDS_NT) void msda_bwd_value_lds_kernel(
+    const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts, const float* __restrict__ loc,
+    const float* __restrict__ attn, const float* __restrict__ gout, const unsigned* __restrict__ absmax, int S, int M,
+    int L, int Lq, int P, float* __restrict__ gvalue) {
+  constexpr int D = 32, NT = MSDA_LDS_NT, UN = 4;        // UN sample pairs in flight per wave
+  __shared__ unsigned long long tile[MSDA_TILE_CELLS * D];
+  const MsdaTile k = msda_find_tile(shapes, starts, L, blockIdx.x);
+  if (!k.valid) return;                                  // the grid is an upper bound on the tile count
+  const int m = blockIdx.y, n = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, d = lane & 31;
+  const int tw = k.c1 - k.c0, cells = (k.r1 - k.r0) * tw;
+  for (int i = tid; i < cells * D; i += NT) tile[i] = 0ull;
+  // fixed-point scale: 2^(40 - e) with 2^e >= max|grad_out| * max|attn| (bilinear weights are <= 1)
+  const float bound = __uint_as_float(absmax[0]) * __uint_as_float(absmax[1]);
+  int e = 0;
+  if (bound > 0.f && bound < __builtin_huge_valf()) (void)frexpf(bound, &e);      // bound = f * 2^e, f in [0.5, 1)
+  const double to_fixed = ldexp(1.0, MSDA_FIXED_BITS - e), from_fixed = ldexp(1.0, e - MSDA_FIXED_BITS);
+  __syncthreads();
+  const long long total = (long long)Lq * P;
+  const size_t pair_stride = (size_t)M * L * P;          // (q -> q+1) in units of samples
+  const size_t pair0 = ((size_t)n * Lq * M + m) * L * P + (size_t)k.l * P;
+  const float fH = (float)k.H, fW = (float)k.W;
+  const float* go = gout + ((size_t)n * Lq * M + m) * D + d;       // + q * M * D
+  const size_t go_stride = (size_t)M * D;
+  const int total_i = (int)total;
+  for (int i0 = 0; i0 < total_i; i0 += NT) {
+    const int i = i0 + tid;
+    bool pass = false;
+    int q = 0;
+    float h_im = 0.f, w_im = 0.f, aw = 0.f;
+    if (i < total_i) {
+      q = i / P;
+      const int pt = i - q * P;
+      const size_t sidx = pair0 + (size_t)q * pair_stride + pt;
+      const float lx = loc[sidx * 2], ly = loc[sidx * 2 + 1];
+      w_im = lx * fW - 0.5f;
+      h_im = ly * fH - 0.5f;
+      if (h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW) {
+        const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im);
+        const bool rows = (h0 >= k.r0 && h0 < k.r1) || (h0 + 1 >= k.r0 && h0 + 1 < k.r1);     // h0 = -1 / h0+1 = H never match
+        const bool cols = (w0 >= k.c0 && w0 < k.c1) || (w0 + 1 >= k.c0 && w0 + 1 < k.c1);
+        pass = rows && cols;
+        if (pass) aw = attn[sidx];
+      }
+    }
+    unsigned long long mask = __ballot(pass);
+    while (mask) {
+      // up to UN pairs of passing samples: lanes 0-31 take the even ones, lanes 32-63 the odd ones; all gout rows are
+      // requested before the first LDS atomic
+      int sq[UN];
+      float sh[UN], sw[UN], tgv[UN];
+      bool act[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        int s0 = -1, s1 = -1;
+        if (mask) { s0 = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+        if (mask) { s1 = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+        const int src = half ? s1 : s0;
+        act[u] = src >= 0;
+        const int from = src >= 0 ? src : 0;
+        sq[u] = __shfl(q, from);
+        sh[u] = __shfl(h_im, from);
+        sw[u] = __shfl(w_im, from);
+        tgv[u] = __shfl(aw, from);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) tgv[u] *= act[u] ? go[(size_t)sq[u] * go_stride] : 0.f;
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (act[u]) {
+          const float hf = floorf(sh[u]), wf = floorf(sw[u]);
+          const int h0 = (int)hf, w0 = (int)wf;
+          const float lh = sh[u] - hf, lw = sw[u] - wf, hh = 1.f - lh, hw = 1.f - lw;
+          const bool r_lo = h0 >= k.r0 && h0 < k.r1, r_hi = h0 + 1 >= k.r0 && h0 + 1 < k.r1;
+          const bool c_lo = w0 >= k.c0 && w0 < k.c1, c_hi = w0 + 1 >= k.c0 && w0 + 1 < k.c1;
+          unsigned long long* base = tile + ((h0 - k.r0) * tw + (w0 - k.c0)) * D + d;
+          // round(c * 2^(40-e)) as a two's-complement integer: adding 1.5 * 2^52 leaves it in the low mantissa bits
+          // (|c * to_fixed| <= 2^40); a native double -> int64 conversion does not exist on this ISA
+          auto fx = [&](float c) {
+            const double t = fma((double)c, to_fixed, 6755399441055744.0);
+            return (unsigned long long)(__double_as_longlong(t) - 0x4338000000000000ll);
+          };
+          if (r_lo && c_lo) atomicAdd(base, fx(hh * hw * tgv[u]));
+          if (r_lo && c_hi) atomicAdd(base + D, fx(hh * lw * tgv[u]));
+          if (r_hi && c_lo) atomicAdd(base + tw * D, fx(lh * hw * tgv[u]));
+          if (r_hi && c_hi) atomicAdd(base + tw * D + D, fx(lh * lw * tgv[u]));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const size_t rs = (size_t)M * D;
+  float* gv = gvalue + (size_t)n * S * rs + (size_t)m * D + (size_t)k.start * rs;
+  for (int i = tid; i < cells * D; i += NT) {
+    const int cell = i >> 5, ch = i & 31;
+    const int r = cell / tw, c = cell - r * tw;
+    gv[(size_t)((k.r0 + r) * k.W + k.c0 + c) * rs + ch] = (float)((double)(long long)tile[i] * from_fixed);
   }
 }
 
@@ -260,20 +502,56 @@ int msda_backward(const T* value, const int64_t* shapes, const int64_t* starts, 
   int rc = msda_check(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P);
   if (rc) return rc;
   if (!gvalue && N > 0) return MSS_ERR_BAD_ARG;
-  if (N > 0) {
+  const long long npairs = (long long)N * Lq * M;
+  const char* env = getenv("MSS_MSDA_BWD_LDS");      // 0: atomic kernel only, 2: owner-computes path at any size (tests)
+  const int lds_path = env ? atoi(env) : 1;
+  // owner-computes path: fp32, D = 32, at most 2^22 samples per (image, head, level) (fixed-point headroom)
+  const bool owner = lds_path && sizeof(T) == 4 && D == 32 && npairs > 0 && M <= 65535 && N <= 65535 &&
+                     (long long)Lq * P <= (1ll << 22) &&
+                     (lds_path == 2 || npairs * L * P >= (6ll << 20));   // below ~6 M samples the atomic kernel wins
+  if (N > 0 && !owner) {
     hipError_t e = hipMemsetAsync(gvalue, 0, (size_t)N * S * M * D * sizeof(T), stream);
     if (e != hipSuccess) return (int)e;
   }
-  const long long npairs = (long long)N * Lq * M;
   if (npairs == 0) return MSS_OK;
   if (!gout || !gloc || !gattn) return MSS_ERR_BAD_ARG;
+  if (owner) {
+    // grad_value: tiles accumulated in LDS. The first 8 bytes of grad_loc hold max|grad_out|, max|attn| until the
+    // gather pass below overwrites them with the real gradient.
+    unsigned* absmax = reinterpret_cast<unsigned*>(gloc);
+    hipError_t e = hipMemsetAsync(absmax, 0, 2 * sizeof(unsigned), stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(msda_absmax_kernel, dim3(1024), dim3(256), 0, stream, reinterpret_cast<const float*>(gout),
+                       npairs * D, reinterpret_cast<const float*>(attn), npairs * L * P, absmax);
+    // an upper bound on the tile count of any set of level shapes with S positions in all (checked exhaustively on
+    // random shape sets up to 600 x 600); surplus workgroups exit at once
+    const unsigned tiles_bound = (unsigned)(S / 32 + 4 * L + 4);
+    hipLaunchKernelGGL(msda_bwd_value_lds_kernel, dim3(tiles_bound, (unsigned)M, (unsigned)N), dim3(MSDA_LDS_NT), 0, stream, shapes,
+                       starts, reinterpret_cast<const float*>(loc), reinterpret_cast<const float*>(attn),
+                       reinterpret_cast<const float*>(gout), absmax, S, M, L, Lq, P, reinterpret_cast<float*>(gvalue));
+    // grad_loc / grad_attn: the gather pass (no atomics)
+    const size_t smem = (size_t)4 * 8 * L * P * 3 * sizeof(float);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(gout)) & 15) == 0;
+    if (aligned && smem <= 65536) {
+      const long long nblocks = (npairs + 31) / 32;
+      hipLaunchKernelGGL(msda_bwd_gather_fast_kernel, dim3((unsigned)nblocks), dim3(256), smem, stream,
+                         reinterpret_cast<const float*>(value), shapes, starts, reinterpret_cast<const float*>(loc),
+                         reinterpret_cast<const float*>(attn), reinterpret_cast<const float*>(gout), npairs, S, M, L, Lq, P,
+                         reinterpret_cast<float*>(gloc), reinterpret_cast<float*>(gattn));
+    } else {
+      const long long nblocks = (npairs + 7) / 8;
+      hipLaunchKernelGGL((msda_bwd_kernel<T, 32, false>), dim3((unsigned)nblocks), dim3(256), 0, stream, value, shapes,
+                         starts, loc, attn, gout, npairs, S, M, D, L, Lq, P, gvalue, gloc, gattn);
+    }
+    return mss_launch_status();
+  }
   if (D <= 32) {
     const long long nblocks = (npairs + 7) / 8;
-    hipLaunchKernelGGL((msda_bwd_kernel<T, 32>), dim3((unsigned)nblocks), dim3(256), 0, stream, value, shapes,
+    hipLaunchKernelGGL((msda_bwd_kernel<T, 32, true>), dim3((unsigned)nblocks), dim3(256), 0, stream, value, shapes,
                        starts, loc, attn, gout, npairs, S, M, D, L, Lq, P, gvalue, gloc, gattn);
   } else {
     const long long nblocks = (npairs + 3) / 4;
-    hipLaunchKernelGGL((msda_bwd_kernel<T, 64>), dim3((unsigned)nblocks), dim3(256), 0, stream, value, shapes,
+    hipLaunchKernelGGL((msda_bwd_kernel<T, 64, true>), dim3((unsigned)nblocks), dim3(256), 0, stream, value, shapes,
                        starts, loc, attn, gout, npairs, S, M, D, L, Lq, P, gvalue, gloc, gattn);
   }
   return mss_launch_status();

@@ -144,3 +144,60 @@ def test_module_golden():
     with torch.no_grad():
         y = mod(dev(g["query"]), dev(g["refp"]), dev(g["src"]), dev(g["shapes"]), dev(g["starts"]))
     np.testing.assert_allclose(y.cpu().numpy(), g["out"], rtol=1e-3, atol=1e-3)
+
+
+@pytest.fixture
+def force_bwd(monkeypatch):
+    def set_mode(mode):          # "0": atomic scatter kernel, "2": owner-computes LDS tiles at any size
+        monkeypatch.setenv("MSS_MSDA_BWD_LDS", mode)
+    return set_mode
+
+
+@pytest.mark.parametrize("mode", ["0", "2"])
+@pytest.mark.parametrize("N,Lq,shapes", [
+    (2, 1500, [(22, 22), (44, 44), (88, 88)]),          # C4 geometry
+    (1, 900, [(32, 64), (64, 128)]),                     # wide levels: several column tiles
+    (2, 257, [(1, 300), (300, 1), (17, 17), (5, 3)]),    # thin and tiny levels, ragged tiles
+])
+def test_backward_formulations_vs_oracle(F, force_bwd, mode, N, Lq, shapes):
+    """Both grad_value formulations (memory-side atomics; tiles owned by a workgroup, 64-bit fixed point in LDS) and
+    both gather passes against the numpy oracle, with locations spilling over every border."""
+    force_bwd(mode)
+    rng = np.random.default_rng(len(shapes) * 100 + N)
+    shp = np.array(shapes, dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(shp.prod(1))[:-1]]).astype(np.int64)
+    S, L = int(shp.prod(1).sum()), len(shapes)
+    value = rng.standard_normal((N, S, 8, 32), dtype=np.float32)
+    loc = rng.uniform(-0.2, 1.2, (N, Lq, 8, L, 4, 2)).astype(np.float32)
+    attn = rng.random((N, Lq, 8, L, 4), dtype=np.float32)
+    attn /= attn.sum((-1, -2), keepdims=True)
+    gout = (rng.standard_normal((N, Lq, 256), dtype=np.float32) * 3).astype(np.float32)
+    out, v, l, a = run(F, dict(value=value, shapes=shp, starts=starts, loc=loc, attn=attn, grad_out=gout))
+    gv, gl, ga = omsda.backward(value, shp, starts, loc, attn, gout)
+    np.testing.assert_allclose(v.grad.cpu().numpy(), gv, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(l.grad.cpu().numpy(), gl, rtol=1e-3, atol=3e-3)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), ga, rtol=1e-3, atol=1e-4)
+
+
+def test_owner_backward_is_order_independent_and_matches_atomics_at_full_size(F, force_bwd):
+    """C4 at N=16 (15.6 M samples, the size that takes the owner-computes path by default): grad_value of the two
+    formulations agree, the fixed-point path is bit-reproducible, and a huge dynamic range of grad_out survives."""
+    torch.manual_seed(1)
+    shapes = torch.as_tensor([(22, 22), (44, 44), (88, 88)], dtype=torch.long).cuda()
+    starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S, N = int(shapes.prod(1).sum()), 16
+    v = torch.randn(N, S, 8, 32, device="cuda")
+    loc = torch.rand(N, S, 8, 3, 4, 2, device="cuda") * 1.1 - 0.05
+    attn = torch.softmax(torch.randn(N, S, 8, 12, device="cuda"), -1).view(N, S, 8, 3, 4)
+    g = torch.randn(N, S, 256, device="cuda")
+    g[:, ::7] *= 1e-4                                      # 1e4 dynamic range between queries
+    from multishiftseg_amd import MultiScaleDeformableAttention as MSDA
+    res = {}
+    for mode in ("0", "2", "2b"):
+        force_bwd(mode[0])
+        res[mode] = MSDA.ms_deform_attn_backward(v, shapes, starts, loc, attn, g, 64)
+    assert torch.equal(res["2"][0], res["2b"][0])          # integer accumulation: same bits every time
+    scale = res["0"][0].abs().max().item()
+    assert (res["0"][0] - res["2"][0]).abs().max().item() < 2e-5 * scale
+    torch.testing.assert_close(res["0"][1], res["2"][1], rtol=1e-3, atol=1e-3 * res["0"][1].abs().max().item())
+    torch.testing.assert_close(res["0"][2], res["2"][2], rtol=1e-3, atol=1e-4 * res["0"][2].abs().max().item())
