@@ -182,6 +182,8 @@ def main():
             tj = json.load(open(tpath))
             fam = tj.get("families", {}).get(dom + "_kernel")
             out["roofline"]["traffic"] = round(fam["hbm_bytes_per_launch"] if fam else tj["hbm_bytes_per_launch"])
+            # the same counters as a rate over this run's measured launch time (8000 GB/s HBM peak for comparison)
+            out["roofline"]["memory_side_GBs"] = round(out["roofline"]["traffic"] / (out["roofline"]["avg_launch_ms"] * 1e-3) / 1e9, 1)
             out["roofline"]["traffic_note"] = ("bytes per launch, L2-memory-side (Infinity-Cache hits included), from "
                                                "profiles/conv_traffic_latest.json: " + tj["correction"])
         except Exception:
