@@ -14,6 +14,7 @@ from torch.autograd.function import once_differentiable
 from torch.nn.init import constant_, xavier_uniform_
 
 from . import MultiScaleDeformableAttention as MSDA
+from .linear import linear
 
 
 class MSDeformAttnFunction(Function):
@@ -83,12 +84,12 @@ class MSDeformAttn(nn.Module):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
-        value = self.value_proj(input_flatten)
+        value = linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
-        offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-        weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        offsets = linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        weights = linear(query, self.attention_weights.weight, self.attention_weights.bias).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
         weights = F.softmax(weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
         if reference_points.shape[-1] == 2:
             normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
@@ -100,4 +101,4 @@ class MSDeformAttn(nn.Module):
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
         output = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                             locations.contiguous(), weights.contiguous(), self.im2col_step)
-        return self.output_proj(output)
+        return linear(output, self.output_proj.weight, self.output_proj.bias)

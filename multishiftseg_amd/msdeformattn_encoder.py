@@ -9,8 +9,8 @@ given (res5 -> res3 in the decoder, msdeformattn.py:319), ``spatial_shapes`` int
 ``level_start_index``, reference points at pixel centres. The detectron2-dependent shell around it
 (``MSDeformAttnPixelDecoder``: input_proj convs + GroupNorm, FPN) is out of scope.
 
-The attention itself is the HIP op (multishiftseg_amd.ms_deform_attn.MSDeformAttn); LayerNorm and the
-FFN Linears are library ops. Masks are all-False in the reference (msdeformattn.py:62), so valid
+The attention itself is the HIP op (multishiftseg_amd.ms_deform_attn.MSDeformAttn); the Linears run on the repository's
+fp32 MFMA GEMM kernels (multishiftseg_amd/linear.py); LayerNorm is a library op. Masks are all-False in the reference (msdeformattn.py:62), so valid
 ratios are 1 and are folded away here.
 """
 import copy
@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .linear import linear
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -71,7 +72,11 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         q = src if pos is None else src + pos
         src = self.norm1(src + self.dropout1(
             self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)))
-        ffn = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        if self.activation is F.relu:            # ReLU rides in the GEMM epilogue
+            hidden = linear(src, self.linear1.weight, self.linear1.bias, relu=True)
+        else:
+            hidden = self.activation(linear(src, self.linear1.weight, self.linear1.bias))
+        ffn = linear(self.dropout2(hidden), self.linear2.weight, self.linear2.bias)
         return self.norm2(src + self.dropout3(ffn))
 
 
