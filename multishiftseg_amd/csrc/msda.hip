@@ -259,7 +259,6 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_fast_kernel(
   for (int l = 0; l < L; ++l) {
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
     const float* vl = vbase + (size_t)starts[l] * row_stride;
-#pragma unroll 2
     for (int pt = 0; pt < P; ++pt) {
       const int sidx = l * P + pt;
       const float lx = myloc[sidx * 2], ly = myloc[sidx * 2 + 1];
