@@ -35,7 +35,7 @@ FWD_GMAC_1024x2048 = 5827.2            # conv MACs of one forward a
 STAGE2_STEP_OVER_FWD = 1.287           # stage-2 step FLOPs / forward FLOPs
 
 
-def cpu_baseline(h=256, w=512):
+def cpu_baseline(h=320, w=640):
     """The numpy oracle (a port, not the reference) on the host cores: one eval forward of a
     1x3xhxw image; converted to the metric's unit by the algorithmic-FLOP ratio of a stage-2 train
     step at the benchmark resolution."""
