@@ -374,7 +374,11 @@ __global__ __launch_bounds__(MSDA_LDS_NT) void msda_bwd_value_lds_kernel(
   const float bound = __uint_as_float(absmax[0]) * __uint_as_float(absmax[1]);
   int e = 0;
   if (bound > 0.f && bound < __builtin_huge_valf()) (void)frexpf(bound, &e);      // bound = f * 2^e, f in [0.5, 1)
-  const double to_fixed = ldexp(1.0, MSDA_FIXED_BITS - e), from_fixed = ldexp(1.0, e - MSDA_FIXED_BITS);
+  // a non-finite grad_out / attn poisons the whole gradient (the reference's float atomics would poison the cells it
+  // reaches): every element written below becomes NaN instead of a silently wrong finite number
+  const bool finite = bound < __builtin_huge_valf();      // false for inf and NaN
+  const double to_fixed = ldexp(1.0, MSDA_FIXED_BITS - e);
+  const double from_fixed = finite ? ldexp(1.0, e - MSDA_FIXED_BITS) : (double)__builtin_nanf("");
   __syncthreads();
   const long long total = (long long)Lq * P;
   const size_t pair_stride = (size_t)M * L * P;          // (q -> q+1) in units of samples

@@ -201,3 +201,20 @@ def test_owner_backward_is_order_independent_and_matches_atomics_at_full_size(F,
     assert (res["0"][0] - res["2"][0]).abs().max().item() < 2e-5 * scale
     torch.testing.assert_close(res["0"][1], res["2"][1], rtol=1e-3, atol=1e-3 * res["0"][1].abs().max().item())
     torch.testing.assert_close(res["0"][2], res["2"][2], rtol=1e-3, atol=1e-4 * res["0"][2].abs().max().item())
+
+
+def test_owner_backward_propagates_non_finite_gradients(F, force_bwd):
+    """Fixed-point accumulation cannot represent inf/NaN: a non-finite grad_out must still surface as NaN."""
+    force_bwd("2")
+    from multishiftseg_amd import MultiScaleDeformableAttention as MSDA
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long).cuda()
+    starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    v = torch.randn(2, 30, 8, 32, device="cuda")
+    loc = torch.rand(2, 7, 8, 2, 4, 2, device="cuda")
+    attn = torch.rand(2, 7, 8, 2, 4, device="cuda")
+    g = torch.randn(2, 7, 256, device="cuda")
+    gv, _, _ = MSDA.ms_deform_attn_backward(v, shapes, starts, loc, attn, g, 2)
+    assert torch.isfinite(gv).all()
+    g[1, 3, 5] = float("inf")
+    gv, _, _ = MSDA.ms_deform_attn_backward(v, shapes, starts, loc, attn, g, 2)
+    assert not torch.isfinite(gv).all()
