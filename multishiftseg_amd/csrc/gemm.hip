@@ -21,7 +21,11 @@
 namespace {
 
 constexpr int NT = 256, BM = 128, BN = 128, BK = 16;
-constexpr int LDK = BK + 4;            // +4 floats: ds_read_b128 of 16 distinct rows is conflict-free
+// LDS rows are 16 floats with NO padding; the four 16-byte chunks of row r are rotated by (r >> 2): a staging write
+// (16 lanes = 4 rows x 4 chunks) and a fragment read (16 lanes = 16 rows x 1 chunk) then both touch 16 disjoint
+// 4-bank spans. (The +4-float padding of conv_igemm is conflict-free for the reads only: PMC showed a third of the
+// LDS cycles as bank conflicts from the ds_write_b128 side.)
+constexpr int LDK = BK;
 constexpr int WTM = 64, WTN = 64, TM = 2, TN = 2;
 constexpr int CPR = BK / 4;            // float4 chunks per tile row
 constexpr int RPP = NT / CPR;          // rows staged per pass
@@ -37,6 +41,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_nt_kernel(MssConvArgs p, long long
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int chunk = tid % CPR, row0 = tid / CPR;
+  const int wchunk = (chunk + (row0 >> 2)) & 3;          // RPP = 64 rows per pass: (row0 + j * 64) >> 2 has the same low bits
   const int n_it = p.C / BK;
   const long long stride = gridDim.x;
   const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
@@ -101,24 +106,26 @@ __global__ __launch_bounds__(NT, 3) void gemm_nt_kernel(MssConvArgs p, long long
         val.x = fmaxf(val.x, relu_floor); val.y = fmaxf(val.y, relu_floor);
         val.z = fmaxf(val.z, relu_floor); val.w = fmaxf(val.w, relu_floor);
       }
-      *reinterpret_cast<f32x4*>(&As[(buf * BM + row0 + j * RPP) * LDK + chunk * 4]) = val;
+      *reinterpret_cast<f32x4*>(&As[(buf * BM + row0 + j * RPP) * LDK + wchunk * 4]) = val;
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j)
-      *reinterpret_cast<f32x4*>(&Bs[(buf * BN + row0 + j * RPP) * LDK + chunk * 4]) = breg[j];
+      *reinterpret_cast<f32x4*>(&Bs[(buf * BN + row0 + j * RPP) * LDK + wchunk * 4]) = breg[j];
   };
 
-  const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
-  const float* Abase = &As[(wm * WTM + frag_row) * LDK + frag_k];
-  const float* Bbase = &Bs[(wn * WTN + frag_row) * LDK + frag_k];
+  const int frag_row = lane & 31, frag_h = lane >> 5;
+  const int rot = frag_row >> 2;                           // tile rows are frag_row + multiples of 32: same rotation
+  const float* Abase = &As[(wm * WTM + frag_row) * LDK];
+  const float* Bbase = &Bs[(wn * WTN + frag_row) * LDK];
+  const int koff[2] = {((frag_h + rot) & 3) * 4, ((2 + frag_h + rot) & 3) * 4};   // logical chunk kc * 2 + frag_h
   f32x4 fa[2][TM], fb[2][TN];
   auto load_frags = [&](int set, int buf, int kc) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
-      fa[set][i] = *reinterpret_cast<const f32x4*>(Abase + (buf * BM + i * 32) * LDK + kc * 8);
+      fa[set][i] = *reinterpret_cast<const f32x4*>(Abase + (buf * BM + i * 32) * LDK + koff[kc]);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      fb[set][j] = *reinterpret_cast<const f32x4*>(Bbase + (buf * BN + j * 32) * LDK + kc * 8);
+      fb[set][j] = *reinterpret_cast<const f32x4*>(Bbase + (buf * BN + j * 32) * LDK + koff[kc]);
   };
   f32x16 acc[TM][TN];
   auto zero_acc = [&]() {
