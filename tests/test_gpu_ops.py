@@ -345,3 +345,51 @@ def test_batchnorm_statistics_from_the_producing_kernel(K, cin, cout, r, stride,
     ref = torch.nn.functional.batch_norm(y.nchw(), None, None, bn_a.weight, bn_a.bias, training=True, eps=bn_a.eps)
     got = y.nchw() * st_a.scale[None, :, None, None] + st_a.shift[None, :, None, None]
     np.testing.assert_allclose(got.cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_conv_paths_random_shapes(K):
+    """Seeded sweep over the three forward paths (persistent GEMM, implicit GEMM, Winograd m = 2 / 4) with odd image
+    sizes, channel counts around the tile edges, every dilation of the network, prologue / residual / ReLU / statistics
+    switches -- against torch's CPU convolution."""
+    rng = np.random.default_rng(2024)
+    checked = {"gemm_nt": 0, "conv_igemm": 0, "wino2": 0, "wino4": 0}
+    for case in range(40):
+        r = int(rng.choice([1, 3, 3]))
+        cin = int(rng.choice([16, 32, 48, 64, 80, 144, 272]))
+        cout = int(rng.choice([20, 48, 64, 68, 128, 132, 192, 260]))
+        n, h, w = int(rng.integers(1, 4)), int(rng.integers(3, 40)), int(rng.integers(3, 40))
+        stride = int(rng.choice([1, 1, 1, 2]))
+        dil = int(rng.choice([1, 2, 4, 12, 24, 36])) if r == 3 else 1
+        pad = dil if r == 3 else 0
+        use_aff, use_res, out_relu = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+        x = rng.standard_normal((n, cin, h, w), dtype=np.float32)
+        wt = (rng.standard_normal((cout, cin, r, r), dtype=np.float32) / np.sqrt(cin * r * r)).astype(np.float32)
+        sc, sh = rng.uniform(0.5, 1.5, cin).astype(np.float32), rng.standard_normal(cin).astype(np.float32)
+        a = torch.from_numpy(x)
+        if use_aff:
+            a = torch.relu(a * torch.from_numpy(sc)[None, :, None, None] + torch.from_numpy(sh)[None, :, None, None])
+        ref = torch.nn.functional.conv2d(a, torch.from_numpy(wt), stride=stride, dilation=dil, padding=pad)
+        res = rng.standard_normal(tuple(ref.shape), dtype=np.float32)
+        if use_res:
+            ref = ref + torch.from_numpy(res)
+        ref = ref.numpy()
+        xa = K.Act.from_nchw(dev(x))
+        aff = (dev(sc), dev(sh)) if use_aff else None
+        resa = K.Act.from_nchw(dev(res), ld=((cout + 3) // 4) * 4) if use_res else None
+        tol = 2e-4 * max(1.0, float(np.abs(ref).max()))
+        # direct / GEMM path
+        y = K.conv2d(xa, K.pack_weight(dev(wt)), stride=stride, dil=dil, pad=pad, in_affine=aff, in_relu=use_aff, res=resa,
+                     out_relu=out_relu, want_stats=True)
+        want = np.maximum(ref, 0) if out_relu else ref
+        np.testing.assert_allclose(y.nchw().cpu().numpy(), want, rtol=0, atol=tol, err_msg=f"case {case} direct")
+        if y.stats is not None:                          # statistics of exactly what was stored
+            got_sum = y.stats[:, 0].double().sum(0).cpu().numpy()
+            np.testing.assert_allclose(got_sum, want.astype(np.float64).sum((0, 2, 3)), rtol=1e-4, atol=1e-2, err_msg=f"case {case} stats")
+        checked["gemm_nt" if (r == 1 and stride == 1 and cout > 64 and cin >= 32) else "conv_igemm"] += 1
+        # Winograd path
+        if r == 3 and stride == 1 and cout % 4 == 0:
+            for tile in (2, 4):
+                yw = K.conv2d_winograd(xa, K.pack_weight_wino(dev(wt), tile=tile), dil=dil, in_affine=aff, in_relu=use_aff, res=resa)
+                np.testing.assert_allclose(yw.nchw().cpu().numpy(), ref, rtol=0, atol=tol, err_msg=f"case {case} wino{tile}")
+                checked[f"wino{tile}"] += 1
+    assert all(v >= 4 for v in checked.values()), checked
