@@ -51,6 +51,17 @@ int mss_msda_backward_f64(const double* value, const int64_t* spatial_shapes, co
                           int S, int M, int D, int L, int Lq, int P, double* grad_value, double* grad_loc,
                           double* grad_attn, void* stream);
 
+/* Operand preparation of the MSDeformAttn module in one pass (ops/modules/ms_deform_attn.py:100-109, the
+ * reference_points[..., 2] branch): attn = softmax over the L*P logits of each (query, head), sampling_loc =
+ * reference_points[n,q,l] + offsets / (W_l, H_l). offsets [N,Lq,M,L,P,2], logits [N,Lq,M,L*P], reference_points
+ * [N,Lq,L,2]; L*P <= 20 (MSS_ERR_UNSUPPORTED above). The backward returns the gradients w.r.t. offsets and logits. */
+int mss_msda_prepare_f32(const float* offsets, const float* logits, const float* reference_points,
+                         const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P, float* sampling_loc,
+                         float* attn_weight, void* stream);
+int mss_msda_prepare_backward_f32(const float* attn_weight, const float* grad_attn, const float* grad_loc,
+                                  const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P, float* grad_offsets,
+                                  float* grad_logits, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * B2 -- DeepWV3Plus operator set (replaces the cuDNN/ATen ops under
  *        lib/network/deepv3/deepv3.py:258-285 and lib/network/deepv3/wider_resnet.py:169-182)      */

@@ -462,6 +462,80 @@ __global__ __launch_bounds__(MSDA_LDS_NT) void msda_bwd_value_lds_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Operand preparation of the MSDeformAttn module (ops/modules/ms_deform_attn.py:100-109) in one pass:
+//   attn = softmax over the L*P logits of a (query, head);  loc = reference_point[l] + offset / (W_l, H_l)
+// instead of softmax + view + stack + div + add as five elementwise library kernels over the 12-36 values per (q, m).
+// One thread per (n, q, m). Backward: d_logit = attn * (g_attn - sum(attn * g_attn)), d_offset = g_loc / (W_l, H_l).
+// A workgroup stages the contiguous logits / offsets of its 256 pairs through LDS (coalesced loads and stores; a
+// thread then owns one pair's row: stride L*P and 2*L*P floats, odd multiples of 4 banks for the usual 12 / 24).
+constexpr int MSDA_MAX_LP = 20;       // 256 pairs x 3 x L*P floats of LDS per workgroup (60 KB at 20)
+__global__ __launch_bounds__(256) void msda_prepare_kernel(const float* __restrict__ offsets, const float* __restrict__ logits,
+                                                           const float* __restrict__ ref, const int64_t* __restrict__ shapes,
+                                                           long long npairs, int M, int L, int P, float* __restrict__ loc,
+                                                           float* __restrict__ attn) {
+  extern __shared__ float sm[];
+  const int LP = L * P;
+  float* sl = sm;                 // [256][LP]      logits -> attention weights
+  float* so = sm + 256 * LP;      // [256][2 LP]    offsets -> locations
+  const long long pair0 = (long long)blockIdx.x * 256;
+  const int np = (int)min((long long)256, npairs - pair0);
+  for (int i = threadIdx.x; i < np * LP; i += 256) sl[i] = logits[pair0 * LP + i];
+  for (int i = threadIdx.x; i < np * LP * 2; i += 256) so[i] = offsets[pair0 * LP * 2 + i];
+  __syncthreads();
+  if ((int)threadIdx.x < np) {
+    const long long nq = (pair0 + threadIdx.x) / M;
+    float* lg = sl + threadIdx.x * LP;
+    float* off = so + threadIdx.x * LP * 2;
+    float mx = -__builtin_huge_valf();
+    for (int i = 0; i < LP; ++i) mx = fmaxf(mx, lg[i]);
+    float sum = 0.f;
+    for (int i = 0; i < LP; ++i) { const float e = expf(lg[i] - mx); lg[i] = e; sum += e; }
+    const float inv = 1.f / sum;
+    for (int l = 0; l < L; ++l) {
+      const float fw = (float)shapes[2 * l + 1], fh = (float)shapes[2 * l];
+      const float rx = ref[(nq * L + l) * 2], ry = ref[(nq * L + l) * 2 + 1];
+      for (int pt = 0; pt < P; ++pt) {
+        const int i = l * P + pt;
+        lg[i] *= inv;
+        off[i * 2] = rx + off[i * 2] / fw;
+        off[i * 2 + 1] = ry + off[i * 2 + 1] / fh;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < np * LP; i += 256) attn[pair0 * LP + i] = sl[i];
+  for (int i = threadIdx.x; i < np * LP * 2; i += 256) loc[pair0 * LP * 2 + i] = so[i];
+}
+
+__global__ __launch_bounds__(256) void msda_prepare_bwd_kernel(const float* __restrict__ attn, const float* __restrict__ gattn,
+                                                               const float* __restrict__ gloc, const int64_t* __restrict__ shapes,
+                                                               long long npairs, int L, int P, float* __restrict__ goffsets,
+                                                               float* __restrict__ glogits) {
+  extern __shared__ float sm[];
+  const int LP = L * P;
+  float* sa = sm;                 // [256][LP]   attn
+  float* sg = sm + 256 * LP;      // [256][LP]   g_attn -> d_logits
+  const long long pair0 = (long long)blockIdx.x * 256;
+  const int np = (int)min((long long)256, npairs - pair0);
+  for (int i = threadIdx.x; i < np * LP; i += 256) { sa[i] = attn[pair0 * LP + i]; sg[i] = gattn[pair0 * LP + i]; }
+  // d_offsets is elementwise: coalesced straight through
+  for (int i = threadIdx.x; i < np * LP * 2; i += 256) {
+    const int l = (i / 2 % LP) / P;
+    goffsets[pair0 * LP * 2 + i] = gloc[pair0 * LP * 2 + i] / (float)shapes[2 * l + ((i & 1) ? 0 : 1)];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < np) {
+    const float* a = sa + threadIdx.x * LP;
+    float* ga = sg + threadIdx.x * LP;
+    float dot = 0.f;
+    for (int i = 0; i < LP; ++i) dot += a[i] * ga[i];
+    for (int i = 0; i < LP; ++i) ga[i] = a[i] * (ga[i] - dot);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < np * LP; i += 256) glogits[pair0 * LP + i] = sg[i];
+}
+
 template <typename T>
 int msda_check(const T* value, const int64_t* shapes, const int64_t* starts, const T* loc, const T* attn, int N,
                int S, int M, int D, int L, int Lq, int P) {
@@ -605,6 +679,32 @@ int mss_msda_backward_f32(const float* value, const int64_t* spatial_shapes, con
   return msda_backward<float>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, N,
                               S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn,
                               static_cast<hipStream_t>(stream));
+}
+
+int mss_msda_prepare_f32(const float* offsets, const float* logits, const float* reference_points,
+                         const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P, float* sampling_loc,
+                         float* attn_weight, void* stream) {
+  if (N < 0 || Lq < 0 || M <= 0 || L <= 0 || P <= 0 || L * P > MSDA_MAX_LP) return MSS_ERR_UNSUPPORTED;
+  const long long npairs = (long long)N * Lq * M;
+  if (npairs == 0) return MSS_OK;
+  if (!offsets || !logits || !reference_points || !spatial_shapes || !sampling_loc || !attn_weight) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(msda_prepare_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), (size_t)256 * 3 * L * P * sizeof(float),
+                     static_cast<hipStream_t>(stream),
+                     offsets, logits, reference_points, spatial_shapes, npairs, M, L, P, sampling_loc, attn_weight);
+  return mss_launch_status();
+}
+
+int mss_msda_prepare_backward_f32(const float* attn_weight, const float* grad_attn, const float* grad_loc,
+                                  const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P, float* grad_offsets,
+                                  float* grad_logits, void* stream) {
+  if (N < 0 || Lq < 0 || M <= 0 || L <= 0 || P <= 0 || L * P > MSDA_MAX_LP) return MSS_ERR_UNSUPPORTED;
+  const long long npairs = (long long)N * Lq * M;
+  if (npairs == 0) return MSS_OK;
+  if (!attn_weight || !grad_attn || !grad_loc || !spatial_shapes || !grad_offsets || !grad_logits) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(msda_prepare_bwd_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256),
+                     (size_t)256 * 2 * L * P * sizeof(float), static_cast<hipStream_t>(stream), attn_weight, grad_attn, grad_loc, spatial_shapes, npairs, L, P,
+                     grad_offsets, grad_logits);
+  return mss_launch_status();
 }
 
 int mss_msda_backward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,

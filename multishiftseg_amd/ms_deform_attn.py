@@ -14,6 +14,7 @@ from torch.autograd.function import once_differentiable
 from torch.nn.init import constant_, xavier_uniform_
 
 from . import MultiScaleDeformableAttention as MSDA
+from ._lib import call, ptr
 from .linear import linear
 
 
@@ -35,6 +36,33 @@ class MSDeformAttnFunction(Function):
         grad_value, grad_loc, grad_attn = MSDA.ms_deform_attn_backward(value, shapes, starts, loc, attn,
                                                                        grad_output.contiguous(), ctx.im2col_step)
         return grad_value, None, None, grad_loc, grad_attn, None
+
+
+class _PrepareFn(Function):
+    """softmax over the L*P logits + sampling locations from offsets and reference points, one HIP pass each way
+    (ops/modules/ms_deform_attn.py:100-109, the 2-d reference-point branch)."""
+
+    @staticmethod
+    def forward(ctx, offsets, logits, reference_points, spatial_shapes):
+        N, Lq, M, L, P, _ = offsets.shape
+        offsets, logits = offsets.contiguous(), logits.contiguous()
+        ref = reference_points.contiguous().float()
+        loc = torch.empty_like(offsets)
+        attn = torch.empty((N, Lq, M, L, P), device=offsets.device, dtype=torch.float32)
+        call("mss_msda_prepare_f32", ptr(offsets), ptr(logits), ptr(ref), ptr(spatial_shapes), N, Lq, M, L, P, ptr(loc), ptr(attn))
+        ctx.save_for_backward(attn, spatial_shapes)
+        return loc, attn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloc, gattn):
+        attn, spatial_shapes = ctx.saved_tensors
+        N, Lq, M, L, P = attn.shape
+        goff = torch.empty((N, Lq, M, L, P, 2), device=attn.device, dtype=torch.float32)
+        glog = torch.empty((N, Lq, M, L * P), device=attn.device, dtype=torch.float32)
+        call("mss_msda_prepare_backward_f32", ptr(attn), ptr(gattn.contiguous()), ptr(gloc.contiguous()), ptr(spatial_shapes),
+             N, Lq, M, L, P, ptr(goff), ptr(glog))
+        return goff, glog, None, None
 
 
 def _is_power_of_2(n):
@@ -88,17 +116,24 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
-        offsets = linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-        weights = linear(query, self.attention_weights.weight, self.attention_weights.bias).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
-        weights = F.softmax(weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
-        if reference_points.shape[-1] == 2:
-            normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
-            locations = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
-        elif reference_points.shape[-1] == 4:
-            locations = reference_points[:, :, None, :, None, :2] \
-                + offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        offsets = linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias).view(
+            N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        weights = linear(query, self.attention_weights.weight, self.attention_weights.bias).view(
+            N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        if (reference_points.shape[-1] == 2 and offsets.is_cuda and offsets.dtype == torch.float32
+                and self.n_levels * self.n_points <= 20 and input_spatial_shapes.dtype == torch.int64
+                and not reference_points.requires_grad):
+            locations, weights = _PrepareFn.apply(offsets, weights, reference_points, input_spatial_shapes.contiguous())
         else:
-            raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
+            weights = F.softmax(weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
+            if reference_points.shape[-1] == 2:
+                normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+                locations = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
+            elif reference_points.shape[-1] == 4:
+                locations = reference_points[:, :, None, :, None, :2] \
+                    + offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+            else:
+                raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
         output = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                             locations.contiguous(), weights.contiguous(), self.im2col_step)
         return linear(output, self.output_proj.weight, self.output_proj.bias)

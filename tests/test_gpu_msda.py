@@ -218,3 +218,27 @@ def test_owner_backward_propagates_non_finite_gradients(F, force_bwd):
     g[1, 3, 5] = float("inf")
     gv, _, _ = MSDA.ms_deform_attn_backward(v, shapes, starts, loc, attn, g, 2)
     assert not torch.isfinite(gv).all()
+
+
+@pytest.mark.parametrize("N,Lq,M,L,P", [(2, 37, 8, 3, 4), (1, 5, 2, 2, 2), (3, 300, 8, 4, 4), (1, 1, 1, 1, 1)])
+def test_prepare_op_matches_reference_arithmetic(N, Lq, M, L, P):
+    """8f-3: softmax + sampling-location arithmetic of ops/modules/ms_deform_attn.py:100-109 in one HIP pass,
+    forward and backward, against the same torch expressions."""
+    from multishiftseg_amd.ms_deform_attn import _PrepareFn
+    torch.manual_seed(N * 100 + Lq)
+    shapes = torch.randint(2, 90, (L, 2), device="cuda")
+    off = (torch.randn(N, Lq, M, L, P, 2, device="cuda") * 3).requires_grad_(True)
+    lg = (torch.randn(N, Lq, M, L * P, device="cuda") * 2).requires_grad_(True)
+    ref = torch.rand(N, Lq, L, 2, device="cuda")
+    loc, attn = _PrepareFn.apply(off, lg, ref, shapes)
+    g_loc, g_attn = torch.randn_like(loc), torch.randn_like(attn)
+    (loc * g_loc).sum().backward(retain_graph=True)
+    (attn * g_attn).sum().backward()
+    got = [t.detach().clone() for t in (loc, attn, off.grad, lg.grad)]
+    off.grad = lg.grad = None
+    w = torch.softmax(lg, -1).view(N, Lq, M, L, P)
+    normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+    lo = ref[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+    ((lo * g_loc).sum() + (w * g_attn).sum()).backward()
+    for a, r, name in zip(got, (lo, w, off.grad, lg.grad), ("loc", "attn", "d_offsets", "d_logits")):
+        torch.testing.assert_close(a, r.detach(), rtol=1e-5, atol=1e-6, msg=name)
