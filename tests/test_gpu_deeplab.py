@@ -123,9 +123,11 @@ def test_train_step_golden(deeplab_params, stage, names, lr):
         assert okay.mean() > 0.995, (name, okay.mean())
 
 
-@pytest.mark.parametrize("n,h,w,train", [(1, 200, 264, False), (3, 72, 104, False), (2, 88, 120, True)])
+@pytest.mark.parametrize("n,h,w,train", [(1, 200, 264, False), (3, 72, 104, False), (2, 88, 120, True), (1, 90, 150, False),
+                                          (2, 70, 70, True)])
 def test_forward_vs_oracle_ragged_sizes(model, deeplab_params, n, h, w, train):
-    """Sizes whose /2, /4, /8 maps are odd / not multiples of the tiles (25x33, 9x13, 11x15), batch 3,
+    """Sizes whose /2, /4, /8 maps are odd / not multiples of the tiles (25x33, 9x13, 11x15), sizes that are not
+    multiples of 8 (90x150 -> 45x75 -> 23x38 -> 12x19; 70x70, the 700x700 crop scaled down), batch 3,
     and train-mode BatchNorm (batch statistics) + injected Dropout2d masks, against the numpy oracle."""
     from multishiftseg_amd import synth
     from oracle import deepv3 as odeepv3
