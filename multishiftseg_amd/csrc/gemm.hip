@@ -214,6 +214,8 @@ int launch_gemm(const MssConvArgs& p, hipStream_t stream) {
 
 }  // namespace
 
+int mss_gemm_nt_bf16x6_launch(MssConvArgs p, void* stream);   // gemm_bf16x6.hip (experimental, opt-in)
+
 // Shapes this kernel takes from mss_conv2d_forward_f32 (conv_igemm.hip); p.M is set.
 bool mss_gemm_nt_eligible(const MssConvArgs& p) {
   if (p.R * p.S != 1 || p.stride != 1 || p.pad != 0 || p.H != p.OH || p.W != p.OW) return false;
@@ -231,5 +233,9 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
   p.ntiles = mss_cdiv(p.K, BN);
   if (p.Kpad < p.ntiles * BN) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    const char* e = getenv("MSS_GEMM_BF16X6");            // experimental split-bf16 evaluation of the same fp32 GEMM
+    if (e && atoi(e)) return mss_gemm_nt_bf16x6_launch(p, stream);
+  }
   return p.in_scale ? launch_gemm<true>(p, s) : launch_gemm<false>(p, s);
 }

@@ -393,3 +393,38 @@ def test_conv_paths_random_shapes(K):
                 np.testing.assert_allclose(yw.nchw().cpu().numpy(), ref, rtol=0, atol=tol, err_msg=f"case {case} wino{tile}")
                 checked[f"wino{tile}"] += 1
     assert all(v >= 4 for v in checked.values()), checked
+
+
+@pytest.mark.parametrize("rows,c,k,batch", [(300, 64, 128, 1), (1000, 256, 192, 1), (257, 512, 256, 3), (4096, 1024, 128, 2)])
+def test_bf16x6_gemm_is_fp32_accurate(K, monkeypatch, rows, c, k, batch):
+    """EXPERIMENTAL opt-in (MSS_GEMM_BF16X6=1): the fp32 GEMM evaluated with six bf16 MFMAs per block on operands split
+    into three bf16 terms. Against float64 it must be as accurate as the native fp32 MFMA kernel (both ~1e-7 of max|y|)."""
+    import ctypes
+    from multishiftseg_amd import _lib
+    from multishiftseg_amd._lib import MssConvArgs, call, ptr
+    torch.manual_seed(rows + c)
+    x = torch.relu(torch.randn(batch, rows, c, device="cuda")) * (torch.rand(1, 1, c, device="cuda") * 4 + 0.25)
+    kpad = _lib.value("mss_conv2d_kpad", k)
+    w = torch.zeros(batch, kpad, c, device="cuda")
+    w[:, :k] = torch.randn(batch, k, c, device="cuda") / c ** 0.5
+    ref = torch.einsum("bmc,bkc->bmk", x.double(), w[:, :k].double())
+
+    def run():
+        y = torch.empty(batch, rows, k, device="cuda")
+        a = MssConvArgs()
+        a.x, a.w, a.y = ptr(x), ptr(w), ptr(y)
+        a.N, a.H, a.W, a.C, a.ldx = 1, 1, rows, c, c
+        a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, rows, k, kpad, k
+        a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+        a.batch, a.x_bs, a.w_bs, a.y_bs = batch, rows * c, kpad * c, rows * k
+        call("mss_conv2d_forward_f32", ctypes.byref(a))
+        return y
+    y32 = run()
+    monkeypatch.setenv("MSS_GEMM_BF16X6", "1")
+    y6 = run()
+    monkeypatch.delenv("MSS_GEMM_BF16X6")
+    scale = ref.abs().max().item()
+    e32 = (y32.double() - ref).abs().max().item() / scale
+    e6 = (y6.double() - ref).abs().max().item() / scale
+    assert e32 < 2e-6 and e6 < 2e-6 and e6 < 3 * e32 + 2e-7, (e32, e6)
+    assert not torch.equal(y32, y6)          # it really is a different evaluation
