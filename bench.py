@@ -68,6 +68,8 @@ def main():
                     help="local: per-rank loss (no loss collectives); global: reference semantics over all ranks' pairs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ood", action="store_true")
+    ap.add_argument("--no-experimental", action="store_true",
+                    help="skip the extra, separately reported run with MSS_GEMM_BF16X6=1 (N=1 only; never part of `value`)")
     args = ap.parse_args()
 
     from multishiftseg_amd import ddp, kernels as K, synth
@@ -204,6 +206,26 @@ def main():
     if wg:
         out["wgrad"] = {"achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                         "kernel_ms_per_step": round(wg["ms"] / max(args.steps, 1), 2)}
+
+    if world == 1 and not args.no_experimental:
+        # EXPERIMENTAL, reported apart from `value`: the same step with the fp32 GEMMs evaluated on the bf16 matrix cores
+        # (three-way operand split, six MFMAs per block, fp32 accumulate; csrc/gemm_bf16x6.hip). Same parity tests pass.
+        os.environ["MSS_GEMM_BF16X6"] = "1"
+        try:
+            one_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                one_step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / args.steps
+            out["experimental_fp32_via_bf16x6"] = {
+                "images_per_s": round(2 * pairs / dt, 4), "ms_per_step": round(dt * 1e3, 3),
+                "note": "opt-in MSS_GEMM_BF16X6=1, NOT the headline: every gemm_nt launch computes the same fp32 GEMM with "
+                        "operands split into 3 bf16 terms and 6 bf16 MFMAs per block (fp32 accumulate); error against "
+                        "float64 equals the native fp32 MFMA kernel's (tests/test_gpu_ops.py::test_bf16x6_gemm_is_fp32_accurate)"}
+        finally:
+            os.environ.pop("MSS_GEMM_BF16X6", None)
 
     if not args.no_ood:
         # OOD-score path (test_deeplab.py:86-90): eval forward -> per-pixel anomaly score
