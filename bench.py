@@ -35,24 +35,130 @@ FWD_GMAC_1024x2048 = 5827.2            # conv MACs of one forward a
 STAGE2_STEP_OVER_FWD = 1.287           # stage-2 step FLOPs / forward FLOPs
 
 
-def cpu_baseline(h=320, w=640):
-    """The numpy oracle (a port, not the reference) on the host cores: one eval forward of a
-    1x3xhxw image; converted to the metric's unit by the algorithmic-FLOP ratio of a stage-2 train
-    step at the benchmark resolution."""
-    from multishiftseg_amd import synth
-    from oracle import deepv3 as odeepv3
+def _host_info():
+    import subprocess
+    info = {"nproc": os.cpu_count(), "torch_threads": torch.get_num_threads()}
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
+        for ln in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            key, _, val = ln.partition(":")
+            if key.strip() in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core"):
+                info["lscpu_" + key.strip().lower().replace(" ", "_").replace("(s)", "s")] = val.strip()
+    except Exception as exc:
+        info["lscpu_error"] = str(exc)
+    return info
+
+
+def cpu_baseline(bench_hw):
+    """SURVEY 8(d) "CPU baseline beside it", on this host's cores, in this process, before the GPU timings:
+      * C1 exactly (1x3x512x1024 eval forward + per-pixel OOD score) with the graph composed from STOCK torch CPU ops
+        (oracle/deepv3_torch.py: F.conv2d / F.batch_norm / F.interpolate(align_corners=True) / logsumexp -- a port, not
+        the reference's files): 1 warm-up + 3 timed runs, median;
+      * the numpy restatement (oracle/deepv3.py) on the same C1 image, once;
+      * one stock-torch forward of a single image at the benchmark resolution, from which the train-step figure is
+        derived by the stage-2 step/forward FLOP ratio (a 2-image CPU train step would take minutes)."""
+    import statistics
+    from multishiftseg_amd import synth
+    from oracle import deepv3 as odeepv3, deepv3_torch
     params = synth.deepwv3plus_params(0)
-    img = synth.synth_image(3, 1, h, w)
-    odeepv3.forward(params, synth.synth_image(3, 1, 64, 128))      # warm-up (BLAS thread pool, page-in)
-    t0 = time.time()
-    odeepv3.forward(params, img)
-    dt = time.time() - t0
-    return dict(seconds=dt, cores=int(cores), h=h, w=w, fwd_gmac=FWD_GMAC_1024x2048 * h * w / (1024 * 2048))
+    pt = deepv3_torch.to_torch(params)
+    img = torch.from_numpy(synth.synth_image(3, 1, 512, 1024))
+    runs = []
+    with torch.no_grad():
+        for i in range(4):
+            t0 = time.perf_counter()
+            score, logit = deepv3_torch.forward_t(pt, img)
+            dt = time.perf_counter() - t0
+            if i:
+                runs.append(dt)
+        H, W = bench_hw
+        big = torch.from_numpy(synth.synth_image(3, 1, H, W))
+        t0 = time.perf_counter()
+        deepv3_torch.forward_t(pt, big)
+        t_big = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ns, nl = odeepv3.forward(params, img.numpy())
+    t_np = time.perf_counter() - t0
+    agree = float(np.abs(nl - logit.numpy()).max())
+    return dict(c1_runs_s=[round(r, 3) for r in runs], c1_median_s=statistics.median(runs), c1_numpy_s=t_np,
+                c1_numpy_vs_torch_max_abs_logit_diff=agree, bench_fwd_s=t_big, bench_hw=[H, W], host=_host_info())
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes through torch.distributed.run as a
+    CHILD process (never exec: this image forbids replacing a process image once a GPU runtime is loaded, and the
+    parent must not touch the GPU at all -- it has not: nothing before this point makes a HIP call), relay what
+    the ranks print (rank 0 prints the one JSON line) and exit with the launcher's status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args):
+    """--workload launchcheck: no model. Every rank pushes K steps of stage-2-sized synthetic gradients through
+    ddp.GradAllReduce (the bucketed side-stream all-reduce the training step uses) and checks the averaged values.
+    Exercises launcher + process group + collective path on whatever backend the box offers (nccl = RCCL on GPUs, gloo on
+    CPU), so the RCCL branch can be proven without the 137 M-parameter model."""
+    from multishiftseg_amd import ddp
+    rank, world, local_rank, device = ddp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    sizes = [("g0", 4864), ("g1", 1 << 20), ("g2", 9 << 20), ("g3", 9 << 20)] if device.type == "cuda" else \
+        [("g0", 4864), ("g1", 1 << 16), ("g2", 1 << 18)]
+    named = [(n, torch.zeros(sz, device=device)) for n, sz in sizes]
+    sync = ddp.GradAllReduce(named, bucket_bytes=(48 << 20) if device.type == "cuda" else (1 << 19))
+
+    def one_step(k):
+        grads = [(n, torch.full((sz,), float(rank + 1 + k), device=device)) for n, sz in sizes]
+        for n, g in grads:
+            sync(n, g)
+        sync.backward_done()
+        return grads
+
+    def sync_dev():
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        one_step(k)
+    if world > 1:
+        dist.barrier()
+    sync_dev()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        grads = one_step(k)
+    sync_dev()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    want = sum(r + 1 + (args.steps - 1) for r in range(world)) / world
+    ok = all(bool(torch.allclose(g, torch.full_like(g, want))) for _, g in grads)
+    if world > 1:
+        t = torch.tensor([elapsed, 0.0 if ok else 1.0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, ok = float(t[0]), float(t[1]) == 0.0
+    nbytes = 4 * sum(sz for _, sz in sizes)
+    if rank == 0:
+        print(json.dumps({"metric": "launch check: bucketed gradient all-reduce steps/s (no model)", "value": round(args.steps / elapsed, 3),
+                          "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "launchcheck", "parallelism": f"dp{world}", "backend": dist.get_backend() if world > 1 else None,
+                                     "rccl_ranks": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else 0),
+                                     "gloo_ranks": (dist.get_world_size() if world > 1 and dist.get_backend() == "gloo" else 0),
+                                     "device": device.type, "bytes_per_step": nbytes, "averages_correct": ok}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
 
 
 def main():
@@ -60,9 +166,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2_700", "tiny"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2_700", "tiny", "launchcheck"],
                     help="c3: 1 pair of 1024x2048 per GPU; c2: 8 pairs of 768x768 (BASELINE's wording of exps/DeepLab.yaml batch 8); "
-                         "c2_700: 8 pairs of 700x700 (the crop size exps/DeepLab.yaml actually uses); tiny: smoke")
+                         "c2_700: 8 pairs of 700x700 (the crop size exps/DeepLab.yaml actually uses); tiny: smoke; "
+                         "launchcheck: launcher + process group + bucketed all-reduce only (runs on CPU/gloo too)")
     ap.add_argument("--stage", type=int, default=2, choices=[1, 2])
     ap.add_argument("--loss-sync", default="local", choices=["local", "global"],
                     help="local: per-rank loss (no loss collectives); global: reference semantics over all ranks' pairs")
@@ -71,6 +178,11 @@ def main():
     ap.add_argument("--no-experimental", action="store_true",
                     help="skip the extra, separately reported run with MSS_GEMM_BF16X6=1 (N=1 only; never part of `value`)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+    if args.workload == "launchcheck":
+        return launch_check(args)
 
     from multishiftseg_amd import ddp, kernels as K, synth
     from multishiftseg_amd.deepv3 import DeepWV3Plus
@@ -87,7 +199,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline((H, W))
 
     params = synth.deepwv3plus_params(0)
     model = DeepWV3Plus(19)
@@ -161,7 +273,9 @@ def main():
         "config": {"workload": f"{args.workload}: {2 * pairs} images ({pairs} orig+aug pair(s)) of {H}x{W} per GPU, "
                                f"stage-{args.stage} trainable set, train-mode BN/Dropout2d on the frozen trunk",
                    "images_per_gpu": 2 * pairs, "height": H, "width": W, "stage": args.stage,
-                   "parallelism": f"dp{world}", "loss_pairing": "device", "loss_sync": args.loss_sync, "loss": round(loss_val, 4)},
+                   "parallelism": f"dp{world}",
+                   "rccl_ranks": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else 0),
+                   "loss_pairing": "device", "loss_sync": args.loss_sync, "loss": round(loss_val, 4)},
         "roofline": {"bound": "mfma", "kernel": dom + "_kernel (fp32 v_mfma_f32_32x32x2_f32)",
                      "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
@@ -256,14 +370,20 @@ def main():
                             "image": f"1x3x{H}x{W}"}
 
     if cpu is not None:
-        # CPU forward seconds for the sample -> train images/s at the benchmark resolution
-        t_fwd_full = cpu["seconds"] * (H * W) / (cpu["h"] * cpu["w"])
-        t_step_img = t_fwd_full * (STAGE2_STEP_OVER_FWD if args.stage == 2 else 1.0)
-        out["cpu_baseline"] = {"value": round(1.0 / t_step_img, 6), "unit": "images/s", "cores": cpu["cores"],
-                               "kind": "port",
-                               "sample": f"numpy oracle eval forward of one 1x3x{cpu['h']}x{cpu['w']} image "
-                                         f"({cpu['seconds']:.2f} s, {cpu['fwd_gmac']:.0f} GMAC), scaled by pixel count to "
-                                         f"{H}x{W} and by the stage-{args.stage} step/forward FLOP ratio"}
+        ratio = STAGE2_STEP_OVER_FWD if args.stage == 2 else 1.0
+        out["cpu_baseline"] = {
+            "value": round(1.0 / (cpu["bench_fwd_s"] * ratio), 6), "unit": "images/s", "cores": cpu["host"]["torch_threads"],
+            "kind": "port",
+            "sample": f"stock torch CPU ops composing the same graph (oracle/deepv3_torch.py): ONE eval forward of a 1x3x{H}x{W} image "
+                      f"({cpu['bench_fwd_s']:.2f} s) x the stage-{args.stage} step/forward FLOP ratio {ratio} (SURVEY 8d) -> train images/s; "
+                      "C1 (1x3x512x1024 eval forward + OOD score): 1 warm-up + 3 runs, median, in `c1`",
+            "c1": {"image": "1x3x512x1024", "torch_runs_s": cpu["c1_runs_s"], "torch_median_s": round(cpu["c1_median_s"], 3),
+                   "torch_mpix_s": round(512 * 1024 / cpu["c1_median_s"] / 1e6, 4),
+                   "torch_tflops": round(2 * 1456.8e9 / cpu["c1_median_s"] / 1e12, 3),
+                   "numpy_restatement_s": round(cpu["c1_numpy_s"], 2),
+                   "numpy_mpix_s": round(512 * 1024 / cpu["c1_numpy_s"] / 1e6, 4),
+                   "numpy_vs_torch_max_abs_logit_diff": cpu["c1_numpy_vs_torch_max_abs_logit_diff"]},
+            "host": cpu["host"]}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

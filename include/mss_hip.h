@@ -101,10 +101,14 @@ int mss_conv2d_forward_route(const MssConvArgs* args);
  * then Kpad/Cp refer to the swapped roles. */
 int mss_conv2d_pack_weights_f32(const float* w, float* packed, int K, int C, int R, int S, int Kpad, int Cp,
                                 int flip, void* stream);
-/* weight gradient: dwp[tap][k][c] += sum_m dy[m][k]*act(x[m@tap][c]); dwp zeroed by the caller.
- * replaces the autograd wgrad of nn.Conv2d for aspp/bot_aspp/bot_fine/ood_head
+/* weight gradient: dwp[tap][k][c] = sum_m dy[m][k]*act(x[m@tap][c]); dwp [taps][Kpad][Cp] is fully overwritten.
+ * Deterministic (no atomics; pixel-range partials are summed in a fixed order: the reference pins
+ * cudnn.deterministic, lib/utils/utils.py:10-13). ws: scratch of mss_conv2d_wgrad_workspace_bytes(args, Cp) bytes
+ * (NULL allowed when that is 0). Replaces the autograd wgrad of nn.Conv2d for aspp/bot_aspp/bot_fine/ood_head
  * (exps/DeepLab.yaml:10-11, train_deeplab.py:113-132) */
-int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dwp, int Cp, void* stream);
+long long mss_conv2d_wgrad_workspace_bytes(const MssConvArgs* args, int Cp);
+int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dwp, int Cp, float* ws,
+                         long long ws_bytes, void* stream);
 int mss_conv2d_unpack_wgrad_f32(const float* packed, float* grad, int K, int C, int R, int S, int Kpad,
                                 int Cp, int accumulate, void* stream);
 
@@ -310,9 +314,10 @@ int mss_oodm_measures_f64(const unsigned int* pos_sorted, long long P, const uns
 
 /* Calibration kernels (bench.py: achievable peaks of this device next to the datasheet ones).
  * mss_peak_mfma_f32: blocks x 4 waves x iters x 16 back-to-back v_mfma_f32_32x32x2_f32 (4096 FLOP
- * each), out >= blocks*256 floats. mss_peak_stream_f32: float4 copy of n floats (8*n bytes moved). */
+ * each), out >= blocks*256 floats. mss_peak_stream_f32: float4 copy of n floats (8*n bytes moved);
+ * variant 0..3 = plain / 4 loads in flight / + nontemporal / + contiguous 16-KB chunks per workgroup. */
 int mss_peak_mfma_f32(float* out, int blocks, int iters, void* stream);
-int mss_peak_stream_f32(const float* src, float* dst, long long n, void* stream);
+int mss_peak_stream_f32(const float* src, float* dst, long long n, int variant, void* stream);
 
 #ifdef __cplusplus
 }

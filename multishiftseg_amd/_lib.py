@@ -67,7 +67,8 @@ SIGNATURES = {
     "mss_conv2d_kpad": [I],
     "mss_conv2d_forward_route": [POINTER(MssConvArgs)],
     "mss_conv2d_pack_weights_f32": [P, P, I, I, I, I, I, I, I, P],
-    "mss_conv2d_wgrad_f32": [POINTER(MssConvArgs), P, I, P, I, P],
+    "mss_conv2d_wgrad_workspace_bytes": [POINTER(MssConvArgs), I],
+    "mss_conv2d_wgrad_f32": [POINTER(MssConvArgs), P, I, P, I, P, L, P],
     "mss_conv2d_unpack_wgrad_f32": [P, P, I, I, I, I, I, I, I, P],
     "mss_nchw_to_nhwc_pad_f32": [P, P, I, I, I, I, I, P],
     "mss_bn_stats_nhwc_f32": [P, L, I, I, P, P],
@@ -116,12 +117,13 @@ SIGNATURES = {
     "mss_oodm_rank_blocks": [L],
     "mss_oodm_measures_f64": [P, L, P, L, c_double, P, P, P, P],
     "mss_peak_mfma_f32": [P, I, I, P],
-    "mss_peak_stream_f32": [P, P, L, P],
+    "mss_peak_stream_f32": [P, P, L, I, P],
 }
 # entry points that return a plain value rather than a status code
 _VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
-                    "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts"}
-_RETURNS_LONGLONG = {"mss_wino_num_tiles", "mss_oodm_sort_temp_bytes"}
+                    "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts",
+                    "mss_conv2d_wgrad_workspace_bytes"}
+_RETURNS_LONGLONG = {"mss_wino_num_tiles", "mss_oodm_sort_temp_bytes", "mss_conv2d_wgrad_workspace_bytes"}
 
 _lib = None
 

@@ -336,8 +336,11 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __rest
 // row stride is conflict-free; the stride is a multiple of 4 floats so staging uses ds_write_b128.
 // Same in-wave pipeline as the forward kernel: loads for pixel block t+1 issued first, written to
 // LDS before the second-to-last chunk, one barrier before the last chunk.
-// Grid: (ktiles*ctiles, taps, splits); the pixel range is split across blockIdx.z and the
-// partial sums land in the zero-initialised dWp by fp32 atomics.
+// Grid: (ktiles*ctiles, taps, splits); the pixel range is split across blockIdx.z. No atomics: with one split the
+// tile is stored straight into dWp; with several, split z stores its partial tile into slab z of a workspace
+// ([splits][taps][Kpad][Cp], every element written by exactly one workgroup) and wgrad_reduce_kernel adds the slabs
+// in split order -- the weight gradient is bit-reproducible run to run (the reference pins cudnn.deterministic,
+// lib/utils/utils.py:10-13).
 template <int BKO, int BCI, int BP, int WK>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const float* __restrict__ dy, int lddy,
                                                         float* __restrict__ dwp, int Cp, int pix_per_split) {
@@ -518,25 +521,43 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
   const int colq = lane & 31, rowq = 4 * (lane >> 5);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
+    // rows in [K, Kpad) and columns in [C, Cp) were fed zeros, so their accumulators are exact zeros: storing them
+    // too means every element of the [Kpad][Cp] slab is written and nobody has to clear it first
     const int col = c0 + wn * WTC + j * 32 + colq;
-    if (col >= p.C) continue;
+    if (col >= Cp) continue;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = k0 + wm * WTK + i * 32 + (q & 3) + 8 * (q >> 2) + rowq;
-        if (row < p.K) atomicAdd(&dwp[((size_t)tap * p.Kpad + row) * Cp + col], acc[i][j][q]);
+        if (row < p.Kpad) dwp[(((size_t)blockIdx.z * gridDim.y + tap) * p.Kpad + row) * Cp + col] = acc[i][j][q];
       }
   }
 }
 
-template <int BKO, int BCI, int BP, int WK>
-int launch_wgrad(MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, hipStream_t stream) {
-  const int ktiles = mss_cdiv(p.K, BKO), ctiles = mss_cdiv(p.C, BCI), taps = p.batch > 1 ? p.batch : p.R * p.S;
+// dwp[tap][row][col] = sum over splits (ascending) of ws[split][tap][row][col], float4 over col (Cp % 4 == 0)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dwp,
+                                                           long long slab4, int splits) {
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(ws);
+  f32x4* d4 = reinterpret_cast<f32x4*>(dwp);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < slab4;
+       i += (long long)gridDim.x * blockDim.x) {
+    f32x4 a = w4[i];
+    for (int sp = 1; sp < splits; ++sp) a += w4[(long long)sp * slab4 + i];
+    d4[i] = a;
+  }
+}
+
+struct WgradPlan { int ktiles, ctiles, taps, splits, pps; };
+
+template <int BKO, int BCI, int BP>
+WgradPlan wgrad_plan(const MssConvArgs& p) {
+  WgradPlan pl;
+  pl.ktiles = mss_cdiv(p.K, BKO); pl.ctiles = mss_cdiv(p.C, BCI); pl.taps = p.batch > 1 ? p.batch : p.R * p.S;
   // Pixel splits: pick the smallest split count whose grid fills its last round of resident workgroups to >= 95 %
-  // (a 1152-block grid on 768 slots runs 2 rounds for 1.5 rounds of work); more splits only add atomic traffic on
-  // the [R*S][K][C] slab. Small slabs (the 19 x 256 head gradient: 2 tiles) need hundreds of splits to fill the chip.
-  const int base = ktiles * ctiles * taps;
+  // (a 1152-block grid on 768 slots runs 2 rounds for 1.5 rounds of work); more splits only add partial-slab traffic.
+  // Small slabs (the 19 x 256 head gradient: 2 tiles) need hundreds of splits to fill the chip.
+  const int base = pl.ktiles * pl.ctiles * pl.taps;
   const int slots = 768;   // 3 workgroups per CU (34 KB LDS, 154 registers)
   int max_splits = mss_cdiv(p.M, BP * 8);
   if (max_splits > 1024) max_splits = 1024;
@@ -549,12 +570,36 @@ int launch_wgrad(MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, 
     if (eff > best + 1e-9) { best = eff; splits = sp; }
     if (eff >= 0.95 && total >= slots) break;
   }
-  int pps = mss_cdiv(mss_cdiv(p.M, splits), BP) * BP;
-  splits = mss_cdiv(p.M, pps);
+  pl.pps = mss_cdiv(mss_cdiv(p.M, splits), BP) * BP;
+  pl.splits = mss_cdiv(p.M, pl.pps);
+  return pl;
+}
+
+// bytes of partial-slab workspace the launch needs (0 when the pixel range is not split)
+template <int BKO, int BCI, int BP>
+long long wgrad_ws_bytes(const MssConvArgs& p, int Cp) {
+  const WgradPlan pl = wgrad_plan<BKO, BCI, BP>(p);
+  return pl.splits > 1 ? (long long)pl.splits * pl.taps * p.Kpad * Cp * 4 : 0;
+}
+
+template <int BKO, int BCI, int BP, int WK>
+int launch_wgrad(MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, float* ws, long long ws_bytes,
+                 hipStream_t stream) {
+  const WgradPlan pl = wgrad_plan<BKO, BCI, BP>(p);
+  const long long slab = (long long)pl.taps * p.Kpad * Cp;
+  if (pl.splits > 1 && (!ws || ws_bytes < (long long)pl.splits * slab * 4)) return MSS_ERR_BAD_ARG;
   const size_t smem = (size_t)2 * BP * (BKO + 4 + BCI + 4) * sizeof(float);
   // staging after the whole MFMA block, and BP=32, were measured: within 1-4 % slower
   auto kern = conv_wgrad_kernel<BKO, BCI, BP, WK>;
-  hipLaunchKernelGGL(kern, dim3(ktiles * ctiles, taps, splits), dim3(NT), smem, stream, p, dy, lddy, dwp, Cp, pps);
+  hipLaunchKernelGGL(kern, dim3(pl.ktiles * pl.ctiles, pl.taps, pl.splits), dim3(NT), smem, stream, p, dy, lddy,
+                     pl.splits > 1 ? ws : dwp, Cp, pl.pps);
+  if (pl.splits > 1) {
+    // every element of every partial slab was written (see the kernel's epilogue), so whole slabs are swept
+    const long long slab4 = slab / 4;
+    long long blocks = (slab4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, ws, dwp, slab4, pl.splits);
+  }
   return mss_launch_status();
 }
 
@@ -573,9 +618,11 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return MSS_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  static int force_bk = -1, use_gemm = -1;
-  if (force_bk < 0) { const char* e = getenv("MSS_CONV_BK"); force_bk = e ? atoi(e) : 0; }
-  if (use_gemm < 0) { const char* e = getenv("MSS_GEMM"); use_gemm = e ? atoi(e) : 1; }   // MSS_GEMM=0: A/B experiments
+  // read per call (not cached): the parity tests switch routes inside one process (MSS_GEMM=0: every layer on the
+  // implicit-GEMM kernel; tests/test_gpu_fullsize.py compares it with the GEMM/Winograd routes)
+  int force_bk = 0, use_gemm = 1;
+  { const char* e = getenv("MSS_CONV_BK"); force_bk = e ? atoi(e) : 0; }
+  { const char* e = getenv("MSS_GEMM"); use_gemm = e ? atoi(e) : 1; }
   if (use_gemm) {
     const int rc = mss_gemm_nt_dispatch(p, stream);
     if (rc >= 0) return rc;
@@ -622,20 +669,33 @@ int mss_conv2d_unpack_wgrad_f32(const float* packed, float* grad, int K, int C, 
   return mss_launch_status();
 }
 
-// dwp must be zero on entry ([R*S][Kpad][Cp]); args describes the *forward* conv (x, geometry,
-// optional prologue on x); dy is the NHWC output gradient with pixel stride lddy.
-int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dwp, int Cp, void* stream) {
+// Bytes of scratch mss_conv2d_wgrad_f32 needs for these arguments (0: the pixel range is not split).
+long long mss_conv2d_wgrad_workspace_bytes(const MssConvArgs* args, int Cp) {
+  MssConvArgs p = *args;
+  p.M = p.N * p.OH * p.OW;
+  if (p.M <= 0) return 0;
+  if (p.K <= 32) return wgrad_ws_bytes<32, 128, 16>(p, Cp);
+  if (p.K <= 64) return wgrad_ws_bytes<64, 128, 16>(p, Cp);
+  return wgrad_ws_bytes<128, 128, 16>(p, Cp);
+}
+
+// dwp ([R*S][Kpad][Cp], Kpad >= K, Cp >= C multiples of 4) is fully overwritten (padding = 0); args
+// describes the *forward* conv (x, geometry, optional prologue on x); dy is the NHWC output gradient with pixel
+// stride lddy; ws: scratch of mss_conv2d_wgrad_workspace_bytes bytes (may be NULL when that is 0), contents
+// irrelevant on entry. Deterministic: no atomics, fixed summation order.
+int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dwp, int Cp, float* ws,
+                         long long ws_bytes, void* stream) {
   MssConvArgs p = *args;
   if (!p.x || !dy || !dwp) return MSS_ERR_BAD_ARG;
-  if (p.C % 4 || p.ldx % 4 || lddy % 4 || p.R * p.S > 9) return MSS_ERR_UNSUPPORTED;
+  if (p.C % 4 || p.ldx % 4 || lddy % 4 || p.R * p.S > 9 || Cp % 4) return MSS_ERR_UNSUPPORTED;
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return MSS_OK;
   if (p.batch > 1 && (p.R * p.S != 1 || p.batch > 65535)) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // output-channel tile: 32 rows (1x4 waves) for the 19-channel heads, 64 for bot_fine's 48, else 128
-  if (p.K <= 32) return launch_wgrad<32, 128, 16, 1>(p, dy, lddy, dwp, Cp, s);
-  if (p.K <= 64) return launch_wgrad<64, 128, 16, 2>(p, dy, lddy, dwp, Cp, s);
-  return launch_wgrad<128, 128, 16, 2>(p, dy, lddy, dwp, Cp, s);
+  if (p.K <= 32) return launch_wgrad<32, 128, 16, 1>(p, dy, lddy, dwp, Cp, ws, ws_bytes, s);
+  if (p.K <= 64) return launch_wgrad<64, 128, 16, 2>(p, dy, lddy, dwp, Cp, ws, ws_bytes, s);
+  return launch_wgrad<128, 128, 16, 2>(p, dy, lddy, dwp, Cp, ws, ws_bytes, s);
 }
 
 }  // extern "C"

@@ -457,7 +457,7 @@ inline int grid_for(long long work_items, int cap = 256 * 16) {
 
 int rcl_check(const MssRclArgs* a) {
   if (!a || !a->logit || !a->score || !a->target) return MSS_ERR_BAD_ARG;
-  if (a->B < 2 || a->C < 1 || a->H < 1 || a->W < 1) return MSS_ERR_BAD_ARG;
+  if (a->B < 2 || (a->B & 1) || a->C < 1 || a->H < 1 || a->W < 1) return MSS_ERR_BAD_ARG;  // [orig...; aug...] pairs
   if ((long long)a->B * a->H * a->W >= (1ll << 31)) return MSS_ERR_UNSUPPORTED;
   return MSS_OK;
 }

@@ -26,11 +26,44 @@ __global__ __launch_bounds__(256) void peak_mfma_kernel(float* __restrict__ out,
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// variant 0: one 16-B load and store per thread and iteration (round 1: 4.8 TB/s)
+// variant 1: four independent loads in flight per thread before the four stores
+// variant 2: as 1 with nontemporal loads and stores (streaming data is read and written once)
+// variant 3: as 2, a workgroup owns contiguous 16-KB chunks (4 consecutive float4 per lane and pass)
+template <int VARIANT>
 __global__ __launch_bounds__(256) void peak_stream_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst,
                                                           long long n4) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-       i += (long long)gridDim.x * blockDim.x)
-    dst[i] = src[i];
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (VARIANT == 0) {
+    for (; i < n4; i += stride) dst[i] = src[i];
+    return;
+  }
+  if (VARIANT == 3) {
+    const long long chunk = 256 * 4;
+    for (long long c = (long long)blockIdx.x * chunk; c + chunk <= n4; c += (long long)gridDim.x * chunk) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(&src[c + u * 256 + threadIdx.x]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v[u], &dst[c + u * 256 + threadIdx.x]);
+    }
+    const long long done = n4 / chunk * chunk;
+    for (i = done + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+    return;
+  }
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      v[u] = VARIANT == 2 ? __builtin_nontemporal_load(&src[i + u * stride]) : src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (VARIANT == 2) __builtin_nontemporal_store(v[u], &dst[i + u * stride]);
+      else dst[i + u * stride] = v[u];
+    }
+  }
+  for (; i < n4; i += stride) dst[i] = src[i];
 }
 
 }  // namespace
@@ -44,11 +77,19 @@ int mss_peak_mfma_f32(float* out, int blocks, int iters, void* stream) {
   return mss_launch_status();
 }
 
-// copies n floats (n % 4 == 0); bytes moved = 8 * n.
-int mss_peak_stream_f32(const float* src, float* dst, long long n, void* stream) {
-  if (!src || !dst || n <= 0 || n % 4) return MSS_ERR_BAD_ARG;
-  hipLaunchKernelGGL(peak_stream_kernel, dim3(256 * 8), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst), n / 4);
+// copies n floats (n % 4 == 0); bytes moved = 8 * n. variant: see peak_stream_kernel (tools/peaks.py reports the best).
+int mss_peak_stream_f32(const float* src, float* dst, long long n, int variant, void* stream) {
+  if (!src || !dst || n <= 0 || n % 4 || variant < 0 || variant > 3) return MSS_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const f32x4* a = reinterpret_cast<const f32x4*>(src);
+  f32x4* b = reinterpret_cast<f32x4*>(dst);
+  const dim3 grid(256 * 8), block(256);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(peak_stream_kernel<0>, grid, block, 0, s, a, b, n / 4); break;
+    case 1: hipLaunchKernelGGL(peak_stream_kernel<1>, grid, block, 0, s, a, b, n / 4); break;
+    case 2: hipLaunchKernelGGL(peak_stream_kernel<2>, grid, block, 0, s, a, b, n / 4); break;
+    default: hipLaunchKernelGGL(peak_stream_kernel<3>, grid, block, 0, s, a, b, n / 4); break;
+  }
   return mss_launch_status();
 }
 

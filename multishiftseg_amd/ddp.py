@@ -26,10 +26,12 @@ class GradAllReduce:
     def __init__(self, named_params, bucket_bytes=64 << 20, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.buckets = []       # list of lists of names
+        self.buckets = []       # list of lists of names (fixed at construction: every rank reduces the same layout)
         self.where = {}         # name -> bucket index
+        self.shapes = {}        # name -> (shape, dtype, device) for zero-filling a gradient that did not arrive
         cur, cur_bytes = [], 0
         for name, p in named_params:
+            self.shapes[name] = (tuple(p.shape), p.dtype, p.device)
             nbytes = p.numel() * p.element_size()
             if cur and cur_bytes + nbytes > bucket_bytes:
                 self.buckets.append(cur)
@@ -57,28 +59,38 @@ class GradAllReduce:
             self._launch(i)
 
     def _launch(self, i):
-        items = [(n, self.pending[i][n]) for n in self.buckets[i]]
+        # a gradient that is absent this step (parameter frozen after construction, unused branch) travels as zeros
+        # so that the message layout never depends on which gradients a rank happened to produce
+        items = []
+        for n in self.buckets[i]:
+            g = self.pending[i].get(n)
+            if g is None:
+                shape, dtype, dev = self.shapes[n]
+                g = torch.zeros(shape, dtype=dtype, device=dev)
+                items.append((n, g, False))
+            else:
+                items.append((n, g, True))
         self.pending[i] = {}
         if items[0][1].is_cuda:
             if self.comm_stream is None:
                 self.comm_stream = torch.cuda.Stream()
-            flat = torch.cat([g.reshape(-1) for _, g in items])
+            flat = torch.cat([g.reshape(-1) for _, g, _ in items])
             flat.div_(self.world)
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 work = dist.all_reduce(flat, group=self.group, async_op=True)
             flat.record_stream(self.comm_stream)
         else:
-            flat = torch.cat([g.reshape(-1) for _, g in items])
+            flat = torch.cat([g.reshape(-1) for _, g, _ in items])
             flat.div_(self.world)
             work = dist.all_reduce(flat, group=self.group, async_op=True)
         self.inflight.append((flat, items, work))
 
     def flush(self):
-        """Launch buckets that never filled (parameters frozen since construction)."""
+        """Launch buckets that never filled (some of their parameters produced no gradient this step). The bucket
+        layout itself is never changed."""
         for i, pend in enumerate(self.pending):
             if pend:
-                self.buckets[i] = [n for n in self.buckets[i] if n in pend]
                 self._launch(i)
 
     def backward_done(self):
@@ -88,10 +100,21 @@ class GradAllReduce:
         for flat, items, work in self.inflight:
             work.wait()          # CUDA: makes the current stream wait for the collective, no host block
             off = 0
-            for _, g in items:
+            for _, g, present in items:
                 n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
+                if present:
+                    g.copy_(flat[off:off + n].view_as(g))
                 off += n
+        self._reset()
+
+    def abort(self):
+        """The backward is unwinding from an exception: start no further collective (the other ranks may never reach
+        theirs), wait for the ones already in flight and forget this step's gradients."""
+        for _, _, work in self.inflight:
+            try:
+                work.wait()
+            except Exception:
+                pass
         self._reset()
 
 

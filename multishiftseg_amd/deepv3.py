@@ -285,10 +285,14 @@ class DeepWV3Plus(nn.Module):
                     sink(k, v)
         grads = _Grads()
         try:
-            return self._head_backward_impl(s, dscore, dlogit, names, need, grads)
-        finally:
-            if sink is not None and hasattr(sink, "backward_done"):
-                sink.backward_done()
+            out = self._head_backward_impl(s, dscore, dlogit, names, need, grads)
+        except BaseException:
+            if sink is not None and hasattr(sink, "abort"):
+                sink.abort()       # no collective is started while an exception unwinds (ranks would deadlock)
+            raise
+        if sink is not None and hasattr(sink, "backward_done"):
+            sink.backward_done()
+        return out
 
     def _head_backward_impl(self, s, dscore, dlogit, names, need, grads):
         x, m2, raw, dec0, f0, f1, dec12 = s["x"], s["m2"], s["raw"], s["dec0"], s["f0"], s["f1"], s["dec12"]

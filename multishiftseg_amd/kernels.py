@@ -241,11 +241,19 @@ def _conv_launch(x, pw, out, OH, OW, stride, dil, pad, in_affine, in_relu, out_a
         call("mss_conv2d_forward_f32", ctypes.byref(a))
 
 
+def _wgrad_workspace(a, Cp, device):
+    """Scratch for the partial slabs of a pixel-split weight gradient (deterministic two-stage sum)."""
+    nbytes = _lib.value("mss_conv2d_wgrad_workspace_bytes", ctypes.byref(a), Cp)
+    if nbytes <= 0:
+        return None, 0
+    return torch.empty(nbytes // 4, device=device, dtype=torch.float32), nbytes
+
+
 def conv2d_wgrad(x, dy, K, C, R, S, stride=1, dil=1, pad=0, in_affine=None, in_relu=False):
     """Weight gradient [K,C,R,S] of y = conv(prologue(x)); dy: Act with K channels."""
     Kpad = _round_up(K, 4)
     Cp = _round_up(C, 4)
-    dwp = torch.zeros((R * S, Kpad, Cp), device=x.buf.device, dtype=torch.float32)
+    dwp = torch.empty((R * S, Kpad, Cp), device=x.buf.device, dtype=torch.float32)   # fully overwritten by the kernel
     a = MssConvArgs()
     a.x = x.ptr
     if in_affine is not None:
@@ -256,8 +264,9 @@ def conv2d_wgrad(x, dy, K, C, R, S, stride=1, dil=1, pad=0, in_affine=None, in_r
     a.OH, a.OW, a.K, a.Kpad = dy.H, dy.W, K, Kpad
     a.R, a.S, a.stride, a.dil, a.pad = R, S, stride, dil, pad
     a.in_relu = int(in_relu)
+    ws, ws_bytes = _wgrad_workspace(a, Cp, x.buf.device)
     with _Timed("conv_wgrad", 2.0 * x.N * dy.H * dy.W * K * C * R * S, (x.N, x.H, x.W, C, K, R, stride, dil)):
-        call("mss_conv2d_wgrad_f32", ctypes.byref(a), dy.ptr, dy.ld, ptr(dwp), Cp)
+        call("mss_conv2d_wgrad_f32", ctypes.byref(a), dy.ptr, dy.ld, ptr(dwp), Cp, ptr(ws), ws_bytes)
     grad = torch.empty((K, C, R, S), device=x.buf.device, dtype=torch.float32)
     call("mss_conv2d_unpack_wgrad_f32", ptr(dwp), ptr(grad), K, C, R, S, Kpad, Cp, 0)
     return grad
@@ -406,15 +415,16 @@ def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=
         assert tuple(xt.shape) == (P, T, C)
         dyt = torch.empty((P, T, K), device=dev, dtype=torch.float32)
         call("mss_wino_grad_output_transform_f32", dy.ptr, dy.ld, N, H, W, K, dil, ts, ptr(dyt))
-        du = torch.zeros((P, Kpad, Cp), device=dev, dtype=torch.float32)
+        du = torch.empty((P, Kpad, Cp), device=dev, dtype=torch.float32)     # fully overwritten by the kernel
         a = MssConvArgs()
         a.x = ptr(xt)
         a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
         a.OH, a.OW, a.K, a.Kpad = 1, T, K, Kpad
         a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
         a.batch, a.x_bs, a.y_bs = P, T * C, T * K
+        ws, ws_bytes = _wgrad_workspace(a, Cp, dev)
         with _Timed("conv_wgrad", 2.0 * P * T * K * C, (P, 1, T, C, K, 1, 1, 1)):
-            call("mss_conv2d_wgrad_f32", ctypes.byref(a), ptr(dyt), K, ptr(du), Cp)
+            call("mss_conv2d_wgrad_f32", ctypes.byref(a), ptr(dyt), K, ptr(du), Cp, ptr(ws), ws_bytes)
         grad = torch.empty((K, C, 3, 3), device=dev, dtype=torch.float32)
         call("mss_wino_weight_grad_transform_f32", ptr(du), ptr(grad), K, C, Kpad, Cp, ts)
     return grad

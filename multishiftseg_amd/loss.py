@@ -108,7 +108,13 @@ class RelContrastiveLoss(nn.Module):
             raise RuntimeError("RelContrastiveLoss needs an (original, augmented) pair: batch >= 2")
         dev = logits.device
         total, half = B * H * W, (B // 2) * H * W
-        a, select = self._args(logits, score, targets, w_aug_scale=float(Wn))   # grads come out x world (see docstring)
+        if B % 2:
+            raise RuntimeError(f"RelContrastiveLoss needs [orig...; aug...] pairs: batch {B} is odd")
+        # Gradients come out multiplied by the world size (see docstring). With the easiest-k selection the kernel divides
+        # by the GLOBAL k, so the factor goes into the weight; without it the kernel divides by the LOCAL half, which
+        # already is (global half) / world, so no extra factor is needed (and none for the original half either way).
+        select_on = bool(self.conduct_pixel_selection and 0.0 < self.selection_ratio < 1.0)
+        a, select = self._args(logits, score, targets, w_aug_scale=float(Wn) if select_on else 1.0)
         ra = ctypes.byref(a)
         lse = torch.empty(total, device=dev, dtype=torch.float32)
         ce_aug = torch.empty(half, device=dev, dtype=torch.float32)
@@ -188,6 +194,8 @@ class RelContrastiveLoss(nn.Module):
         B, C, H, W = logits.shape
         if B < 2:
             raise RuntimeError("RelContrastiveLoss needs an (original, augmented) pair: batch >= 2")
+        if B % 2:
+            raise RuntimeError(f"RelContrastiveLoss needs [orig...; aug...] pairs: batch {B} is odd")
         dev = logits.device
         h = B // 2
         total, half = B * H * W, h * H * W

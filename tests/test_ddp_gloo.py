@@ -47,6 +47,29 @@ def _worker(rank, world, port, out):
     sync2("ood_head.weight", g)
     sync2.backward_done()
     ok = ok and torch.allclose(g, torch.full_like(g, (world - 1) / 2))
+    # a gradient absent in one step and present in the next: the bucket layout must not have been rewritten, and ranks
+    # that disagree on which gradients exist still exchange messages of the same size (absent = zeros)
+    layout = [list(b) for b in sync2.buckets]
+    g1 = torch.full((19, 256, 1, 1), float(rank + 1))
+    g2 = torch.full((48, 128, 1, 1), 10.0 * (rank + 1))
+    sync2("ood_head.weight", g1)
+    if rank == 0:
+        sync2("bot_fine.weight", g2)          # only rank 0 produced this one
+    sync2.backward_done()
+    ok = ok and sync2.buckets == layout
+    ok = ok and torch.allclose(g1, torch.full_like(g1, (1 + world) / 2))
+    if rank == 0:
+        ok = ok and torch.allclose(g2, torch.full_like(g2, 10.0 / world))
+    # an exception during the backward starts no collective and leaves the object reusable
+    g3 = torch.full((19, 256, 1, 1), 7.0)
+    sync2("ood_head.weight", g3)
+    sync2.abort()
+    ok = ok and not any(sync2.pending) and not sync2.inflight and torch.allclose(g3, torch.full_like(g3, 7.0))
+    for n in shapes:
+        grads[n].fill_(float(rank))
+        sync2(n, grads[n])
+    sync2.backward_done()
+    ok = ok and all(torch.allclose(grads[n], torch.full_like(grads[n], (world - 1) / 2)) for n in shapes)
     out[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
@@ -82,3 +105,22 @@ def test_trainer_stage_sets():
     assert sum(p.numel() for p in p2) == 30749952
     assert set(n2) <= set(BACKWARD_ORDER)
     assert not any(p.requires_grad for n, p in m.named_parameters() if n.startswith("mod"))
+
+
+def test_bench_self_launch_gloo():
+    """`python bench.py --gpus 2` without a launcher starts two fresh rank processes itself (torch.distributed.run as a
+    child, never exec) and relays ONE JSON line from rank 0. launchcheck is the model-free workload that runs on CPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MSS_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "launchcheck"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["config"]["gloo_ranks"] == 2 and j["config"]["averages_correct"] is True
+    assert j["config"]["rccl_ranks"] == 0

@@ -95,3 +95,13 @@ def test_device_pairing_statistics():
     np.testing.assert_allclose(tb[[1, 2, 5]], ta[[1, 2, 5]], rtol=1e-6)      # ce_orig, ce_aug, c_in: deterministic
     np.testing.assert_allclose(tb[[3, 4]], ta[[3, 4]], rtol=0.05)            # c_orig, c_aug: same expectation
     assert torch.isfinite(sr.grad).all() and abs(float(sr.grad.sum())) < 1e-3  # +coef/-coef pairs cancel
+
+
+def test_odd_batch_is_refused():
+    """[orig...; aug...] pairs: an odd batch has no pairing (and used to overrun the augmented-CE buffer)."""
+    from multishiftseg_amd.loss import RelContrastiveLoss
+    crit = RelContrastiveLoss({"ce_weights": [50, 10], "conduct_pixel_selection": True, "selection_ratio": 0.8,
+                               "inoutaug_contras_margins_tri": [10, 5, 5]})
+    lt = torch.zeros(3, 19, 8, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="odd"):
+        crit(lt, torch.zeros(3, 8, 8, device="cuda"), torch.zeros(3, 8, 8, dtype=torch.int64, device="cuda"))

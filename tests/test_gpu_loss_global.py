@@ -56,11 +56,14 @@ def _worker(rank, world, port, crafted, params, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("crafted", [True, False])
-def test_global_sync_equals_single_process_on_concatenated_batch(crafted):
+@pytest.mark.parametrize("crafted,select", [(True, True), (False, True), (True, False), (False, False)])
+def test_global_sync_equals_single_process_on_concatenated_batch(crafted, select):
+    """select=False: conduct_pixel_selection off -- the augmented CE is a plain mean over the (global) half, whose
+    pre-multiplied gradient is w1 / local half (it used to come out world-size times too large)."""
     from multishiftseg_amd.loss import RelContrastiveLoss
     world = 2
-    params = dict(PARAMS, inoutaug_contras_margins_tri=[100, 100, 5]) if crafted else PARAMS
+    params = dict(PARAMS, inoutaug_contras_margins_tri=[100, 100, 5]) if crafted else dict(PARAMS)
+    params["conduct_pixel_selection"] = select
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), crafted, params, out), nprocs=world, join=True)

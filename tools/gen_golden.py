@@ -154,17 +154,40 @@ def gen_deeplab(DeepWV3Plus):
     return model
 
 
-def gen_train_step(DeepWV3Plus, ref_loss):
-    """a-7: one optimizer step of each training stage on a (2+2)x3x96x128 batch, train-mode BN on
-    the frozen trunk, Dropout2d masks and the loss permutations recorded and stored."""
-    pairs, h, w = 2, 96, 128
+def gen_deeplab_big(DeepWV3Plus, n=1, h=592, w=600):
+    """Eval forward at a size where the build's Winograd policy picks F(4x4,3x3) for all three ASPP rates on its own
+    (the /8 map is 74x75: 4x4 / 4x4 / 3x3 residue sub-grids at dilation 12 / 24 / 36) and nothing divides evenly
+    (296x300 -> 148x150 -> 74x75). Big outputs are stored as strided slices + float64 checksums."""
+    model = build_ref_model(DeepWV3Plus)
+    model.eval()
+    img = synth.synth_image(3, n, h, w)
+    with torch.no_grad():
+        score, logit = model(torch.from_numpy(img))
+    logit_n, score_n = t2n(logit), t2n(score)
+    top2 = np.sort(logit_n, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-3
+    save(f"deepwv3plus_eval_{n}x{h}x{w}", image_seed=np.int64(3), shape=np.array([n, h, w]),
+         score_sub=score_n[:, ::2, ::2], logit_sub=logit_n[:, :, ::4, ::4], label=logit_n.argmax(1).astype(np.uint8),
+         clear_bits=np.packbits(clear), score_abs_sum=np.float64(np.abs(score_n.astype(np.float64)).sum()),
+         logit_abs_sum=np.float64(np.abs(logit_n.astype(np.float64)).sum()),
+         logit_row=logit_n[:, :, h // 3], score_row=score_n[:, h // 3])
+    print(f"   eval {n}x{h}x{w}: logit range [{logit_n.min():.3g},{logit_n.max():.3g}], clear pixels {clear.mean():.4f}")
+
+
+def gen_train_step(DeepWV3Plus, ref_loss, pairs=2, h=96, w=128, fixture="deepwv3plus_train_step",
+                   stages=("stage1", "stage2"), fp64_replay=True, score_stride=1, logit_stride=4, truncate_perms=False):
+    """a-7: one optimizer step of each training stage on a (pairs+pairs)x3xhxw batch (default (2+2)x3x96x128),
+    train-mode BN on the frozen trunk, Dropout2d masks and the loss permutations recorded and stored."""
     img = synth.synth_image(2, 2 * pairs, h, w)
     target = synth.synth_targets(2, pairs, h, w)
     loss_params = {"ce_weights": [50, 10], "conduct_pixel_selection": True, "selection_ratio": 0.8,
                    "inoutaug_contras_margins_tri": [10, 5, 5]}        # exps/DeepLab.yaml:30-35
     out = dict(image_seed=np.int64(2), shape=np.array([pairs, h, w]), target=target.astype(np.uint8))
+    out["score_stride"], out["logit_stride"] = np.int64(score_stride), np.int64(logit_stride)
     for stage, (names, lr) in {"stage1": (["ood_head"], 1e-4),
                                "stage2": (["aspp", "bot_fine", "bot_aspp", "ood_head"], 1e-6)}.items():
+        if stage not in stages:
+            continue
         model = build_ref_model(DeepWV3Plus)
         model.uncertainty_func_init()                                   # train_deeplab.py:108-111
         params = []
@@ -208,13 +231,16 @@ def gen_train_step(DeepWV3Plus, ref_loss):
             torch.randperm = real_randperm
         pre = stage + "_"
         out[pre + "loss"] = t2n(loss)
-        out[pre + "score"] = t2n(score)
-        out[pre + "logit_sub"] = t2n(logit)[:, :, ::4, ::4]
+        out[pre + "score"] = t2n(score)[:, ::score_stride, ::score_stride]
+        out[pre + "logit_sub"] = t2n(logit)[:, :, ::logit_stride, ::logit_stride]
+        out[pre + "score_abs_sum"] = np.float64(np.abs(t2n(score).astype(np.float64)).sum())
+        out[pre + "logit_abs_sum"] = np.float64(np.abs(t2n(logit).astype(np.float64)).sum())
         out[pre + "target_mut"] = t2n(tgt).astype(np.uint8)
         out[pre + "drop_mod6"] = masks["mod6"]
         out[pre + "drop_mod7"] = masks["mod7"]
+        n_used = min(len(p) for p in perms)        # loss.py:149-156 keeps only the first n = min(set sizes) entries
         for i, p in enumerate(perms):
-            out[pre + f"perm{i}"] = p.astype(np.int32)
+            out[pre + f"perm{i}"] = (p[:n_used] if truncate_perms else p).astype(np.int32)
         sd = model.state_dict()
         for k in ("mod2.block1.bn1.0.running_mean", "mod2.block1.bn1.0.running_var",
                   "mod7.block1.convs.bn3.0.running_mean", "mod7.block1.convs.bn3.0.running_var",
@@ -233,7 +259,7 @@ def gen_train_step(DeepWV3Plus, ref_loss):
             delta = t2n(dict(model.named_parameters())[n_].detach() - b)
             if delta.size <= 70000:
                 out[pre + "delta_" + n_] = delta
-        if stage == "stage2":
+        if stage == "stage2" and fp64_replay:
             # conditioning of the small gradients: the same step of the reference in float64 (same masks, same
             # permutations). rel-L2(fp32 reference, fp64 reference) per tensor is the noise floor a parity test
             # can ask of any fp32 implementation; stored as gradnoise_<name>.
@@ -257,6 +283,7 @@ def gen_train_step(DeepWV3Plus, ref_loss):
                 if p.requires_grad and n_ in grads and grads[n_].numel() <= 70000:
                     g32, g64 = grads[n_].double().numpy(), p.grad.numpy()
                     out[pre + "gradnoise_" + n_] = np.float64(np.sqrt(((g32 - g64) ** 2).sum()) / (np.sqrt((g64 ** 2).sum()) + 1e-300))
+        if stage == "stage2":
             # sensitivity of the same gradients to forward rounding: the fp32 reference again, with the two tensors
             # the decoder consumes (mod7 and mod2 outputs) multiplied by (1 + 4e-6 * N(0,1)) -- the size of one
             # Winograd F(4x4,3x3) layer's fp32 error. rel-L2 change per tensor = gradsens_<name>.
@@ -287,10 +314,11 @@ def gen_train_step(DeepWV3Plus, ref_loss):
                     out[pre + "gradsens_" + n_] = np.float64(np.sqrt(((g0 - g1) ** 2).sum()) / (np.sqrt((g0 ** 2).sum()) + 1e-300))
             sens = sorted(((float(v), k) for k, v in out.items() if k.startswith(pre + "gradsens_")), reverse=True)[:6]
             print(f"   stage2 jittered replay (4e-6 relative noise on mod7/mod2 outputs): largest gradient rel-L2 change: {sens}")
-            noisy = sorted(((float(v), k) for k, v in out.items() if k.startswith(pre + "gradnoise_")), reverse=True)[:5]
-            print(f"   stage2 float64 replay: loss {float(loss64):.6f}; largest fp32-vs-fp64 gradient rel-L2: {noisy}")
+            if fp64_replay:
+                noisy = sorted(((float(v), k) for k, v in out.items() if k.startswith(pre + "gradnoise_")), reverse=True)[:5]
+                print(f"   stage2 float64 replay: loss {float(loss64):.6f}; largest fp32-vs-fp64 gradient rel-L2: {noisy}")
         print(f"   {stage}: loss {float(loss):.6f}, {len(grads)} trainable tensors, perms {[len(p) for p in perms]}")
-    save("deepwv3plus_train_step", **out)
+    save(fixture, **out)
 
 
 # ------------------------------------------------------------------------------------------ loss
@@ -532,6 +560,13 @@ def main():
         print("deeplab"); gen_deeplab(DeepWV3Plus)
     if "train" in which:
         print("train"); gen_train_step(DeepWV3Plus, ref_loss)
+    # the two big fixtures take minutes on 8 cores: only on request (python tools/gen_golden.py deeplab_big train_big)
+    if "deeplab_big" in which:
+        print("deeplab_big"); gen_deeplab_big(DeepWV3Plus)
+    if "train_big" in which:
+        print("train_big")
+        gen_train_step(DeepWV3Plus, ref_loss, pairs=1, h=592, w=600, fixture="deepwv3plus_train_step_2x592x600",
+                       stages=("stage2",), fp64_replay=False, score_stride=4, logit_stride=8, truncate_perms=True)
 
 
 if __name__ == "__main__":

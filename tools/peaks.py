@@ -22,15 +22,19 @@ def measure():
     n = 1 << 28   # 1 GiB source, 1 GiB destination: far beyond the 256 MiB Infinity Cache
     a = torch.empty(n, device="cuda").normal_()
     b = torch.empty(n, device="cuda")
-    call("mss_peak_stream_f32", ptr(a), ptr(b), n)
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(5):
-        call("mss_peak_stream_f32", ptr(a), ptr(b), n)
-    e.record()
-    torch.cuda.synchronize()
-    res["stream_copy_GBs"] = 5 * 8.0 * n / (s.elapsed_time(e) * 1e-3) / 1e9
+    best = 0.0
+    for variant in range(4):
+        call("mss_peak_stream_f32", ptr(a), ptr(b), n, variant)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(5):
+            call("mss_peak_stream_f32", ptr(a), ptr(b), n, variant)
+        e.record()
+        torch.cuda.synchronize()
+        res[f"stream_copy_v{variant}_GBs"] = 5 * 8.0 * n / (s.elapsed_time(e) * 1e-3) / 1e9
+        best = max(best, res[f"stream_copy_v{variant}_GBs"])
+    res["stream_copy_GBs"] = best
     return res
 
 
