@@ -139,10 +139,14 @@ int mss_wino_weight_grad_transform_f32(const float* du, float* dw, int K, int C,
 int mss_nchw_to_nhwc_pad_f32(const float* x, float* y, int N, int C, int H, int W, int Cp, void* stream);
 
 /* BatchNorm2d pieces (mynn.py:8-12 Norm2d = nn.BatchNorm2d, eps 1e-5, momentum 0.1).
- * stats: per-channel batch mean and biased variance of an NHWC tensor (M pixels); `accum` is a
- * zero-initialised double[2*C] workspace. */
-/* accum += column sums of a partial-sum matrix [nparts][2][C] written by a producer (MssConvArgs.stats,
- * mss_wino_output_transform_f32): the statistics pass then never re-reads the activation. */
+ * stats: per-channel batch mean and biased variance of an NHWC tensor (M pixels). `accum` is a scratch of
+ * mss_col_reduce_accum_doubles(M, C) doubles (contents irrelevant on entry): its first 2*C entries receive the
+ * sums (sum | sum of squares), the rest holds the first stage's per-workgroup partials, which a second kernel adds
+ * in a fixed order -- no atomics, bit-reproducible (the reference pins cudnn.deterministic, lib/utils/utils.py:10-13). */
+long long mss_col_reduce_accum_doubles(long long M, int C);
+/* accum[0:2C] = column sums of a partial-sum matrix [nparts][2][C] written by a producer (MssConvArgs.stats,
+ * mss_wino_output_transform_f32): the statistics pass then never re-reads the activation. accum as above with
+ * M = nparts. */
 int mss_bn_stats_partials_f32(const float* partials, long long nparts, int C, double* accum, void* stream);
 int mss_bn_stats_nhwc_f32(const float* x, long long M, int C, int ldx, double* accum, void* stream);
 /* finalise: from accum -> (mean, var) -> scale = gamma*rsqrt(var+eps), shift = beta-mean*scale;
@@ -158,8 +162,8 @@ int mss_bn_fold_eval_f32(const float* gamma, const float* beta, const float* run
 int mss_affine_relu_nhwc_f32(const float* x, int ldx, float* y, int ldy, long long M, int C, const float* scale,
                              const float* shift, int relu, void* stream);
 /* backward of y = relu(bn_train(x)): given dy and x (pre-BN), scale/save_mean/save_invstd/gamma,
- * accumulates per-channel sums into accum (double[2*C], zeroed by caller): sum(dz), sum(dz*xhat)
- * where dz = dy * (y>0). */
+ * per-channel sums into accum[0:2C] (scratch of mss_col_reduce_accum_doubles(M, C) doubles, as above):
+ * sum(dz), sum(dz*xhat) where dz = dy * (y>0). */
 int mss_bn_relu_bwd_reduce_f32(const float* dy, int lddy, const float* x, int ldx, long long M, int C,
                                const float* scale, const float* shift, const float* save_mean,
                                const float* save_invstd, int relu, double* accum, void* stream);
@@ -173,14 +177,16 @@ int mss_bn_relu_bwd_apply_f32(const float* dy, int lddy, const float* x, int ldx
 /* MaxPool2d(3, stride 2, padding 1) on NHWC (wider_resnet.py:353-355). */
 int mss_maxpool3s2_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int OH,
                             int OW, void* stream);
-/* AdaptiveAvgPool2d(1) (deepv3.py:77,87): y[n][c] = mean over HW. */
-int mss_gap_nhwc_f32(const float* x, int ldx, float* y, int N, int HW, int C, void* stream);
+/* AdaptiveAvgPool2d(1) (deepv3.py:77,87): y[n][c] = mean over HW. ws: scratch of mss_colsum_workspace_floats(N, HW, C)
+ * floats (pixel-range partials, added in a fixed order: no atomics). */
+long long mss_colsum_workspace_floats(int N, int HW, int C);
+int mss_gap_nhwc_f32(const float* x, int ldx, float* y, int N, int HW, int C, float* ws, void* stream);
 /* broadcast y[n][p][c] = relu?(v[n][c]*scale[c]+shift[c]) over HW pixels: the "Upsample" of the
  * 1x1 image-pooling map (deepv3.py:86). */
 int mss_broadcast_rows_nhwc_f32(const float* v, float* y, int ldy, int N, int HW, int C, const float* scale,
                                 const float* shift, int relu, void* stream);
 /* backward of the broadcast: dv[n][c] = sum_p dy[n][p][c] */
-int mss_colsum_nhwc_f32(const float* dy, int lddy, float* dv, int N, int HW, int C, void* stream);
+int mss_colsum_nhwc_f32(const float* dy, int lddy, float* dv, int N, int HW, int C, float* ws, void* stream);
 
 /* F.interpolate(mode='bilinear', align_corners=True) (mynn.py:28-33) on NHWC, forward and its
  * transpose (gather form, deterministic). Optional prologue affine+relu on the input. */

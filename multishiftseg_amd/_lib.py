@@ -78,9 +78,11 @@ SIGNATURES = {
     "mss_bn_relu_bwd_reduce_f32": [P, I, P, I, L, I, P, P, P, P, I, P, P],
     "mss_bn_relu_bwd_apply_f32": [P, I, P, I, P, I, L, I, P, P, P, P, P, I, P, P, P, P],
     "mss_maxpool3s2_nhwc_f32": [P, I, P, I, I, I, I, I, I, I, P],
-    "mss_gap_nhwc_f32": [P, I, P, I, I, I, P],
+    "mss_col_reduce_accum_doubles": [L, I],
+    "mss_colsum_workspace_floats": [I, I, I],
+    "mss_gap_nhwc_f32": [P, I, P, I, I, I, P, P],
     "mss_broadcast_rows_nhwc_f32": [P, P, I, I, I, I, P, P, I, P],
-    "mss_colsum_nhwc_f32": [P, I, P, I, I, I, P],
+    "mss_colsum_nhwc_f32": [P, I, P, I, I, I, P, P],
     "mss_upsample_ac_nhwc_f32": [P, I, P, I, I, I, I, I, I, I, P],
     "mss_upsample_ac_nhwc_bwd_f32": [P, I, P, I, I, I, I, I, I, I, P],
     "mss_ood_score_f32": [P, I, P, I, I, I, I, I, I, I, P, P, P, P],
@@ -122,8 +124,9 @@ SIGNATURES = {
 # entry points that return a plain value rather than a status code
 _VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
                     "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts",
-                    "mss_conv2d_wgrad_workspace_bytes"}
-_RETURNS_LONGLONG = {"mss_wino_num_tiles", "mss_oodm_sort_temp_bytes", "mss_conv2d_wgrad_workspace_bytes"}
+                    "mss_conv2d_wgrad_workspace_bytes", "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats"}
+_RETURNS_LONGLONG = {"mss_wino_num_tiles", "mss_oodm_sort_temp_bytes", "mss_conv2d_wgrad_workspace_bytes",
+                     "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats"}
 
 _lib = None
 

@@ -43,11 +43,13 @@ __global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, float* __re
 // ---------------------------------------------------------------- per-channel reductions
 // Generic column reducer over an NHWC matrix [M][C]: thread (tx, ty) owns channel quad
 // q = blockIdx.x*QPB + tx and walks rows ty, ty+RPB, ... of its row range; partial sums are kept
-// in fp32 for at most 256 rows, then flushed to fp64, combined over ty through LDS and added to
-// the global fp64 accumulators with one atomic per channel per block.
+// in fp32 for at most 256 rows, then flushed to fp64, combined over ty through LDS and stored as this
+// block's row of a partial matrix part[gridDim.y][2C] (plain stores: no atomics, so the sums are
+// bit-reproducible); col_reduce_final_kernel adds the rows in a fixed order.
 // F(row, c0, out a[4], out b[4]) produces the two quantities to be summed.
 template <typename F>
 __device__ __forceinline__ void col_reduce2(long long M, int C, double* __restrict__ accum, F f) {
+  double* __restrict__ part = accum + 2 * (size_t)C + (size_t)blockIdx.y * 2 * C;
   const int C4 = C >> 2;
   const int QPB = C4 < 32 ? C4 : 32;            // channel quads per block
   const int RPB = blockDim.x / QPB;             // row lanes per block
@@ -86,10 +88,25 @@ __device__ __forceinline__ void col_reduce2(long long M, int C, double* __restri
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      atomicAdd(&accum[q * 4 + k], da[k]);
-      atomicAdd(&accum[C + q * 4 + k], db[k]);
+      part[q * 4 + k] = da[k];
+      part[C + q * 4 + k] = db[k];
     }
   }
+}
+
+// accum[col] = sum over the nparts rows of part (= accum + ncols), ascending, 4 interleaved row lanes per column
+// combined in a fixed order. block 256 = 64 columns x 4 row lanes.
+__global__ __launch_bounds__(256) void col_reduce_final_kernel(double* __restrict__ accum, int nparts, int ncols) {
+  const double* __restrict__ part = accum + ncols;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  double s = 0.0;
+  if (col < ncols)
+    for (int r = rl; r < nparts; r += 4) s += part[(size_t)r * ncols + col];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && col < ncols)
+    accum[col] = ((red[threadIdx.x] + red[threadIdx.x + 64]) + red[threadIdx.x + 128]) + red[threadIdx.x + 192];
 }
 
 inline dim3 col_reduce_grid(long long M, int C) {
@@ -260,11 +277,11 @@ __global__ void maxpool3s2_kernel(const float* __restrict__ x, int ldx, float* _
   }
 }
 
-// y[n][c] += mult * sum_{p in split} x[n][p][c]; grid (C/64, N, splits), block 256 = 16 channel
-// quads x 16 row lanes; y is zeroed by the launcher and the splits combine with fp32 atomics, so a
-// [2,32768,4096] reduction runs on 4096 workgroups instead of 128.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
-                                                     int HW, int C, float mult, int rows_per_split) {
+// ws[split][n][c] = sum_{p in split} x[n][p][c]; grid (C/64, N, splits), block 256 = 16 channel
+// quads x 16 row lanes, so a [2,32768,4096] reduction runs on 4096 workgroups instead of 128. The splits are
+// combined by colsum_final_kernel in ascending order (no atomics: bit-reproducible).
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, float* __restrict__ ws,
+                                                     int HW, int C, int rows_per_split) {
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = (blockIdx.x * 16 + tx) * 4;
   const int n = blockIdx.y;
@@ -279,23 +296,39 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   __syncthreads();
   if (ty == 0 && c < C) {
     for (int yy = 1; yy < 16; ++yy) acc += red[yy * 16 + tx];
-    float* o = y + (long long)n * C + c;
-    atomicAdd(o + 0, acc.x * mult); atomicAdd(o + 1, acc.y * mult);
-    atomicAdd(o + 2, acc.z * mult); atomicAdd(o + 3, acc.w * mult);
+    st4(ws + ((long long)blockIdx.z * gridDim.y + n) * C + c, acc);
   }
 }
 
-inline int launch_colsum(const float* x, int ldx, float* y, int N, int HW, int C, float mult, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(y, 0, (size_t)N * C * sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
-  const int gx = (C / 4 + 15) / 16;
-  int splits = 2048 / (gx * N > 0 ? gx * N : 1);
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, float* __restrict__ y,
+                                                           long long NC, int splits, float mult) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NC) return;
+  float s = 0.f;
+  for (int sp = 0; sp < splits; ++sp) s += ws[(long long)sp * NC + i];
+  y[i] = s * mult;
+}
+
+struct ColsumPlan { int gx, splits, rps; };
+inline ColsumPlan colsum_plan(int N, int HW, int C) {
+  ColsumPlan pl;
+  pl.gx = (C / 4 + 15) / 16;
+  int splits = 2048 / (pl.gx * N > 0 ? pl.gx * N : 1);
   const int max_splits = (HW + 127) / 128;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  const int rps = (HW + splits - 1) / splits;
-  splits = (HW + rps - 1) / rps;
-  hipLaunchKernelGGL(colsum_kernel, dim3(gx, N, splits), dim3(256), 0, st, x, ldx, y, HW, C, mult, rps);
+  pl.rps = (HW + splits - 1) / splits;
+  pl.splits = (HW + pl.rps - 1) / pl.rps;
+  return pl;
+}
+
+inline int launch_colsum(const float* x, int ldx, float* y, int N, int HW, int C, float mult, float* ws,
+                         hipStream_t st) {
+  const ColsumPlan pl = colsum_plan(N, HW, C);
+  hipLaunchKernelGGL(colsum_kernel, dim3(pl.gx, N, pl.splits), dim3(256), 0, st, x, ldx, ws, HW, C, pl.rps);
+  const long long NC = (long long)N * C;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, ws, y, NC, pl.splits,
+                     mult);
   return mss_launch_status();
 }
 
@@ -663,18 +696,32 @@ int mss_nchw_to_nhwc_pad_f32(const float* x, float* y, int N, int C, int H, int 
   return mss_launch_status();
 }
 
+// doubles the `accum` argument of the three per-channel reductions below must hold: [2C] results followed by the
+// partial matrix of the first stage (contents irrelevant on entry; nothing has to be zeroed)
+long long mss_col_reduce_accum_doubles(long long M, int C) {
+  if (M <= 0 || C <= 0) return 2 * (long long)(C > 0 ? C : 0);
+  return 2 * (long long)C * (1 + (long long)col_reduce_grid(M, C).y);
+}
+long long mss_colsum_workspace_floats(int N, int HW, int C) {
+  if (N <= 0 || HW <= 0 || C <= 0) return 0;
+  return (long long)colsum_plan(N, HW, C).splits * N * C;
+}
+
 int mss_bn_stats_nhwc_f32(const float* x, long long M, int C, int ldx, double* accum, void* stream) {
   if (!x || !accum || C % 4 || ldx % 4) return MSS_ERR_BAD_ARG;
   if (M <= 0) return MSS_OK;
-  hipLaunchKernelGGL(bn_stats_kernel, col_reduce_grid(M, C), dim3(256), 0, S_(stream), x, M, C, ldx, accum);
+  const dim3 grid = col_reduce_grid(M, C);
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, S_(stream), x, M, C, ldx, accum);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, S_(stream), accum, (int)grid.y, 2 * C);
   return mss_launch_status();
 }
 
 int mss_bn_stats_partials_f32(const float* partials, long long nparts, int C, double* accum, void* stream) {
   if (!partials || !accum || C % 4) return MSS_ERR_BAD_ARG;
   if (nparts <= 0) return MSS_OK;
-  hipLaunchKernelGGL(bn_stats_partials_kernel, col_reduce_grid(nparts, C), dim3(256), 0, S_(stream), partials, nparts, C,
-                     accum);
+  const dim3 grid = col_reduce_grid(nparts, C);
+  hipLaunchKernelGGL(bn_stats_partials_kernel, grid, dim3(256), 0, S_(stream), partials, nparts, C, accum);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, S_(stream), accum, (int)grid.y, 2 * C);
   return mss_launch_status();
 }
 
@@ -710,8 +757,10 @@ int mss_bn_relu_bwd_reduce_f32(const float* dy, int lddy, const float* x, int ld
   if (!dy || !x || !scale || !shift || !save_mean || !save_invstd || !accum) return MSS_ERR_BAD_ARG;
   if (C % 4 || ldx % 4 || lddy % 4) return MSS_ERR_BAD_ARG;
   if (M <= 0) return MSS_OK;
-  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, col_reduce_grid(M, C), dim3(256), 0, S_(stream), dy, lddy, x, ldx,
+  const dim3 grid = col_reduce_grid(M, C);
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, grid, dim3(256), 0, S_(stream), dy, lddy, x, ldx,
                      M, C, scale, shift, save_mean, save_invstd, relu, accum);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, S_(stream), accum, (int)grid.y, 2 * C);
   return mss_launch_status();
 }
 
@@ -741,14 +790,14 @@ int mss_maxpool3s2_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N, i
   return mss_launch_status();
 }
 
-int mss_gap_nhwc_f32(const float* x, int ldx, float* y, int N, int HW, int C, void* stream) {
-  if (!x || !y || C % 4 || ldx % 4 || HW <= 0) return MSS_ERR_BAD_ARG;
-  return launch_colsum(x, ldx, y, N, HW, C, 1.f / (float)HW, S_(stream));
+int mss_gap_nhwc_f32(const float* x, int ldx, float* y, int N, int HW, int C, float* ws, void* stream) {
+  if (!x || !y || !ws || C % 4 || ldx % 4 || HW <= 0) return MSS_ERR_BAD_ARG;
+  return launch_colsum(x, ldx, y, N, HW, C, 1.f / (float)HW, ws, S_(stream));
 }
 
-int mss_colsum_nhwc_f32(const float* dy, int lddy, float* dv, int N, int HW, int C, void* stream) {
-  if (!dy || !dv || C % 4 || lddy % 4 || HW <= 0) return MSS_ERR_BAD_ARG;
-  return launch_colsum(dy, lddy, dv, N, HW, C, 1.f, S_(stream));
+int mss_colsum_nhwc_f32(const float* dy, int lddy, float* dv, int N, int HW, int C, float* ws, void* stream) {
+  if (!dy || !dv || !ws || C % 4 || lddy % 4 || HW <= 0) return MSS_ERR_BAD_ARG;
+  return launch_colsum(dy, lddy, dv, N, HW, C, 1.f, ws, S_(stream));
 }
 
 int mss_broadcast_rows_nhwc_f32(const float* v, float* y, int ldy, int N, int HW, int C, const float* scale,

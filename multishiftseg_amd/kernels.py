@@ -450,6 +450,11 @@ class BNState:
     __slots__ = ("scale", "shift", "save_mean", "save_invstd", "M", "train")
 
 
+def _col_accum(M, C, device):
+    """Scratch of the deterministic two-stage per-channel reductions: [2C] sums + the first stage's partial rows."""
+    return torch.empty(_lib.value("mss_col_reduce_accum_doubles", M, C), device=device, dtype=torch.float64)
+
+
 def bn_fold(bn, x=None, train=False, M=None, x_rows=None):
     """Fold nn.BatchNorm2d `bn` into (scale, shift). train=True computes batch statistics of the
     NHWC activation x (Act) and updates the running buffers exactly like F.batch_norm
@@ -466,16 +471,18 @@ def bn_fold(bn, x=None, train=False, M=None, x_rows=None):
              float(bn.eps), C, ptr(st.scale), ptr(st.shift))
         st.M = None
         return st
-    accum = torch.zeros(2 * C, device=dev, dtype=torch.float64)
     if x_rows is not None:          # plain [M, C] matrix (image-pooling branch)
         M = x_rows.shape[0]
+        accum = _col_accum(M, C, dev)
         call("mss_bn_stats_nhwc_f32", ptr(x_rows), M, C, x_rows.shape[1], ptr(accum))
     elif x.stats is not None and x.stats.shape[2] == C and x.C == C:   # left by the producing kernel: no re-read of x
         M = x.M
+        accum = _col_accum(x.stats.shape[0], C, dev)
         call("mss_bn_stats_partials_f32", ptr(x.stats), x.stats.shape[0], C, ptr(accum))
         x.stats = None
     else:
         M = x.M
+        accum = _col_accum(M, C, dev)
         call("mss_bn_stats_nhwc_f32", x.ptr, M, C, x.ld, ptr(accum))
     st.M = M
     st.save_mean = torch.empty(C, device=dev, dtype=torch.float32)
@@ -508,7 +515,7 @@ def bn_relu_backward(dy, x, st, relu=True, want_param_grads=False, x_rows=None, 
     dgamma = dbeta = None
     accum = None
     if st.train:
-        accum = torch.zeros(2 * C, device=dev, dtype=torch.float64)
+        accum = _col_accum(M, C, dev)
         call("mss_bn_relu_bwd_reduce_f32", dyp, lddy, xp, ldx, M, C, ptr(st.scale), ptr(st.shift), ptr(st.save_mean),
              ptr(st.save_invstd), int(relu), ptr(accum))
         if want_param_grads:
@@ -530,13 +537,15 @@ def maxpool3s2(x):
 
 def gap(x):
     y = torch.empty((x.N, x.C), device=x.buf.device, dtype=torch.float32)
-    call("mss_gap_nhwc_f32", x.ptr, x.ld, ptr(y), x.N, x.H * x.W, x.C)
+    ws = torch.empty(_lib.value("mss_colsum_workspace_floats", x.N, x.H * x.W, x.C), device=x.buf.device, dtype=torch.float32)
+    call("mss_gap_nhwc_f32", x.ptr, x.ld, ptr(y), x.N, x.H * x.W, x.C, ptr(ws))
     return y
 
 
 def colsum(dy):
     y = torch.empty((dy.N, dy.C), device=dy.buf.device, dtype=torch.float32)
-    call("mss_colsum_nhwc_f32", dy.ptr, dy.ld, ptr(y), dy.N, dy.H * dy.W, dy.C)
+    ws = torch.empty(_lib.value("mss_colsum_workspace_floats", dy.N, dy.H * dy.W, dy.C), device=dy.buf.device, dtype=torch.float32)
+    call("mss_colsum_nhwc_f32", dy.ptr, dy.ld, ptr(y), dy.N, dy.H * dy.W, dy.C, ptr(ws))
     return y
 
 

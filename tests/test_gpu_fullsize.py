@@ -245,6 +245,8 @@ def test_three_routes_agree_at_bench_size(deeplab_params, tag, pairs, h, w):
     m.load_state_dict(saved)
     again = _stage2_step(m, img, target, masks, seed=4242)
     nondet = [k for k, gr in out["winograd"][3].items() if not torch.equal(gr, again[3][k])]
+    if not torch.equal(out["winograd"][0], again[0]) or not torch.equal(out["winograd"][1], again[1]):
+        nondet.insert(0, "forward outputs (score/logit)")
     ref = out["igemm_only"]
     rep = {"wino_tiles": tiles, "nondeterministic_grads": nondet}
     bad = []
@@ -266,8 +268,11 @@ def test_three_routes_agree_at_bench_size(deeplab_params, tag, pairs, h, w):
         for k, v in r["grad_rel_l2"].items():
             # image-pooling branch at 2 images per GPU: BatchNorm over 2 samples is sign(x0 - x1) -- its input gradient
             # is O(eps) and pure rounding noise in ANY implementation (reference gradsens confirms), so only its size is held
+            # Otherwise: the exact-arithmetic route (direct3x3: same taps, other summation order) must stay within 2e-3;
+            # Winograd F(4x4) perturbs every trunk activation by ~4e-6 relative, to which the REFERENCE's own gradients
+            # respond with up to 8.4e-3 rel-L2 (gradsens_* in deepwv3plus_train_step_2x592x600.npz): 6e-3 is asked.
             loose = pairs == 1 and k.startswith("aspp.img_conv")
-            if v > (0.5 if loose else 2e-3):
+            if v > (0.5 if loose else (6e-3 if route == "winograd" else 2e-3)):
                 bad.append((route, k, v))
     _note(f"three_routes[{tag}]", rep)
     assert not nondet, nondet

@@ -40,7 +40,7 @@ def main():
         row(f"rel_contrastive_loss value+grads {B}x19x{H}x{W}", ms, B * H * W * 168.0, "168 B/px minimum")
     # BN statistics + maxpool + upsample at train sizes
     x = K.Act(torch.randn(2, 512, 1024, 128, device=dev))
-    acc = torch.zeros(256, device=dev, dtype=torch.float64)
+    acc = K._col_accum(x.M, 128, dev)
     from multishiftseg_amd._lib import call, ptr
     ms = timeit(lambda: call("mss_bn_stats_nhwc_f32", x.ptr, x.M, 128, x.ld, ptr(acc)))
     row("bn_stats 2x512x1024x128", ms, x.M * 128 * 4.0)
