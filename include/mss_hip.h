@@ -230,10 +230,13 @@ typedef struct MssRclArgs {
 } MssRclArgs;
 /* counters: double[16]; slots 0 sum_ce_orig, 1 n_in_orig, 2 n_in_aug, 3 n_ood, 4 sum_c_in,
  * 5 n_same_in, 6 sum_ce_aug_all, 7 sum_selected_ce, 8 n_selected, 9 sum_c_orig, 10 sum_c_aug,
- * 11 n_pairs. pass1 zeroes them.
- * pass1 (loss.py:46-60,90-96): lse[B*H*W], ce_aug[(B/2)*H*W] (+inf where ignored),
- * kind[B*H*W] (0 void / 1 in-distribution / 2 OOD, from the UNmutated targets). */
-int mss_rcl_pass1_f32(const MssRclArgs* a, float* lse, float* ce_aug, uint8_t* kind, double* counters,
+ * 11 n_pairs, 12 labels in [C, 99) or < 0 (F.nll_loss raises on those, loss.py:59: here the loss turns NaN and
+ * out[6] of finalize reports the count). pass1 zeroes them.
+ * pass1 (loss.py:46-69,90-96): lse[B*H*W] (only the augmented half is guaranteed to be written), ce_aug[(B/2)*H*W]
+ * (+inf where ignored), kind[B*H*W] (0 void / 1 in-distribution / 2 OOD, from the UNmutated targets); B must be even
+ * ([orig...; aug...] pairs). dlogit (optional [B,C,H,W]): pass1 also writes the gradient of every pixel whose weight
+ * does not depend on the selection: the original half always, the augmented half when a->select == 0. */
+int mss_rcl_pass1_f32(const MssRclArgs* a, float* lse, float* ce_aug, uint8_t* kind, double* counters, float* dlogit,
                       void* stream);
 /* exact k-th smallest of ce_aug, k = int(float32(ratio) * float32(n_in_aug)) as torch computes
  * it (loss.py:98-99); replaces torch.topk (loss.py:102). hist_ws: uint32[256]; sel: uint32[8]
@@ -247,8 +250,9 @@ int mss_rcl_select_init_f32(const double* counters, float selection_ratio, uint3
 int mss_rcl_select_hist_f32(const float* ce_aug, long long n, const uint32_t* sel, int shift, uint32_t* hist_ws,
                             void* stream);
 int mss_rcl_select_pick_f32(uint32_t* sel, uint32_t* hist_ws, int shift, void* stream);
-/* pass2: dlogit (NCHW, assigned; may be NULL) = grad_scale * d loss / d logit, target mutation,
- * counters[7..8]. */
+/* pass2 (selection mode only; a no-op when a->select == 0): the AUGMENTED half of dlogit (NCHW, assigned; may be
+ * NULL) = grad_scale * d loss / d logit for the selected pixels and 0 for the others, target mutation, counters[7..8].
+ * The original half was written by pass1. */
 int mss_rcl_pass2_f32(const MssRclArgs* a, const float* lse, const float* ce_aug, const uint8_t* kind,
                       uint32_t* sel, double* counters, float grad_scale, float* dlogit, void* stream);
 /* row-major ordered compaction of pixel indices into the three sets of loss.py:122-124
@@ -324,6 +328,10 @@ int mss_oodm_measures_f64(const unsigned int* pos_sorted, long long P, const uns
  * variant 0..3 = plain / 4 loads in flight / + nontemporal / + contiguous 16-KB chunks per workgroup. */
 int mss_peak_mfma_f32(float* out, int blocks, int iters, void* stream);
 int mss_peak_stream_f32(const float* src, float* dst, long long n, int variant, void* stream);
+/* layout experiment behind the Winograd-domain layout: one coalesced float4 read, ns (16|36) float4 writes
+ * into ns slabs that are n floats apart (blocked = 0) or adjacent per block of blk_floats floats (blocked = 1). */
+int mss_peak_scatter_f32(const float* src, float* dst, long long n, int ns, int blocked, long long blk_floats,
+                         void* stream);
 
 #ifdef __cplusplus
 }

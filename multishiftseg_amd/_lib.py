@@ -88,7 +88,7 @@ SIGNATURES = {
     "mss_ood_score_f32": [P, I, P, I, I, I, I, I, I, I, P, P, P, P],
     "mss_ood_score_bwd_f32": [P, I, P, P, I, I, I, I, I, I, P, I, P, I, P],
     "mss_m2f_score_f32": [P, P, I, I, I, I, I, I, I, P, P],
-    "mss_rcl_pass1_f32": [POINTER(MssRclArgs), P, P, P, P, P],
+    "mss_rcl_pass1_f32": [POINTER(MssRclArgs), P, P, P, P, P, P],
     "mss_rcl_select_f32": [P, L, P, F, P, P, P],
     "mss_rcl_pass2_f32": [POINTER(MssRclArgs), P, P, P, P, P, F, P, P],
     "mss_rcl_num_compact_blocks": [I, I, I],
@@ -120,6 +120,7 @@ SIGNATURES = {
     "mss_oodm_measures_f64": [P, L, P, L, c_double, P, P, P, P],
     "mss_peak_mfma_f32": [P, I, I, P],
     "mss_peak_stream_f32": [P, P, L, I, P],
+    "mss_peak_scatter_f32": [P, P, L, I, I, L, P],
 }
 # entry points that return a plain value rather than a status code
 _VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",

@@ -2,22 +2,31 @@
 // handful of streaming passes instead of the ~25 ATen kernels + topk + host randperm of the
 // reference (lib/loss.py:34-156).
 //
-//   pass1   one read of logit/score/target: per-pixel logsumexp + CE, pixel kind, partial sums,
-//           the augmented half's CE values for the selection                (loss.py:46-60,90-96)
+//   pass1   one read of logit/score/target: per-pixel logsumexp + CE, pixel kind, partial sums, the augmented
+//           half's CE values for the selection, AND the gradient of every pixel whose weight is already known:
+//           the original half always, the augmented half when no selection is asked (loss.py:46-69,90-96)
 //   select  exact k-th smallest CE by 4 x 8-bit radix histograms on the fp32 bit pattern
 //           (replaces torch.topk over ~4 M values, loss.py:98-102)
-//   pass2   softmax-minus-onehot gradient written once, target mutation     (loss.py:103-111)
+//   pass2   augmented half only (selection mode): softmax-minus-onehot gradient of the selected pixels (the logits of
+//           the ~20 % rejected pixels are not re-read), zeros elsewhere, target mutation (loss.py:103-111)
 //   compact ordered stream compaction of the three score sets              (loss.py:122-124)
 //   pairs   hinge terms over permuted pairs + scatter of dscore             (loss.py:129-137)
 //   cin     in-distribution consistency term                                (loss.py:139-145)
-// HBM traffic: logit is read twice (pass1, pass2) and dlogit written once.
+// HBM traffic per pixel with selection: 76 B logits once (+76 B again for the selected augmented pixels: 0.4 x 76 on
+// average), dlogit 76 B written once, target/score/kind/lse/ce side data ~25 B: ~210 B against the 168 B of SURVEY 8(d),
+// which assumes the gradient weights are known up front (they are not: k = int(0.8 * #in-distribution augmented pixels)
+// and the threshold CE exist only after every augmented logit has been seen).
+// The fast kernels take 4 consecutive pixels per lane (16-B loads on every class plane, all 19 in flight, the 19x4
+// logits stay in registers between the max, the sum and the gradient); H*W % 4 != 0 or C != 19 use the scalar ones.
 #include "mss_common.h"
 #include "../../include/mss_hip.h"
 
 namespace {
 
 enum { CNT_SUM_CE_ORIG = 0, CNT_N_IN_ORIG, CNT_N_IN_AUG, CNT_N_OOD, CNT_SUM_CIN, CNT_N_SAME, CNT_SUM_CE_AUG_ALL,
-       CNT_SUM_SEL, CNT_N_SEL, CNT_SUM_CORIG, CNT_SUM_CAUG, CNT_N_PAIRS };
+       CNT_SUM_SEL, CNT_N_SEL, CNT_SUM_CORIG, CNT_SUM_CAUG, CNT_N_PAIRS, CNT_BAD_TARGET };
+
+typedef long long i64x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t f2key(float f) {
   uint32_t b = __float_as_uint(f);
@@ -43,19 +52,21 @@ __device__ __forceinline__ void block_add(const float (&v)[NV], double* dst, con
 
 __global__ __launch_bounds__(256) void rcl_pass1_kernel(MssRclArgs a, float* __restrict__ lse_out,
                                                         float* __restrict__ ce_aug, uint8_t* __restrict__ kind_out,
-                                                        double* __restrict__ counters) {
+                                                        double* __restrict__ counters, float* __restrict__ dlogit) {
   const long long HW = (long long)a.H * a.W;
   const long long total = (long long)a.B * HW;
   const int h = a.B / 2;
   const long long half = (long long)h * HW;
-  float acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  const float g_orig = a.w_ce_orig / (float)half, g_aug = a.w_ce_aug / (float)half;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int b = (int)(i / HW);
     const long long p = i - (long long)b * HW;
     const int64_t t = a.target[i];
-    const bool in = t < 99;                      // in_id  (loss.py:31,47)
+    bool in = t < 99;                            // in_id  (loss.py:31,47)
     const bool ood = t > 99 && t != 255;         // void_id (loss.py:32,46)
+    if (in && (t < 0 || t >= a.C)) { in = false; acc[7] += 1.f; }   // nll_loss raises on such a label: flagged, never indexed
     const float* lp = a.logit + (long long)b * a.C * HW + p;
     float m = -__builtin_huge_valf();
     for (int c = 0; c < a.C; ++c) m = fmaxf(m, lp[(long long)c * HW]);
@@ -81,14 +92,126 @@ __global__ __launch_bounds__(256) void rcl_pass1_kernel(MssRclArgs a, float* __r
       acc[6] += ce;
     }
     acc[3] += ood ? 1.f : 0.f;
+    if (dlogit && (b < h || !a.select)) {        // gradient weight known without the selection: written here, once
+      float* dp = dlogit + (long long)b * a.C * HW + p;
+      const float g = in ? (b < h ? g_orig : g_aug) : 0.f;
+      for (int c = 0; c < a.C; ++c)
+        dp[(long long)c * HW] = g != 0.f ? g * (expf(lp[(long long)c * HW] - lse) - (c == (int)t ? 1.f : 0.f)) : 0.f;
+    }
   }
-  __shared__ int slots[7];
+  __shared__ int slots[8];
   if (threadIdx.x == 0) {
     slots[0] = CNT_SUM_CE_ORIG; slots[1] = CNT_N_IN_ORIG; slots[2] = CNT_N_IN_AUG; slots[3] = CNT_N_OOD;
-    slots[4] = CNT_SUM_CIN; slots[5] = CNT_N_SAME; slots[6] = CNT_SUM_CE_AUG_ALL;
+    slots[4] = CNT_SUM_CIN; slots[5] = CNT_N_SAME; slots[6] = CNT_SUM_CE_AUG_ALL; slots[7] = CNT_BAD_TARGET;
   }
   __syncthreads();
-  block_add<7>(acc, counters, slots);
+  block_add<8>(acc, counters, slots);
+}
+
+// 4 consecutive pixels of one image plane per lane (H*W % 4 == 0), C classes compile-time.
+template <int C>
+__global__ __launch_bounds__(256) void rcl_pass1_v4_kernel(MssRclArgs a, float* __restrict__ lse_out,
+                                                           float* __restrict__ ce_aug, uint8_t* __restrict__ kind_out,
+                                                           double* __restrict__ counters, float* __restrict__ dlogit) {
+  const long long HW = (long long)a.H * a.W;
+  const long long total4 = (long long)a.B * HW / 4;
+  const int h = a.B / 2;
+  const long long half = (long long)h * HW;
+  const float g_orig = a.w_ce_orig / (float)half, g_aug = a.w_ce_aug / (float)half;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long long g4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; g4 < total4;
+       g4 += (long long)gridDim.x * blockDim.x) {
+    const long long i = g4 * 4;
+    const int b = (int)(i / HW);
+    const long long p = i - (long long)b * HW;
+    // uniform plane base (SGPR pair) + one 32-bit per-lane byte offset shared by all C loads / stores (the launcher
+    // guarantees B*C*H*W*4 < 2^32): 19 independent 64-bit per-lane addresses would cost 76 more registers
+    const unsigned voff = (unsigned)(((long long)b * C * HW + p) * 4);
+    const char* lbase = reinterpret_cast<const char*>(a.logit);
+    f32x4 v[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = *reinterpret_cast<const f32x4*>(lbase + (size_t)c * HW * 4 + voff);
+    const i64x2 t01 = *reinterpret_cast<const i64x2*>(a.target + i), t23 = *reinterpret_cast<const i64x2*>(a.target + i + 2);
+    const long long t[4] = {t01.x, t01.y, t23.x, t23.y};
+    int tt[4];
+    uint32_t kinds = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bool in = t[e] < 99;                                           // in_id  (loss.py:31,47)
+      const bool ood = t[e] > 99 && t[e] != 255;                     // void_id (loss.py:32,46)
+      if (in && (t[e] < 0 || t[e] >= C)) { in = false; acc[7] += 1.f; }   // nll_loss raises: flagged, never indexed
+      tt[e] = in ? (int)t[e] : -1;
+      kinds |= (uint32_t)(in ? 1 : (ood ? 2 : 0)) << (8 * e);
+      acc[3] += ood ? 1.f : 0.f;
+    }
+    f32x4 m = v[0], xt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      m.x = fmaxf(m.x, v[c].x); m.y = fmaxf(m.y, v[c].y); m.z = fmaxf(m.z, v[c].z); m.w = fmaxf(m.w, v[c].w);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xt[e] = tt[e] == c ? v[c][e] : xt[e];     // raw logit of the target class
+    }
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      v[c].x = expf(v[c].x - m.x); v[c].y = expf(v[c].y - m.y); v[c].z = expf(v[c].z - m.z); v[c].w = expf(v[c].w - m.w);
+      sum += v[c];
+    }
+    f32x4 lse, ce, gsc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lse[e] = m[e] + logf(sum[e]);
+      ce[e] = tt[e] >= 0 ? lse[e] - xt[e] : 0.f;
+      gsc[e] = 0.f;
+    }
+    *reinterpret_cast<uint32_t*>(kind_out + i) = kinds;
+    if (b < h) {
+      const i64x2 u01 = *reinterpret_cast<const i64x2*>(a.target + i + half), u23 = *reinterpret_cast<const i64x2*>(a.target + i + half + 2);
+      const long long u[4] = {u01.x, u01.y, u23.x, u23.y};
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.score + i), s1 = *reinterpret_cast<const f32x4*>(a.score + i + half);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[0] += ce[e];
+        acc[1] += tt[e] >= 0 ? 1.f : 0.f;
+        if (tt[e] >= 0 && u[e] < 99) {          // pair (i, i + half): in-distribution consistency term (loss.py:141-145)
+          acc[4] += fmaxf(s1[e] - s0[e] - a.m2, 0.f);
+          acc[5] += 1.f;
+        }
+        gsc[e] = tt[e] >= 0 ? g_orig : 0.f;
+      }
+    } else {
+      f32x4 cev;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cev[e] = tt[e] >= 0 ? ce[e] : __builtin_huge_valf();
+        acc[2] += tt[e] >= 0 ? 1.f : 0.f;
+        acc[6] += ce[e];
+        gsc[e] = tt[e] >= 0 ? g_aug : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(ce_aug + (i - half)) = cev;
+      *reinterpret_cast<f32x4*>(lse_out + i) = lse;      // pass 2 only ever reads the augmented half's
+    }
+    if (dlogit && (b < h || !a.select)) {
+      char* dbase = reinterpret_cast<char*>(dlogit);
+      f32x4 inv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) inv[e] = gsc[e] / sum[e];          // g * softmax_c = g * exp(x_c - m) / sum
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        f32x4 o = v[c] * inv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (tt[e] == c) o[e] -= gsc[e];
+        *reinterpret_cast<f32x4*>(dbase + (size_t)c * HW * 4 + voff) = o;
+      }
+    }
+  }
+  __shared__ int slots[8];
+  if (threadIdx.x == 0) {
+    slots[0] = CNT_SUM_CE_ORIG; slots[1] = CNT_N_IN_ORIG; slots[2] = CNT_N_IN_AUG; slots[3] = CNT_N_OOD;
+    slots[4] = CNT_SUM_CIN; slots[5] = CNT_N_SAME; slots[6] = CNT_SUM_CE_AUG_ALL; slots[7] = CNT_BAD_TARGET;
+  }
+  __syncthreads();
+  block_add<8>(acc, counters, slots);
 }
 
 // ---- radix select --------------------------------------------------------------------------
@@ -144,6 +267,8 @@ __global__ void rcl_pick_kernel(uint32_t* sel, uint32_t* hist, int shift) {
 }
 
 // ---- pass 2 ---------------------------------------------------------------------------------
+// Selection mode only, augmented half only: which pixels made the easiest-k cut (key < threshold, plus `need_eq` of the
+// ones equal to it, first come first served), their gradient, the target mutation of all the others.
 __global__ __launch_bounds__(256) void rcl_pass2_kernel(MssRclArgs a, const float* __restrict__ lse,
                                                         const float* __restrict__ ce_aug,
                                                         const uint8_t* __restrict__ kind, uint32_t* sel,
@@ -151,46 +276,117 @@ __global__ __launch_bounds__(256) void rcl_pass2_kernel(MssRclArgs a, const floa
                                                         float* __restrict__ dlogit) {
   const long long HW = (long long)a.H * a.W;
   const long long total = (long long)a.B * HW;
-  const int h = a.B / 2;
-  const long long half = (long long)h * HW;
+  const long long half = (long long)(a.B / 2) * HW;
   const uint32_t thr = sel[0], k = sel[2], need_eq = sel[3];
-  const float g_orig = grad_scale * a.w_ce_orig / (float)half;
-  const float g_aug = a.select ? (k ? grad_scale * a.w_ce_aug / (float)k : 0.f) : grad_scale * a.w_ce_aug / (float)half;
+  const float g_aug = k ? grad_scale * a.w_ce_aug / (float)k : 0.f;
   float acc[2] = {0.f, 0.f};
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+  for (long long i = half + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int b = (int)(i / HW);
     const long long p = i - (long long)b * HW;
-    const bool in = kind[i] == 1;
-    float g = 0.f;
-    if (b < h) {
-      if (in) g = g_orig;
-    } else if (!a.select) {
-      if (in) g = g_aug;
-    } else {
-      bool chosen = false;
-      if (in && k) {
-        const float ce = ce_aug[i - half];
-        const uint32_t key = f2key(ce);
-        if (key < thr) chosen = true;
-        else if (key == thr) chosen = atomicAdd(&sel[4], 1u) < need_eq;
-        if (chosen) { acc[0] += ce; acc[1] += 1.f; }
-      }
-      if (chosen) g = g_aug;
-      else a.target[i] = 255;                    // loss.py:110-111,115 (every non-selected pixel)
+    bool chosen = false;
+    if (kind[i] == 1 && k) {
+      const float ce = ce_aug[i - half];
+      const uint32_t key = f2key(ce);
+      if (key < thr) chosen = true;
+      else if (key == thr) chosen = atomicAdd(&sel[4], 1u) < need_eq;
+      if (chosen) { acc[0] += ce; acc[1] += 1.f; }
     }
+    int t = -1;
+    if (chosen) t = (int)a.target[i];
+    else a.target[i] = 255;                      // loss.py:110-111,115 (every non-selected pixel)
     if (dlogit) {
       float* dp = dlogit + (long long)b * a.C * HW + p;
-      if (g != 0.f) {
+      if (chosen) {
         const float* lp = a.logit + (long long)b * a.C * HW + p;
         const float l = lse[i];
-        const int t = (int)a.target[i];
-        for (int c = 0; c < a.C; ++c) {
-          float pr = expf(lp[(long long)c * HW] - l);
-          dp[(long long)c * HW] = g * (pr - (c == t ? 1.f : 0.f));
-        }
+        for (int c = 0; c < a.C; ++c) dp[(long long)c * HW] = g_aug * (expf(lp[(long long)c * HW] - l) - (c == t ? 1.f : 0.f));
       } else {
         for (int c = 0; c < a.C; ++c) dp[(long long)c * HW] = 0.f;
+      }
+    }
+  }
+  __shared__ int slots[2];
+  if (threadIdx.x == 0) { slots[0] = CNT_SUM_SEL; slots[1] = CNT_N_SEL; }
+  __syncthreads();
+  block_add<2>(acc, counters, slots);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void rcl_pass2_v4_kernel(MssRclArgs a, const float* __restrict__ lse,
+                                                           const float* __restrict__ ce_aug,
+                                                           const uint8_t* __restrict__ kind, uint32_t* sel,
+                                                           double* __restrict__ counters, float grad_scale,
+                                                           float* __restrict__ dlogit) {
+  const long long HW = (long long)a.H * a.W;
+  const long long half = (long long)(a.B / 2) * HW;
+  const long long n4 = ((long long)a.B * HW - half) / 4;
+  const uint32_t thr = sel[0], k = sel[2], need_eq = sel[3];
+  const float g_aug = k ? grad_scale * a.w_ce_aug / (float)k : 0.f;
+  float acc[2] = {0.f, 0.f};
+  for (long long g4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; g4 < n4;
+       g4 += (long long)gridDim.x * blockDim.x) {
+    const long long i = half + g4 * 4;
+    const int b = (int)(i / HW);
+    const long long p = i - (long long)b * HW;
+    const f32x4 ce = *reinterpret_cast<const f32x4*>(ce_aug + (i - half));
+    const uint32_t kinds = *reinterpret_cast<const uint32_t*>(kind + i);
+    bool chosen[4];
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      chosen[e] = false;
+      if (((kinds >> (8 * e)) & 255u) == 1u && k) {
+        const uint32_t key = f2key(ce[e]);
+        if (key < thr) chosen[e] = true;
+        else if (key == thr) chosen[e] = atomicAdd(&sel[4], 1u) < need_eq;
+        if (chosen[e]) { acc[0] += ce[e]; acc[1] += 1.f; }
+      }
+      any |= chosen[e];
+    }
+    int t[4] = {-1, -1, -1, -1};
+    if (any) {
+      const i64x2 t01 = *reinterpret_cast<const i64x2*>(a.target + i), t23 = *reinterpret_cast<const i64x2*>(a.target + i + 2);
+      const long long tv[4] = {t01.x, t01.y, t23.x, t23.y};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = chosen[e] ? (int)tv[e] : -1;
+      if (!(chosen[0] && chosen[1] && chosen[2] && chosen[3])) {
+        i64x2 n01 = t01, n23 = t23;
+        if (!chosen[0]) n01.x = 255;
+        if (!chosen[1]) n01.y = 255;
+        if (!chosen[2]) n23.x = 255;
+        if (!chosen[3]) n23.y = 255;
+        *reinterpret_cast<i64x2*>(a.target + i) = n01;
+        *reinterpret_cast<i64x2*>(a.target + i + 2) = n23;
+      }
+    } else {
+      const i64x2 v255 = {255, 255};             // loss.py:110-111,115 (every non-selected pixel)
+      *reinterpret_cast<i64x2*>(a.target + i) = v255;
+      *reinterpret_cast<i64x2*>(a.target + i + 2) = v255;
+    }
+    if (dlogit) {
+      const unsigned voff = (unsigned)(((long long)b * C * HW + p) * 4);
+      char* dbase = reinterpret_cast<char*>(dlogit);
+      if (any) {
+        const char* lbase = reinterpret_cast<const char*>(a.logit);
+        f32x4 v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = *reinterpret_cast<const f32x4*>(lbase + (size_t)c * HW * 4 + voff);
+        const f32x4 l = *reinterpret_cast<const f32x4*>(lse + i);
+        f32x4 gv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[e] = chosen[e] ? g_aug : 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = gv[e] * (expf(v[c][e] - l[e]) - (t[e] == c ? 1.f : 0.f));
+          *reinterpret_cast<f32x4*>(dbase + (size_t)c * HW * 4 + voff) = o;
+        }
+      } else {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C; ++c) *reinterpret_cast<f32x4*>(dbase + (size_t)c * HW * 4 + voff) = z;
       }
     }
   }
@@ -448,6 +644,9 @@ __global__ void rcl_finalize_kernel(MssRclArgs a, const double* __restrict__ cou
   const float c_in = (float)(counters[CNT_SUM_CIN] / counters[CNT_N_SAME]);
   out[0] = (a.w_ce_orig * ce_orig + a.w_ce_aug * ce_aug) + a.w_contras * ((c_orig + c_aug) + c_in);
   out[1] = ce_orig; out[2] = ce_aug; out[3] = c_orig; out[4] = c_aug; out[5] = c_in;
+  // labels in [C, 99) or below 0: F.nll_loss raises on them (loss.py:59); here the loss turns NaN and the count is reported
+  out[6] = (float)counters[CNT_BAD_TARGET];
+  if (counters[CNT_BAD_TARGET] > 0) out[0] = __builtin_nanf("");
 }
 
 inline int grid_for(long long work_items, int cap = 256 * 16) {
@@ -470,15 +669,29 @@ extern "C" {
 
 int mss_rcl_num_compact_blocks(int B, int H, int W) { return (int)(((long long)B * H * W + CB - 1) / CB); }
 
-int mss_rcl_pass1_f32(const MssRclArgs* a, float* lse, float* ce_aug, uint8_t* kind, double* counters,
+static bool rcl_vec4(const MssRclArgs* a) {
+  return a->C == 19 && ((long long)a->H * a->W) % 4 == 0 && (long long)a->B * a->C * a->H * a->W * 4 < (1ll << 32) &&
+         ((reinterpret_cast<uintptr_t>(a->logit) | reinterpret_cast<uintptr_t>(a->score) | reinterpret_cast<uintptr_t>(a->target)) & 15) == 0;
+}
+
+// dlogit (optional, [B][C][H][W]): pass 1 writes the gradient of every pixel whose weight does not depend on the
+// selection -- the original half always, the augmented half when a->select == 0 (then pass 2 is not needed at all).
+int mss_rcl_pass1_f32(const MssRclArgs* a, float* lse, float* ce_aug, uint8_t* kind, double* counters, float* dlogit,
                       void* stream) {
   int rc = rcl_check(a);
   if (rc) return rc;
   if (!lse || !ce_aug || !kind || !counters) return MSS_ERR_BAD_ARG;
   hipError_t e = hipMemsetAsync(counters, 0, 16 * sizeof(double), S_(stream));
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(rcl_pass1_kernel, dim3(grid_for((long long)a->B * a->H * a->W)), dim3(256), 0, S_(stream), *a,
-                     lse, ce_aug, kind, counters);
+  const long long total = (long long)a->B * a->H * a->W;
+  const bool v4 = rcl_vec4(a) && ((reinterpret_cast<uintptr_t>(lse) | reinterpret_cast<uintptr_t>(ce_aug) |
+                                   reinterpret_cast<uintptr_t>(kind) | reinterpret_cast<uintptr_t>(dlogit)) & 15) == 0;
+  if (v4)
+    hipLaunchKernelGGL(rcl_pass1_v4_kernel<19>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, S_(stream), *a, lse,
+                       ce_aug, kind, counters, dlogit);
+  else
+    hipLaunchKernelGGL(rcl_pass1_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), *a, lse, ce_aug, kind,
+                       counters, dlogit);
   return mss_launch_status();
 }
 
@@ -548,8 +761,16 @@ int mss_rcl_pass2_f32(const MssRclArgs* a, const float* lse, const float* ce_aug
   int rc = rcl_check(a);
   if (rc) return rc;
   if (!lse || !ce_aug || !kind || !sel || !counters) return MSS_ERR_BAD_ARG;
-  hipLaunchKernelGGL(rcl_pass2_kernel, dim3(grid_for((long long)a->B * a->H * a->W)), dim3(256), 0, S_(stream), *a,
-                     lse, ce_aug, kind, sel, counters, grad_scale, dlogit);
+  if (!a->select) return MSS_OK;       // nothing left to do: pass 1 wrote the whole gradient
+  const long long n_aug = (long long)(a->B - a->B / 2) * a->H * a->W;
+  const bool v4 = rcl_vec4(a) && ((reinterpret_cast<uintptr_t>(lse) | reinterpret_cast<uintptr_t>(ce_aug) |
+                                   reinterpret_cast<uintptr_t>(kind) | reinterpret_cast<uintptr_t>(dlogit)) & 15) == 0;
+  if (v4)
+    hipLaunchKernelGGL(rcl_pass2_v4_kernel<19>, dim3(grid_for(n_aug / 4, 8192)), dim3(256), 0, S_(stream), *a, lse,
+                       ce_aug, kind, sel, counters, grad_scale, dlogit);
+  else
+    hipLaunchKernelGGL(rcl_pass2_kernel, dim3(grid_for(n_aug)), dim3(256), 0, S_(stream), *a, lse, ce_aug, kind, sel,
+                       counters, grad_scale, dlogit);
   return mss_launch_status();
 }
 

@@ -66,9 +66,40 @@ __global__ __launch_bounds__(256) void peak_stream_kernel(const f32x4* __restric
   for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+// Layout experiment for the Winograd transforms: every thread reads ONE float4 (coalesced) and writes NS float4, one
+// into each of NS "position slabs". blocked = 0: slab s of item i at dst[s * n4 + i] (the [P][T][C] layout: NS write
+// streams tens of MB apart per wave); blocked = 1: items are grouped in blocks of `blk` float4 and the NS slabs of a
+// block are adjacent, dst[(i / blk) * NS * blk + s * blk + i % blk] (the [T/128][P][128][C] layout: all stores of a
+// workgroup land within NS * blk * 16 bytes).
+template <int NS>
+__global__ __launch_bounds__(256) void peak_scatter_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst,
+                                                           long long n4, int blocked, long long blk) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 v = src[i];
+    const long long base = blocked ? (i / blk) * NS * blk + (i % blk) : i;
+    const long long step = blocked ? blk : n4;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) dst[base + s * step] = v * (float)(s + 1);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// reads n floats, writes ns * n floats (ns = 16 or 36); bytes moved = 4 * n * (1 + ns). dst: ns * n floats.
+int mss_peak_scatter_f32(const float* src, float* dst, long long n, int ns, int blocked, long long blk_floats,
+                         void* stream) {
+  if (!src || !dst || n <= 0 || n % 4 || (ns != 16 && ns != 36) || blk_floats % 4 || blk_floats <= 0) return MSS_ERR_BAD_ARG;
+  if (blocked && n % blk_floats) return MSS_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const f32x4* a = reinterpret_cast<const f32x4*>(src);
+  f32x4* b = reinterpret_cast<f32x4*>(dst);
+  if (ns == 16) hipLaunchKernelGGL(peak_scatter_kernel<16>, dim3(2048), dim3(256), 0, s, a, b, n / 4, blocked, blk_floats / 4);
+  else hipLaunchKernelGGL(peak_scatter_kernel<36>, dim3(2048), dim3(256), 0, s, a, b, n / 4, blocked, blk_floats / 4);
+  return mss_launch_status();
+}
 
 // out: at least blocks*256 floats. FLOPs performed = blocks * 4 waves * iters * 16 MFMAs * 4096.
 int mss_peak_mfma_f32(float* out, int blocks, int iters, void* stream) {

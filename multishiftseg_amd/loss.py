@@ -122,8 +122,9 @@ class RelContrastiveLoss(nn.Module):
         counters = torch.empty(16, device=dev, dtype=torch.float64)
         sel = torch.zeros(8, device=dev, dtype=torch.int32)
         hist = torch.empty(256, device=dev, dtype=torch.int32)
-        call("mss_rcl_pass1_f32", ra, ptr(lse), ptr(ce_aug), ptr(kind), ptr(counters))
-        dist.all_reduce(counters, group=g)                     # slots 0..6 are sums/counts; 7.. are still zero
+        dlogit = torch.empty_like(logits) if need_dl else None
+        call("mss_rcl_pass1_f32", ra, ptr(lse), ptr(ce_aug), ptr(kind), ptr(counters), ptr(dlogit))
+        dist.all_reduce(counters, group=g)                     # slots 0..6 and 12 are sums/counts; the rest still zero
         if select:
             call("mss_rcl_select_init_f32", ptr(counters), float(self.selection_ratio), ptr(hist), ptr(sel))
             local_last = None
@@ -139,8 +140,6 @@ class RelContrastiveLoss(nn.Module):
             dist.all_gather(eqs, local_eq, group=g)
             before = torch.stack(eqs[:rank]).sum() if rank else torch.zeros((), device=dev, dtype=torch.int32)
             sel[3] = torch.clamp(sel[3] - before, min=0).minimum(local_eq[0])
-        dlogit = torch.empty_like(logits) if need_dl else None
-        if select or need_dl:
             call("mss_rcl_pass2_f32", ra, ptr(lse), ptr(ce_aug), ptr(kind), ptr(sel), ptr(counters), 1.0, ptr(dlogit))
         nb = _lib.value("mss_rcl_num_compact_blocks", B, H, W)
         idx = torch.empty((3, total), device=dev, dtype=torch.int32)
@@ -215,11 +214,10 @@ class RelContrastiveLoss(nn.Module):
         counters = torch.empty(16, device=dev, dtype=torch.float64)
         sel = torch.zeros(8, device=dev, dtype=torch.int32)
         hist = torch.empty(256, device=dev, dtype=torch.int32)
-        call("mss_rcl_pass1_f32", ra, ptr(lse), ptr(ce_aug), ptr(kind), ptr(counters))
+        dlogit = torch.empty_like(logits) if need_dl else None
+        call("mss_rcl_pass1_f32", ra, ptr(lse), ptr(ce_aug), ptr(kind), ptr(counters), ptr(dlogit))
         if select:
             call("mss_rcl_select_f32", ptr(ce_aug), half, ptr(counters), float(self.selection_ratio), ptr(hist), ptr(sel))
-        dlogit = torch.empty_like(logits) if need_dl else None
-        if select or need_dl:
             call("mss_rcl_pass2_f32", ra, ptr(lse), ptr(ce_aug), ptr(kind), ptr(sel), ptr(counters), 1.0, ptr(dlogit))
         # contrastive part
         nb = _lib.value("mss_rcl_num_compact_blocks", B, H, W)
@@ -240,6 +238,9 @@ class RelContrastiveLoss(nn.Module):
                      (s0 + 1 + slot) & 0xFFFFFFFF, (s0 + 7) & 0xFFFFFFFF, float(margin), ptr(counters), slot, wc, ptr(dscore))
         else:
             n_orig, n_aug, n_ood = (int(v) for v in n_out[:3].tolist())      # host sync, as the reference's .sum()/int()
+            n_bad = int(counters[12].item())
+            if n_bad:       # F.nll_loss raises here (loss.py:59); the device-pairing mode reports NaN + last_terms[6]
+                raise IndexError(f"{n_bad} target value(s) outside [0, {C}) and below in_id=99")
             n = min(max_samples, n_ood, n_orig, n_aug)                         # loss.py:149-156
             if perms is None:
                 perms = [torch.randperm(k) for k in (n_orig, n_aug, n_ood)]    # CPU default generator, loss.py:129-131

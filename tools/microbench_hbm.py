@@ -56,6 +56,44 @@ def main():
     xx = K.Act(torch.randn(2, 128, 256, 4096, device=dev))
     ms = timeit(lambda: K.gap(xx))
     row("gap 2x128x256x4096", ms, xx.M * 4096 * 4.0)
+    wino_transforms(dev)
+    layout_experiment(dev)
+
+
+def wino_transforms(dev):
+    """The three streaming transforms of the Winograd layers at the shapes of the 2x1024x2048 step."""
+    from multishiftseg_amd import _lib
+    from multishiftseg_amd._lib import call, ptr
+    for (N, H, W, C, dil) in ((2, 512, 1024, 128, 1), (2, 512, 1024, 256, 1), (2, 256, 512, 256, 1), (2, 128, 256, 512, 1),
+                              (2, 128, 256, 1024, 4), (2, 128, 256, 4096, 12), (2, 128, 256, 4096, 24)):
+        ts = K.wino_tile(H, W, dil)
+        P = (ts + 2) ** 2
+        T = _lib.value("mss_wino_num_tiles", N, H, W, dil, ts)
+        x = K.Act(torch.randn(N, H, W, C, device=dev))
+        xt = torch.empty((P, T, C), device=dev)
+        sc = torch.rand(C, device=dev) + 0.5
+        sh = torch.randn(C, device=dev)
+        ms = timeit(lambda: call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ts, ptr(sc), ptr(sh), 1, ptr(xt)), iters=10)
+        row(f"wino_input_transform F{ts} {N}x{H}x{W}x{C} d{dil}", ms, 4.0 * (x.M * C + P * T * C), "x once + X' once")
+        y = K.Act.empty(N, H, W, C, dev)
+        ms = timeit(lambda: call("mss_wino_output_transform_f32", ptr(xt), N, H, W, C, dil, ts, x.ptr, x.ld, y.ptr, y.ld, None), iters=10)
+        row(f"wino_output_transform(+res) F{ts} {N}x{H}x{W}x{C} d{dil}", ms, 4.0 * (2 * x.M * C + P * T * C), "Y' once + res + y")
+        ms = timeit(lambda: call("mss_wino_grad_output_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ts, ptr(xt)), iters=10)
+        row(f"wino_grad_output_transform F{ts} {N}x{H}x{W}x{C} d{dil}", ms, 4.0 * (x.M * C + P * T * C))
+        del x, xt, y
+
+
+def layout_experiment(dev):
+    """Does the [P][T][C] layout (36 write streams tens of MB apart) cost bandwidth against a tile-block-major one?"""
+    from multishiftseg_amd._lib import call, ptr
+    n = 1 << 25                                  # 128 MB read, 36x = 4.8 GB written
+    src = torch.randn(n, device=dev)
+    for ns in (16, 36):
+        dst = torch.empty(ns * n, device=dev)
+        for blocked, blk in ((0, 4), (1, 128 * 128), (1, 128 * 256), (1, 128 * 1024), (1, 16 * 128)):
+            ms = timeit(lambda: call("mss_peak_scatter_f32", ptr(src), ptr(dst), n, ns, blocked, blk), iters=5)
+            row(f"scatter ns={ns} blocked={blocked} blk_floats={blk}", ms, 4.0 * n * (1 + ns))
+        del dst
 
 
 if __name__ == "__main__":
