@@ -137,6 +137,10 @@ int mss_wino_weight_grad_transform_f32(const float* du, float* dw, int K, int C,
 
 /* image NCHW [N,C,H,W] -> NHWC [N,H,W,Cp] with channels C..Cp-1 zero (feeds mod1.conv1). */
 int mss_nchw_to_nhwc_pad_f32(const float* x, float* y, int N, int C, int H, int W, int Cp, void* stream);
+/* stem (mod1.conv1, 3 -> 64 channels, 3x3, padding 1; wider_resnet.py:303) as a dense GEMM: img [N,3,H,W] NCHW ->
+ * out [N,H,W,32] NHWC with channel j = c*9 + r*3 + s holding img[n][c][y+r-1][x+s-1] (zero padding), 27..31 zero: the
+ * column order of weight.reshape(64, 27). The 1x1 convolution of that tensor with the reshaped weight IS conv1. */
+int mss_im2col3x3_c3_f32(const float* img, float* out, int N, int H, int W, void* stream);
 
 /* BatchNorm2d pieces (mynn.py:8-12 Norm2d = nn.BatchNorm2d, eps 1e-5, momentum 0.1).
  * stats: per-channel batch mean and biased variance of an NHWC tensor (M pixels). `accum` is a scratch of

@@ -40,6 +40,42 @@ __global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, float* __re
   }
 }
 
+// ---------------------------------------------------------------- stem: image NCHW -> 3x3 patches, NHWC 32 channels
+// mod1.conv1 (3 -> 64, 3x3, padding 1; wider_resnet.py:303) as a GEMM with K = 27: channel j = c*9 + r*3 + s of output
+// pixel (y, x) holds img[n][c][y+r-1][x+s-1] (0 outside), channels 27..31 are 0 -- the order of weight.reshape(64, 27).
+// The implicit-GEMM kernel needs 16-channel taps, i.e. K = 144 with 13/16 zeros for a 3-channel image (13.5 TFLOP/s);
+// this way the MFMA kernel sees a dense 32-deep 1x1 convolution. A workgroup gathers 256 consecutive pixels of a row
+// (coalesced 4-byte loads along x), transposes through LDS and writes 32 KB contiguously.
+__global__ __launch_bounds__(256) void im2col3x3_c3_kernel(const float* __restrict__ img, float* __restrict__ out,
+                                                           int H, int W) {
+  __shared__ float tile[256 * 33];
+  const int n = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * 256, x = x0 + threadIdx.x;
+  const float* base = img + (long long)n * 3 * H * W;
+  float* mine = tile + threadIdx.x * 33;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int yy = y + r - 1;
+      const bool oky = yy >= 0 && yy < H;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int xx = x + t - 1;
+        mine[c * 9 + r * 3 + t] = (oky && xx >= 0 && xx < W) ? base[((long long)c * H + yy) * W + xx] : 0.f;
+      }
+    }
+#pragma unroll
+  for (int j = 27; j < 32; ++j) mine[j] = 0.f;
+  __syncthreads();
+  const int npx = min(256, W - x0);
+  float* dst = out + (((long long)n * H + y) * W + x0) * 32;
+  for (int i = threadIdx.x; i < npx * 8; i += 256) {
+    const int px = i >> 3, q = (i & 7) * 4;
+    const float* src = tile + px * 33 + q;
+    st4(dst + (long long)px * 32 + q, f32x4{src[0], src[1], src[2], src[3]});
+  }
+}
+
 // ---------------------------------------------------------------- per-channel reductions
 // Generic column reducer over an NHWC matrix [M][C]: thread (tx, ty) owns channel quad
 // q = blockIdx.x*QPB + tx and walks rows ty, ty+RPB, ... of its row range; partial sums are kept
@@ -64,7 +100,18 @@ __device__ __forceinline__ void col_reduce2(long long M, int C, double* __restri
     long long r = r0 + ty;
     while (r < r1) {
       float fa[4] = {0, 0, 0, 0}, fb[4] = {0, 0, 0, 0};
-      for (int it = 0; it < 256 && r < r1; ++it, r += RPB) {
+      int it = 0;
+      // four rows per trip: their loads are independent, so four 16-byte requests per lane are in flight instead of one
+      for (; it + 4 <= 256 && r + 3ll * RPB < r1; it += 4, r += 4ll * RPB) {
+        float a[4][4], b[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f(r + (long long)u * RPB, q * 4, a[u], b[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { fa[k] += a[u][k]; fb[k] += b[u][k]; }
+      }
+      for (; it < 256 && r < r1; ++it, r += RPB) {
         float a[4], b[4];
         f(r, q * 4, a, b);
 #pragma unroll
@@ -355,7 +402,9 @@ __global__ void broadcast_rows_kernel(const float* __restrict__ v, float* __rest
 struct Tap { int i0, i1; float l0, l1; };
 __device__ __forceinline__ Tap ac_tap(int o, float scale, int in) {
   Tap t;
-  const float src = scale * (float)o;
+  // __fmul_rn: never contracted into the subtraction below. ATen rounds scale * o to fp32 first (area_pixel_compute_
+  // source_index); an fma(scale, o, -i0) is more accurate but moves the weights by up to 3e-5 at o ~ 700
+  const float src = __fmul_rn(scale, (float)o);
   t.i0 = (int)src;
   t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
   t.l1 = src - (float)t.i0;
@@ -364,24 +413,23 @@ __device__ __forceinline__ Tap ac_tap(int o, float scale, int in) {
 }
 inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
-__global__ void upsample_ac_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int N,
-                                   int IH, int IW, int OH, int OW, int C, float sh, float sw) {
-  const int C4 = C >> 2;
-  const long long total = (long long)N * OH * OW * C4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    long long p = i / C4;
-    const int ox = (int)(p % OW); p /= OW;
-    const int oy = (int)(p % OH);
-    const int n = (int)(p / OH);
-    const Tap ty = ac_tap(oy, sh, IH), tx = ac_tap(ox, sw, IW);
-    const float* b = x + (long long)n * IH * IW * ldx + c;
-    const f32x4 v00 = ld4(b + ((long long)ty.i0 * IW + tx.i0) * ldx), v01 = ld4(b + ((long long)ty.i0 * IW + tx.i1) * ldx);
-    const f32x4 v10 = ld4(b + ((long long)ty.i1 * IW + tx.i0) * ldx), v11 = ld4(b + ((long long)ty.i1 * IW + tx.i1) * ldx);
-    const f32x4 o = ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
-    st4(y + ((long long)(n * OH + oy) * OW + ox) * ldy + c, o);
-  }
+// grid (ceil(OW * C/4 / 256), OH, N): the row and the image come from the block index, so the only division left is
+// one 32-bit divide by C/4 (the 64-bit div/mod chain of a flat index cost more than the four loads)
+__global__ __launch_bounds__(256) void upsample_ac_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                          int ldy, int IH, int IW, int OH, int OW, int C, float sh,
+                                                          float sw) {
+  const unsigned C4 = (unsigned)C >> 2;
+  const unsigned item = blockIdx.x * 256u + threadIdx.x;
+  const unsigned ox = item / C4;
+  if (ox >= (unsigned)OW) return;
+  const int c = (int)(item - ox * C4) * 4;
+  const int oy = blockIdx.y, n = blockIdx.z;
+  const Tap ty = ac_tap(oy, sh, IH), tx = ac_tap((int)ox, sw, IW);
+  const float* b = x + (long long)n * IH * IW * ldx + c;
+  const f32x4 v00 = ld4(b + ((long long)ty.i0 * IW + tx.i0) * ldx), v01 = ld4(b + ((long long)ty.i0 * IW + tx.i1) * ldx);
+  const f32x4 v10 = ld4(b + ((long long)ty.i1 * IW + tx.i0) * ldx), v11 = ld4(b + ((long long)ty.i1 * IW + tx.i1) * ldx);
+  const f32x4 o = ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
+  st4(y + ((long long)(n * OH + oy) * OW + ox) * ldy + c, o);
 }
 
 // candidate output range [lo, hi] whose source index can touch input cell i
@@ -430,6 +478,50 @@ __global__ void upsample_ac_bwd_kernel(const float* __restrict__ dy, int lddy, f
     }
     st4(dx + ((long long)(n * IH + iy) * IW + ix) * lddx + c, acc);
   }
+}
+
+// The same gather for up-sampling factors up to ~4 (at most MAXR candidate outputs per axis): grid (ceil(IW * C/4 /
+// 256), IH, N), the x weights are computed once per thread, and the MAXR loads of an output row are independent and
+// issued together (the generic kernel had one load in flight per lane behind ~15 VALU instructions each).
+template <int MAXR>
+__global__ __launch_bounds__(256) void upsample_ac_bwd_fast_kernel(const float* __restrict__ dy, int lddy,
+                                                                   float* __restrict__ dx, int lddx, int IH, int IW,
+                                                                   int OH, int OW, int C, float sh, float sw) {
+  const unsigned C4 = (unsigned)C >> 2;
+  const unsigned item = blockIdx.x * 256u + threadIdx.x;
+  const unsigned ix = item / C4;
+  if (ix >= (unsigned)IW) return;
+  const int c = (int)(item - ix * C4) * 4;
+  const int iy = blockIdx.y, n = blockIdx.z;
+  int ylo, yhi, xlo, xhi;
+  ac_range(iy, sh, OH, ylo, yhi);
+  ac_range((int)ix, sw, OW, xlo, xhi);
+  // ac_range is padded by one or two candidates per side for rounding safety: drop the zero-weight ends
+  while (xlo < xhi && ac_weight(xlo, (int)ix, sw, IW) == 0.f) ++xlo;
+  while (xhi > xlo && ac_weight(xhi, (int)ix, sw, IW) == 0.f) --xhi;
+  float wx[MAXR];
+  int xo[MAXR];
+#pragma unroll
+  for (int k = 0; k < MAXR; ++k) {
+    const int ox = xlo + k;
+    wx[k] = ox <= xhi ? ac_weight(ox, (int)ix, sw, IW) : 0.f;
+    xo[k] = ox <= xhi ? ox : -1;
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* b = dy + (long long)n * OH * OW * lddy + c;
+  for (int oy = ylo; oy <= yhi; ++oy) {
+    const float wy = ac_weight(oy, iy, sh, IH);          // block-uniform
+    if (wy == 0.f) continue;
+    const float* row = b + (long long)oy * OW * lddy;
+    f32x4 v[MAXR];
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) v[k] = xo[k] >= 0 ? ld4(row + (long long)xo[k] * lddy) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 rowacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) rowacc += wx[k] * v[k];
+    acc += wy * rowacc;
+  }
+  st4(dx + ((long long)(n * IH + iy) * IW + ix) * lddx + c, acc);
 }
 
 // ---------------------------------------------------------------- OOD-score tail
@@ -565,6 +657,110 @@ __global__ __launch_bounds__(256) void ood_score_tiled_kernel(const float* __res
   }
 }
 
+// Vector version of the tiled tail for OW % 4 == 0 and a 40-channel-contiguous source (the fused K = 48 heads buffer:
+// dec1 = channels 0..18, dec2 = channels 20..38 of the same pixel row): a workgroup owns TH x TW = 8 x 128 output
+// pixels; every source pixel of its footprint is read ONCE as ten 16-byte loads (160 contiguous bytes), the dec1 part
+// goes to LDS channel-quad-major (slots XOR-swizzled so the stride-2 bilinear taps of neighbouring lanes fall on
+// different bank groups), the dec2 part is reduced to -logsumexp on the spot. Each lane then produces 4 consecutive
+// output pixels of one row: ds_read_b128 taps, float4 stores on every NCHW class plane (uniform plane base + one 32-bit
+// lane offset), one uchar4 label store.
+template <int C, int TH, int TW>
+__global__ __launch_bounds__(256) void ood_score_v4_kernel(const float* __restrict__ dec, int ld, int c1, int c2,
+                                                           int IH, int IW, int OH, int OW, float sh, float sw,
+                                                           int SRmax, int SCmax, float* __restrict__ score,
+                                                           float* __restrict__ logit, uint8_t* __restrict__ label) {
+  constexpr int CQ = (C + 3) / 4;          // channel quads (5 for 19 classes)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int NP = SRmax * SCmax + 16;       // slots per quad plane (swizzle stays inside: p ^ 1 < NP)
+  float* en = lds;                         // [NP] energies
+  f32x4* sv = reinterpret_cast<f32x4*>(lds + ((NP + 3) & ~3));   // [CQ][NP] float4
+  const int n = blockIdx.z;
+  const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+  const int oy1 = min(oy0 + TH, OH) - 1, ox1 = min(ox0 + TW, OW) - 1;
+  const int r0 = ac_tap(oy0, sh, IH).i0, r1 = ac_tap(oy1, sh, IH).i1;
+  const int cc0 = ac_tap(ox0, sw, IW).i0, cc1 = ac_tap(ox1, sw, IW).i1;
+  const int SR = r1 - r0 + 1, SC = cc1 - cc0 + 1;
+  const int npix = SR * SC;
+  const long long nb = (long long)n * IH * IW;
+  auto slot = [](int p) { return p ^ ((p >> 3) & 1); };
+  const bool want_logit = logit || label;
+  for (int pix = threadIdx.x; pix < npix; pix += 256) {
+    const int rr = pix / SC, cc = pix - rr * SC;
+    const float* q = dec + (nb + (long long)(r0 + rr) * IW + (cc0 + cc)) * ld;
+    if (want_logit) {
+#pragma unroll
+      for (int k = 0; k < CQ; ++k) sv[k * NP + slot(pix)] = ld4(q + c1 + 4 * k);
+    }
+    if (score) {
+      float v[CQ * 4];
+#pragma unroll
+      for (int k = 0; k < CQ; ++k) {
+        const f32x4 t = ld4(q + c2 + 4 * k);
+        v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+      }
+      float m = v[0];
+#pragma unroll
+      for (int c = 1; c < C; ++c) m = fmaxf(m, v[c]);
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) sum += expf(v[c] - m);
+      en[pix] = -(m + logf(sum));          // energy_func: -logsumexp (deepv3.py:251-253)
+    }
+  }
+  __syncthreads();
+  const int ty = threadIdx.x / (TW / 4), xq = threadIdx.x % (TW / 4);
+  const int oy = oy0 + ty, ox = ox0 + 4 * xq;
+  if (oy > oy1 || ox > ox1) return;        // OW % 4 == 0: a quad is inside or outside as a whole
+  const Tap tapy = ac_tap(oy, sh, IH);
+  const int rowa = (tapy.i0 - r0) * SC - cc0, rowb = (tapy.i1 - r0) * SC - cc0;
+  int pa0[4], pa1[4], pb0[4], pb1[4];
+  float l0[4], l1[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const Tap t = ac_tap(ox + e, sw, IW);
+    pa0[e] = rowa + t.i0; pa1[e] = rowa + t.i1; pb0[e] = rowb + t.i0; pb1[e] = rowb + t.i1;
+    l0[e] = t.l0; l1[e] = t.l1;
+  }
+  const long long plane = (long long)OH * OW;
+  const long long opix = (long long)oy * OW + ox;
+  if (score) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = tapy.l0 * (l0[e] * en[pa0[e]] + l1[e] * en[pa1[e]]) + tapy.l1 * (l0[e] * en[pb0[e]] + l1[e] * en[pb1[e]]);
+    st4(score + (long long)n * plane + opix, o);
+  }
+  if (want_logit) {
+    float best[4] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+    int arg[4] = {0, 0, 0, 0};
+    const unsigned voff = (unsigned)(((long long)n * C * plane + opix) * 4);    // launcher: N*C*OH*OW*4 < 2^32
+    char* lbase = reinterpret_cast<char*>(logit);
+#pragma unroll
+    for (int k = 0; k < CQ; ++k) {
+      f32x4 val[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 a0 = sv[k * NP + slot(pa0[e])], a1 = sv[k * NP + slot(pa1[e])];
+        const f32x4 b0 = sv[k * NP + slot(pb0[e])], b1 = sv[k * NP + slot(pb1[e])];
+        val[e] = tapy.l0 * (l0[e] * a0 + l1[e] * a1) + tapy.l1 * (l0[e] * b0 + l1[e] * b1);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 4 * k + j;
+        if (c >= C) break;
+        const f32x4 o = {val[0][j], val[1][j], val[2][j], val[3][j]};
+        if (logit) *reinterpret_cast<f32x4*>(lbase + (size_t)c * plane * 4 + voff) = o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (o[e] > best[e] || (o[e] != o[e] && best[e] == best[e])) { best[e] = o[e]; arg[e] = c; }   // first max; NaN wins like torch
+      }
+    }
+    if (label)
+      *reinterpret_cast<uint32_t*>(label + (long long)n * plane + opix) =
+          (uint32_t)arg[0] | ((uint32_t)arg[1] << 8) | ((uint32_t)arg[2] << 16) | ((uint32_t)arg[3] << 24);
+  }
+}
+
 // backward of the tail: one thread per half-resolution pixel (gather form of the transpose)
 template <int C>
 __global__ __launch_bounds__(256) void ood_score_bwd_kernel(const float* __restrict__ dec2, int ld2,
@@ -696,6 +892,12 @@ int mss_nchw_to_nhwc_pad_f32(const float* x, float* y, int N, int C, int H, int 
   return mss_launch_status();
 }
 
+int mss_im2col3x3_c3_f32(const float* img, float* out, int N, int H, int W, void* stream) {
+  if (!img || !out || N <= 0 || H <= 0 || W <= 0 || H > 65535 || N > 65535) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(im2col3x3_c3_kernel, dim3((W + 255) / 256, H, N), dim3(256), 0, S_(stream), img, out, H, W);
+  return mss_launch_status();
+}
+
 // doubles the `accum` argument of the three per-channel reductions below must hold: [2C] results followed by the
 // partial matrix of the first stage (contents irrelevant on entry; nothing has to be zeroed)
 long long mss_col_reduce_accum_doubles(long long M, int C) {
@@ -811,16 +1013,25 @@ int mss_broadcast_rows_nhwc_f32(const float* v, float* y, int ldy, int N, int HW
 int mss_upsample_ac_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N, int IH, int IW, int OH, int OW,
                              int C, void* stream) {
   if (!x || !y || C % 4 || ldx % 4 || ldy % 4) return MSS_ERR_BAD_ARG;
-  hipLaunchKernelGGL(upsample_ac_kernel, dim3(grid_for((long long)N * OH * OW * (C / 4))), dim3(256), 0, S_(stream),
-                     x, ldx, y, ldy, N, IH, IW, OH, OW, C, ac_scale(IH, OH), ac_scale(IW, OW));
+  if (OH > 65535 || N > 65535) return MSS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(upsample_ac_kernel, dim3((unsigned)(((long long)OW * (C / 4) + 255) / 256), OH, N), dim3(256), 0,
+                     S_(stream), x, ldx, y, ldy, IH, IW, OH, OW, C, ac_scale(IH, OH), ac_scale(IW, OW));
   return mss_launch_status();
 }
 
 int mss_upsample_ac_nhwc_bwd_f32(const float* dy, int lddy, float* dx, int lddx, int N, int IH, int IW, int OH,
                                  int OW, int C, void* stream) {
   if (!dy || !dx || C % 4 || lddx % 4 || lddy % 4) return MSS_ERR_BAD_ARG;
+  const float sh = ac_scale(IH, OH), sw = ac_scale(IW, OW);
+  // candidates per axis: ceil((i+1)/s) + 1 - (floor((i-1)/s) - 1) + 1 <= 2/s + 5
+  constexpr int MAXR = 14;
+  if (sw > 0.f && 2.f / sw + 5.f <= (float)MAXR && IH <= 65535 && N <= 65535) {
+    hipLaunchKernelGGL(upsample_ac_bwd_fast_kernel<MAXR>, dim3((unsigned)(((long long)IW * (C / 4) + 255) / 256), IH, N),
+                       dim3(256), 0, S_(stream), dy, lddy, dx, lddx, IH, IW, OH, OW, C, sh, sw);
+    return mss_launch_status();
+  }
   hipLaunchKernelGGL(upsample_ac_bwd_kernel, dim3(grid_for((long long)N * IH * IW * (C / 4))), dim3(256), 0,
-                     S_(stream), dy, lddy, dx, lddx, N, IH, IW, OH, OW, C, ac_scale(IH, OH), ac_scale(IW, OW));
+                     S_(stream), dy, lddy, dx, lddx, N, IH, IW, OH, OW, C, sh, sw);
   return mss_launch_status();
 }
 
@@ -834,6 +1045,23 @@ int mss_ood_score_f32(const float* dec2, int ld2, const float* dec1, int ld1, in
     constexpr int TH = 8, TW = 128;
     const float sh = ac_scale(IH, OH), sw = ac_scale(IW, OW);
     const int SRmax = (int)((TH - 1) * sh) + 3, SCmax = (int)((TW - 1) * sw) + 3;
+    // both heads in one pixel-contiguous buffer (the K = 48 fused heads GEMM output), 16-byte aligned everywhere
+    const float* base = dec1 ? (dec2 ? (dec1 < dec2 ? dec1 : dec2) : dec1) : dec2;
+    const long long off1 = dec1 ? dec1 - base : 0, off2 = dec2 ? dec2 - base : 0;
+    const int ld = dec1 ? ld1 : ld2;
+    const int NP = SRmax * SCmax + 16;
+    const size_t smem4 = ((size_t)((NP + 3) & ~3) + (size_t)5 * NP * 4) * sizeof(float);
+    const bool v4 = OW % 4 == 0 && (!dec1 || !dec2 || ld1 == ld2) && ld % 4 == 0 && off1 % 4 == 0 && off2 % 4 == 0 &&
+                    off1 + 20 <= ld && off2 + 20 <= ld && smem4 <= 64 * 1024 && N <= 65535 &&
+                    (long long)N * 19 * OH * OW * 4 < (1ll << 32) &&
+                    ((reinterpret_cast<uintptr_t>(base) | reinterpret_cast<uintptr_t>(score) |
+                      reinterpret_cast<uintptr_t>(logit_nchw) | reinterpret_cast<uintptr_t>(label)) & 15) == 0;
+    if (v4) {
+      hipLaunchKernelGGL((ood_score_v4_kernel<19, TH, TW>), dim3((OW + TW - 1) / TW, (OH + TH - 1) / TH, N), dim3(256),
+                         smem4, S_(stream), base, ld, (int)off1, (int)off2, IH, IW, OH, OW, sh, sw, SRmax, SCmax, score,
+                         logit_nchw, label);
+      return mss_launch_status();
+    }
     const size_t smem = (size_t)SRmax * SCmax * (19 + 1) * sizeof(float);
     if (smem <= 48 * 1024 && N <= 65535) {   // up-sampling: the source footprint of a tile is small
       hipLaunchKernelGGL((ood_score_tiled_kernel<19, TH, TW>), dim3((OW + TW - 1) / TW, (OH + TH - 1) / TH, N),

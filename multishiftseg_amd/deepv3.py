@@ -14,6 +14,7 @@ only -- their forward is never called. What runs instead (all in libmss_hip.so):
     without autograd; the decoder/heads run inside ONE autograd.Function whose backward is a fixed
     sequence of dgrad/wgrad/BN-backward kernels.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -193,8 +194,12 @@ class DeepWV3Plus(nn.Module):
                         res=shortcut, want_stats=train)
 
     def _run_trunk(self, inp):
-        a = K.image_to_nhwc(inp, 16)
-        a = K.conv2d(a, K.packed(self.mod1.conv1.weight), pad=1)
+        if os.environ.get("MSS_STEM_IM2COL", "1") != "0":
+            # 3 -> 64 stem as a dense K = 27 (32) GEMM on explicit 3x3 patches; MSS_STEM_IM2COL=0: the implicit-GEMM
+            # kernel on the image padded to 16 channels (K = 144, 13/16 zeros) -- kept as the independent second route
+            a = K.conv2d(K.stem_im2col(inp), K.packed_stem(self.mod1.conv1.weight))
+        else:
+            a = K.conv2d(K.image_to_nhwc(inp, 16), K.packed(self.mod1.conv1.weight), pad=1)
         m2 = None
         for mod_id in range(6):
             name = f"mod{mod_id + 2}"

@@ -445,6 +445,27 @@ def image_to_nhwc(img, Cp=16):
     return out
 
 
+def stem_im2col(img):
+    """[N,3,H,W] NCHW image -> Act [N,H,W,32]: the 27 taps of a 3x3 / padding-1 window per pixel (+5 zero channels)."""
+    n, c, h, w = img.shape
+    if c != 3:
+        raise ValueError(f"the stem expects a 3-channel image, got {c}")
+    img = img.contiguous()
+    out = Act.empty(n, h, w, 32, img.device)
+    call("mss_im2col3x3_c3_f32", ptr(img), out.ptr, n, h, w)
+    return out
+
+
+def packed_stem(param):
+    """mod1.conv1.weight [64,3,3,3] as the 1x1 weight [64,32,1,1] that matches stem_im2col's channel order."""
+    def make():
+        k = param.shape[0]
+        w = torch.zeros((k, 32, 1, 1), device=param.device, dtype=torch.float32)
+        w[:, :27, 0, 0] = param.detach().reshape(k, 27)
+        return pack_weight(w)
+    return _cached_pack(param, ("stem",), make)
+
+
 class BNState:
     """Folded BatchNorm: y = x*scale + shift (+ what the backward needs in train mode)."""
     __slots__ = ("scale", "shift", "save_mean", "save_invstd", "M", "train")

@@ -26,7 +26,8 @@ pytestmark = pytest.mark.gpu
 LOSS_PARAMS = {"ce_weights": [50, 10], "conduct_pixel_selection": True, "selection_ratio": 0.8,
                "inoutaug_contras_margins_tri": [10, 5, 5]}
 STAGE2 = ["aspp", "bot_fine", "bot_aspp", "ood_head"]
-ROUTES = {"winograd": {}, "direct3x3": {"MSS_WINOGRAD": "0"}, "igemm_only": {"MSS_WINOGRAD": "0", "MSS_GEMM": "0"}}
+ROUTES = {"winograd": {}, "direct3x3": {"MSS_WINOGRAD": "0"},
+          "igemm_only": {"MSS_WINOGRAD": "0", "MSS_GEMM": "0", "MSS_STEM_IM2COL": "0"}}
 _report = {}
 
 
@@ -46,7 +47,7 @@ class _Env:
         self.env = env
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ("MSS_WINOGRAD", "MSS_GEMM", "MSS_WINO_TILE")}
+        self.old = {k: os.environ.get(k) for k in ("MSS_WINOGRAD", "MSS_GEMM", "MSS_WINO_TILE", "MSS_STEM_IM2COL")}
         for k in self.old:
             os.environ.pop(k, None)
         os.environ.update(self.env)

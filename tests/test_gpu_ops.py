@@ -221,7 +221,10 @@ def test_m2f_score(K):
 
 @pytest.mark.parametrize("tile", [2, 4])
 @pytest.mark.parametrize("cin,cout,dil,n,h,w", [(32, 64, 1, 2, 12, 14), (64, 32, 2, 1, 13, 17), (32, 128, 4, 2, 16, 22),
-                                                 (48, 64, 1, 1, 7, 9), (64, 64, 4, 1, 5, 6)])
+                                                 (48, 64, 1, 1, 7, 9), (64, 64, 4, 1, 5, 6),
+                                                 # several channel chunks of the LDS-staged input transform, the last one
+                                                 # ragged: 2x4-tile blocks x 64 channels / 1x2-tile blocks x 256 channels
+                                                 (160, 32, 1, 1, 11, 18), (336, 16, 12, 1, 30, 41)])
 def test_winograd_conv_vs_oracle(K, cin, cout, dil, n, h, w, tile):
     """Winograd F(2x2,3x3) / F(4x4,3x3) path: dilation handled through residue sub-grids, ragged tiles,
     fused BatchNorm+ReLU prologue and residual epilogue."""
