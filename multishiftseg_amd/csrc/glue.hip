@@ -402,9 +402,12 @@ __global__ void broadcast_rows_kernel(const float* __restrict__ v, float* __rest
 struct Tap { int i0, i1; float l0, l1; };
 __device__ __forceinline__ Tap ac_tap(int o, float scale, int in) {
   Tap t;
-  // __fmul_rn: never contracted into the subtraction below. ATen rounds scale * o to fp32 first (area_pixel_compute_
-  // source_index); an fma(scale, o, -i0) is more accurate but moves the weights by up to 3e-5 at o ~ 700
-  const float src = __fmul_rn(scale, (float)o);
+  // ATen rounds scale * o to fp32 first (area_pixel_compute_source_index) and subtracts afterwards. Under the default
+  // -ffp-contract=fast the product would be fused into the subtraction below (fma(scale, o, -i0): more accurate, but
+  // it moves the weights by up to 3e-5 at o ~ 700 and the interpolated values by 2e-4); the empty asm pins the rounded
+  // product in a register (__fmul_rn is a plain multiply in HIP and does not prevent the contraction)
+  float src = scale * (float)o;
+  asm volatile("" : "+v"(src));
   t.i0 = (int)src;
   t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
   t.l1 = src - (float)t.i0;

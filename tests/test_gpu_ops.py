@@ -225,9 +225,12 @@ def test_m2f_score(K):
                                                  # several channel chunks of the LDS-staged input transform, the last one
                                                  # ragged: 2x4-tile blocks x 64 channels / 1x2-tile blocks x 256 channels
                                                  (160, 32, 1, 1, 11, 18), (336, 16, 12, 1, 30, 41)])
-def test_winograd_conv_vs_oracle(K, cin, cout, dil, n, h, w, tile):
+def test_winograd_conv_vs_oracle(K, cin, cout, dil, n, h, w, tile, monkeypatch):
     """Winograd F(2x2,3x3) / F(4x4,3x3) path: dilation handled through residue sub-grids, ragged tiles,
-    fused BatchNorm+ReLU prologue and residual epilogue."""
+    fused BatchNorm+ReLU prologue and residual epilogue. MSS_WINO_INPUT_LDS=2 sends every F(4x4) input transform
+    through the LDS-staged kernel (the policy would keep these small, ragged maps on the one-thread-per-tile kernel,
+    which the whole-network tests and the other op tests cover)."""
+    monkeypatch.setenv("MSS_WINO_INPUT_LDS", "2")
     rng = np.random.default_rng(cin + cout + dil)
     x = rng.standard_normal((n, cin, h, w), dtype=np.float32)
     wt = (rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) / np.sqrt(cin * 9)).astype(np.float32)
