@@ -141,19 +141,36 @@ __device__ __forceinline__ void col_reduce2(long long M, int C, double* __restri
   }
 }
 
-// accum[col] = sum over the nparts rows of part (= accum + ncols), ascending, 4 interleaved row lanes per column
-// combined in a fixed order. block 256 = 64 columns x 4 row lanes.
+// accum[col] = sum over the nparts rows of part (= accum + ncols). Block 256 = 4 columns x 64 row lanes: lane rl adds
+// rows rl, rl+64, ... (all its loads issued before the first add: the partials were just written and sit in L2, the cost
+// is latency, not bytes), then the 64 lane sums are combined by a fixed-shape tree. The order never depends on
+// timing, so the result is bit-reproducible.
 __global__ __launch_bounds__(256) void col_reduce_final_kernel(double* __restrict__ accum, int nparts, int ncols) {
   const double* __restrict__ part = accum + ncols;
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int col = blockIdx.x * 4 + cl;
   double s = 0.0;
-  if (col < ncols)
-    for (int r = rl; r < nparts; r += 4) s += part[(size_t)r * ncols + col];
+  if (col < ncols) {
+    for (int r0 = rl; r0 < nparts; r0 += 64 * 16) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int r = r0 + 64 * u;
+        v[u] = r < nparts ? part[(size_t)r * ncols + col] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+  }
   __shared__ double red[256];
   red[threadIdx.x] = s;
   __syncthreads();
-  if (rl == 0 && col < ncols)
-    accum[col] = ((red[threadIdx.x] + red[threadIdx.x + 64]) + red[threadIdx.x + 128]) + red[threadIdx.x + 192];
+#pragma unroll
+  for (int half = 32; half >= 1; half >>= 1) {
+    if (rl < half) red[threadIdx.x] += red[threadIdx.x + 4 * half];
+    __syncthreads();
+  }
+  if (rl == 0 && col < ncols) accum[col] = red[threadIdx.x];
 }
 
 inline dim3 col_reduce_grid(long long M, int C) {
@@ -255,36 +272,53 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(
   });
 }
 
-__global__ void bn_relu_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
-                                         int ldx, float* __restrict__ dx, int lddx, long long M, int C,
-                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                         const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
-                                         int relu, const double* __restrict__ accum) {
+// dx = scale * (dz - mean(dz) - xhat * mean(dz * xhat)), dz = dy * (y > 0). A thread owns one channel quad (its per-channel
+// constants are loaded once and folded: dx = A*dz - B - D*(x - mean)) and walks rows; grid (quad groups, row groups). The
+// flat-index form spent more instructions on a 64-bit div/mod and 18 constant loads per element than on the data.
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
+    const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx, float* __restrict__ dx, int lddx,
+    long long M, int C, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu,
+    const double* __restrict__ accum, int QPB) {
   const int C4 = C >> 2;
-  const long long total = M * C4;
-  const float invM = 1.f / (float)M;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / C4;
-    const int c = (int)(i - r * C4) * 4;
-    f32x4 g = ld4(dy + r * lddy + c);
-    f32x4 v = ld4(x + r * ldx + c);
-    f32x4 sc = ld4(scale + c), sh = ld4(shift + c);
+  const int RPB = 256 / QPB;
+  const int tx = threadIdx.x % QPB, ty = threadIdx.x / QPB;
+  const int q = blockIdx.x * QPB + tx;
+  if (q >= C4 || ty >= RPB) return;
+  const int c = q * 4;
+  const f32x4 sc = ld4(scale + c), sh = ld4(shift + c);
+  f32x4 Bc = {0.f, 0.f, 0.f, 0.f}, Dc = {0.f, 0.f, 0.f, 0.f}, mu = {0.f, 0.f, 0.f, 0.f};
+  if (accum) {
+    const float invM = 1.f / (float)M;
+    mu = ld4(save_mean + c);
+    const f32x4 is = ld4(save_invstd + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float s1 = (float)accum[c + k], s2 = (float)accum[C + c + k];
+      Bc[k] = sc[k] * (s1 * invM);
+      Dc[k] = sc[k] * (s2 * invM) * is[k];
+    }
+  }
+  const long long rstep = (long long)gridDim.y * RPB;
+  long long r = (long long)blockIdx.y * RPB + ty;
+  auto one = [&](const f32x4 g, const f32x4 v) {
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float dz = g[k];
       if (relu && !(v[k] * sc[k] + sh[k] > 0.f)) dz = 0.f;
-      if (accum) {
-        const float xhat = (v[k] - save_mean[c + k]) * save_invstd[c + k];
-        const float s1 = (float)accum[c + k], s2 = (float)accum[C + c + k];
-        o[k] = sc[k] * (dz - s1 * invM - xhat * s2 * invM);
-      } else {
-        o[k] = sc[k] * dz;
-      }
+      o[k] = sc[k] * dz - Bc[k] - Dc[k] * (v[k] - mu[k]);
     }
-    st4(dx + r * lddx + c, o);
+    return o;
+  };
+  for (; r + 3 * rstep < M; r += 4 * rstep) {
+    f32x4 g[4], v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { g[u] = ld4(dy + (r + u * rstep) * lddy + c); v[u] = ld4(x + (r + u * rstep) * ldx + c); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) st4(dx + (r + u * rstep) * lddx + c, one(g[u], v[u]));
   }
+  for (; r < M; r += rstep) st4(dx + r * lddx + c, one(ld4(dy + r * lddy + c), ld4(x + r * ldx + c)));
 }
 
 __global__ void bn_param_grad_kernel(const double* __restrict__ accum, int C, float* dgamma, float* dbeta) {
@@ -824,6 +858,131 @@ __global__ __launch_bounds__(256) void ood_score_bwd_kernel(const float* __restr
   }
 }
 
+// Tiled backward of the tail for the x2 case (OW % 4 == 0, at most MAXW contributing outputs per axis): a workgroup
+// owns TSY x TSX = 4 x 64 half-resolution pixels (one per thread) and walks the 19 class planes of dlogit plus dscore
+// as 5 groups of 4 planes: each group's output footprint (~10 rows x 132 columns per plane) is staged in LDS with
+// coalesced 16-byte loads, one plane row at a time, instead of ~30 candidate positions x 19 strided 4-byte loads per
+// thread (which ran at 1 TB/s). Every thread then writes its 48-channel row of the fused-heads gradient (ddec1 =
+// channels c1.., ddec2 = channels c2.., the padding channels as zeros, so the buffer needs no memset).
+template <int C, int MAXW>
+__global__ __launch_bounds__(256) void ood_score_bwd_tiled_kernel(
+    const float* __restrict__ dec2, int ld2, const float* __restrict__ dscore, const float* __restrict__ dlogit, int IH,
+    int IW, int OH, int OW, float sh, float sw, float* __restrict__ dd, int ldd, int c1, int c2, int RR, int RC) {
+  constexpr int TSY = 4, TSX = 64, G = 4;            // G planes per pass; planes 0..C-1 = dlogit, plane C = dscore
+  extern __shared__ __attribute__((aligned(16))) float lds[];     // [G][RR][RC]
+  const int n = blockIdx.z, iy0 = blockIdx.y * TSY, ix0 = blockIdx.x * TSX;
+  const int tx = threadIdx.x % TSX, tyl = threadIdx.x / TSX;
+  const int iy = iy0 + tyl, ix = ix0 + tx;
+  const bool live = iy < IH && ix < IW;
+  // footprint of the tile in the output (block-uniform)
+  int ylo, yhi, xlo, xhi, t0, t1;
+  ac_range(iy0, sh, OH, ylo, t1);
+  ac_range(min(iy0 + TSY, IH) - 1, sh, OH, t0, yhi);
+  ac_range(ix0, sw, OW, xlo, t1);
+  ac_range(min(ix0 + TSX, IW) - 1, sw, OW, t0, xhi);
+  xlo &= ~3;                                          // 16-byte aligned rows
+  const int nrow = yhi - ylo + 1, ncol4 = (xhi - xlo + 4) >> 2;   // <= RR, <= RC / 4 by construction
+  // this thread's weights (trimmed to the non-zero ones)
+  int oy_a = 0, ox_a = 0, ny = 0, nx = 0;
+  float wy[MAXW], wx[MAXW];
+#pragma unroll
+  for (int k = 0; k < MAXW; ++k) { wy[k] = 0.f; wx[k] = 0.f; }
+  if (live) {
+    int a, b;
+    ac_range(iy, sh, OH, a, b);
+    while (a < b && ac_weight(a, iy, sh, IH) == 0.f) ++a;
+    while (b > a && ac_weight(b, iy, sh, IH) == 0.f) --b;
+    oy_a = a; ny = b - a + 1;
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) if (k < ny) wy[k] = ac_weight(a + k, iy, sh, IH);
+    ac_range(ix, sw, OW, a, b);
+    while (a < b && ac_weight(a, ix, sw, IW) == 0.f) ++a;
+    while (b > a && ac_weight(b, ix, sw, IW) == 0.f) --b;
+    ox_a = a; nx = b - a + 1;
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) if (k < nx) wx[k] = ac_weight(a + k, ix, sw, IW);
+  }
+  const int ro = oy_a - ylo, co = ox_a - xlo;
+  const long long plane = (long long)OH * OW;
+  float gl[C + 1];
+#pragma unroll
+  for (int c = 0; c <= C; ++c) gl[c] = 0.f;
+#pragma unroll
+  for (int pass = 0; pass < (C + 1 + G - 1) / G; ++pass) {
+    __syncthreads();
+    // stage G planes x nrow rows x ncol4 float4
+    const int per_plane = nrow * ncol4;
+    for (int i = threadIdx.x; i < G * per_plane; i += 256) {
+      const int g = i / per_plane, rem = i - g * per_plane;
+      const int rr = rem / ncol4, c4 = rem - rr * ncol4;
+      const int pl = pass * G + g;
+      const int ox = xlo + 4 * c4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pl <= C && ox < OW) {
+        const float* src = pl < C ? (dlogit ? dlogit + ((long long)n * C + pl) * plane : nullptr)
+                                  : (dscore ? dscore + (long long)n * plane : nullptr);
+        if (src) v = ld4(src + (long long)(ylo + rr) * OW + ox);
+      }
+      *reinterpret_cast<f32x4*>(&lds[(g * RR + rr) * RC + 4 * c4]) = v;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int pl = pass * G + g;
+        if (pl > C) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < MAXW; ++a) {
+          if (a >= ny) break;
+          const float* row = &lds[(g * RR + ro + a) * RC + co];
+          float racc = 0.f;
+#pragma unroll
+          for (int b = 0; b < MAXW; ++b) if (b < nx) racc += wx[b] * row[b];
+          acc += wy[a] * racc;
+        }
+        gl[pl] = acc;
+      }
+    }
+  }
+  if (!live) return;
+  const long long spix = ((long long)n * IH + iy) * IW + ix;
+  float* o = dd + spix * ldd;
+  // ddec1: channels c1 .. c1+C-1 (+ padding up to the next multiple of 4)
+  constexpr int CQ = (C + 3) / 4;
+#pragma unroll
+  for (int k = 0; k < CQ; ++k) {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (4 * k + j < C && dlogit) ? gl[4 * k + j] : 0.f;
+    st4(o + c1 + 4 * k, v);
+  }
+  // ddec2 = -gs * softmax(dec2)   (d(-lse)/dx_c = -softmax_c)
+  {
+    const float* q = dec2 + spix * ld2;
+    float v[CQ * 4];
+#pragma unroll
+    for (int k = 0; k < CQ; ++k) { const f32x4 t = ld4(q + 4 * k); v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
+    float m = v[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) m = fmaxf(m, v[c]);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - m); sum += v[c]; }
+    const float kk = dscore ? -gl[C] / sum : 0.f;
+#pragma unroll
+    for (int k = 0; k < CQ; ++k) {
+      f32x4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = 4 * k + j < C ? kk * v[4 * k + j] : 0.f;
+      st4(o + c2 + 4 * k, w);
+    }
+  }
+  // channels outside the two heads (the GEMM's padding rows): zeros
+  for (int c = 0; c < ldd; c += 4)
+    if ((c < c1 || c >= c1 + 4 * CQ) && (c < c2 || c >= c2 + 4 * CQ)) st4(o + c, f32x4{0.f, 0.f, 0.f, 0.f});
+}
+
 // ---------------------------------------------------------------- Mask2Former anomaly score
 // block = one row segment of 256 pixels of one image; class probabilities of the image's Q
 // queries live in LDS as [Q][CP] (CP = C rounded up to 4) and are read as broadcast b128.
@@ -917,7 +1076,7 @@ int mss_bn_stats_nhwc_f32(const float* x, long long M, int C, int ldx, double* a
   if (M <= 0) return MSS_OK;
   const dim3 grid = col_reduce_grid(M, C);
   hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, S_(stream), x, M, C, ldx, accum);
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, S_(stream), accum, (int)grid.y, 2 * C);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, S_(stream), accum, (int)grid.y, 2 * C);
   return mss_launch_status();
 }
 
@@ -926,7 +1085,7 @@ int mss_bn_stats_partials_f32(const float* partials, long long nparts, int C, do
   if (nparts <= 0) return MSS_OK;
   const dim3 grid = col_reduce_grid(nparts, C);
   hipLaunchKernelGGL(bn_stats_partials_kernel, grid, dim3(256), 0, S_(stream), partials, nparts, C, accum);
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, S_(stream), accum, (int)grid.y, 2 * C);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, S_(stream), accum, (int)grid.y, 2 * C);
   return mss_launch_status();
 }
 
@@ -965,7 +1124,7 @@ int mss_bn_relu_bwd_reduce_f32(const float* dy, int lddy, const float* x, int ld
   const dim3 grid = col_reduce_grid(M, C);
   hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, grid, dim3(256), 0, S_(stream), dy, lddy, x, ldx,
                      M, C, scale, shift, save_mean, save_invstd, relu, accum);
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, S_(stream), accum, (int)grid.y, 2 * C);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, S_(stream), accum, (int)grid.y, 2 * C);
   return mss_launch_status();
 }
 
@@ -978,8 +1137,18 @@ int mss_bn_relu_bwd_apply_f32(const float* dy, int lddy, const float* x, int ldx
   if (accum && (!save_mean || !save_invstd)) return MSS_ERR_BAD_ARG;
   if (C % 4 || ldx % 4 || lddy % 4 || lddx % 4) return MSS_ERR_BAD_ARG;
   if (M <= 0) return MSS_OK;
-  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, S_(stream), dy, lddy, x,
-                     ldx, dx, lddx, M, C, scale, shift, save_mean, save_invstd, relu, accum);
+  {
+    const int C4 = C / 4;
+    const int QPB = C4 < 64 ? C4 : 64;
+    const int gx = (C4 + QPB - 1) / QPB, RPB = 256 / QPB;
+    long long gy = 4096 / gx;                               // ~4096 workgroups
+    const long long max_gy = (M + (long long)RPB * 8 - 1) / ((long long)RPB * 8);
+    if (gy > max_gy) gy = max_gy;
+    if (gy < 1) gy = 1;
+    if (gy > 65535) gy = 65535;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, S_(stream), dy, lddy, x, ldx, dx,
+                       lddx, M, C, scale, shift, save_mean, save_invstd, relu, accum, QPB);
+  }
   if (accum && (dgamma || dbeta))
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, S_(stream), accum, C, dgamma,
                        dbeta);
@@ -1085,6 +1254,28 @@ int mss_ood_score_bwd_f32(const float* dec2, int ld2, const float* dscore, const
   if (C != 19) return MSS_ERR_UNSUPPORTED;
   if (ddec2 && !dec2) return MSS_ERR_BAD_ARG;
   if ((long long)N * IH * IW == 0) return MSS_OK;
+  {
+    // tiled path: both heads' gradients go into one pixel-contiguous buffer (the 48-wide input of the fused-heads dgrad)
+    constexpr int MAXW = 6, TSY = 4, TSX = 64;
+    const float sh = ac_scale(IH, OH), sw = ac_scale(IW, OW);
+    const bool up = sh > 0.f && sw > 0.f && (int)(2.f / sh) + 2 <= MAXW && (int)(2.f / sw) + 2 <= MAXW;
+    if (up && ddec1 && ddec2 && ldd1 == ldd2 && OW % 4 == 0 && ldd1 % 4 == 0 && ld2 % 4 == 0 && N <= 65535) {
+      float* base = ddec1 < ddec2 ? ddec1 : ddec2;
+      const long long c1 = ddec1 - base, c2 = ddec2 - base;
+      const int RR = (int)((TSY + 1) / sh) + 6, RC = ((int)((TSX + 1) / sw) + 10 + 3) & ~3;
+      const size_t smem = (size_t)4 * RR * RC * sizeof(float);
+      const bool ok = c1 % 4 == 0 && c2 % 4 == 0 && c1 + 20 <= ldd1 && c2 + 20 <= ldd1 && (c1 + 20 <= c2 || c2 + 20 <= c1) &&
+                      smem <= 64 * 1024 &&
+                      ((reinterpret_cast<uintptr_t>(base) | reinterpret_cast<uintptr_t>(dec2) | reinterpret_cast<uintptr_t>(dscore) |
+                        reinterpret_cast<uintptr_t>(dlogit_nchw)) & 15) == 0;
+      if (ok) {
+        hipLaunchKernelGGL((ood_score_bwd_tiled_kernel<19, MAXW>), dim3((IW + TSX - 1) / TSX, (IH + TSY - 1) / TSY, N),
+                           dim3(256), smem, S_(stream), dec2, ld2, dscore, dlogit_nchw, IH, IW, OH, OW, sh, sw, base, ldd1,
+                           (int)c1, (int)c2, RR, RC);
+        return mss_launch_status();
+      }
+    }
+  }
   hipLaunchKernelGGL(ood_score_bwd_kernel<19>, dim3(grid_for((long long)N * IH * IW, 256, 1 << 20)), dim3(256), 0,
                      S_(stream), dec2, ld2, ddec2 ? dscore : nullptr, ddec1 ? dlogit_nchw : nullptr, N, IH, IW, OH,
                      OW, ac_scale(IH, OH), ac_scale(IW, OW), ddec2, ldd2, ddec1, ldd1);

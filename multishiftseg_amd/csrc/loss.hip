@@ -222,7 +222,7 @@ __global__ void rcl_select_init_kernel(const double* __restrict__ counters, floa
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const float n_in = (float)counters[CNT_N_IN_AUG];
     const uint32_t k = (uint32_t)(int)(ratio * n_in);  // int(selection_ratio * total_num), float32 as in torch
-    sel[0] = 0; sel[1] = 0; sel[2] = k; sel[3] = 0; sel[4] = 0; sel[5] = k;
+    sel[0] = 0; sel[1] = 0; sel[2] = k; sel[3] = 0; sel[4] = 0; sel[5] = k; sel[6] = 0;
   }
   for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
 }
@@ -243,6 +243,76 @@ __global__ __launch_bounds__(256) void rcl_hist_kernel(const float* __restrict__
   }
   __syncthreads();
   if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+// One radix pass of the local (single-process) selection in ONE launch: histogram as rcl_hist_kernel, then the last
+// workgroup to finish (ticket in sel[6]) picks the digit with a 256-lane prefix sum and clears hist / the ticket for the
+// next pass. WAVE_AGG: the first pass looks at the sign + exponent byte, which takes ~6 distinct values for CE values --
+// every lane of a wave hits the same few LDS words, so a wave adds ONE count per distinct digit instead of 64 serialised
+// atomics (41 us -> a few us on 2.1 M values).
+template <bool WAVE_AGG>
+__global__ __launch_bounds__(256) void rcl_hist_pick_kernel(const float* __restrict__ v, long long n, uint32_t* sel,
+                                                            int shift, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t lh[256];
+  __shared__ uint32_t scan[256];
+  __shared__ int last;
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t prefix = sel[0];
+  const uint32_t mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+  if (sel[2] != 0) {
+    const long long step = (long long)gridDim.x * blockDim.x;
+    const long long n_round = (n + step - 1) / step * step;     // whole waves stay converged through the ballot loop
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += step) {
+      uint32_t key = 0;
+      bool take = false;
+      if (i < n) { key = f2key(v[i]); take = (key & mask) == (prefix & mask); }
+      const uint32_t digit = (key >> shift) & 255u;
+      if (WAVE_AGG) {
+        unsigned long long todo = __ballot(take);
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const uint32_t d0 = (uint32_t)__shfl((int)digit, leader);
+          const unsigned long long same = __ballot(take && digit == d0) & todo;
+          if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lh[d0], (uint32_t)__popcll(same));
+          todo &= ~same;
+        }
+      } else if (take) {
+        atomicAdd(&lh[digit], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&sel[6], 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // ---- pick (one workgroup): digit d with excl(d) < krem <= incl(d)
+  const uint32_t cnt = __hip_atomic_load(&hist[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  scan[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const uint32_t t = threadIdx.x >= (unsigned)o ? scan[threadIdx.x - o] : 0u;
+    __syncthreads();
+    scan[threadIdx.x] += t;
+    __syncthreads();
+  }
+  if (sel[2] != 0) {
+    const uint32_t krem = sel[5], incl = scan[threadIdx.x], excl = incl - cnt;
+    const bool mine = excl < krem && krem <= incl;
+    const bool fallback = threadIdx.x == 255 && krem > incl;     // cannot happen for a consistent k; mirrors the serial pick
+    if (mine || fallback) {
+      sel[0] |= (uint32_t)threadIdx.x << shift;
+      sel[1] += excl;
+      sel[5] = krem - excl;
+      if (shift == 0) sel[3] = krem - excl;     // how many elements equal to the threshold are taken
+    }
+  }
+  hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0) sel[6] = 0;
 }
 
 __global__ void rcl_pick_kernel(uint32_t* sel, uint32_t* hist, int shift) {
@@ -687,7 +757,9 @@ int mss_rcl_pass1_f32(const MssRclArgs* a, float* lse, float* ce_aug, uint8_t* k
   const bool v4 = rcl_vec4(a) && ((reinterpret_cast<uintptr_t>(lse) | reinterpret_cast<uintptr_t>(ce_aug) |
                                    reinterpret_cast<uintptr_t>(kind) | reinterpret_cast<uintptr_t>(dlogit)) & 15) == 0;
   if (v4)
-    hipLaunchKernelGGL(rcl_pass1_v4_kernel<19>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, S_(stream), *a, lse,
+    // 768 = 3 resident workgroups per CU (147 registers): every workgroup ends with 8 double atomics on the same 8 counters,
+    // and same-address atomics retire at ~80 per microsecond -- 8192 workgroups spent more time there than streaming
+    hipLaunchKernelGGL(rcl_pass1_v4_kernel<19>, dim3(grid_for(total / 4, 768)), dim3(256), 0, S_(stream), *a, lse,
                        ce_aug, kind, counters, dlogit);
   else
     hipLaunchKernelGGL(rcl_pass1_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), *a, lse, ce_aug, kind,
@@ -700,11 +772,10 @@ int mss_rcl_select_f32(const float* ce_aug, long long n, const double* counters,
   if (!ce_aug || !counters || !hist_ws || !sel || n <= 0) return MSS_ERR_BAD_ARG;
   hipLaunchKernelGGL(rcl_select_init_kernel, dim3(1), dim3(256), 0, S_(stream), counters, selection_ratio, sel,
                      hist_ws);
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    hipLaunchKernelGGL(rcl_hist_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, S_(stream), ce_aug, n, sel, shift,
-                       hist_ws);
-    hipLaunchKernelGGL(rcl_pick_kernel, dim3(1), dim3(256), 0, S_(stream), sel, hist_ws, shift);
-  }
+  const dim3 grid(grid_for(n, 1024));
+  hipLaunchKernelGGL(rcl_hist_pick_kernel<true>, grid, dim3(256), 0, S_(stream), ce_aug, n, sel, 24, hist_ws);
+  for (int shift = 16; shift >= 0; shift -= 8)
+    hipLaunchKernelGGL(rcl_hist_pick_kernel<false>, grid, dim3(256), 0, S_(stream), ce_aug, n, sel, shift, hist_ws);
   return mss_launch_status();
 }
 
@@ -766,7 +837,7 @@ int mss_rcl_pass2_f32(const MssRclArgs* a, const float* lse, const float* ce_aug
   const bool v4 = rcl_vec4(a) && ((reinterpret_cast<uintptr_t>(lse) | reinterpret_cast<uintptr_t>(ce_aug) |
                                    reinterpret_cast<uintptr_t>(kind) | reinterpret_cast<uintptr_t>(dlogit)) & 15) == 0;
   if (v4)
-    hipLaunchKernelGGL(rcl_pass2_v4_kernel<19>, dim3(grid_for(n_aug / 4, 8192)), dim3(256), 0, S_(stream), *a, lse,
+    hipLaunchKernelGGL(rcl_pass2_v4_kernel<19>, dim3(grid_for(n_aug / 4, 1024)), dim3(256), 0, S_(stream), *a, lse,
                        ce_aug, kind, sel, counters, grad_scale, dlogit);
   else
     hipLaunchKernelGGL(rcl_pass2_kernel, dim3(grid_for(n_aug)), dim3(256), 0, S_(stream), *a, lse, ce_aug, kind, sel,
@@ -804,7 +875,8 @@ int mss_rcl_pairs_device_f32(const float* score, const int32_t* idx_a, const int
                              double* counters, int slot, float grad_w, float* dscore, void* stream) {
   if (!score || !idx_a || !idx_o || !n_out || !counters) return MSS_ERR_BAD_ARG;
   if ((slot != 0 && slot != 1) || (set_a != 0 && set_a != 1)) return MSS_ERR_BAD_ARG;
-  hipLaunchKernelGGL(rcl_pairs_kernel<true>, dim3(2048), dim3(256), 0, S_(stream), score, idx_a, nullptr, idx_o,
+  // 256 workgroups: the pair count is only known on the device, and each workgroup ends with one same-address atomic
+  hipLaunchKernelGGL(rcl_pairs_kernel<true>, dim3(256), dim3(256), 0, S_(stream), score, idx_a, nullptr, idx_o,
                      nullptr, 0ll, n_out, set_a, max_samples, seed_a, seed_o, margin, counters,
                      slot == 0 ? CNT_SUM_CORIG : CNT_SUM_CAUG, grad_w, dscore);
   return mss_launch_status();

@@ -307,8 +307,8 @@ class DeepWV3Plus(nn.Module):
         dscore = dscore.contiguous() if dscore is not None else None
         dlogit = dlogit.contiguous() if dlogit is not None else None
         ddec12 = Act.zeros(N, h2, w2, 48, dev)
-        K.ood_score_bwd(dec12.slice(20, 19), dscore, dlogit, ddec12.slice(20, 19) if dscore is not None else None,
-                        ddec12.slice(0, 19) if dlogit is not None else None, OH, OW)
+        # both slices always: the tiled kernel writes the whole 48-channel row (zeros where a gradient is absent)
+        K.ood_score_bwd(dec12.slice(20, 19), dscore, dlogit, ddec12.slice(20, 19), ddec12.slice(0, 19), OH, OW)
         aff_f1 = (s["st_f1"].scale, s["st_f1"].shift)
         if need["ood_head.weight"]:
             grads["ood_head.weight"] = K.conv2d_wgrad(f1, ddec12.slice(20, 19), 19, 256, 1, 1, in_affine=aff_f1,

@@ -193,18 +193,29 @@ def test_ood_score_tail(K):
         np.testing.assert_allclose(logit.cpu().numpy(), rl, rtol=1e-5, atol=1e-5)
         got = logit.cpu().numpy()
         np.testing.assert_array_equal(label.cpu().numpy(), got.argmax(1))   # bit-exact vs its own logits
-    # backward vs torch autograd of the same composition
-    dt = torch.from_numpy(d).requires_grad_(True)
-    lg = torch.nn.functional.interpolate(dt[:, 0:19], size=(26, 34), mode="bilinear", align_corners=True)
-    sc = torch.nn.functional.interpolate(-torch.logsumexp(dt[:, 20:39], 1, keepdim=True), size=(26, 34), mode="bilinear",
-                                         align_corners=True)[:, 0]
-    gl = torch.from_numpy(rng.standard_normal(tuple(lg.shape), dtype=np.float32))
-    gs = torch.from_numpy(rng.standard_normal(tuple(sc.shape), dtype=np.float32))
-    (lg * gl).sum().backward(retain_graph=True)
-    (sc * gs).sum().backward()
-    dd = K.Act.zeros(n, h, w, 48, "cuda")
-    K.ood_score_bwd(da.slice(20, 19), gs.cuda(), gl.cuda(), dd.slice(20, 19), dd.slice(0, 19), 26, 34)
-    np.testing.assert_allclose(dd.nchw().cpu().numpy(), dt.grad.numpy(), rtol=1e-4, atol=1e-5)
+    # backward vs torch autograd of the same composition: (26, 34) takes the per-pixel gather kernel (OW % 4 != 0), the other
+    # two the LDS-tiled one (several 4x64 tiles, ragged edges); there the 48-channel rows are written whole, so the
+    # destination starts as NaN and the padding channels must come back as zeros
+    for (hh, ww, oh, ow, tiled) in [(13, 17, 26, 34, False), (13, 18, 26, 36, True), (37, 70, 74, 140, True)]:
+        d2 = rng.standard_normal((n, 48, hh, ww), dtype=np.float32) * 3
+        da2 = K.Act.from_nchw(dev(d2))
+        dt = torch.from_numpy(d2).requires_grad_(True)
+        lg = torch.nn.functional.interpolate(dt[:, 0:19], size=(oh, ow), mode="bilinear", align_corners=True)
+        sc = torch.nn.functional.interpolate(-torch.logsumexp(dt[:, 20:39], 1, keepdim=True), size=(oh, ow), mode="bilinear",
+                                             align_corners=True)[:, 0]
+        gl = torch.from_numpy(rng.standard_normal(tuple(lg.shape), dtype=np.float32))
+        gs = torch.from_numpy(rng.standard_normal(tuple(sc.shape), dtype=np.float32))
+        (lg * gl).sum().backward(retain_graph=True)
+        (sc * gs).sum().backward()
+        dd = K.Act(torch.full((n, hh, ww, 48), float("nan"), device="cuda")) if tiled else K.Act.zeros(n, hh, ww, 48, "cuda")
+        K.ood_score_bwd(da2.slice(20, 19), gs.cuda(), gl.cuda(), dd.slice(20, 19), dd.slice(0, 19), oh, ow)
+        np.testing.assert_allclose(dd.nchw().cpu().numpy(), dt.grad.numpy(), rtol=1e-4, atol=1e-5, err_msg=str((hh, ww)))
+        if tiled:   # only one of the two gradients present: the other head's channels are zeros, not garbage
+            dd = K.Act(torch.full((n, hh, ww, 48), float("nan"), device="cuda"))
+            K.ood_score_bwd(da2.slice(20, 19), gs.cuda(), None, dd.slice(20, 19), dd.slice(0, 19), oh, ow)
+            got = dd.nchw().cpu().numpy()
+            np.testing.assert_allclose(got[:, 20:39], dt.grad.numpy()[:, 20:39], rtol=1e-4, atol=1e-5)
+            assert np.all(got[:, 0:20] == 0) and np.all(got[:, 39:] == 0)
 
 
 def test_m2f_score(K):
