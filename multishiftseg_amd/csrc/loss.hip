@@ -245,17 +245,15 @@ __global__ __launch_bounds__(256) void rcl_hist_kernel(const float* __restrict__
   if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
 
-// One radix pass of the local (single-process) selection in ONE launch: histogram as rcl_hist_kernel, then the last
-// workgroup to finish (ticket in sel[6]) picks the digit with a 256-lane prefix sum and clears hist / the ticket for the
-// next pass. WAVE_AGG: the first pass looks at the sign + exponent byte, which takes ~6 distinct values for CE values --
-// every lane of a wave hits the same few LDS words, so a wave adds ONE count per distinct digit instead of 64 serialised
-// atomics (41 us -> a few us on 2.1 M values).
+// Histogram of one radix digit for the local (single-process) selection. WAVE_AGG: the first pass looks at the sign +
+// exponent byte, which takes ~6 distinct values for CE values -- every lane of a wave hits the same few LDS words, so a
+// wave adds ONE count per distinct digit instead of 64 serialised atomics (41 us -> a few us on 2.1 M values).
+// (A single-launch variant whose last workgroup also picked the digit was measured at 65 us per pass: the release
+// fence + returning ticket atomic of 1024 workgroups cost more than the second launch.)
 template <bool WAVE_AGG>
-__global__ __launch_bounds__(256) void rcl_hist_pick_kernel(const float* __restrict__ v, long long n, uint32_t* sel,
-                                                            int shift, uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(256) void rcl_hist2_kernel(const float* __restrict__ v, long long n, const uint32_t* sel,
+                                                        int shift, uint32_t* __restrict__ hist) {
   __shared__ uint32_t lh[256];
-  __shared__ uint32_t scan[256];
-  __shared__ int last;
   lh[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t prefix = sel[0];
@@ -284,14 +282,12 @@ __global__ __launch_bounds__(256) void rcl_hist_pick_kernel(const float* __restr
   }
   __syncthreads();
   if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(&sel[6], 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  // ---- pick (one workgroup): digit d with excl(d) < krem <= incl(d)
-  const uint32_t cnt = __hip_atomic_load(&hist[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// digit d with excl(d) < krem <= incl(d), by a 256-lane prefix sum (the serial scan of rcl_pick_kernel took 8 us)
+__global__ __launch_bounds__(256) void rcl_pick_par_kernel(uint32_t* sel, uint32_t* hist, int shift) {
+  __shared__ uint32_t scan[256];
+  const uint32_t cnt = hist[threadIdx.x];
   scan[threadIdx.x] = cnt;
   __syncthreads();
   for (int o = 1; o < 256; o <<= 1) {
@@ -312,7 +308,6 @@ __global__ __launch_bounds__(256) void rcl_hist_pick_kernel(const float* __restr
     }
   }
   hist[threadIdx.x] = 0;
-  if (threadIdx.x == 0) sel[6] = 0;
 }
 
 __global__ void rcl_pick_kernel(uint32_t* sel, uint32_t* hist, int shift) {
@@ -773,9 +768,11 @@ int mss_rcl_select_f32(const float* ce_aug, long long n, const double* counters,
   hipLaunchKernelGGL(rcl_select_init_kernel, dim3(1), dim3(256), 0, S_(stream), counters, selection_ratio, sel,
                      hist_ws);
   const dim3 grid(grid_for(n, 1024));
-  hipLaunchKernelGGL(rcl_hist_pick_kernel<true>, grid, dim3(256), 0, S_(stream), ce_aug, n, sel, 24, hist_ws);
-  for (int shift = 16; shift >= 0; shift -= 8)
-    hipLaunchKernelGGL(rcl_hist_pick_kernel<false>, grid, dim3(256), 0, S_(stream), ce_aug, n, sel, shift, hist_ws);
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (shift == 24) hipLaunchKernelGGL(rcl_hist2_kernel<true>, grid, dim3(256), 0, S_(stream), ce_aug, n, sel, shift, hist_ws);
+    else hipLaunchKernelGGL(rcl_hist2_kernel<false>, grid, dim3(256), 0, S_(stream), ce_aug, n, sel, shift, hist_ws);
+    hipLaunchKernelGGL(rcl_pick_par_kernel, dim3(1), dim3(256), 0, S_(stream), sel, hist_ws, shift);
+  }
   return mss_launch_status();
 }
 

@@ -26,11 +26,16 @@ template <> struct Vec4<float> { typedef f32x4 type; };
 
 // ------------------------------------------------------------------------------------------
 // forward, fast path
-template <int LPH>
+// FUSED: `loc` / `attn` are the raw sampling offsets and attention logits of the module's two Linears and `ref` the
+// reference points [N,Lq,L,2] (ops/modules/ms_deform_attn.py:100-109): the softmax over the L*P logits and the
+// location arithmetic loc = ref + offset / (W_l, H_l) happen here, on the values the wave has staged in LDS anyway, so
+// the [N,Lq,M,L,P,2] / [N,Lq,M,L,P] tensors (11.7 MB per call at C4, read AND written by a separate kernel) never
+// exist. Same operation order as msda_prepare_kernel, so both routes agree to the last bit.
+template <int LPH, bool FUSED>
 __global__ __launch_bounds__(256) void msda_fwd_fast_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
-    const float* __restrict__ loc, const float* __restrict__ attn, long long npairs, int S, int M, int L, int Lq,
-    int P, float* __restrict__ out) {
+    const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ ref, long long npairs, int S,
+    int M, int L, int Lq, int P, float* __restrict__ out) {
   constexpr int D = 4 * LPH;
   constexpr int HPW = 64 / LPH;  // pairs per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -64,15 +69,30 @@ __global__ __launch_bounds__(256) void msda_fwd_fast_kernel(
   const float* myattn = sattn + g * LP;
   const size_t row_stride = (size_t)M * D;  // floats between consecutive spatial positions
   const float* vbase = value + (size_t)n * S * row_stride + (size_t)m * D + 4 * j;
+  float mx = 0.f, inv = 1.f;
+  if (FUSED) {      // every lane of the pair's group redoes the 12-term softmax statistics from LDS: no exchange needed
+    mx = -__builtin_huge_valf();
+    for (int i = 0; i < LP; ++i) mx = fmaxf(mx, myattn[i]);
+    float sum = 0.f;
+    for (int i = 0; i < LP; ++i) sum += expf(myattn[i] - mx);
+    inv = 1.f / sum;
+  }
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int l = 0; l < L; ++l) {
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
     const float* vl = vbase + (size_t)starts[l] * row_stride;
+    float rx = 0.f, ry = 0.f;
+    if (FUSED) { rx = ref[(nq * L + l) * 2]; ry = ref[(nq * L + l) * 2 + 1]; }
 #pragma unroll 4
     for (int pt = 0; pt < P; ++pt) {
-      const float lx = myloc[(l * P + pt) * 2], ly = myloc[(l * P + pt) * 2 + 1];
-      const float aw = myattn[l * P + pt];
+      float lx = myloc[(l * P + pt) * 2], ly = myloc[(l * P + pt) * 2 + 1];
+      float aw = myattn[l * P + pt];
+      if (FUSED) {
+        lx = rx + lx / (float)W;
+        ly = ry + ly / (float)H;
+        aw = expf(aw - mx) * inv;
+      }
       const float w_im = lx * W - 0.5f, h_im = ly * H - 0.5f;
       const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
       const float hf = floorf(h_im), wf = floorf(w_im);
@@ -562,14 +582,18 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* starts, c
 
 template <int LPH>
 int msda_forward_fast(const float* value, const int64_t* shapes, const int64_t* starts, const float* loc,
-                      const float* attn, int N, int S, int M, int L, int Lq, int P, float* out,
+                      const float* attn, const float* ref, int N, int S, int M, int L, int Lq, int P, float* out,
                       hipStream_t stream) {
   constexpr int HPW = 64 / LPH;
   const long long npairs = (long long)N * Lq * M;
   const long long nblocks = (npairs + 4 * HPW - 1) / (4 * HPW);
   const size_t smem = (size_t)4 * HPW * L * P * 3 * sizeof(float);
-  hipLaunchKernelGGL(msda_fwd_fast_kernel<LPH>, dim3((unsigned)nblocks), dim3(256), smem, stream, value, shapes,
-                     starts, loc, attn, npairs, S, M, L, Lq, P, out);
+  if (ref)
+    hipLaunchKernelGGL((msda_fwd_fast_kernel<LPH, true>), dim3((unsigned)nblocks), dim3(256), smem, stream, value, shapes,
+                       starts, loc, attn, ref, npairs, S, M, L, Lq, P, out);
+  else
+    hipLaunchKernelGGL((msda_fwd_fast_kernel<LPH, false>), dim3((unsigned)nblocks), dim3(256), smem, stream, value, shapes,
+                       starts, loc, attn, ref, npairs, S, M, L, Lq, P, out);
   return mss_launch_status();
 }
 
@@ -653,16 +677,38 @@ int mss_msda_forward_f32(const float* value, const int64_t* spatial_shapes, cons
   const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   const size_t smem_per_lp = (size_t)4 * 3 * sizeof(float) * L * P;
   if (aligned && D == 32 && smem_per_lp * 8 <= 65536)
-    return msda_forward_fast<8>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, L,
+    return msda_forward_fast<8>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, N, S, M, L,
                                 Lq, P, out, s);
   if (aligned && D == 16 && smem_per_lp * 16 <= 65536)
-    return msda_forward_fast<4>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, L,
+    return msda_forward_fast<4>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, N, S, M, L,
                                 Lq, P, out, s);
   if (aligned && D == 64 && smem_per_lp * 4 <= 65536)
-    return msda_forward_fast<16>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, L,
+    return msda_forward_fast<16>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, N, S, M, L,
                                  Lq, P, out, s);
   return msda_forward<float>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L,
                              Lq, P, out, s);
+}
+
+// forward straight from the module's raw projections (softmax + location arithmetic inside the sampling kernel); fp32,
+// head dimension 16 / 32 / 64 only -- MSS_ERR_UNSUPPORTED otherwise (the caller then runs prepare + forward)
+int mss_msda_forward_fused_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                               const float* offsets, const float* logits, const float* reference_points, int N, int S,
+                               int M, int D, int L, int Lq, int P, float* out, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = msda_check(value, spatial_shapes, level_start_index, offsets, logits, N, S, M, D, L, Lq, P);
+  if (rc) return rc;
+  if ((long long)N * Lq * M == 0) return MSS_OK;
+  if (!out || !reference_points) return MSS_ERR_BAD_ARG;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  const size_t smem_per_lp = (size_t)4 * 3 * sizeof(float) * L * P;
+  if (!aligned) return MSS_ERR_UNSUPPORTED;
+  if (D == 32 && smem_per_lp * 8 <= 65536)
+    return msda_forward_fast<8>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s);
+  if (D == 16 && smem_per_lp * 16 <= 65536)
+    return msda_forward_fast<4>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s);
+  if (D == 64 && smem_per_lp * 4 <= 65536)
+    return msda_forward_fast<16>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s);
+  return MSS_ERR_UNSUPPORTED;
 }
 
 int mss_msda_forward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,

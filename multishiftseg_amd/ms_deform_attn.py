@@ -4,6 +4,7 @@ ops/modules/ms_deform_attn.py:35-125): same class names, arguments and parameter
 the HIP op. Unlike the reference module there is no ``try/except`` around the op: a failing kernel
 raises instead of silently falling back to a slow PyTorch path (ms_deform_attn.py:116-121)."""
 import math
+import os
 import warnings
 
 import torch
@@ -65,6 +66,40 @@ class _PrepareFn(Function):
         return goff, glog, None, None
 
 
+class _FusedSampleFn(Function):
+    """the op fed with the raw offsets / logits of the two Linears; softmax + location arithmetic run inside
+    the sampling kernel (mss_msda_forward_fused_f32), so sampling_locations / attention_weights never touch HBM in the
+    forward. The backward rebuilds them with the one-pass prepare kernel (bit-identical values), runs the op's
+    backward and maps the gradients back to offsets / logits."""
+
+    @staticmethod
+    def forward(ctx, value, spatial_shapes, level_start_index, offsets, logits, reference_points):
+        N, S, M, D = value.shape
+        _, Lq, _, L, P, _ = offsets.shape
+        value, offsets, logits = value.contiguous(), offsets.contiguous(), logits.contiguous()
+        ref = reference_points.contiguous().float()
+        out = torch.empty((N, Lq, M * D), device=value.device, dtype=torch.float32)
+        call("mss_msda_forward_fused_f32", ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offsets), ptr(logits),
+             ptr(ref), N, S, M, D, L, Lq, P, ptr(out))
+        ctx.save_for_backward(value, spatial_shapes, level_start_index, offsets, logits, ref)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, starts, offsets, logits, ref = ctx.saved_tensors
+        N, Lq, M, L, P, _ = offsets.shape
+        loc = torch.empty_like(offsets)
+        attn = torch.empty((N, Lq, M, L, P), device=offsets.device, dtype=torch.float32)
+        call("mss_msda_prepare_f32", ptr(offsets), ptr(logits), ptr(ref), ptr(shapes), N, Lq, M, L, P, ptr(loc), ptr(attn))
+        gvalue, gloc, gattn = MSDA.ms_deform_attn_backward(value, shapes, starts, loc, attn, grad_output.contiguous(), 128)
+        goff = torch.empty_like(offsets)
+        glog = torch.empty((N, Lq, M, L * P), device=offsets.device, dtype=torch.float32)
+        call("mss_msda_prepare_backward_f32", ptr(attn), ptr(gattn.contiguous()), ptr(gloc.contiguous()), ptr(shapes),
+             N, Lq, M, L, P, ptr(goff), ptr(glog))
+        return gvalue, None, None, goff, glog, None
+
+
 def _is_power_of_2(n):
     if (not isinstance(n, int)) or n < 0:
         raise ValueError(f"invalid input for _is_power_of_2: {n} (type: {type(n)})")
@@ -120,9 +155,16 @@ class MSDeformAttn(nn.Module):
             N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         weights = linear(query, self.attention_weights.weight, self.attention_weights.bias).view(
             N, Len_q, self.n_heads, self.n_levels * self.n_points)
-        if (reference_points.shape[-1] == 2 and offsets.is_cuda and offsets.dtype == torch.float32
+        fast = (reference_points.shape[-1] == 2 and offsets.is_cuda and offsets.dtype == torch.float32
                 and self.n_levels * self.n_points <= 20 and input_spatial_shapes.dtype == torch.int64
-                and not reference_points.requires_grad):
+                and not reference_points.requires_grad)
+        if fast and self.d_model // self.n_heads in (16, 32, 64) and value.dtype == torch.float32 \
+                and os.environ.get("MSS_MSDA_FUSED", "1") != "0":
+            # one kernel: softmax + locations + sampling (no [N,Lq,M,L,P,2] / [N,Lq,M,L,P] round trip through HBM)
+            output = _FusedSampleFn.apply(value, input_spatial_shapes.contiguous(), input_level_start_index.contiguous(),
+                                          offsets, weights, reference_points)
+            return linear(output, self.output_proj.weight, self.output_proj.bias)
+        if fast:
             locations, weights = _PrepareFn.apply(offsets, weights, reference_points, input_spatial_shapes.contiguous())
         else:
             weights = F.softmax(weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)

@@ -242,3 +242,37 @@ def test_prepare_op_matches_reference_arithmetic(N, Lq, M, L, P):
     ((lo * g_loc).sum() + (w * g_attn).sum()).backward()
     for a, r, name in zip(got, (lo, w, off.grad, lg.grad), ("loc", "attn", "d_offsets", "d_logits")):
         torch.testing.assert_close(a, r.detach(), rtol=1e-5, atol=1e-6, msg=name)
+
+
+@pytest.mark.parametrize("N,Lq,M,D,shapes,P", [(2, 300, 8, 32, [(22, 22), (44, 44), (88, 88)], 4), (1, 77, 4, 16, [(9, 13), (5, 6)], 2),
+                                              (1, 50, 2, 64, [(12, 10)], 4)])
+def test_fused_sampling_equals_prepare_then_sample(N, Lq, M, D, shapes, P):
+    """8f-3: the sampling kernel fed with raw offsets / logits (softmax + location arithmetic inside) against the two-kernel
+    route prepare -> sample: outputs bit-identical, gradients w.r.t. value / offsets / logits identical."""
+    from multishiftseg_amd.ms_deform_attn import MSDeformAttnFunction, _FusedSampleFn, _PrepareFn
+    torch.manual_seed(Lq + D)
+    L = len(shapes)
+    shp = torch.as_tensor(shapes, dtype=torch.long, device="cuda")
+    starts = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    S = int(shp.prod(1).sum())
+    value = torch.randn(N, S, M, D, device="cuda").requires_grad_(True)
+    off = (torch.randn(N, Lq, M, L, P, 2, device="cuda") * 4).requires_grad_(True)
+    lg = (torch.randn(N, Lq, M, L * P, device="cuda") * 2).requires_grad_(True)
+    ref = torch.rand(N, Lq, L, 2, device="cuda") * 1.2 - 0.1                     # some reference points outside [0, 1]
+    gout = torch.randn(N, Lq, M * D, device="cuda")
+    out_f = _FusedSampleFn.apply(value, shp, starts, off, lg, ref)
+    out_f.backward(gout)
+    got = [t.grad.clone() for t in (value, off, lg)]
+    value.grad = off.grad = lg.grad = None
+    loc, attn = _PrepareFn.apply(off, lg, ref, shp)
+    out_r = MSDeformAttnFunction.apply(value, shp, starts, loc, attn, 128)
+    out_r.backward(gout)
+    assert torch.equal(out_f, out_r)
+    for a, b, name in zip(got, (value.grad, off.grad, lg.grad), ("d_value", "d_offsets", "d_logits")):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6, msg=name)
+
+
+def test_module_golden_unfused_route(monkeypatch):
+    """The reference module's output through prepare -> sample (MSS_MSDA_FUSED=0); test_module_golden covers the fused default."""
+    monkeypatch.setenv("MSS_MSDA_FUSED", "0")
+    test_module_golden()

@@ -56,8 +56,26 @@ def main():
     xx = K.Act(torch.randn(2, 128, 256, 4096, device=dev))
     ms = timeit(lambda: K.gap(xx))
     row("gap 2x128x256x4096", ms, xx.M * 4096 * 4.0)
-    wino_transforms(dev)
-    layout_experiment(dev)
+    # backward of the tail and BatchNorm+ReLU backward at the 2x1024x2048 step's sizes
+    dec = K.Act(torch.randn(2, 512, 1024, 48, device=dev))
+    ds = torch.randn(2, 1024, 2048, device=dev)
+    dl = torch.randn(2, 19, 1024, 2048, device=dev)
+    dd = K.Act.zeros(2, 512, 1024, 48, dev)
+    ms = timeit(lambda: K.ood_score_bwd(dec.slice(20, 19), ds, dl, dd.slice(20, 19), dd.slice(0, 19), 1024, 2048))
+    row("ood_score_bwd 2x1024x2048", ms, 2 * 1024 * 2048 * (19 * 4 + 4) + dec.M * (19 * 4 + 48 * 4.0))
+    del dec, ds, dl, dd
+    import torch.nn as nn
+    xb = K.Act(torch.randn(2, 512, 1024, 256, device=dev))
+    dyb = K.Act(torch.randn(2, 512, 1024, 256, device=dev))
+    bn = nn.BatchNorm2d(256).to(dev)
+    st = K.bn_fold(bn, xb, train=True)
+    ms = timeit(lambda: K.bn_relu_backward(dyb, xb, st, want_param_grads=True), iters=5)
+    row("bn_relu_backward (reduce + apply) 2x512x1024x256", ms, xb.M * 256 * 4.0 * 5, "reduce: dy,x; apply: dy,x -> dx")
+    ms = timeit(lambda: K.bn_fold(bn, xb, train=True), iters=5)
+    row("bn_fold train (stats over x) 2x512x1024x256", ms, xb.M * 256 * 4.0)
+    del xb, dyb
+    if os.environ.get("MSS_BENCH_SKIP_WINO") != "1":
+        wino_transforms(dev)
 
 
 def wino_transforms(dev):
