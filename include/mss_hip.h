@@ -335,6 +335,31 @@ int mss_oodm_rank_blocks(long long P);
 int mss_oodm_measures_f64(const unsigned int* pos_sorted, long long P, const unsigned int* neg_sorted, long long N,
                           double recall_level, unsigned long long* u2_part, double* ap_part, double* out, void* stream);
 
+/* ---- Mask2Former pixel decoder glue (csrc/norm.hip; msdeformattn.py:116-131,215-219,262-281,314-358) ----
+ * y = LayerNorm(x + res) over the last dimension C (multiple of 256, <= 1024; res may be NULL): the post-norm residual
+ * sites of MSDeformAttnTransformerEncoderLayer in one pass. stat (optional) [rows][2] = (mean, rstd) for the backward. */
+int mss_add_layernorm_f32(const float* x, const float* res, long long rows, int C, const float* gamma, const float* beta,
+                          float eps, float* y, float* stat, void* stream);
+/* backward: dz [rows][C] (= gradient w.r.t. x and w.r.t. res), dgamma / dbeta [C] (optional). ws: scratch of
+ * mss_add_layernorm_bwd_workspace_floats floats; per-workgroup partials added in a fixed order (no atomics). */
+long long mss_add_layernorm_bwd_workspace_floats(long long rows, int C);
+int mss_add_layernorm_bwd_f32(const float* gy, const float* x, const float* res, const float* stat, long long rows, int C,
+                              const float* gamma, float* dz, float* dgamma, float* dbeta, float* ws, void* stream);
+/* nn.GroupNorm(groups, C) on NHWC x [N][HW][C] (pixel stride ldx, sample stride x_sample_stride floats), optional ReLU,
+ * output with its own pixel / sample strides (e.g. straight into the encoder's token buffer [N][sum HW][C]).
+ * C/groups a multiple of 4, C <= 1024. ws: scratch of mss_groupnorm_workspace_floats floats. Deterministic. */
+long long mss_groupnorm_workspace_floats(int N, int HW, int C, int groups);
+int mss_groupnorm_nhwc_f32(const float* x, int ldx, long long x_sample_stride, int N, int HW, int C, int groups,
+                           const float* gamma, const float* beta, float eps, int relu, float* y, int ldy,
+                           long long y_sample_stride, float* ws, void* stream);
+/* FPN top-down step (msdeformattn.py:344): y = lat + F.interpolate(top, size=(OH, OW), mode="bilinear",
+ * align_corners=False); NHWC with pixel strides (top also with a sample stride: a level inside the token buffer). */
+int mss_upsample_bilinear_add_nhwc_f32(const float* top, int ldt, long long top_sample_stride, int N, int IH, int IW,
+                                       const float* lat, int ldl, float* y, int ldy, int OH, int OW, int C, void* stream);
+/* NHWC (pixel stride ldx, sample stride x_sample_stride floats) -> contiguous NCHW: the decoder returns NCHW maps like
+ * the reference. */
+int mss_nhwc_to_nchw_f32(const float* x, int ldx, long long x_sample_stride, int N, int HW, int C, float* y, void* stream);
+
 /* Calibration kernels (bench.py: achievable peaks of this device next to the datasheet ones).
  * mss_peak_mfma_f32: blocks x 4 waves x iters x 16 back-to-back v_mfma_f32_32x32x2_f32 (4096 FLOP
  * each), out >= blocks*256 floats. mss_peak_stream_f32: float4 copy of n floats (8*n bytes moved);

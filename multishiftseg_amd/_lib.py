@@ -120,6 +120,13 @@ SIGNATURES = {
     "mss_oodm_sort_u32": [P, P, L, P, L, P],
     "mss_oodm_rank_blocks": [L],
     "mss_oodm_measures_f64": [P, L, P, L, c_double, P, P, P, P],
+    "mss_add_layernorm_f32": [P, P, L, I, P, P, F, P, P, P],
+    "mss_add_layernorm_bwd_workspace_floats": [L, I],
+    "mss_add_layernorm_bwd_f32": [P, P, P, P, L, I, P, P, P, P, P, P],
+    "mss_groupnorm_workspace_floats": [I, I, I, I],
+    "mss_groupnorm_nhwc_f32": [P, I, L, I, I, I, I, P, P, F, I, P, I, L, P, P],
+    "mss_upsample_bilinear_add_nhwc_f32": [P, I, L, I, I, I, P, I, P, I, I, I, I, P],
+    "mss_nhwc_to_nchw_f32": [P, I, L, I, I, I, P, P],
     "mss_peak_mfma_f32": [P, I, I, P],
     "mss_peak_stream_f32": [P, P, L, I, P],
     "mss_peak_scatter_f32": [P, P, L, I, I, L, P],
@@ -127,9 +134,11 @@ SIGNATURES = {
 # entry points that return a plain value rather than a status code
 _VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
                     "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts",
-                    "mss_conv2d_wgrad_workspace_bytes", "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats"}
+                    "mss_conv2d_wgrad_workspace_bytes", "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
+                    "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats"}
 _RETURNS_LONGLONG = {"mss_wino_num_tiles", "mss_oodm_sort_temp_bytes", "mss_conv2d_wgrad_workspace_bytes",
-                     "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats"}
+                     "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
+                     "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats"}
 
 _lib = None
 

@@ -1,0 +1,347 @@
+// Normalisation / resampling glue of the Mask2Former pixel decoder, NHWC fp32:
+//   * residual add + LayerNorm in one pass, forward and backward (msdeformattn.py:116-131: norm1(src + attn), norm2(src +
+//     ffn)) -- one wave per token row, statistics by DPP/shuffle sums, no LDS;
+//   * GroupNorm(32, C) of the input projections and FPN convs (msdeformattn.py:215-219,262-281): per-(sample, group)
+//     statistics in two deterministic stages (no atomics), then a streaming apply (+ReLU) that can write straight into
+//     the encoder's token buffer [N, sum(HW), C] (a per-sample output stride);
+//   * bilinear align_corners=False up-sampling fused with the lateral add of the FPN top-down path (msdeformattn.py:344);
+//   * NHWC -> NCHW for the module boundary (the reference returns NCHW maps).
+#include "mss_common.h"
+#include "../../include/mss_hip.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// y = LN(x + res) * gamma + beta over the last dimension C = 4 * 64 * Q (Q float4 per lane); one wave per row.
+template <int Q>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                            long long rows, int C, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            float* __restrict__ y, float* __restrict__ stat) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 v[Q];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    const int c = (lane + 64 * k) * 4;
+    v[k] = ld4(x + row * C + c);
+    if (res) v[k] += ld4(res + row * C + c);
+    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+  const float mean = mss_wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    const f32x4 d = v[k] - mean;
+    q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+  }
+  const float rstd = rsqrtf(mss_wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    const int c = (lane + 64 * k) * 4;
+    st4(y + row * C + c, (v[k] - mean) * rstd * ld4(gamma + c) + ld4(beta + c));
+  }
+  if (stat && lane == 0) { stat[2 * row] = mean; stat[2 * row + 1] = rstd; }
+}
+
+// backward: dz = rstd * (g*gamma - mean_C(g*gamma) - xhat * mean_C(g*gamma*xhat)), the same for x and res; per-workgroup
+// partial sums of (g*xhat | g) per channel go to part[block][2][C] and are added in block order by ln_param_grad_kernel.
+template <int Q>
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                const float* __restrict__ res, const float* __restrict__ stat,
+                                                                long long rows, int C, const float* __restrict__ gamma,
+                                                                float* __restrict__ dz, float* __restrict__ part,
+                                                                int rows_per_block) {
+  __shared__ f32x4 red[2][4][64 * Q];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 dg[Q], db[Q], gm[Q];
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    dg[k] = f32x4{0.f, 0.f, 0.f, 0.f}; db[k] = dg[k];
+    gm[k] = ld4(gamma + (lane + 64 * k) * 4);
+  }
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (long long row = r0 + wave; row < r1; row += 4) {
+    const float mean = stat[2 * row], rstd = stat[2 * row + 1];
+    f32x4 g[Q], xh[Q];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const int c = (lane + 64 * k) * 4;
+      f32x4 z = ld4(x + row * C + c);
+      if (res) z += ld4(res + row * C + c);
+      g[k] = ld4(gy + row * C + c);
+      xh[k] = (z - mean) * rstd;
+      const f32x4 gg = g[k] * gm[k];
+      s1 += (gg.x + gg.y) + (gg.z + gg.w);
+      const f32x4 t = gg * xh[k];
+      s2 += (t.x + t.y) + (t.z + t.w);
+      dg[k] += g[k] * xh[k];
+      db[k] += g[k];
+    }
+    const float m1 = mss_wave_sum(s1) / (float)C, m2 = mss_wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const int c = (lane + 64 * k) * 4;
+      st4(dz + row * C + c, rstd * (g[k] * gm[k] - m1 - xh[k] * m2));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < Q; ++k) { red[0][wave][lane + 64 * k] = dg[k]; red[1][wave][lane + 64 * k] = db[k]; }
+  __syncthreads();
+  if (wave == 0) {
+    float* o = part + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const int i = lane + 64 * k;
+      st4(o + i * 4, ((red[0][0][i] + red[0][1][i]) + red[0][2][i]) + red[0][3][i]);
+      st4(o + C + i * 4, ((red[1][0][i] + red[1][1][i]) + red[1][2][i]) + red[1][3][i]);
+    }
+  }
+}
+
+// out[col] = sum over blocks (ascending) of part[block][col]; 4 columns x 64 row lanes per workgroup, fixed-shape tree
+__global__ __launch_bounds__(256) void ordered_colsum_kernel(const float* __restrict__ part, int nparts, int ncols,
+                                                             long long row_stride, float* __restrict__ out) {
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int col = blockIdx.x * 4 + cl;
+  float s = 0.f;
+  if (col < ncols)
+    for (int r = rl; r < nparts; r += 64) s += part[(size_t)r * row_stride + col];
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+#pragma unroll
+  for (int half = 32; half >= 1; half >>= 1) {
+    if (rl < half) red[threadIdx.x] += red[threadIdx.x + 4 * half];
+    __syncthreads();
+  }
+  if (rl == 0 && col < ncols) out[col] = red[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------ GroupNorm
+// stage 1: grid (chunks, N); lane = channel quad (C/4 <= 256 quads over the 256 threads' x dimension), rows walked by
+// the remaining threads; partial (sum, sumsq) per quad -> part[n][chunk][2][C/4]
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int ldx, long long sample_stride,
+                                                       int HW, int C, float* __restrict__ part, int rows_per_chunk) {
+  const int C4 = C >> 2;
+  const int QPB = C4 < 256 ? C4 : 256, RPB = 256 / QPB;
+  const int tx = threadIdx.x % QPB, ty = threadIdx.x / QPB;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * rows_per_chunk, p1 = min(HW, p0 + rows_per_chunk);
+  __shared__ float red[2][256];
+  float s = 0.f, q = 0.f;
+  if (ty < RPB) {
+    const float* b = x + (long long)n * sample_stride + tx * 4;
+    for (int p = p0 + ty; p < p1; p += RPB) {
+      const f32x4 v = ld4(b + (long long)p * ldx);
+      s += (v.x + v.y) + (v.z + v.w);
+      q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  }
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
+  __syncthreads();
+  if (ty == 0) {
+    for (int yy = 1; yy < RPB; ++yy) { s += red[0][yy * QPB + tx]; q += red[1][yy * QPB + tx]; }
+    float* o = part + (((size_t)n * gridDim.x + blockIdx.x) * 2) * C4;
+    o[tx] = s; o[C4 + tx] = q;
+  }
+}
+
+// stage 2: one thread per (n, group): chunks and the group's quads added in a fixed order, in double
+__global__ void gn_finalize_kernel(const float* __restrict__ part, int N, int nchunks, int C, int groups, int HW,
+                                   float eps, float* __restrict__ stat) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * groups) return;
+  const int n = i / groups, g = i - n * groups;
+  const int C4 = C >> 2, qpg = (C / groups) >> 2;      // quads per group
+  double s = 0.0, q = 0.0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float* o = part + (((size_t)n * nchunks + ch) * 2) * C4;
+    for (int k = 0; k < qpg; ++k) { s += o[g * qpg + k]; q += o[C4 + g * qpg + k]; }
+  }
+  const double cnt = (double)HW * (C / groups);
+  const double mean = s / cnt;
+  double var = q / cnt - mean * mean;
+  if (var < 0) var = 0;
+  stat[2 * i] = (float)mean;
+  stat[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// apply: grid (ceil(HW * C/4 / 256), N)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int ldx, long long x_sample_stride,
+                                                       int HW, int C, int groups, const float* __restrict__ stat,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int relu, float* __restrict__ y, int ldy, long long y_sample_stride) {
+  const unsigned C4 = (unsigned)C >> 2;
+  const unsigned item = blockIdx.x * 256u + threadIdx.x;
+  const unsigned p = item / C4;
+  if (p >= (unsigned)HW) return;
+  const int c = (int)(item - p * C4) * 4;
+  const int n = blockIdx.y;
+  const int g = c / (C / groups);                       // C/groups is a multiple of 4: a quad never straddles groups
+  const float mean = stat[2 * (n * groups + g)], rstd = stat[2 * (n * groups + g) + 1];
+  f32x4 v = (ld4(x + (long long)n * x_sample_stride + (long long)p * ldx + c) - mean) * rstd * ld4(gamma + c) + ld4(beta + c);
+  if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  st4(y + (long long)n * y_sample_stride + (long long)p * ldy + c, v);
+}
+
+// ------------------------------------------------------------------------------------------ FPN top-down add
+// y = lat + bilinear(top -> OH x OW), align_corners=False (half-pixel centres, source index clamped at 0 as ATen's
+// area_pixel_compute_source_index does); grid (ceil(OW * C/4 / 256), OH, N)
+__global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restrict__ top, int ldt, long long top_ss, int IH,
+                                                           int IW, const float* __restrict__ lat, int ldl,
+                                                           float* __restrict__ y, int ldy, int OH, int OW, int C, float sh,
+                                                           float sw) {
+  const unsigned C4 = (unsigned)C >> 2;
+  const unsigned item = blockIdx.x * 256u + threadIdx.x;
+  const unsigned ox = item / C4;
+  if (ox >= (unsigned)OW) return;
+  const int c = (int)(item - ox * C4) * 4;
+  const int oy = blockIdx.y, n = blockIdx.z;
+  auto tap = [](int o, float scale, int in, int& i0, int& i1, float& l1) {
+    float src = ((float)o + 0.5f) * scale;
+    asm volatile("" : "+v"(src));                       // ATen rounds the product before subtracting 0.5
+    src -= 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+  };
+  int y0, y1, x0, x1;
+  float ly, lx;
+  tap(oy, sh, IH, y0, y1, ly);
+  tap((int)ox, sw, IW, x0, x1, lx);
+  const float* b = top + (long long)n * top_ss + c;
+  const f32x4 v00 = ld4(b + ((long long)y0 * IW + x0) * ldt), v01 = ld4(b + ((long long)y0 * IW + x1) * ldt);
+  const f32x4 v10 = ld4(b + ((long long)y1 * IW + x0) * ldt), v11 = ld4(b + ((long long)y1 * IW + x1) * ldt);
+  const long long o = ((long long)(n * OH + oy) * OW + ox);
+  const f32x4 up = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  st4(y + o * ldy + c, ld4(lat + o * ldl + c) + up);
+}
+
+// ------------------------------------------------------------------------------------------ NHWC -> NCHW
+// 64 pixels x 64 channels per workgroup through LDS; grid (ceil(HW/64), ceil(C/64), N)
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, int ldx, long long x_ss, int HW,
+                                                           int C, float* __restrict__ y) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int p = p0 + r, c = c0 + tx;
+    tile[r][tx] = (p < HW && c < C) ? x[(long long)n * x_ss + (long long)p * ldx + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, p = p0 + tx;
+    if (c < C && p < HW) y[((long long)n * C + c) * HW + p] = tile[tx][r];
+  }
+}
+
+}  // namespace
+
+#define S_(x) static_cast<hipStream_t>(x)
+
+extern "C" {
+
+int mss_add_layernorm_f32(const float* x, const float* res, long long rows, int C, const float* gamma, const float* beta,
+                          float eps, float* y, float* stat, void* stream) {
+  if (!x || !gamma || !beta || !y || rows < 0) return MSS_ERR_BAD_ARG;
+  if (rows == 0) return MSS_OK;
+  if (C % 256 || C > 1024) return MSS_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  switch (C / 256) {
+    case 1: hipLaunchKernelGGL(add_layernorm_kernel<1>, grid, dim3(256), 0, S_(stream), x, res, rows, C, gamma, beta, eps, y, stat); break;
+    case 2: hipLaunchKernelGGL(add_layernorm_kernel<2>, grid, dim3(256), 0, S_(stream), x, res, rows, C, gamma, beta, eps, y, stat); break;
+    case 3: hipLaunchKernelGGL(add_layernorm_kernel<3>, grid, dim3(256), 0, S_(stream), x, res, rows, C, gamma, beta, eps, y, stat); break;
+    default: hipLaunchKernelGGL(add_layernorm_kernel<4>, grid, dim3(256), 0, S_(stream), x, res, rows, C, gamma, beta, eps, y, stat); break;
+  }
+  return mss_launch_status();
+}
+
+// workspace floats for the backward's per-workgroup partial sums of (dgamma | dbeta)
+long long mss_add_layernorm_bwd_workspace_floats(long long rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  long long blocks = (rows + 63) / 64;
+  if (blocks > 1024) blocks = 1024;
+  return blocks * 2 * C;
+}
+
+int mss_add_layernorm_bwd_f32(const float* gy, const float* x, const float* res, const float* stat, long long rows, int C,
+                              const float* gamma, float* dz, float* dgamma, float* dbeta, float* ws, void* stream) {
+  if (!gy || !x || !stat || !gamma || !dz || !ws || rows < 0) return MSS_ERR_BAD_ARG;
+  if (rows == 0) return MSS_OK;
+  if (C % 256 || C > 1024) return MSS_ERR_UNSUPPORTED;
+  long long blocks = (rows + 63) / 64;
+  if (blocks > 1024) blocks = 1024;
+  const int rpb = (int)((rows + blocks - 1) / blocks);
+  blocks = (rows + rpb - 1) / rpb;
+  const dim3 grid((unsigned)blocks);
+  switch (C / 256) {
+    case 1: hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
+    case 2: hipLaunchKernelGGL(add_layernorm_bwd_kernel<2>, grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
+    case 3: hipLaunchKernelGGL(add_layernorm_bwd_kernel<3>, grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
+    default: hipLaunchKernelGGL(add_layernorm_bwd_kernel<4>, grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
+  }
+  // part is [block][2][C]: rows of dgamma at stride 2C from offset 0, rows of dbeta from offset C
+  if (dgamma) hipLaunchKernelGGL(ordered_colsum_kernel, dim3((C + 3) / 4), dim3(256), 0, S_(stream), ws, (int)blocks, C, 2ll * C, dgamma);
+  if (dbeta) hipLaunchKernelGGL(ordered_colsum_kernel, dim3((C + 3) / 4), dim3(256), 0, S_(stream), ws + C, (int)blocks, C, 2ll * C, dbeta);
+  return mss_launch_status();
+}
+
+// GroupNorm over NHWC x [N][HW][C] (pixel stride ldx, sample stride x_sample_stride floats): y = (x - mean[n,g]) *
+// rstd[n,g] * gamma[c] + beta[c] (+ReLU) written with its own pixel / sample strides. ws: mss_groupnorm_workspace_floats.
+long long mss_groupnorm_workspace_floats(int N, int HW, int C, int groups) {
+  if (N <= 0 || HW <= 0 || C <= 0 || groups <= 0) return 0;
+  long long chunks = (HW + 255) / 256;
+  if (chunks > 512) chunks = 512;
+  return (long long)N * chunks * 2 * (C / 4) + 2ll * N * groups;
+}
+
+int mss_groupnorm_nhwc_f32(const float* x, int ldx, long long x_sample_stride, int N, int HW, int C, int groups,
+                           const float* gamma, const float* beta, float eps, int relu, float* y, int ldy,
+                           long long y_sample_stride, float* ws, void* stream) {
+  if (!x || !gamma || !beta || !y || !ws || N < 0 || HW <= 0) return MSS_ERR_BAD_ARG;
+  if (N == 0) return MSS_OK;
+  if (C % 4 || ldx % 4 || ldy % 4 || groups <= 0 || C % groups || (C / groups) % 4 || C / 4 > 256 || N > 65535)
+    return MSS_ERR_UNSUPPORTED;
+  long long chunks = (HW + 255) / 256;
+  if (chunks > 512) chunks = 512;
+  const int rpc = (int)((HW + chunks - 1) / chunks);
+  chunks = (HW + rpc - 1) / rpc;
+  float* part = ws;
+  float* stat = ws + (size_t)N * chunks * 2 * (C / 4);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)chunks, N), dim3(256), 0, S_(stream), x, ldx, x_sample_stride, HW, C, part, rpc);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * groups + 63) / 64), dim3(64), 0, S_(stream), part, N, (int)chunks, C, groups, HW, eps, stat);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)(((long long)HW * (C / 4) + 255) / 256), N), dim3(256), 0, S_(stream), x, ldx,
+                     x_sample_stride, HW, C, groups, stat, gamma, beta, relu, y, ldy, y_sample_stride);
+  return mss_launch_status();
+}
+
+// y = lat + bilinear(top [N,IH,IW,C] -> OH x OW, align_corners=False); all NHWC with their own pixel strides
+int mss_upsample_bilinear_add_nhwc_f32(const float* top, int ldt, long long top_sample_stride, int N, int IH, int IW,
+                                       const float* lat, int ldl, float* y, int ldy, int OH, int OW, int C, void* stream) {
+  if (!top || !lat || !y || C % 4 || ldt % 4 || ldl % 4 || ldy % 4) return MSS_ERR_BAD_ARG;
+  if ((long long)N * OH * OW == 0) return MSS_OK;
+  if (OH > 65535 || N > 65535) return MSS_ERR_UNSUPPORTED;
+  const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;     // area_pixel_compute_scale, align_corners=False
+  hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)(((long long)OW * (C / 4) + 255) / 256), OH, N), dim3(256), 0,
+                     S_(stream), top, ldt, top_sample_stride, IH, IW, lat, ldl, y, ldy, OH, OW, C, sh, sw);
+  return mss_launch_status();
+}
+
+int mss_nhwc_to_nchw_f32(const float* x, int ldx, long long x_sample_stride, int N, int HW, int C, float* y, void* stream) {
+  if (!x || !y || N < 0 || HW <= 0 || C <= 0) return MSS_ERR_BAD_ARG;
+  if (N == 0) return MSS_OK;
+  if (N > 65535 || (C + 63) / 64 > 65535) return MSS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 63) / 64, (C + 63) / 64, N), dim3(256), 0, S_(stream), x, ldx, x_sample_stride, HW, C, y);
+  return mss_launch_status();
+}
+
+}  // extern "C"

@@ -656,3 +656,107 @@ def m2f_score_fused(class_logits, mask_logits_nhwc, image_size, size=None):
     out = torch.empty((B, H, W), device=cls.device, dtype=torch.float32)
     call("mss_m2f_fused_score_f32", ptr(cls), ptr(lg), B, Q, C1 - 1, hm, wm, ldq, Hi, Wi, H, W, ptr(out))
     return out
+
+
+# ---- Mask2Former pixel-decoder glue (csrc/norm.hip) --------------------------------------------------------------------
+def groupnorm(x, gn, relu=False, out=None, out_sample_stride=None, out_ld=None):
+    """nn.GroupNorm `gn` on an Act (NHWC). `out`: optional float tensor to write into (e.g. the encoder's token buffer
+    [N, sum(HW), C] at a level's offset) with pixel stride `out_ld` and sample stride `out_sample_stride` floats."""
+    N, HW, C = x.N, x.H * x.W, x.C
+    dev = x.buf.device
+    ws = torch.empty(_lib.value("mss_groupnorm_workspace_floats", N, HW, C, gn.num_groups), device=dev, dtype=torch.float32)
+    if out is None:
+        y = Act.empty(N, x.H, x.W, C, dev)
+        optr, old, oss = y.ptr, y.ld, HW * y.ld
+    else:
+        y, optr, old, oss = out, ptr(out), out_ld, out_sample_stride
+    call("mss_groupnorm_nhwc_f32", x.ptr, x.ld, HW * x.ld, N, HW, C, gn.num_groups, ptr(gn.weight), ptr(gn.bias), float(gn.eps),
+         int(relu), optr, old, oss, ptr(ws))
+    return y
+
+
+class TokenLevel:
+    """One level of a token buffer [N, S, C] seen as an NHWC map: rows [start, start + H*W) of every sample."""
+    __slots__ = ("buf", "start", "N", "H", "W", "C", "ld", "sample_stride")
+
+    def __init__(self, buf, start, H, W):
+        assert buf.dim() == 3 and buf.is_contiguous() and buf.dtype == torch.float32
+        self.buf, self.start, self.H, self.W = buf, start, H, W
+        self.N, S, self.C = buf.shape
+        self.ld, self.sample_stride = self.C, S * self.C
+
+    @property
+    def ptr(self):
+        return ctypes.c_void_p(self.buf.data_ptr() + 4 * self.start * self.C)
+
+
+def _strided(x):
+    """(pointer, pixel stride, sample stride) of an Act or a TokenLevel."""
+    return (x.ptr, x.ld, x.sample_stride if isinstance(x, TokenLevel) else x.H * x.W * x.ld)
+
+
+def upsample_bilinear_add(top, lat):
+    """lat + F.interpolate(top, size=lat.shape[-2:], mode="bilinear", align_corners=False) (msdeformattn.py:344).
+    top: Act or TokenLevel, lat: Act."""
+    assert top.C == lat.C and top.N == lat.N
+    y = Act.empty(lat.N, lat.H, lat.W, lat.C, lat.buf.device)
+    tp, tld, tss = _strided(top)
+    call("mss_upsample_bilinear_add_nhwc_f32", tp, tld, tss, top.N, top.H, top.W, lat.ptr, lat.ld, y.ptr, y.ld, lat.H, lat.W, lat.C)
+    return y
+
+
+def nhwc_to_nchw(x):
+    """Act or TokenLevel -> contiguous NCHW tensor (module boundary of the pixel decoder)."""
+    y = torch.empty((x.N, x.C, x.H, x.W), device=x.buf.device, dtype=torch.float32)
+    xp, xld, xss = _strided(x)
+    call("mss_nhwc_to_nchw_f32", xp, xld, xss, x.N, x.H * x.W, x.C, ptr(y))
+    return y
+
+
+def nchw_to_act(t, Cp=None):
+    """NCHW tensor -> Act with the channel count padded up to a multiple of 16 (the MFMA kernels' K granularity)."""
+    n, c, h, w = t.shape
+    Cp = Cp or _round_up(c, 16)
+    t = t.contiguous().float()
+    out = Act.empty(n, h, w, Cp, t.device)
+    call("mss_nchw_to_nhwc_pad_f32", ptr(t), out.ptr, n, c, h, w, Cp)
+    return out
+
+
+class _AddLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x + res) in one HIP pass each way (msdeformattn.py:116-131 norm1 / norm2 sites)."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, eps):
+        C = x.shape[-1]
+        x2, r2 = x.contiguous(), (res.contiguous() if res is not None else None)
+        rows = x2.numel() // C
+        y = torch.empty_like(x2)
+        stat = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+        call("mss_add_layernorm_f32", ptr(x2), ptr(r2), rows, C, ptr(weight), ptr(bias), float(eps), ptr(y), ptr(stat))
+        ctx.save_for_backward(x2, r2, weight, stat)
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, res, weight, stat = ctx.saved_tensors
+        C = x.shape[-1]
+        rows = x.numel() // C
+        gy = gy.contiguous()
+        dz = torch.empty_like(x)
+        dg = torch.empty_like(weight)
+        db = torch.empty_like(weight)
+        ws = torch.empty(_lib.value("mss_add_layernorm_bwd_workspace_floats", rows, C), device=x.device, dtype=torch.float32)
+        call("mss_add_layernorm_bwd_f32", ptr(gy), ptr(x), ptr(res), ptr(stat), rows, C, ptr(weight), ptr(dz), ptr(dg), ptr(db), ptr(ws))
+        return dz, (dz if ctx.has_res else None), dg, db, None
+
+
+def add_layernorm(x, res, ln):
+    """nn.LayerNorm `ln` applied to x + res (res may be None). Falls back to torch for shapes the kernel does not take."""
+    C = x.shape[-1]
+    if x.is_cuda and x.dtype == torch.float32 and C % 256 == 0 and C <= 1024 and ln.elementwise_affine and ln.bias is not None \
+            and tuple(ln.normalized_shape) == (C,):
+        return _AddLayerNormFn.apply(x, res, ln.weight, ln.bias, ln.eps)
+    return ln(x if res is None else x + res)

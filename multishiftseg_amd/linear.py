@@ -57,7 +57,11 @@ class _LinearFn(Function):
         return gx, gw, gb, None
 
 
-MIN_ROWS = 65536       # below this a call is launch-bound and the library path's lower host overhead wins (N=1 crops)
+# Rows below which a call goes to the library GEMM instead. Round 1 used 65536 (N = 1 calls are launch-bound and torch's
+# host path is shorter); the default is now 0: every eligible Linear of the MSDeformAttn module / encoder runs on the
+# repository's own MFMA kernels, N = 1 included (MSS_LINEAR_MIN_ROWS restores a gate for A/B measurements).
+import os
+MIN_ROWS = int(os.environ.get("MSS_LINEAR_MIN_ROWS", "0"))
 
 
 def linear(x, weight, bias=None, relu=False):

@@ -196,3 +196,17 @@ def test_torch_oracle_train_step(deeplab_params):
         np.testing.assert_allclose(p[name].grad.double().norm().item(), float(g[k]), rtol=1e-3, err_msg=name)
     for k in [k for k in g.files if k.startswith(pre + "rs_")]:
         np.testing.assert_allclose(p[k[len(pre) + 3:]].numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_pixel_decoder_ops_oracle():
+    """GroupNorm, residual + LayerNorm (+ gradients) and half-pixel bilinear + add against ATen's outputs (ops2.npz)."""
+    g = golden("ops2")
+    np.testing.assert_allclose(nnops.groupnorm(g["gn_x"], 8, g["gn_gamma"], g["gn_beta"]), g["gn_y"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(nnops.add_layernorm(g["ln_a"], g["ln_b"], g["ln_gamma"], g["ln_beta"]), g["ln_y"], rtol=1e-5, atol=2e-6)
+    dz, dg, db = nnops.add_layernorm_bwd(g["ln_a"], g["ln_b"], g["ln_gamma"], g["ln_gy"])
+    np.testing.assert_allclose(dz, g["ln_da"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(dg, g["ln_dgamma"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(db, g["ln_dbeta"], rtol=1e-5, atol=1e-5)
+    for tag in ("x2", "odd", "same"):
+        lat = g[f"up_{tag}_lat"]
+        np.testing.assert_allclose(lat + nnops.upsample_bilinear_hp(g["up_top"], lat.shape[2:]), g[f"up_{tag}_y"], rtol=1e-5, atol=2e-6)

@@ -109,6 +109,37 @@ def gen_ops():
     save("ops", **out)
 
 
+def gen_ops2():
+    """ATen ops the Mask2Former pixel decoder is made of (msdeformattn.py:116-131,215-219,344): GroupNorm(32), residual +
+    LayerNorm (with autograd gradients), bilinear align_corners=False up-sampling + add."""
+    rng = np.random.default_rng(12)
+    out = {}
+    x = (rng.standard_normal((2, 64, 7, 9), dtype=np.float32) * 2 + 0.3)
+    gn = torch.nn.GroupNorm(8, 64)
+    with torch.no_grad():
+        gn.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, 64).astype(np.float32)))
+        gn.bias.copy_(torch.from_numpy(rng.standard_normal(64).astype(np.float32)))
+    out.update(gn_x=x, gn_gamma=t2n(gn.weight), gn_beta=t2n(gn.bias), gn_y=t2n(gn(torch.from_numpy(x))))
+    a = torch.from_numpy(rng.standard_normal((3, 11, 256), dtype=np.float32)).requires_grad_(True)
+    b = torch.from_numpy(rng.standard_normal((3, 11, 256), dtype=np.float32)).requires_grad_(True)
+    ln = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ln.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, 256).astype(np.float32)))
+        ln.bias.copy_(torch.from_numpy(rng.standard_normal(256).astype(np.float32)))
+    y = ln(a + b)
+    gy = torch.from_numpy(rng.standard_normal((3, 11, 256), dtype=np.float32))
+    y.backward(gy)
+    out.update(ln_a=t2n(a), ln_b=t2n(b), ln_gamma=t2n(ln.weight), ln_beta=t2n(ln.bias), ln_y=t2n(y), ln_gy=t2n(gy),
+               ln_da=t2n(a.grad), ln_dgamma=t2n(ln.weight.grad), ln_dbeta=t2n(ln.bias.grad))
+    top = rng.standard_normal((2, 8, 5, 7), dtype=np.float32)
+    for tag, size in {"x2": (10, 14), "odd": (11, 13), "same": (5, 7)}.items():
+        lat = rng.standard_normal((2, 8) + size, dtype=np.float32)
+        out[f"up_{tag}_lat"] = lat
+        out[f"up_{tag}_y"] = t2n(torch.from_numpy(lat) + F.interpolate(torch.from_numpy(top), size=size, mode="bilinear", align_corners=False))
+    out["up_top"] = top
+    save("ops2", **out)
+
+
 # --------------------------------------------------------------------------------------- DeepLab
 def build_ref_model(DeepWV3Plus, seed=0):
     torch.manual_seed(0)
@@ -481,6 +512,93 @@ def gen_encoder():
          names=np.array(list(sd.keys())), offsets_bias=t2n(sd["encoder.layers.0.self_attn.sampling_offsets.bias"]))
 
 
+def import_reference_decoder():
+    """The pixel-decoder shell (msdeformattn.py:164-358) needs more of detectron2 / fvcore than the encoder classes: the
+    Conv2d wrapper (conv -> norm -> activation), get_norm("GN") = GroupNorm(32, C), ShapeSpec, c2_xavier_fill and the
+    @configurable decorator. Both libraries are absent and un-vendored (detectron2 is installed from git HEAD, unpinned:
+    README.md:53-54), so these five names are restated here from their published behaviour -- third-party code, never
+    the reference -- and the reference file itself is imported unchanged. Parity of the shell is pinned up to that
+    restatement."""
+    import collections
+    import importlib
+
+    class Conv2d(torch.nn.Conv2d):                       # detectron2.layers.wrappers.Conv2d
+        def __init__(self, *args, **kwargs):
+            norm = kwargs.pop("norm", None)
+            activation = kwargs.pop("activation", None)
+            super().__init__(*args, **kwargs)
+            self.norm = norm
+            self.activation = activation
+
+        def forward(self, x):
+            x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+            if self.norm is not None:
+                x = self.norm(x)
+            if self.activation is not None:
+                x = self.activation(x)
+            return x
+
+    def get_norm(norm, out_channels):                    # detectron2.layers.batch_norm.get_norm, the cases the configs use
+        if norm is None or norm == "":
+            return None
+        assert norm == "GN", norm
+        return torch.nn.GroupNorm(32, out_channels)
+
+    def c2_xavier_fill(module):                          # fvcore.nn.weight_init.c2_xavier_fill
+        torch.nn.init.kaiming_uniform_(module.weight, a=1)
+        if module.bias is not None:
+            torch.nn.init.constant_(module.bias, 0)
+
+    base = os.path.join(REF, "lib/network/mask2former/modeling")
+    stubs = {
+        "fvcore": {}, "fvcore.nn": {}, "fvcore.nn.weight_init": {"c2_xavier_fill": c2_xavier_fill},
+        "detectron2": {}, "detectron2.config": {"configurable": lambda f=None, **k: f if f is not None else (lambda g: g)},
+        "detectron2.layers": {"Conv2d": Conv2d, "ShapeSpec": collections.namedtuple("ShapeSpec", ["channels", "stride"]),
+                              "get_norm": get_norm},
+        "detectron2.modeling": {"SEM_SEG_HEADS_REGISTRY": types.SimpleNamespace(register=lambda: (lambda c: c))},
+    }
+    for name, attrs in stubs.items():
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+    sys.modules["fvcore.nn"].weight_init = sys.modules["fvcore.nn.weight_init"]
+    for name, sub in {"m2fdec": "", "m2fdec.pixel_decoder": "pixel_decoder", "m2fdec.transformer_decoder": "transformer_decoder"}.items():
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(base, sub)]
+        sys.modules[name] = m
+    mod = importlib.import_module("m2fdec.pixel_decoder.msdeformattn")
+    return mod.MSDeformAttnPixelDecoder, stubs["detectron2.layers"]["ShapeSpec"]
+
+
+def gen_decoder():
+    """a-11: MSDeformAttnPixelDecoder.forward_features of the reference (2 encoder layers, the anomaly_ft.yaml geometry:
+    res2..res5 = 256/512/1024/2048 channels at strides 4..32, GN norm, common_stride 4) on a 2-image batch, CPU."""
+    Dec, ShapeSpec = import_reference_decoder()
+    torch.manual_seed(61)
+    shape = {"res2": ShapeSpec(256, 4), "res3": ShapeSpec(512, 8), "res4": ShapeSpec(1024, 16), "res5": ShapeSpec(2048, 32)}
+    dec = Dec(shape, transformer_dropout=0.0, transformer_nheads=8, transformer_dim_feedforward=1024, transformer_enc_layers=2,
+              conv_dim=256, mask_dim=256, norm="GN", transformer_in_features=["res3", "res4", "res5"], common_stride=4).eval()
+    sd = {}
+    for k, v in dec.state_dict().items():
+        if k.endswith("sampling_offsets.bias"):
+            sd[k] = v.clone()                               # keep the ring initialisation
+        else:                                               # 1-d weights / biases come out non-trivial (synth.gen_tensor)
+            sd[k] = torch.from_numpy(synth.gen_tensor(10, "m2fdec." + k, tuple(v.shape), gain=1.0))
+    dec.load_state_dict(sd)
+    rng = np.random.default_rng(62)
+    H, W = 96, 160
+    feats = {k: rng.standard_normal((2, s.channels, H // s.stride, W // s.stride), dtype=np.float32) for k, s in shape.items()}
+    with torch.no_grad():
+        mask, out0, ms = dec.forward_features({k: torch.from_numpy(v) for k, v in feats.items()})
+    save("m2f_decoder", names=np.array(list(sd.keys())), seed=np.int64(62), hw=np.array([H, W]),
+         offsets_bias=t2n(sd["transformer.encoder.layers.0.self_attn.sampling_offsets.bias"]),
+         mask_sub=t2n(mask)[:, ::4], mask_abs_sum=np.float64(np.abs(t2n(mask).astype(np.float64)).sum()),
+         out0=t2n(out0), ms1=t2n(ms[1])[:, ::2], ms2_sub=t2n(ms[2])[:, ::4],
+         ms2_abs_sum=np.float64(np.abs(t2n(ms[2]).astype(np.float64)).sum()))
+    print(f"   decoder: mask {tuple(mask.shape)} |max| {float(mask.abs().max()):.3g}, out0 {tuple(out0.shape)}, "
+          f"levels {[tuple(m.shape) for m in ms]}")
+
+
 def gen_m2f():
     """train_m2f.py:387-407 cannot be imported (detectron2 absent); its five lines of torch
     arithmetic are evaluated here verbatim on random inputs."""
@@ -541,17 +659,21 @@ def gen_metric():
 
 
 def main():
-    which = set(sys.argv[1:]) or {"ops", "deeplab", "train", "loss", "msda", "m2f", "encoder", "metric"}
+    which = set(sys.argv[1:]) or {"ops", "deeplab", "train", "loss", "msda", "m2f", "encoder", "decoder", "metric"}
     torch.set_num_threads(8)
     DeepWV3Plus, ref_loss, core, MSDeformAttn = import_reference()
     if "ops" in which:
         print("ops"); gen_ops()
+    if "ops2" in which or "ops" in which:
+        print("ops2"); gen_ops2()
     if "msda" in which:
         print("msda"); gen_msda(core, MSDeformAttn)
     if "m2f" in which:
         print("m2f"); gen_m2f()
     if "encoder" in which:
         print("encoder"); gen_encoder()
+    if "decoder" in which:
+        print("decoder"); gen_decoder()
     if "loss" in which:
         print("loss"); gen_loss(ref_loss)
     if "metric" in which:
