@@ -55,7 +55,7 @@ int mss_msda_backward_f64(const double* value, const int64_t* spatial_shapes, co
  * logits [N,Lq,M,L*P] (attention_weights Linear), reference_points [N,Lq,L,2] -- with the softmax and the location
  * arithmetic of ops/modules/ms_deform_attn.py:100-109 inside the sampling kernel: sampling_loc / attn_weight are never
  * materialised. fp32, D in {16, 32, 64}; MSS_ERR_UNSUPPORTED otherwise (run mss_msda_prepare_f32 + mss_msda_forward_f32).
- * Bit-identical to that two-kernel route. */
+ * Equal to that two-kernel route up to the summation order of the L*P exponentials; L*P <= 20. */
 int mss_msda_forward_fused_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                const float* offsets, const float* logits, const float* reference_points, int N, int S,
                                int M, int D, int L, int Lq, int P, float* out, void* stream);

@@ -24,13 +24,16 @@ namespace {
 template <typename T> struct Vec4;
 template <> struct Vec4<float> { typedef f32x4 type; };
 
+template <typename T, int LPP>
+__device__ __forceinline__ T pair_reduce(T v);     // sum over the LPP lanes of a pair's group (defined with the backward)
+
 // ------------------------------------------------------------------------------------------
 // forward, fast path
 // FUSED: `loc` / `attn` are the raw sampling offsets and attention logits of the module's two Linears and `ref` the
 // reference points [N,Lq,L,2] (ops/modules/ms_deform_attn.py:100-109): the softmax over the L*P logits and the
 // location arithmetic loc = ref + offset / (W_l, H_l) happen here, on the values the wave has staged in LDS anyway, so
 // the [N,Lq,M,L,P,2] / [N,Lq,M,L,P] tensors (11.7 MB per call at C4, read AND written by a separate kernel) never
-// exist. Same operation order as msda_prepare_kernel, so both routes agree to the last bit.
+// exist. Same arithmetic as msda_prepare_kernel except the order in which the L*P exponentials are added.
 template <int LPH, bool FUSED>
 __global__ __launch_bounds__(256) void msda_fwd_fast_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
@@ -60,8 +63,8 @@ __global__ __launch_bounds__(256) void msda_fwd_fast_kernel(
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   const int g = lane / LPH, j = lane % LPH;
-  if (g >= npw) return;
-  const long long pair = pair0 + g;
+  const bool mine = g < npw;                    // lanes without a pair stay until the wave-level barriers are done
+  const long long pair = pair0 + (mine ? g : 0);
   const int m = (int)(pair % M);
   const long long nq = pair / M;
   const int n = (int)(nq / Lq);
@@ -69,30 +72,51 @@ __global__ __launch_bounds__(256) void msda_fwd_fast_kernel(
   const float* myattn = sattn + g * LP;
   const size_t row_stride = (size_t)M * D;  // floats between consecutive spatial positions
   const float* vbase = value + (size_t)n * S * row_stride + (size_t)m * D + 4 * j;
-  float mx = 0.f, inv = 1.f;
-  if (FUSED) {      // every lane of the pair's group redoes the 12-term softmax statistics from LDS: no exchange needed
-    mx = -__builtin_huge_valf();
-    for (int i = 0; i < LP; ++i) mx = fmaxf(mx, myattn[i]);
-    float sum = 0.f;
-    for (int i = 0; i < LP; ++i) sum += expf(myattn[i] - mx);
-    inv = 1.f / sum;
+  if (FUSED && mine) {
+    // The LPH lanes of a pair turn its staged raw values into attention weights and locations IN PLACE, each lane taking
+    // every LPH-th sample (2 exps + 4 divisions per lane at L*P = 12, instead of every lane redoing all 12): the maximum
+    // from LDS, the partial sums of exponentials combined by an LPH-lane shuffle tree. A wave executes in lockstep and
+    // LDS operations of one wave complete in order, so the reads of the raw logits precede the overwriting stores.
+    float* ml = sloc + g * LP * 2;
+    float* ma = sattn + g * LP;
+    float mx = -__builtin_huge_valf();
+    for (int i = 0; i < LP; ++i) mx = fmaxf(mx, ma[i]);
+    constexpr int MAXI = (20 + LPH - 1) / LPH;          // L*P <= 20 (checked by the launcher)
+    float e[MAXI];
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXI; ++t) {
+      const int i = j + t * LPH;
+      e[t] = i < LP ? expf(ma[i] - mx) : 0.f;
+      part += e[t];
+    }
+    const float inv = 1.f / pair_reduce<float, LPH>(part);
+#pragma unroll
+    for (int t = 0; t < MAXI; ++t) {
+      const int i = j + t * LPH;
+      if (i < LP) {
+        const int l = i / P;
+        ma[i] = e[t] * inv;
+        ml[2 * i] = ref[(nq * L + l) * 2] + ml[2 * i] / (float)shapes[2 * l + 1];
+        ml[2 * i + 1] = ref[(nq * L + l) * 2 + 1] + ml[2 * i + 1] / (float)shapes[2 * l];
+      }
+    }
   }
+  if (FUSED) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if (!mine) return;
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int l = 0; l < L; ++l) {
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
     const float* vl = vbase + (size_t)starts[l] * row_stride;
-    float rx = 0.f, ry = 0.f;
-    if (FUSED) { rx = ref[(nq * L + l) * 2]; ry = ref[(nq * L + l) * 2 + 1]; }
 #pragma unroll 4
     for (int pt = 0; pt < P; ++pt) {
-      float lx = myloc[(l * P + pt) * 2], ly = myloc[(l * P + pt) * 2 + 1];
-      float aw = myattn[l * P + pt];
-      if (FUSED) {
-        lx = rx + lx / (float)W;
-        ly = ry + ly / (float)H;
-        aw = expf(aw - mx) * inv;
-      }
+      const float lx = myloc[(l * P + pt) * 2], ly = myloc[(l * P + pt) * 2 + 1];
+      const float aw = myattn[l * P + pt];
       const float w_im = lx * W - 0.5f, h_im = ly * H - 0.5f;
       const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
       const float hf = floorf(h_im), wf = floorf(w_im);
@@ -699,6 +723,7 @@ int mss_msda_forward_fused_f32(const float* value, const int64_t* spatial_shapes
   if (rc) return rc;
   if ((long long)N * Lq * M == 0) return MSS_OK;
   if (!out || !reference_points) return MSS_ERR_BAD_ARG;
+  if (L * P > 20) return MSS_ERR_UNSUPPORTED;           // per-lane sample slots of the in-LDS softmax (as mss_msda_prepare_f32)
   const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   const size_t smem_per_lp = (size_t)4 * 3 * sizeof(float) * L * P;
   if (!aligned) return MSS_ERR_UNSUPPORTED;
