@@ -360,6 +360,22 @@ int mss_upsample_bilinear_add_nhwc_f32(const float* top, int ldt, long long top_
  * the reference. */
 int mss_nhwc_to_nchw_f32(const float* x, int ldx, long long x_sample_stride, int N, int HW, int C, float* y, void* stream);
 
+/* ---- on-device data path of the DeepLab trainer (csrc/data.hip) ----
+ * One kernel for what DiverseCityscapes.__getitem__ + its transforms + the trainer's batch concat do per step
+ * (lib/dataset/cityscapes.py:153-171, lib/utils/img_utils.py:110-153,246-259,398-435, train_deeplab.py:190-195):
+ * img / gen [B,H,W,3] uint8 (original and generated image, pre-decoded, device), tgt / gen_tgt [B,H,W] uint8;
+ * mix_p [B] double (device; NULL = no mixup): gen <- uint8(p*img + (1-p)*gen) in float64; crop [B][2] int (device): top,
+ * left of the common h x w window; flip [B] int (device, NULL = none): horizontal flip of the window; mean3 / std3:
+ * HOST double[3] (the Python floats of opt.data.mean / std; Normalize uses their float32 roundings, the pasted object the
+ * doubles, as the reference does); obj_img [B][OHmax][OWmax][3] float32 (0..255, already rescaled), obj_mask
+ * [B][OHmax][OWmax] uint8, obj_geom [B][6] int = (y1, x1, bh, bw, h0, w0): the mask's bounding box inside the object and
+ * the paste corner in the window (bh = 0: nothing pasted; all three NULL: no anomaly mix). Outputs: out_img [2B,3,h,w]
+ * float32 and out_tgt [2B,h,w] int64, originals first, then the augmented images. */
+int mss_data_pair_f32(const uint8_t* img, const uint8_t* gen, const uint8_t* tgt, const uint8_t* gen_tgt, int B, int H, int W,
+                      int h, int w, const double* mix_p, const int* crop, const int* flip, const double* mean3,
+                      const double* std3, const float* obj_img, const uint8_t* obj_mask, const int* obj_geom, int OHmax,
+                      int OWmax, float* out_img, int64_t* out_tgt, void* stream);
+
 /* Calibration kernels (bench.py: achievable peaks of this device next to the datasheet ones).
  * mss_peak_mfma_f32: blocks x 4 waves x iters x 16 back-to-back v_mfma_f32_32x32x2_f32 (4096 FLOP
  * each), out >= blocks*256 floats. mss_peak_stream_f32: float4 copy of n floats (8*n bytes moved);

@@ -127,6 +127,7 @@ SIGNATURES = {
     "mss_groupnorm_nhwc_f32": [P, I, L, I, I, I, I, P, P, F, I, P, I, L, P, P],
     "mss_upsample_bilinear_add_nhwc_f32": [P, I, L, I, I, I, P, I, P, I, I, I, I, P],
     "mss_nhwc_to_nchw_f32": [P, I, L, I, I, I, P, P],
+    "mss_data_pair_f32": [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, P, P],
     "mss_peak_mfma_f32": [P, I, I, P],
     "mss_peak_stream_f32": [P, P, L, I, P],
     "mss_peak_scatter_f32": [P, P, L, I, I, L, P],

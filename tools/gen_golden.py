@@ -629,6 +629,75 @@ def gen_m2f():
     save("m2f_fused", **out)
 
 
+def gen_datapath():
+    """f-4: per-sample data path. lib/utils/img_utils.py is imported with cv2 / torchvision stubbed (third-party, absent;
+    mix_func / normalize / extract_bboxes use neither) and its own mix_func does the COCO paste; mixup is the three lines of
+    cityscapes.py:161-164 evaluated verbatim; ToTensor / F.crop / Normalize are the torch expressions torchvision
+    documents (uint8 -> float32 / 255; slicing; sub_(mean).div_(std) with float32 mean / std)."""
+    import importlib.util
+    import random
+    for name in ("cv2", "torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.InterpolationMode = types.SimpleNamespace(BILINEAR=2, NEAREST=0)
+            sys.modules[name] = m
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    spec = importlib.util.spec_from_file_location("ref_img_utils", os.path.join(REF, "lib", "utils", "img_utils.py"))
+    iu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(iu)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    rng = np.random.default_rng(71)
+    B, H, W, h, w = 3, 40, 56, 24, 32
+    img = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    gen = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    tgt = rng.integers(0, 19, (B, H, W)).astype(np.uint8)
+    gen_tgt = np.where(rng.random((B, H, W)) < 0.1, 254, tgt).astype(np.uint8)
+    out = dict(img=img, gen=gen, tgt=tgt, gen_tgt=gen_tgt, crop=np.array([h, w]))
+    random.seed(1234)
+    o_imgs, o_tgts, a_imgs, a_tgts = [], [], [], []
+    for b in range(B):
+        p = min(random.random(), 0.3)                                                      # cityscapes.py:162
+        mix_array = (p * np.array(img[b]) + (1 - p) * np.array(gen[b])).astype(np.uint8)   # cityscapes.py:163
+        top = random.randint(0, H - h)                                                     # img_utils.py:256-257
+        left = random.randint(0, W - w)
+
+        def tf(a):                                    # ToTensor -> F.crop -> Normalize (torchvision semantics)
+            t = torch.from_numpy(a).permute(2, 0, 1).to(torch.float32).div(255)
+            t = t[:, top:top + h, left:left + w].clone()
+            return t.sub_(torch.as_tensor(mean, dtype=torch.float32)[:, None, None]).div_(
+                torch.as_tensor(std, dtype=torch.float32)[:, None, None])
+        x, xg = tf(img[b]), tf(mix_array)
+        t = torch.tensor(np.array(tgt[b], dtype=np.uint8), dtype=torch.long)[top:top + h, left:left + w].clone()
+        tg = torch.tensor(np.array(gen_tgt[b], dtype=np.uint8), dtype=torch.long)[top:top + h, left:left + w].clone()
+        # anomaly mix: an already rescaled object (the cv2.resize of random_scale cannot run here) through the
+        # reference's own mix_func; its two randint draws are recorded
+        oh, ow = int(rng.integers(6, 14)), int(rng.integers(8, 18))
+        o_img = (rng.random((oh, ow, 3)) * 255).astype(np.float32)
+        o_mask = np.zeros((oh, ow), dtype=np.uint8)
+        o_mask[2:oh - 1, 1:ow - 3] = np.where(rng.random((oh - 3, ow - 4)) < 0.7, 254, 0)
+        o_mask[0, 0] = 255                                                                  # a void pixel of the object crop
+        drawn = []
+        real_randint = random.randint
+
+        def logging_randint(a, c):
+            v = real_randint(a, c)
+            drawn.append(v)
+            return v
+        random.randint = logging_randint
+        try:
+            x2, t2 = iu.mix_func(x, t, o_img.copy(), o_mask.copy())
+        finally:
+            random.randint = real_randint
+        boxes = iu.extract_bboxes(np.expand_dims((o_mask != 0) & (o_mask != 255), axis=2))[0]
+        out.update({f"s{b}_p": np.float64(p), f"s{b}_top": np.int64(top), f"s{b}_left": np.int64(left), f"s{b}_obj_img": o_img,
+                    f"s{b}_obj_mask": o_mask, f"s{b}_bbox": boxes.astype(np.int64), f"s{b}_corner": np.array(drawn, dtype=np.int64)})
+        o_imgs.append(t2n(x2)); o_tgts.append(t2n(t2)); a_imgs.append(t2n(xg)); a_tgts.append(t2n(tg))
+    out["images"] = np.stack(o_imgs + a_imgs).astype(np.float32)             # train_deeplab.py:194: cat([img, div_img])
+    out["targets"] = np.stack(o_tgts + a_tgts).astype(np.int64)
+    save("datapath", **out)
+
+
 def gen_metric():
     """8f-1: lib/utils/metric.py eval_ood_measure (loaded by file path: the package __init__ needs wget/h5py) on
     small score/label maps -- continuous scores, heavily tied scores, signed zeros, a recall level that falls
@@ -659,7 +728,7 @@ def gen_metric():
 
 
 def main():
-    which = set(sys.argv[1:]) or {"ops", "deeplab", "train", "loss", "msda", "m2f", "encoder", "decoder", "metric"}
+    which = set(sys.argv[1:]) or {"ops", "deeplab", "train", "loss", "msda", "m2f", "encoder", "decoder", "metric", "datapath"}
     torch.set_num_threads(8)
     DeepWV3Plus, ref_loss, core, MSDeformAttn = import_reference()
     if "ops" in which:
@@ -674,6 +743,8 @@ def main():
         print("encoder"); gen_encoder()
     if "decoder" in which:
         print("decoder"); gen_decoder()
+    if "datapath" in which:
+        print("datapath"); gen_datapath()
     if "loss" in which:
         print("loss"); gen_loss(ref_loss)
     if "metric" in which:
