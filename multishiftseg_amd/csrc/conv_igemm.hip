@@ -207,6 +207,8 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
     issue_loads();
     finish_store(0);
     advance();
+    issue_loads();       // the loader runs TWO K-steps ahead with one register set (see the loop): registers = step 1
+    advance();
   }
   __syncthreads();
 
@@ -246,18 +248,18 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(MssConvArgs p) {
     // The body is branch-free so the scheduler may interleave loads, LDS traffic, prologue math and
     // MFMAs freely: in the last step the loader re-reads its (still valid) last tile and stages it
     // into the buffer nobody reads any more.
-    issue_loads();
+    // The staging registers hold step it+1, requested a whole K-step ago: they go to LDS first and are re-issued at once
+    // for step it+2, so no wave ever waits on a load it has just issued (gemm.hip VARIANT 2: +3-7 % on every shape).
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
       if (kc + 1 < NKC) load_frags((kc + 1) & 1, buf, kc + 1);
-      if (kc == NKC - 2) finish_store(buf ^ 1);
+      if (kc == NKC - 2) { finish_store(buf ^ 1); issue_loads(); advance(); }
       if (kc == NKC - 1) {
         __syncthreads();
         load_frags(NKC & 1, buf ^ 1, 0);
       }
       mfma_chunk(kc & 1);
     }
-    advance();
   }
 
   // ---- epilogue (mss_epilogue.h): affine / residual / ReLU, stores never serialised on a memory round trip ----
@@ -498,18 +500,18 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
   };
 
   const int n_it = mend > mbeg ? (mend - mbeg + BP - 1) / BP : 0;
-  if (n_it > 0) { issue_loads(); finish_store(0); }
+  if (n_it > 0) { issue_loads(); finish_store(0); issue_loads(); }     // registers = pixel block 1 (two blocks ahead, below)
   __syncthreads();
   if (n_it > 0) load_frags(0, 0, 0);
   for (int it = 0; it < n_it; ++it) {
     const int buf = it & 1;
-    // branch-free body (see the forward kernel): in the last step the loader runs past the split's
-    // end, where every row is masked to a dummy address, and stages zeros nobody reads
-    issue_loads();
+    // branch-free body (see the forward kernel): past the split's end every row of the loader is masked to a dummy
+    // address and it stages zeros nobody reads. The registers hold block it+1 (requested a whole step ago): stored first,
+    // then re-issued at once for block it+2.
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
       if (kc + 1 < NKC) load_frags((kc + 1) & 1, buf, kc + 1);
-      if (kc == NKC - 2) finish_store(buf ^ 1);
+      if (kc == NKC - 2) { finish_store(buf ^ 1); issue_loads(); }
       if (kc == NKC - 1) {
         __syncthreads();
         load_frags(NKC & 1, buf ^ 1, 0);

@@ -33,7 +33,12 @@ constexpr int A_LD = BM / RPP, B_LD = BN / RPP;
 constexpr int NKC = BK / 8;
 static_assert(NKC == 2, "the step body below is written for two 8-k chunks");
 
-template <bool AFFINE>
+// VARIANT (A/B, MSS_GEMM_VARIANT): 0 = loads for K-step k+1 issued at the top of step k and written to LDS in the same step
+// (round 1); 1 = the same with the issue pinned at the loop top (the compiler otherwise sinks the four global loads behind
+// the first 16 MFMAs and the LDS reads, 9 MFMAs ahead of their first use); 2 = the loader runs TWO steps ahead with one
+// register set: step k first stores the registers (step k+1's data, requested a whole step ago) to LDS and immediately
+// re-issues them for step k+2, so no wave waits on a load it has just issued.
+template <bool AFFINE, int VARIANT>
 __global__ __launch_bounds__(NT, 3) void gemm_nt_kernel(MssConvArgs p, long long total_tiles, int tiles_per_batch) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                       // [2][BM][LDK]
@@ -157,19 +162,32 @@ __global__ __launch_bounds__(NT, 3) void gemm_nt_kernel(MssConvArgs p, long long
   issue_loads();
   finish_store(0);
   advance();
+  if (VARIANT == 2) { issue_loads(); advance(); }      // registers now hold K-step 1
   zero_acc();
   __syncthreads();
   load_frags(0, 0, 0);
   int buf = 0, k = 0;
   while (true) {
-    issue_loads();                       // K-step k+1 of this tile, or K-step 0 of the next one
-    load_frags(1, buf, 1);
-    finish_store(buf ^ 1);
-    mfma_chunk(0);
-    __syncthreads();
-    load_frags(0, buf ^ 1, 0);
-    mfma_chunk(1);
-    advance();
+    if (VARIANT == 2) {
+      load_frags(1, buf, 1);
+      finish_store(buf ^ 1);             // K-step k+1, requested during step k-1
+      issue_loads();                     // K-step k+2 (possibly of the next tile) into the registers just drained
+      advance();
+      mfma_chunk(0);
+      __syncthreads();
+      load_frags(0, buf ^ 1, 0);
+      mfma_chunk(1);
+    } else {
+      issue_loads();                       // K-step k+1 of this tile, or K-step 0 of the next one
+      if (VARIANT == 1) __builtin_amdgcn_sched_barrier(0);
+      load_frags(1, buf, 1);
+      finish_store(buf ^ 1);
+      mfma_chunk(0);
+      __syncthreads();
+      load_frags(0, buf ^ 1, 0);
+      mfma_chunk(1);
+      advance();
+    }
     buf ^= 1;
     if (++k == n_it) {
       epilogue(cur);
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_nt_kernel(MssConvArgs p, long long
   }
 }
 
-template <bool AFFINE>
+template <bool AFFINE, int VARIANT>
 int launch_gemm(const MssConvArgs& p, hipStream_t stream) {
   const int batch = p.batch > 1 ? p.batch : 1;
   const int tiles_per_batch = p.mtiles * p.ntiles;
@@ -192,7 +210,7 @@ int launch_gemm(const MssConvArgs& p, hipStream_t stream) {
     int dev = 0, n = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<AFFINE>, NT, smem) != hipSuccess || n < 1) n = 3;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<AFFINE, VARIANT>, NT, smem) != hipSuccess || n < 1) n = 3;
     const char* e = getenv("MSS_GEMM_WG_PER_CU");
     if (e && atoi(e) > 0 && atoi(e) < n) n = atoi(e);
     per_cu_max = n;
@@ -208,7 +226,7 @@ int launch_gemm(const MssConvArgs& p, hipStream_t stream) {
     const double eff = (double)total / (double)(rounds * g);
     if (eff > best + 0.02) { best = eff; grid = (int)g; }
   }
-  hipLaunchKernelGGL(gemm_nt_kernel<AFFINE>, dim3(grid), dim3(NT), smem, stream, p, total, tiles_per_batch);
+  hipLaunchKernelGGL((gemm_nt_kernel<AFFINE, VARIANT>), dim3(grid), dim3(NT), smem, stream, p, total, tiles_per_batch);
   return mss_launch_status();
 }
 
@@ -237,5 +255,11 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
     const char* e = getenv("MSS_GEMM_BF16X6");            // experimental split-bf16 evaluation of the same fp32 GEMM
     if (e && atoi(e)) return mss_gemm_nt_bf16x6_launch(p, stream);
   }
-  return p.in_scale ? launch_gemm<true>(p, s) : launch_gemm<false>(p, s);
+  // measured (tools/bench_bgemm.py, tools/bench_1x1.py, r02): variant 2 is +3-7 % on every shape (C = 128: 82.7 -> 86.9,
+  // 512: 127 -> 132, 1024 -> 2048: 132 -> 136 TFLOP/s; 1x1 2048 -> 4096 with prologue/residual/statistics: 123 -> 128)
+  int variant = 2;
+  { const char* e = getenv("MSS_GEMM_VARIANT"); if (e) variant = atoi(e); }
+  if (variant == 1) return p.in_scale ? launch_gemm<true, 1>(p, s) : launch_gemm<false, 1>(p, s);
+  if (variant == 0) return p.in_scale ? launch_gemm<true, 0>(p, s) : launch_gemm<false, 0>(p, s);
+  return p.in_scale ? launch_gemm<true, 2>(p, s) : launch_gemm<false, 2>(p, s);
 }
