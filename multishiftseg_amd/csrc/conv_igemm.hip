@@ -500,18 +500,20 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
   };
 
   const int n_it = mend > mbeg ? (mend - mbeg + BP - 1) / BP : 0;
-  if (n_it > 0) { issue_loads(); finish_store(0); issue_loads(); }     // registers = pixel block 1 (two blocks ahead, below)
+  if (n_it > 0) { issue_loads(); finish_store(0); }
   __syncthreads();
   if (n_it > 0) load_frags(0, 0, 0);
   for (int it = 0; it < n_it; ++it) {
     const int buf = it & 1;
-    // branch-free body (see the forward kernel): past the split's end every row of the loader is masked to a dummy
-    // address and it stages zeros nobody reads. The registers hold block it+1 (requested a whole step ago): stored first,
-    // then re-issued at once for block it+2.
+    // branch-free body (see the forward kernel): in the last step the loader runs past the split's
+    // end, where every row is masked to a dummy address, and stages zeros nobody reads.
+    // (The forward kernels' two-steps-ahead loader was measured here too: 104.8 -> 96.3 TFLOP/s. This loader's pixel
+    // decode is VALU-heavy and does better at the top of the step, next to the fragment reads.)
+    issue_loads();
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
       if (kc + 1 < NKC) load_frags((kc + 1) & 1, buf, kc + 1);
-      if (kc == NKC - 2) { finish_store(buf ^ 1); issue_loads(); }
+      if (kc == NKC - 2) finish_store(buf ^ 1);
       if (kc == NKC - 1) {
         __syncthreads();
         load_frags(NKC & 1, buf ^ 1, 0);

@@ -9,8 +9,10 @@ bench.py prints as roofline.traffic."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
-FAMILIES = ["gemm_nt_kernel", "conv_igemm_kernel", "conv_wgrad_kernel", "wino_input_transform", "wino_output_transform",
-            "wino_grad_output_transform", "bn_stats", "ood_score"]
+FAMILIES = ["gemm_nt_kernel", "conv_igemm_kernel", "conv_wgrad_kernel", "wino_input_transform_lds", "wino_input_transform_kernel",
+            "wino_output_transform", "wino_grad_output_transform", "bn_stats_kernel", "bn_relu_bwd_reduce", "bn_relu_bwd_apply",
+            "ood_score_v4", "ood_score_bwd_tiled", "rcl_pass1_v4", "rcl_pass2_v4", "upsample_ac_kernel", "upsample_ac_bwd_fast",
+            "maxpool3s2", "colsum_kernel", "im2col3x3_c3", "m2f_score_kernel", "adam_kernel"]
 
 
 def collect(d, counter):
@@ -38,7 +40,8 @@ def main():
             f_kb, w_kb = fe[k][1] / fe[k][0], wr[k][1] / wr[k][0]
             fams[k] = {"launches": fe[k][0], "fetch_size_avg_KB": f_kb, "write_size_avg_KB": w_kb,
                        "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024}
-    dom = max((k for k in ("gemm_nt_kernel", "conv_igemm_kernel") if k in fams), key=lambda k: fams[k]["launches"] * fams[k]["hbm_bytes_per_launch"])
+    cands = [k for k in ("gemm_nt_kernel", "conv_igemm_kernel") if k in fams] or list(fams)
+    dom = max(cands, key=lambda k: fams[k]["launches"] * fams[k]["hbm_bytes_per_launch"])
     c = fams[dom]
     out = {"kernel": dom,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1 "
