@@ -539,6 +539,167 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Batched TN GEMM for the Winograd-domain weight gradient: dU[p][k][c] = sum_t dY'[p][t][k] * X'[p][t][c].
+// conv_wgrad_kernel computes the same thing with its convolution loader (pixel decode, tap geometry, per-row masks:
+// 5 VALU instructions per MFMA) and one tile per workgroup; here nothing of that is left: both operands are plain
+// row-major [T][channels] matrices, a PERSISTENT workgroup walks (position, k-tile, c-tile, T-range) work items, and the
+// loader runs two 16-row steps ahead with one register set, across work-item boundaries (gemm.hip, VARIANT 2).
+// MFMA rows = k, columns = c, contraction = t; LDS tiles [2][16][128+4]; fragments by ds_read_b32 (lane i reads column
+// i of row 2s + (lane >> 5): 32 consecutive floats, conflict-free).
+// Work item w = ((split * P + p) * ktiles + kt) * ctiles + ct; its 128x128 tile goes to slab `split` of dst.
+constexpr int TN_BK = 128, TN_BC = 128, TN_BT = 16, TN_LD = 132;
+__global__ __launch_bounds__(NT, 3) void gemm_tn_wgrad_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                              float* __restrict__ dst, int P, int T, int K, int C,
+                                                              long long a_bs, long long b_bs, int Kpad, int Cp,
+                                                              int ktiles, int ctiles, int splits, int t_per_split,
+                                                              long long total) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                              // [2][16][132]
+  float* Bs = smem + 2 * TN_BT * TN_LD;          // [2][16][132]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = tid >> 5, lcol = (tid & 31) * 4;        // loader: rows lrow, lrow + 8; 4 consecutive channels
+  const long long stride = gridDim.x;
+
+  // ---- loader state ----
+  long long ld_w = mss_xcd_remap(blockIdx.x, gridDim.x);
+  const float* a_ptr = A;
+  const float* b_ptr = B;
+  int ld_t = 0, ld_tend = 0;
+  bool a_colok = false, b_colok = false;
+  auto setup = [&](long long w) {
+    const int ct = (int)(w % ctiles); w /= ctiles;
+    const int kt = (int)(w % ktiles); w /= ktiles;
+    const int p = (int)(w % P);
+    const int sp = (int)(w / P);
+    ld_t = sp * t_per_split;
+    ld_tend = min(T, ld_t + t_per_split);
+    a_colok = kt * TN_BK + lcol < K;             // K, C are multiples of 4: a float4 is inside or outside as a whole
+    b_colok = ct * TN_BC + lcol < C;
+    a_ptr = A + (size_t)p * a_bs + (size_t)ld_t * K + (a_colok ? kt * TN_BK + lcol : 0);
+    b_ptr = B + (size_t)p * b_bs + (size_t)ld_t * C + (b_colok ? ct * TN_BC + lcol : 0);
+  };
+  f32x4 areg[2], breg[2];
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = ld_t + lrow + 8 * j;
+      const bool ok = t < ld_tend;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 va = *reinterpret_cast<const f32x4*>(ok ? a_ptr + (size_t)(lrow + 8 * j) * K : A);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(ok ? b_ptr + (size_t)(lrow + 8 * j) * C : B);
+      areg[j] = (ok && a_colok) ? va : z;
+      breg[j] = (ok && b_colok) ? vb : z;
+    }
+  };
+  auto advance = [&]() {
+    ld_t += TN_BT;
+    if (ld_t < ld_tend) {
+      a_ptr += (size_t)TN_BT * K;
+      b_ptr += (size_t)TN_BT * C;
+    } else {
+      ld_w += stride;
+      setup(ld_w < total ? ld_w : ld_w - stride);          // past the end: re-read the last item, never used
+    }
+  };
+  auto finish_store = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      *reinterpret_cast<f32x4*>(&As[(buf * TN_BT + lrow + 8 * j) * TN_LD + lcol]) = areg[j];
+      *reinterpret_cast<f32x4*>(&Bs[(buf * TN_BT + lrow + 8 * j) * TN_LD + lcol]) = breg[j];
+    }
+  };
+  const int fi = lane & 31, fk = lane >> 5;
+  float fa[2][4][2], fb[2][4][2];
+  auto load_frags = [&](int set, int buf, int kc) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int row = buf * TN_BT + kc * 8 + ks * 2 + fk;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[set][ks][i] = As[row * TN_LD + wm * 64 + i * 32 + fi];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[set][ks][j] = Bs[row * TN_LD + wn * 64 + j * 32 + fi];
+    }
+  };
+  f32x16 acc[2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  };
+  auto mfma_chunk = [&](int set) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][ks][i], fb[set][ks][j], acc[i][j], 0, 0, 0);
+  };
+  auto epilogue = [&](long long w) {
+    const int ct = (int)(w % ctiles); w /= ctiles;
+    const int kt = (int)(w % ktiles); w /= ktiles;      // w = split * P + p: the slab index
+    float* o = dst + (size_t)w * Kpad * Cp;
+    const int colq = lane & 31, rowq = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = ct * TN_BC + wn * 64 + j * 32 + colq;
+      if (col >= Cp) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = kt * TN_BK + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + rowq;
+          if (row < Kpad) o[(size_t)row * Cp + col] = acc[i][j][q];     // rows >= K / cols >= C were fed zeros
+        }
+    }
+  };
+
+  long long cur = ld_w;                     // item being multiplied (the launch guarantees cur < total)
+  int steps_left;                           // 16-row steps left in the current item
+  {
+    long long w = cur / ((long long)ktiles * ctiles);
+    const int sp = (int)(w / P);
+    const int t0 = sp * t_per_split;
+    steps_left = (min(T, t0 + t_per_split) - t0 + TN_BT - 1) / TN_BT;
+  }
+  setup(ld_w);
+  issue_loads();
+  finish_store(0);
+  advance();
+  issue_loads();
+  advance();
+  zero_acc();
+  __syncthreads();
+  load_frags(0, 0, 0);
+  int buf = 0;
+  while (true) {
+    load_frags(1, buf, 1);
+    finish_store(buf ^ 1);                  // step +1, requested during the previous step
+    issue_loads();                          // step +2 (possibly of the next work item)
+    advance();
+    mfma_chunk(0);
+    __syncthreads();
+    load_frags(0, buf ^ 1, 0);
+    mfma_chunk(1);
+    buf ^= 1;
+    if (--steps_left == 0) {
+      epilogue(cur);
+      cur += stride;
+      if (cur >= total) break;
+      zero_acc();
+      long long w = cur / ((long long)ktiles * ctiles);
+      const int sp = (int)(w / P);
+      const int t0 = sp * t_per_split;
+      steps_left = (min(T, t0 + t_per_split) - t0 + TN_BT - 1) / TN_BT;
+    }
+  }
+}
+
 // dwp[tap][row][col] = sum over splits (ascending) of ws[split][tap][row][col], float4 over col (Cp % 4 == 0)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dwp,
                                                            long long slab4, int splits) {
@@ -599,6 +760,61 @@ int launch_wgrad(MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, 
                      pl.splits > 1 ? ws : dwp, Cp, pl.pps);
   if (pl.splits > 1) {
     // every element of every partial slab was written (see the kernel's epilogue), so whole slabs are swept
+    const long long slab4 = slab / 4;
+    long long blocks = (slab4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, ws, dwp, slab4, pl.splits);
+  }
+  return mss_launch_status();
+}
+
+// ---- the TN route of the batched (Winograd-domain) weight gradient ----
+struct TnPlan { int ktiles, ctiles, splits, tps; long long total; };
+inline bool tn_eligible(const MssConvArgs& p, int lddy) {
+  static const bool off = getenv("MSS_WGRAD_TN") && atoi(getenv("MSS_WGRAD_TN")) == 0;     // A/B switch
+  return !off && p.batch > 1 && p.R * p.S == 1 && !p.in_scale && !p.in_relu && p.K % 4 == 0 && p.C % 4 == 0 && p.ldx == p.C &&
+         lddy == p.K && p.x_bs % 4 == 0 && p.y_bs % 4 == 0 && p.N == 1 && p.H == 1;
+}
+inline TnPlan tn_plan(const MssConvArgs& p) {
+  TnPlan pl;
+  pl.ktiles = mss_cdiv(p.K, TN_BK); pl.ctiles = mss_cdiv(p.C, TN_BC);
+  const long long base = (long long)p.batch * pl.ktiles * pl.ctiles;
+  const int slots = 768;
+  int max_splits = mss_cdiv(p.M, TN_BT * 8);
+  if (max_splits > 64) max_splits = 64;
+  if (max_splits < 1) max_splits = 1;
+  int splits = 1;
+  double best = 0.0;
+  for (int sp = 1; sp <= max_splits; ++sp) {
+    const long long total = base * sp;
+    const double eff = (double)total / (double)(((total + slots - 1) / slots) * slots);
+    if (eff > best + 1e-9) { best = eff; splits = sp; }
+    if (eff >= 0.95 && total >= slots) break;
+  }
+  pl.tps = mss_cdiv(mss_cdiv(p.M, splits), TN_BT) * TN_BT;
+  pl.splits = mss_cdiv(p.M, pl.tps);
+  pl.total = base * pl.splits;
+  return pl;
+}
+int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, float* ws, long long ws_bytes,
+                    hipStream_t stream) {
+  const TnPlan pl = tn_plan(p);
+  const long long slab = (long long)p.batch * p.Kpad * Cp;
+  if (pl.splits > 1 && (!ws || ws_bytes < (long long)pl.splits * slab * 4)) return MSS_ERR_BAD_ARG;
+  const size_t smem = (size_t)4 * TN_BT * TN_LD * sizeof(float);
+  static int per_cu = 0, cus = 256;
+  if (per_cu == 0) {
+    int dev = 0, n = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_tn_wgrad_kernel, NT, smem) != hipSuccess || n < 1) n = 3;
+    per_cu = n > 3 ? 3 : n;
+  }
+  const long long slots = (long long)per_cu * cus;
+  const int grid = (int)(pl.total < slots ? pl.total : slots);
+  hipLaunchKernelGGL(gemm_tn_wgrad_kernel, dim3(grid), dim3(NT), smem, stream, dy, p.x, pl.splits > 1 ? ws : dwp, p.batch, p.M,
+                     p.K, p.C, p.y_bs, p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+  if (pl.splits > 1) {
     const long long slab4 = slab / 4;
     long long blocks = (slab4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -678,6 +894,10 @@ long long mss_conv2d_wgrad_workspace_bytes(const MssConvArgs* args, int Cp) {
   MssConvArgs p = *args;
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return 0;
+  if (tn_eligible(p, p.K)) {                 // the caller passes lddy == K on this route (checked again at launch)
+    const TnPlan pl = tn_plan(p);
+    return pl.splits > 1 ? (long long)pl.splits * p.batch * p.Kpad * Cp * 4 : 0;
+  }
   if (p.K <= 32) return wgrad_ws_bytes<32, 128, 16>(p, Cp);
   if (p.K <= 64) return wgrad_ws_bytes<64, 128, 16>(p, Cp);
   return wgrad_ws_bytes<128, 128, 16>(p, Cp);
@@ -696,6 +916,7 @@ int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dw
   if (p.M <= 0) return MSS_OK;
   if (p.batch > 1 && (p.R * p.S != 1 || p.batch > 65535)) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (tn_eligible(p, lddy)) return launch_wgrad_tn(p, dy, dwp, Cp, ws, ws_bytes, s);
   // output-channel tile: 32 rows (1x4 waves) for the 19-channel heads, 64 for bot_fine's 48, else 128
   if (p.K <= 32) return launch_wgrad<32, 128, 16, 1>(p, dy, lddy, dwp, Cp, ws, ws_bytes, s);
   if (p.K <= 64) return launch_wgrad<64, 128, 16, 2>(p, dy, lddy, dwp, Cp, ws, ws_bytes, s);
