@@ -549,6 +549,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(MssConvArgs p, const flo
 // i of row 2s + (lane >> 5): 32 consecutive floats, conflict-free).
 // Work item w = ((split * P + p) * ktiles + kt) * ctiles + ct; its 128x128 tile goes to slab `split` of dst.
 constexpr int TN_BK = 128, TN_BC = 128, TN_BT = 16, TN_LD = 132;
+template <bool TWO_AHEAD>
 __global__ __launch_bounds__(NT, 3) void gemm_tn_wgrad_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                               float* __restrict__ dst, int P, int T, int K, int C,
                                                               long long a_bs, long long b_bs, int Kpad, int Cp,
@@ -671,17 +672,23 @@ __global__ __launch_bounds__(NT, 3) void gemm_tn_wgrad_kernel(const float* __res
   issue_loads();
   finish_store(0);
   advance();
-  issue_loads();
-  advance();
+  if (TWO_AHEAD) { issue_loads(); advance(); }
   zero_acc();
   __syncthreads();
   load_frags(0, 0, 0);
   int buf = 0;
   while (true) {
-    load_frags(1, buf, 1);
-    finish_store(buf ^ 1);                  // step +1, requested during the previous step
-    issue_loads();                          // step +2 (possibly of the next work item)
-    advance();
+    if (TWO_AHEAD) {
+      load_frags(1, buf, 1);
+      finish_store(buf ^ 1);                  // step +1, requested during the previous step
+      issue_loads();                          // step +2 (possibly of the next work item)
+      advance();
+    } else {
+      issue_loads();                          // step +1, stored in this step
+      load_frags(1, buf, 1);
+      finish_store(buf ^ 1);
+      advance();
+    }
     mfma_chunk(0);
     __syncthreads();
     load_frags(0, buf ^ 1, 0);
@@ -807,13 +814,18 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
     int dev = 0, n = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_tn_wgrad_kernel, NT, smem) != hipSuccess || n < 1) n = 3;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_tn_wgrad_kernel<false>, NT, smem) != hipSuccess || n < 1) n = 3;
     per_cu = n > 3 ? 3 : n;
   }
   const long long slots = (long long)per_cu * cus;
   const int grid = (int)(pl.total < slots ? pl.total : slots);
-  hipLaunchKernelGGL(gemm_tn_wgrad_kernel, dim3(grid), dim3(NT), smem, stream, dy, p.x, pl.splits > 1 ? ws : dwp, p.batch, p.M,
-                     p.K, p.C, p.y_bs, p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+  const char* e2 = getenv("MSS_WGRAD_TN_AHEAD");
+  if (e2 && atoi(e2) == 2)
+    hipLaunchKernelGGL(gemm_tn_wgrad_kernel<true>, dim3(grid), dim3(NT), smem, stream, dy, p.x, pl.splits > 1 ? ws : dwp, p.batch,
+                       p.M, p.K, p.C, p.y_bs, p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+  else
+    hipLaunchKernelGGL(gemm_tn_wgrad_kernel<false>, dim3(grid), dim3(NT), smem, stream, dy, p.x, pl.splits > 1 ? ws : dwp, p.batch,
+                       p.M, p.K, p.C, p.y_bs, p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
   if (pl.splits > 1) {
     const long long slab4 = slab / 4;
     long long blocks = (slab4 + 255) / 256;

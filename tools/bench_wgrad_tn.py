@@ -1,0 +1,22 @@
+"""Winograd-domain weight-gradient products of the 2x1024x2048 step in isolation (TFLOP/s of executed MFMA work)."""
+import sys, os, json, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multishiftseg_amd import kernels as K
+from multishiftseg_amd._lib import MssConvArgs, call, ptr
+from tools.microbench import timeit
+P = 36
+for (T, C, Ko) in [(5184, 4096, 256), (6912, 4096, 256), (65536, 256, 256), (65536, 304, 256)]:
+    xt = torch.randn(P, T, C, device="cuda")
+    dyt = torch.randn(P, T, Ko, device="cuda")
+    du = torch.empty(P, Ko, C, device="cuda")
+    a = MssConvArgs()
+    a.x = ptr(xt)
+    a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
+    a.OH, a.OW, a.K, a.Kpad = 1, T, Ko, Ko
+    a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+    a.batch, a.x_bs, a.y_bs = P, T * C, T * Ko
+    ws, wsb = K._wgrad_workspace(a, C, "cuda")
+    ms = timeit(lambda: call("mss_conv2d_wgrad_f32", ctypes.byref(a), ptr(dyt), Ko, ptr(du), C, ptr(ws), wsb), iters=5, warm=2)
+    print(json.dumps(dict(T=T, C=C, K=Ko, ms=round(ms, 3), tflops=round(2.0 * P * T * C * Ko / ms / 1e9, 1), ws_MB=round(wsb / 1e6, 1),
+                          tn=os.environ.get("MSS_WGRAD_TN", "1"), ahead=os.environ.get("MSS_WGRAD_TN_AHEAD", "1"))), flush=True)
