@@ -28,6 +28,8 @@ LOSS_PARAMS = {"ce_weights": [50, 10], "conduct_pixel_selection": True, "selecti
 STAGE2 = ["aspp", "bot_fine", "bot_aspp", "ood_head"]
 ROUTES = {"winograd": {}, "direct3x3": {"MSS_WINOGRAD": "0"},
           "igemm_only": {"MSS_WINOGRAD": "0", "MSS_GEMM": "0", "MSS_STEM_IM2COL": "0"}}
+# the experimental fp32-on-bf16-matrix-cores GEMM has to pass the same reference fixtures to be reported at all
+ROUTES_X = dict(ROUTES, bf16x6={"MSS_GEMM_BF16X6": "1"})
 _report = {}
 
 
@@ -47,7 +49,7 @@ class _Env:
         self.env = env
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ("MSS_WINOGRAD", "MSS_GEMM", "MSS_WINO_TILE", "MSS_STEM_IM2COL")}
+        self.old = {k: os.environ.get(k) for k in ("MSS_WINOGRAD", "MSS_GEMM", "MSS_WINO_TILE", "MSS_STEM_IM2COL", "MSS_GEMM_BF16X6")}
         for k in self.old:
             os.environ.pop(k, None)
         os.environ.update(self.env)
@@ -97,7 +99,7 @@ def test_c1_eval_512x1024_vs_torch_oracle(model, deeplab_params):
     np.testing.assert_array_equal(logit.argmax(1)[clear], rl.argmax(1)[clear])
 
 
-@pytest.mark.parametrize("route", list(ROUTES))
+@pytest.mark.parametrize("route", list(ROUTES_X))
 def test_eval_golden_592x600(model, route):
     """Outputs of the reference model itself at a size where F(4x4) is the policy's own choice for dil 12/24/36."""
     from multishiftseg_amd import kernels as K, synth
@@ -105,7 +107,7 @@ def test_eval_golden_592x600(model, route):
     n, h, w = (int(v) for v in g["shape"])
     img = torch.from_numpy(synth.synth_image(int(g["image_seed"]), n, h, w)).cuda()
     model.eval()
-    with _Env(ROUTES[route]):
+    with _Env(ROUTES_X[route]):
         if route == "winograd":
             assert [K.wino_tile(74, 75, r) for r in (12, 24, 36)] == [4, 4, 4]
         with torch.no_grad():
@@ -134,7 +136,7 @@ def _grad_close(got, ref, name, noise, sens, lo=2e-3):
     return rel, bound
 
 
-@pytest.mark.parametrize("route", list(ROUTES))
+@pytest.mark.parametrize("route", list(ROUTES_X))
 def test_train_step_golden_2x592x600(deeplab_params, route):
     """One stage-2 optimizer step of the reference on a (1+1)x3x592x600 batch -- the per-GPU batch shape of C3 -- with
     its Dropout2d masks and loss permutations injected. In the default route every ASPP layer runs F(4x4) and its weight
@@ -159,7 +161,7 @@ def test_train_step_golden_2x592x600(deeplab_params, route):
     target = torch.from_numpy(g["target"].astype(np.int64)).cuda()
     crit = RelContrastiveLoss(LOSS_PARAMS)
     perms = [torch.from_numpy(g[pre + f"perm{i}"].astype(np.int64)) for i in range(3)]
-    with _Env(ROUTES[route]):
+    with _Env(ROUTES_X[route]):
         if route == "winograd":
             assert [K.wino_tile(74, 75, r) for r in (12, 24, 36)] == [4, 4, 4]
         score, logit = m(img)

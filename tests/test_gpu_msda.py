@@ -276,3 +276,46 @@ def test_module_golden_unfused_route(monkeypatch):
     """The reference module's output through prepare -> sample (MSS_MSDA_FUSED=0); test_module_golden covers the fused default."""
     monkeypatch.setenv("MSS_MSDA_FUSED", "0")
     test_module_golden()
+
+
+def test_install_serves_a_reference_style_caller():
+    """Boundary B1: after install() a caller written like the reference's MSDeformAttnFunction
+    (ops/functions/ms_deform_attn_func.py:21,36-37,45-47: `import MultiScaleDeformableAttention as MSDA`, then
+    MSDA.ms_deform_attn_forward / _backward with the reference's argument order) reaches the HIP kernels."""
+    import importlib
+    import sys
+    from multishiftseg_amd import MultiScaleDeformableAttention as shim
+    had = sys.modules.pop("MultiScaleDeformableAttention", None)
+    try:
+        with pytest.raises(ImportError):
+            importlib.import_module("MultiScaleDeformableAttention")        # the compiled extension does not exist here
+        shim.install()
+        import MultiScaleDeformableAttention as MSDA                          # the reference's import line
+        assert MSDA is shim
+
+        class RefStyleFunction(torch.autograd.Function):                      # shape of ms_deform_attn_func.py:32-49
+            @staticmethod
+            def forward(ctx, value, shapes, starts, loc, attn, im2col_step):
+                ctx.im2col_step = im2col_step
+                out = MSDA.ms_deform_attn_forward(value, shapes, starts, loc, attn, ctx.im2col_step)
+                ctx.save_for_backward(value, shapes, starts, loc, attn)
+                return out
+
+            @staticmethod
+            def backward(ctx, grad_output):
+                value, shapes, starts, loc, attn = ctx.saved_tensors
+                gv, gl, ga = MSDA.ms_deform_attn_backward(value, shapes, starts, loc, attn, grad_output.contiguous(), ctx.im2col_step)
+                return gv, None, None, gl, ga, None
+
+        g = golden("msda_m8d32_f32")
+        value, loc, attn = (dev(g[k]).requires_grad_(True) for k in ("value", "loc", "attn"))
+        out = RefStyleFunction.apply(value, dev(g["shapes"]), dev(g["starts"]), loc, attn, 128)
+        out.backward(dev(g["grad_out"]))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(value.grad.cpu().numpy(), g["grad_value"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(loc.grad.cpu().numpy(), g["grad_loc"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(attn.grad.cpu().numpy(), g["grad_attn"], rtol=1e-4, atol=1e-5)
+    finally:
+        sys.modules.pop("MultiScaleDeformableAttention", None)
+        if had is not None:
+            sys.modules["MultiScaleDeformableAttention"] = had
