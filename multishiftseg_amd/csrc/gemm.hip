@@ -20,17 +20,18 @@
 
 namespace {
 
-constexpr int NT = 256, BM = 128, BN = 128, BK = 16;
+constexpr int NT = 256, BM = 128, BK = 16;
 // LDS rows are 16 floats with NO padding; the four 16-byte chunks of row r are rotated by (r >> 2): a staging write
 // (16 lanes = 4 rows x 4 chunks) and a fragment read (16 lanes = 16 rows x 1 chunk) then both touch 16 disjoint
 // 4-bank spans. (The +4-float padding of conv_igemm is conflict-free for the reads only: PMC showed a third of the
 // LDS cycles as bank conflicts from the ds_write_b128 side.)
 constexpr int LDK = BK;
-constexpr int WTM = 64, WTN = 64, TM = 2, TN = 2;
+constexpr int WTM = 64, TM = 2;
 constexpr int CPR = BK / 4;            // float4 chunks per tile row
 constexpr int RPP = NT / CPR;          // rows staged per pass
-constexpr int A_LD = BM / RPP, B_LD = BN / RPP;
+constexpr int A_LD = BM / RPP;
 constexpr int NKC = BK / 8;
+
 static_assert(NKC == 2, "the step body below is written for two 8-k chunks");
 
 // VARIANT (A/B, MSS_GEMM_VARIANT): 0 = loads for K-step k+1 issued at the top of step k and written to LDS in the same step
@@ -38,8 +39,12 @@ static_assert(NKC == 2, "the step body below is written for two 8-k chunks");
 // the first 16 MFMAs and the LDS reads, 9 MFMAs ahead of their first use); 2 = the loader runs TWO steps ahead with one
 // register set: step k first stores the registers (step k+1's data, requested a whole step ago) to LDS and immediately
 // re-issues them for step k+2, so no wave waits on a load it has just issued.
-template <bool AFFINE, int VARIANT>
-__global__ __launch_bounds__(NT, 3) void gemm_nt_kernel(MssConvArgs p, long long total_tiles, int tiles_per_batch) {
+// BN: output-channel extent of a tile. 128 (2x2 waves of 64x64, 4 workgroups per CU) or 256 (2x2 waves of 64x128: 64 MFMAs
+// per wave and barrier instead of 32, a quarter less operand traffic per FLOP and half the per-tile prologue/epilogue
+// share, at 2 workgroups per CU).
+template <bool AFFINE, int VARIANT, int BN>
+__global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvArgs p, long long total_tiles, int tiles_per_batch) {
+  constexpr int WTN = BN / 2, TN = WTN / 32, B_LD = BN / RPP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                       // [2][BM][LDK]
   float* Bs = As + 2 * BM * LDK;          // [2][BN][LDK]
@@ -199,18 +204,18 @@ __global__ __launch_bounds__(NT, 3) void gemm_nt_kernel(MssConvArgs p, long long
   }
 }
 
-template <bool AFFINE, int VARIANT>
+template <bool AFFINE, int VARIANT, int BN>
 int launch_gemm(const MssConvArgs& p, hipStream_t stream) {
   const int batch = p.batch > 1 ? p.batch : 1;
   const int tiles_per_batch = p.mtiles * p.ntiles;
   const long long total = (long long)tiles_per_batch * batch;
   const size_t smem = (size_t)2 * (BM + BN) * LDK * sizeof(float);
-  static int per_cu_max = 0, cus = 256;  // resident workgroups per CU (4: 40 KB LDS, <= 128 registers)
+  static int per_cu_max = 0, cus = 256;  // resident workgroups per CU (BN = 128: 4 with 32 KB LDS and <= 128 registers); one static per instantiation
   if (per_cu_max == 0) {
     int dev = 0, n = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<AFFINE, VARIANT>, NT, smem) != hipSuccess || n < 1) n = 3;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<AFFINE, VARIANT, BN>, NT, smem) != hipSuccess || n < 1) n = 3;
     const char* e = getenv("MSS_GEMM_WG_PER_CU");
     if (e && atoi(e) > 0 && atoi(e) < n) n = atoi(e);
     per_cu_max = n;
@@ -226,7 +231,7 @@ int launch_gemm(const MssConvArgs& p, hipStream_t stream) {
     const double eff = (double)total / (double)(rounds * g);
     if (eff > best + 0.02) { best = eff; grid = (int)g; }
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<AFFINE, VARIANT>), dim3(grid), dim3(NT), smem, stream, p, total, tiles_per_batch);
+  hipLaunchKernelGGL((gemm_nt_kernel<AFFINE, VARIANT, BN>), dim3(grid), dim3(NT), smem, stream, p, total, tiles_per_batch);
   return mss_launch_status();
 }
 
@@ -248,8 +253,8 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
   if (!mss_gemm_nt_eligible(p)) return -1;
   p.H = (p.in_scale && p.in_ss_stride) ? p.OH * p.OW : (p.M > 0 ? p.M : 1);   // rows per affine group
   p.mtiles = mss_cdiv(p.M, BM);
-  p.ntiles = mss_cdiv(p.K, BN);
-  if (p.Kpad < p.ntiles * BN) return MSS_ERR_BAD_ARG;
+  p.ntiles = mss_cdiv(p.K, 128);
+  if (p.Kpad < p.ntiles * 128) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   {
     const char* e = getenv("MSS_GEMM_BF16X6");            // experimental split-bf16 evaluation of the same fp32 GEMM
@@ -259,7 +264,18 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
   // 512: 127 -> 132, 1024 -> 2048: 132 -> 136 TFLOP/s; 1x1 2048 -> 4096 with prologue/residual/statistics: 123 -> 128)
   int variant = 2;
   { const char* e = getenv("MSS_GEMM_VARIANT"); if (e) variant = atoi(e); }
-  if (variant == 1) return p.in_scale ? launch_gemm<true, 1>(p, s) : launch_gemm<false, 1>(p, s);
-  if (variant == 0) return p.in_scale ? launch_gemm<true, 0>(p, s) : launch_gemm<false, 0>(p, s);
-  return p.in_scale ? launch_gemm<true, 2>(p, s) : launch_gemm<false, 2>(p, s);
+  if (variant == 1) return p.in_scale ? launch_gemm<true, 1, 128>(p, s) : launch_gemm<false, 1, 128>(p, s);
+  if (variant == 0) return p.in_scale ? launch_gemm<true, 0, 128>(p, s) : launch_gemm<false, 0, 128>(p, s);
+  // 256-wide tiles when the output channels split evenly, the reduction is long enough and there is work for two rounds of
+  // the 512 slots (MSS_GEMM_BN=128|256 forces one). Measured (tools/bench_bgemm.py, bench_1x1.py): 1x1 2048 -> 4096
+  // 127 -> 133, ASPP 4096 -> 256 123 -> 131, 1024 -> 2048 136 -> 138, C = 304 122 -> 126 TFLOP/s; C = 256: 122 -> 121 (not taken).
+  int bn = 0;
+  { const char* e = getenv("MSS_GEMM_BN"); if (e) bn = atoi(e); }
+  const long long tiles256 = (long long)p.mtiles * (p.K / 256) * (p.batch > 1 ? p.batch : 1);
+  const bool wide = p.K % 256 == 0 && (bn == 256 || (bn == 0 && tiles256 >= 1024 && p.C >= 300));
+  if (wide) {
+    p.ntiles = p.K / 256;
+    return p.in_scale ? launch_gemm<true, 2, 256>(p, s) : launch_gemm<false, 2, 256>(p, s);
+  }
+  return p.in_scale ? launch_gemm<true, 2, 128>(p, s) : launch_gemm<false, 2, 128>(p, s);
 }
