@@ -87,6 +87,8 @@ def test_train_step_golden(deeplab_params, stage, names, lr):
     for k in [k for k in g.files if k.startswith(pre + "rs_")]:
         np.testing.assert_allclose(sd[k[len(pre) + 3:]].cpu().numpy(), g[k], rtol=1e-3, atol=1e-4, err_msg=k)
     pd = dict(m.named_parameters())
+    report = {}
+
     def close(got, ref, name):
         # A single ReLU-threshold flip (pre-activation within 1e-6 of zero) moves one summand of a BN/conv gradient:
         # judge by relative L2 and by the median error, and bound the worst element loosely. Some of these sums are
@@ -99,8 +101,13 @@ def test_train_step_golden(deeplab_params, stage, names, lr):
         scale = np.abs(ref).max() + 1e-12
         err = np.abs(got - ref)
         rel_l2 = np.sqrt((err.astype(np.float64) ** 2).sum()) / (np.sqrt((ref.astype(np.float64) ** 2).sum()) + 1e-30)
-        assert rel_l2 < max(1e-2, 5 * noise, 3 * sens) and np.median(err) / scale < max(1e-3, noise, sens) \
-            and err.max() / scale < max(5e-2, 10 * sens), (name, rel_l2, np.median(err) / scale, err.max() / scale, noise, sens)
+        # round 2 (deterministic, atomic-free weight gradients): rel-L2 <= max(2e-3, 2 x fp32-vs-fp64 noise of the REFERENCE,
+        # 3 x its sensitivity to a 4e-6 jitter of the trunk outputs); round 1 asked for max(1e-2, 5 x, 3 x)
+        bound = max(2e-3, 2 * noise, 3 * sens)
+        report[name] = dict(rel_l2=float(rel_l2), bound=float(bound), noise=noise, sens=sens,
+                            median_over_max=float(np.median(err) / scale), max_over_max=float(err.max() / scale))
+        assert rel_l2 < bound and np.median(err) / scale < max(1e-3, noise, sens) \
+            and err.max() / scale < max(2e-2, 10 * sens), (name, rel_l2, bound, np.median(err) / scale, err.max() / scale, noise, sens)
 
     for k in [k for k in g.files if k.startswith(pre + "grad_") and not k.startswith(pre + "grad_sub_")
               and not k.startswith(pre + "grad_l2_")]:
@@ -121,6 +128,14 @@ def test_train_step_golden(deeplab_params, stage, names, lr):
         ref = g[k]
         okay = np.abs(got - ref) <= 0.05 * lr
         assert okay.mean() > 0.995, (name, okay.mean())
+    import json, os
+    from conftest import ROOT
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", f"train_step_golden_{stage}.json"), "w") as f:
+            json.dump(report, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
 
 
 @pytest.mark.parametrize("n,h,w,train", [(1, 200, 264, False), (3, 72, 104, False), (2, 88, 120, True), (1, 90, 150, False),
