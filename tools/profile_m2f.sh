@@ -19,7 +19,7 @@ python3 tools/bench_encoder.py 16 >> "$OUT/bench_encoder.jsonl" 2> /dev/null
 python3 tools/bench_metric.py > "$OUT/bench_metric.jsonl" 2> /dev/null
 python3 tools/bench_m2f.py > "$OUT/bench_m2f.jsonl" 2> /dev/null
 python3 - "$OUT" <<'PY'
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 out = sys.argv[1]
 res = {}
 for counter, d in (("FETCH_SIZE", "msda_pmc_fetch"), ("WRITE_SIZE", "msda_pmc_write")):
@@ -27,9 +27,10 @@ for counter, d in (("FETCH_SIZE", "msda_pmc_fetch"), ("WRITE_SIZE", "msda_pmc_wr
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != counter:
                 continue
-            k = row["Kernel_Name"].split("(")[0][-60:]
-            if "msda" not in k:
+            m = re.search(r"msda_\w+", row["Kernel_Name"])
+            if not m:
                 continue
+            k = m.group(0)
             e = res.setdefault(k, {}).setdefault(counter, [])
             e.append(float(row["Counter_Value"]))
 summ = {k: {c: {"launches": len(v), "min_KB": min(v), "max_KB": max(v)} for c, v in d.items()} for k, d in res.items()}
