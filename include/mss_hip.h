@@ -352,6 +352,21 @@ long long mss_groupnorm_workspace_floats(int N, int HW, int C, int groups);
 int mss_groupnorm_nhwc_f32(const float* x, int ldx, long long x_sample_stride, int N, int HW, int C, int groups,
                            const float* gamma, const float* beta, float eps, int relu, float* y, int ldy,
                            long long y_sample_stride, float* ws, void* stream);
+/* backward of mss_groupnorm_nhwc_f32 (the pixel decoder is trainable in Mask2Former's second stage): stat = the forward's
+ * [N*groups][2] (mean, rstd), left by the forward at ws + mss_groupnorm_stat_offset(N, HW, C) floats; relu = the forward
+ * fused a ReLU. dx contiguous NHWC (pixel stride lddx), dgamma / dbeta [C] optional. Deterministic (fixed-order sums). */
+long long mss_groupnorm_stat_offset(int N, int HW, int C);
+long long mss_groupnorm_bwd_workspace_floats(int N, int HW, int C, int groups);
+int mss_groupnorm_nhwc_bwd_f32(const float* gy, int ldg, long long g_sample_stride, const float* x, int ldx,
+                               long long x_sample_stride, int N, int HW, int C, int groups, const float* stat,
+                               const float* gamma, const float* beta, int relu, float* dx, int lddx, float* dgamma,
+                               float* dbeta, float* ws, void* stream);
+/* transpose of the bilinear part of mss_upsample_bilinear_add_nhwc_f32: dtop (+)= B^T dy (the lateral gradient is dy). */
+int mss_upsample_bilinear_bwd_nhwc_f32(const float* dy, int lddy, int N, int OH, int OW, float* dtop, int ldt,
+                                       long long top_sample_stride, int IH, int IW, int C, int accumulate, void* stream);
+/* NCHW gradient -> rows of an NHWC / token buffer (pixel stride ldd, sample stride d_sample_stride floats), optional +=. */
+int mss_nchw_to_nhwc_strided_f32(const float* g, int N, int C, int HW, float* dst, int ldd, long long d_sample_stride,
+                                 int accumulate, void* stream);
 /* FPN top-down step (msdeformattn.py:344): y = lat + F.interpolate(top, size=(OH, OW), mode="bilinear",
  * align_corners=False); NHWC with pixel strides (top also with a sample stride: a level inside the token buffer). */
 int mss_upsample_bilinear_add_nhwc_f32(const float* top, int ldt, long long top_sample_stride, int N, int IH, int IW,

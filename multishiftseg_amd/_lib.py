@@ -125,6 +125,11 @@ SIGNATURES = {
     "mss_add_layernorm_bwd_f32": [P, P, P, P, L, I, P, P, P, P, P, P],
     "mss_groupnorm_workspace_floats": [I, I, I, I],
     "mss_groupnorm_nhwc_f32": [P, I, L, I, I, I, I, P, P, F, I, P, I, L, P, P],
+    "mss_groupnorm_stat_offset": [I, I, I],
+    "mss_groupnorm_bwd_workspace_floats": [I, I, I, I],
+    "mss_groupnorm_nhwc_bwd_f32": [P, I, L, P, I, L, I, I, I, I, P, P, P, I, P, I, P, P, P, P],
+    "mss_upsample_bilinear_bwd_nhwc_f32": [P, I, I, I, I, P, I, L, I, I, I, I, P],
+    "mss_nchw_to_nhwc_strided_f32": [P, I, I, I, P, I, L, I, P],
     "mss_upsample_bilinear_add_nhwc_f32": [P, I, L, I, I, I, P, I, P, I, I, I, I, P],
     "mss_nhwc_to_nchw_f32": [P, I, L, I, I, I, P, P],
     "mss_data_pair_f32": [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, P, P],
@@ -136,10 +141,12 @@ SIGNATURES = {
 _VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
                     "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts",
                     "mss_conv2d_wgrad_workspace_bytes", "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
-                    "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats"}
+                    "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats",
+                    "mss_groupnorm_stat_offset", "mss_groupnorm_bwd_workspace_floats"}
 _RETURNS_LONGLONG = {"mss_wino_num_tiles", "mss_oodm_sort_temp_bytes", "mss_conv2d_wgrad_workspace_bytes",
                      "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
-                     "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats"}
+                     "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats",
+                     "mss_groupnorm_stat_offset", "mss_groupnorm_bwd_workspace_floats"}
 
 _lib = None
 

@@ -345,3 +345,242 @@ int mss_nhwc_to_nchw_f32(const float* x, int ldx, long long x_sample_stride, int
 }
 
 }  // extern "C"
+
+// ================================================================================================ backward kernels
+// (the pixel decoder is trained in Mask2Former stage 2: train_m2f.py:291-310 unfreezes sem_seg_head.pixel_decoder)
+namespace {
+
+// GroupNorm backward, stage 1: per (n, chunk, quad) partial sums of g*gamma and g*gamma*xhat (for dx) -> part[n][chunk][2][C/4],
+// and per (n, chunk, channel) partial sums of g*xhat / g (for dgamma / dbeta) -> pgb[n][chunk][2][C]
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ gy, int ldg, long long g_ss,
+                                                           const float* __restrict__ x, int ldx, long long x_ss, int HW, int C,
+                                                           int groups, const float* __restrict__ stat,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int relu, float* __restrict__ part, float* __restrict__ pgb,
+                                                           int rows_per_chunk) {
+  const int C4 = C >> 2;
+  const int QPB = C4 < 256 ? C4 : 256, RPB = 256 / QPB;
+  const int tx = threadIdx.x % QPB, ty = threadIdx.x / QPB;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * rows_per_chunk, p1 = min(HW, p0 + rows_per_chunk);
+  __shared__ f32x4 red[2][256];
+  __shared__ float reds[2][256];
+  f32x4 sgx = {0.f, 0.f, 0.f, 0.f}, sg = {0.f, 0.f, 0.f, 0.f};
+  float s1 = 0.f, s2 = 0.f;
+  if (ty < RPB) {
+    const int c = tx * 4;
+    const int g = c / (C / groups);
+    const float mean = stat[2 * (n * groups + g)], rstd = stat[2 * (n * groups + g) + 1];
+    const f32x4 gm = ld4(gamma + c), bt = ld4(beta + c);
+    for (int p = p0 + ty; p < p1; p += RPB) {
+      const f32x4 xh = (ld4(x + (long long)n * x_ss + (long long)p * ldx + c) - mean) * rstd;
+      f32x4 gv = ld4(gy + (long long)n * g_ss + (long long)p * ldg + c);
+      if (relu) {
+        const f32x4 yv = xh * gm + bt;
+        gv.x = yv.x > 0.f ? gv.x : 0.f; gv.y = yv.y > 0.f ? gv.y : 0.f; gv.z = yv.z > 0.f ? gv.z : 0.f; gv.w = yv.w > 0.f ? gv.w : 0.f;
+      }
+      sgx += gv * xh; sg += gv;
+      const f32x4 gg = gv * gm;
+      s1 += (gg.x + gg.y) + (gg.z + gg.w);
+      const f32x4 t = gg * xh;
+      s2 += (t.x + t.y) + (t.z + t.w);
+    }
+  }
+  red[0][threadIdx.x] = sgx; red[1][threadIdx.x] = sg;
+  reds[0][threadIdx.x] = s1; reds[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (ty == 0) {
+    for (int yy = 1; yy < RPB; ++yy) {
+      sgx += red[0][yy * QPB + tx]; sg += red[1][yy * QPB + tx];
+      s1 += reds[0][yy * QPB + tx]; s2 += reds[1][yy * QPB + tx];
+    }
+    const size_t blk = (size_t)n * gridDim.x + blockIdx.x;
+    part[blk * 2 * C4 + tx] = s1;
+    part[blk * 2 * C4 + C4 + tx] = s2;
+    st4(pgb + blk * 2 * C + tx * 4, sgx);
+    st4(pgb + blk * 2 * C + C + tx * 4, sg);
+  }
+}
+
+// stage 2: per (n, group) the two means of the dx formula, chunks and quads added in a fixed order in double
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int N, int nchunks, int C, int groups, int HW,
+                                       float* __restrict__ m12) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * groups) return;
+  const int n = i / groups, g = i - n * groups;
+  const int C4 = C >> 2, qpg = (C / groups) >> 2;
+  double a = 0.0, b = 0.0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float* o = part + (((size_t)n * nchunks + ch) * 2) * C4;
+    for (int k = 0; k < qpg; ++k) { a += o[g * qpg + k]; b += o[C4 + g * qpg + k]; }
+  }
+  const double cnt = (double)HW * (C / groups);
+  m12[2 * i] = (float)(a / cnt);
+  m12[2 * i + 1] = (float)(b / cnt);
+}
+
+// dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)); grid (ceil(HW*C/4 / 256), N)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ gy, int ldg, long long g_ss,
+                                                           const float* __restrict__ x, int ldx, long long x_ss, int HW, int C,
+                                                           int groups, const float* __restrict__ stat, const float* __restrict__ m12,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int relu, float* __restrict__ dx, int lddx) {
+  const unsigned C4 = (unsigned)C >> 2;
+  const unsigned item = blockIdx.x * 256u + threadIdx.x;
+  const unsigned p = item / C4;
+  if (p >= (unsigned)HW) return;
+  const int c = (int)(item - p * C4) * 4;
+  const int n = blockIdx.y;
+  const int g = c / (C / groups);
+  const float mean = stat[2 * (n * groups + g)], rstd = stat[2 * (n * groups + g) + 1];
+  const float m1 = m12[2 * (n * groups + g)], m2 = m12[2 * (n * groups + g) + 1];
+  const f32x4 gm = ld4(gamma + c);
+  const f32x4 xh = (ld4(x + (long long)n * x_ss + (long long)p * ldx + c) - mean) * rstd;
+  f32x4 gv = ld4(gy + (long long)n * g_ss + (long long)p * ldg + c);
+  if (relu) {
+    const f32x4 yv = xh * gm + ld4(beta + c);
+    gv.x = yv.x > 0.f ? gv.x : 0.f; gv.y = yv.y > 0.f ? gv.y : 0.f; gv.z = yv.z > 0.f ? gv.z : 0.f; gv.w = yv.w > 0.f ? gv.w : 0.f;
+  }
+  st4(dx + ((long long)n * HW + p) * lddx + c, rstd * (gv * gm - m1 - xh * m2));
+}
+
+// transpose of upsample_add_kernel's bilinear part: dtop[n][iy][ix] = sum over outputs of weight * dy; gather form with
+// the candidate output range of each source cell; grid (ceil(IW * C/4 / 256), IH, N). accumulate: dtop += (token buffers
+// that already hold another gradient).
+__global__ __launch_bounds__(256) void upsample_hp_bwd_kernel(const float* __restrict__ dy, int lddy, int OH, int OW,
+                                                              float* __restrict__ dtop, int ldt, long long top_ss, int IH, int IW,
+                                                              int C, float sh, float sw, int accumulate) {
+  const unsigned C4 = (unsigned)C >> 2;
+  const unsigned item = blockIdx.x * 256u + threadIdx.x;
+  const unsigned ix = item / C4;
+  if (ix >= (unsigned)IW) return;
+  const int c = (int)(item - ix * C4) * 4;
+  const int iy = blockIdx.y, n = blockIdx.z;
+  auto weight = [](int o, int i, float scale, int in) {
+    float src = ((float)o + 0.5f) * scale;
+    asm volatile("" : "+v"(src));
+    src -= 0.5f;
+    src = src < 0.f ? 0.f : src;
+    const int i0 = (int)src;
+    const int i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    const float l1 = src - (float)i0;
+    float w = 0.f;
+    if (i0 == i) w += 1.f - l1;
+    if (i1 == i) w += l1;
+    return w;
+  };
+  // outputs whose source index can touch cell i: src in (i-1, i+1) -> o in ((i-0.5)/s - 0.5 - 1, (i+1.5)/s - 0.5 + 1), padded
+  const float ish = 1.f / sh, isw = 1.f / sw;
+  int ylo = (int)floorf(((float)iy - 1.f) * ish) - 2, yhi = (int)ceilf(((float)iy + 2.f) * ish) + 2;
+  int xlo = (int)floorf(((float)ix - 1.f) * isw) - 2, xhi = (int)ceilf(((float)ix + 2.f) * isw) + 2;
+  ylo = ylo < 0 ? 0 : ylo; xlo = xlo < 0 ? 0 : xlo;
+  yhi = yhi > OH - 1 ? OH - 1 : yhi; xhi = xhi > OW - 1 ? OW - 1 : xhi;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* b = dy + (long long)n * OH * OW * lddy + c;
+  for (int oy = ylo; oy <= yhi; ++oy) {
+    const float wy = weight(oy, iy, sh, IH);
+    if (wy == 0.f) continue;
+    f32x4 racc = {0.f, 0.f, 0.f, 0.f};
+    for (int ox = xlo; ox <= xhi; ++ox) {
+      const float wx = weight(ox, (int)ix, sw, IW);
+      if (wx != 0.f) racc += wx * ld4(b + ((long long)oy * OW + ox) * lddy);
+    }
+    acc += wy * racc;
+  }
+  float* o = dtop + (long long)n * top_ss + ((long long)iy * IW + ix) * ldt + c;
+  if (accumulate) acc += ld4(o);
+  st4(o, acc);
+}
+
+// dst (token rows of a level: pixel stride ldd, sample stride d_ss) = NCHW gradient g (contiguous), optional accumulate.
+// 64 pixels x 64 channels per workgroup through LDS; grid (ceil(HW/64), ceil(C/64), N)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_strided_kernel(const float* __restrict__ g, int HW, int C,
+                                                                   float* __restrict__ dst, int ldd, long long d_ss,
+                                                                   int accumulate) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, p = p0 + tx;
+    tile[r][tx] = (c < C && p < HW) ? g[((long long)n * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int p = p0 + r, c = c0 + tx;
+    if (p < HW && c < C) {
+      float* o = dst + (long long)n * d_ss + (long long)p * ldd + c;
+      *o = accumulate ? *o + tile[tx][r] : tile[tx][r];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// backward of mss_groupnorm_nhwc_f32 (same x, strides and statistics layout; relu: the forward fused a ReLU): dx (contiguous
+// NHWC, pixel stride lddx), dgamma / dbeta [C]. ws: mss_groupnorm_bwd_workspace_floats floats. stat = the forward's
+// [N*groups][2] (mean, rstd), which the forward leaves at ws_fwd + N*chunks*2*(C/4) (see mss_groupnorm_stat_offset).
+long long mss_groupnorm_stat_offset(int N, int HW, int C) {
+  long long chunks = (HW + 255) / 256;
+  if (chunks > 512) chunks = 512;
+  const int rpc = (int)((HW + chunks - 1) / chunks);
+  chunks = (HW + rpc - 1) / rpc;
+  return (long long)N * chunks * 2 * (C / 4);
+}
+long long mss_groupnorm_bwd_workspace_floats(int N, int HW, int C, int groups) {
+  if (N <= 0 || HW <= 0 || C <= 0 || groups <= 0) return 0;
+  long long chunks = (HW + 255) / 256;
+  if (chunks > 512) chunks = 512;
+  return (long long)N * chunks * (2 * (C / 4) + 2 * C) + 2ll * N * groups;
+}
+int mss_groupnorm_nhwc_bwd_f32(const float* gy, int ldg, long long g_sample_stride, const float* x, int ldx,
+                               long long x_sample_stride, int N, int HW, int C, int groups, const float* stat,
+                               const float* gamma, const float* beta, int relu, float* dx, int lddx, float* dgamma,
+                               float* dbeta, float* ws, void* stream) {
+  if (!gy || !x || !stat || !gamma || !beta || !dx || !ws || N < 0 || HW <= 0) return MSS_ERR_BAD_ARG;
+  if (N == 0) return MSS_OK;
+  if (C % 4 || ldx % 4 || ldg % 4 || lddx % 4 || groups <= 0 || C % groups || (C / groups) % 4 || C / 4 > 256 || N > 65535)
+    return MSS_ERR_UNSUPPORTED;
+  long long chunks = (HW + 255) / 256;
+  if (chunks > 512) chunks = 512;
+  const int rpc = (int)((HW + chunks - 1) / chunks);
+  chunks = (HW + rpc - 1) / rpc;
+  float* part = ws;
+  float* pgb = part + (size_t)N * chunks * 2 * (C / 4);
+  float* m12 = pgb + (size_t)N * chunks * 2 * C;
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3((unsigned)chunks, N), dim3(256), 0, S_(stream), gy, ldg, g_sample_stride, x, ldx,
+                     x_sample_stride, HW, C, groups, stat, gamma, beta, relu, part, pgb, rpc);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((N * groups + 63) / 64), dim3(64), 0, S_(stream), part, N, (int)chunks, C, groups, HW, m12);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(((long long)HW * (C / 4) + 255) / 256), N), dim3(256), 0, S_(stream), gy, ldg,
+                     g_sample_stride, x, ldx, x_sample_stride, HW, C, groups, stat, m12, gamma, beta, relu, dx, lddx);
+  const int nparts = (int)(N * chunks);
+  if (dgamma) hipLaunchKernelGGL(ordered_colsum_kernel, dim3((C + 3) / 4), dim3(256), 0, S_(stream), pgb, nparts, C, 2ll * C, dgamma);
+  if (dbeta) hipLaunchKernelGGL(ordered_colsum_kernel, dim3((C + 3) / 4), dim3(256), 0, S_(stream), pgb + C, nparts, C, 2ll * C, dbeta);
+  return mss_launch_status();
+}
+
+// transpose of the bilinear part of mss_upsample_bilinear_add_nhwc_f32: dtop (+)= B^T dy; the lateral gradient is dy itself
+int mss_upsample_bilinear_bwd_nhwc_f32(const float* dy, int lddy, int N, int OH, int OW, float* dtop, int ldt,
+                                       long long top_sample_stride, int IH, int IW, int C, int accumulate, void* stream) {
+  if (!dy || !dtop || C % 4 || lddy % 4 || ldt % 4) return MSS_ERR_BAD_ARG;
+  if ((long long)N * IH * IW == 0) return MSS_OK;
+  if (IH > 65535 || N > 65535) return MSS_ERR_UNSUPPORTED;
+  const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
+  hipLaunchKernelGGL(upsample_hp_bwd_kernel, dim3((unsigned)(((long long)IW * (C / 4) + 255) / 256), IH, N), dim3(256), 0, S_(stream),
+                     dy, lddy, OH, OW, dtop, ldt, top_sample_stride, IH, IW, C, sh, sw, accumulate);
+  return mss_launch_status();
+}
+
+// NCHW gradient -> rows of an NHWC / token buffer (pixel stride ldd, sample stride d_sample_stride floats), optional +=
+int mss_nchw_to_nhwc_strided_f32(const float* g, int N, int C, int HW, float* dst, int ldd, long long d_sample_stride,
+                                 int accumulate, void* stream) {
+  if (!g || !dst || N < 0 || HW <= 0 || C <= 0) return MSS_ERR_BAD_ARG;
+  if (N == 0) return MSS_OK;
+  if (N > 65535 || (C + 63) / 64 > 65535) return MSS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(nchw_to_nhwc_strided_kernel, dim3((HW + 63) / 64, (C + 63) / 64, N), dim3(256), 0, S_(stream), g, HW, C, dst, ldd,
+                     d_sample_stride, accumulate);
+  return mss_launch_status();
+}
+
+}  // extern "C"

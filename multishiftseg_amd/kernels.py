@@ -659,9 +659,10 @@ def m2f_score_fused(class_logits, mask_logits_nhwc, image_size, size=None):
 
 
 # ---- Mask2Former pixel-decoder glue (csrc/norm.hip) --------------------------------------------------------------------
-def groupnorm(x, gn, relu=False, out=None, out_sample_stride=None, out_ld=None):
+def groupnorm(x, gn, relu=False, out=None, out_sample_stride=None, out_ld=None, want_stat=False):
     """nn.GroupNorm `gn` on an Act (NHWC). `out`: optional float tensor to write into (e.g. the encoder's token buffer
-    [N, sum(HW), C] at a level's offset) with pixel stride `out_ld` and sample stride `out_sample_stride` floats."""
+    [N, sum(HW), C] at a level's offset) with pixel stride `out_ld` and sample stride `out_sample_stride` floats.
+    want_stat: also return the [N*groups, 2] (mean, rstd) view the backward needs."""
     N, HW, C = x.N, x.H * x.W, x.C
     dev = x.buf.device
     ws = torch.empty(_lib.value("mss_groupnorm_workspace_floats", N, HW, C, gn.num_groups), device=dev, dtype=torch.float32)
@@ -672,7 +673,36 @@ def groupnorm(x, gn, relu=False, out=None, out_sample_stride=None, out_ld=None):
         y, optr, old, oss = out, ptr(out), out_ld, out_sample_stride
     call("mss_groupnorm_nhwc_f32", x.ptr, x.ld, HW * x.ld, N, HW, C, gn.num_groups, ptr(gn.weight), ptr(gn.bias), float(gn.eps),
          int(relu), optr, old, oss, ptr(ws))
+    if want_stat:
+        off = _lib.value("mss_groupnorm_stat_offset", N, HW, C)
+        return y, ws[off:off + 2 * N * gn.num_groups]
     return y
+
+
+def groupnorm_backward(gy_ptr, gy_ld, gy_ss, x, gn, stat, relu=False):
+    """Backward of groupnorm(x, gn, relu): gy given as (pointer, pixel stride, sample stride) so that it may live inside a
+    token buffer. Returns (dx Act, dgamma, dbeta)."""
+    N, HW, C = x.N, x.H * x.W, x.C
+    dev = x.buf.device
+    dx = Act.empty(N, x.H, x.W, C, dev)
+    dg = torch.empty(C, device=dev, dtype=torch.float32)
+    db = torch.empty(C, device=dev, dtype=torch.float32)
+    ws = torch.empty(_lib.value("mss_groupnorm_bwd_workspace_floats", N, HW, C, gn.num_groups), device=dev, dtype=torch.float32)
+    call("mss_groupnorm_nhwc_bwd_f32", gy_ptr, gy_ld, gy_ss, x.ptr, x.ld, HW * x.ld, N, HW, C, gn.num_groups, ptr(stat), ptr(gn.weight),
+         ptr(gn.bias), int(relu), dx.ptr, dx.ld, ptr(dg), ptr(db), ptr(ws))
+    return dx, dg, db
+
+
+def upsample_bilinear_bwd(dy, dtop_ptr, dtop_ld, dtop_ss, IH, IW, accumulate):
+    """Transpose of the bilinear part of upsample_bilinear_add: dtop (+)= B^T dy, dtop given as (pointer, strides)."""
+    call("mss_upsample_bilinear_bwd_nhwc_f32", dy.ptr, dy.ld, dy.N, dy.H, dy.W, dtop_ptr, dtop_ld, dtop_ss, IH, IW, dy.C, int(accumulate))
+
+
+def nchw_into_rows(g, dst_ptr, dst_ld, dst_ss, accumulate=False):
+    """NCHW gradient tensor -> rows of an NHWC / token buffer given as (pointer, pixel stride, sample stride)."""
+    n, c, h, w = g.shape
+    g = g.contiguous().float()
+    call("mss_nchw_to_nhwc_strided_f32", ptr(g), n, c, h * w, dst_ptr, dst_ld, dst_ss, int(accumulate))
 
 
 class TokenLevel:

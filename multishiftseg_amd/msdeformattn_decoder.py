@@ -14,8 +14,13 @@ What runs (all in libmss_hip.so, NHWC inside):
   * the FPN top-down step for the stride-4 level: lateral 1x1 conv -> GroupNorm, bilinear(align_corners=False) + add in
     one kernel reading the finest encoder level in place, 3x3 conv (Winograd / implicit GEMM) -> GroupNorm+ReLU;
   * mask_features 1x1 conv; NHWC -> NCHW only for the five returned maps.
-Forward only: the backward of the shell is not built yet (asking for parameter gradients raises).
+Trainable: the shell is two autograd nodes around the (already differentiable) encoder -- `_InputProjFn` (the three input
+projections -> token buffer) and `_FpnFn` (FPN step + mask_features + the returned maps) -- whose backward runs on the
+same kernels: 1x1 / 3x3 weight and data gradients (conv_wgrad / gemm_nt / Winograd), GroupNorm backward, the transpose of
+the bilinear up-sampling, deterministic bias / affine reductions. Supported for the Mask2Former configuration (three
+transformer levels, one FPN level, norm="GN"); other layouts run forward-only.
 """
+import ctypes
 from collections import namedtuple
 
 import numpy as np
@@ -121,18 +126,35 @@ class MSDeformAttnPixelDecoder(nn.Module):
         return y
 
     # ---- reference API ---------------------------------------------------------------------------------------------------
-    def forward_features(self, features):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("MSDeformAttnPixelDecoder (multishiftseg_amd): the shell's backward (GroupNorm / FPN) is "
-                                      "not built; call under torch.no_grad() or freeze the parameters")
-        with torch.no_grad():
-            return self._forward_features(features)
+    def _trainable_layout(self):
+        return (self.transformer_num_feature_levels == 3 and self.num_fpn_levels == 1 and self.lateral_convs[0].norm is not None
+                and self.lateral_convs[0].bias is None)
 
-    def _forward_features(self, features):
+    def forward_features(self, features):
         names = self.transformer_in_features[::-1]                      # res5 -> res3 (msdeformattn.py:319)
         xs = [features[f].float() for f in names]
         if not xs[0].is_cuda:
             raise RuntimeError("MSDeformAttnPixelDecoder (multishiftseg_amd) runs on an MI355X only; there is no CPU path")
+        want_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+                                                 any(t.requires_grad for t in features.values()))
+        if not want_grad:
+            with torch.no_grad():
+                return self._forward_features(features, xs)
+        if not self._trainable_layout():
+            raise NotImplementedError("MSDeformAttnPixelDecoder (multishiftseg_amd): the backward is built for three transformer "
+                                      "levels + one GroupNorm FPN level (the Mask2Former configs); call under torch.no_grad()")
+        shapes = [(x.shape[2], x.shape[3]) for x in xs]
+        pos = [self.pe_layer(x) for x in xs]
+        ip = [m for proj in self.input_proj for m in (proj[0].weight, proj[0].bias, proj[1].weight, proj[1].bias)]
+        tokens = _InputProjFn.apply(self, *xs, *ip)
+        memory, _, _ = self.transformer.forward_tokens(tokens, pos, shapes)
+        lat, outc = self.lateral_convs[0], self.output_convs[0]
+        x2 = features[self.in_features[0]].float()
+        mask, m0, m1, m2 = _FpnFn.apply(self, shapes, memory, x2, lat.weight, lat.norm.weight, lat.norm.bias, outc.weight,
+                                        outc.norm.weight, outc.norm.bias, self.mask_features.weight, self.mask_features.bias)
+        return mask, m0, [m0, m1, m2]
+
+    def _forward_features(self, features, xs):
         N = xs[0].shape[0]
         shapes = [(x.shape[2], x.shape[3]) for x in xs]
         starts = np.concatenate([[0], np.cumsum([h * w for h, w in shapes])]).tolist()
@@ -166,3 +188,116 @@ class MSDeformAttnPixelDecoder(nn.Module):
 
     def forward(self, features, targets=None):
         raise NotImplementedError("the reference only calls forward_features (msdeformattn.py:314)")
+
+
+def _conv1x1_backward(x_act, dy, conv, need_w, need_b, need_x):
+    """Gradients of y = conv1x1(x) (+bias) given dy (Act): weight [K,C,1,1], bias [K], input (Act) -- each only on request."""
+    k, c = conv.weight.shape[0], conv.weight.shape[1]
+    dw = K.conv2d_wgrad(x_act, dy, k, c, 1, 1) if need_w else None
+    db = K.colsum(dy).sum(0) if need_b else None
+    dx = K.conv2d(dy, K.packed(conv.weight, flip=True)) if need_x else None
+    return dw, db, dx
+
+
+class _InputProjFn(torch.autograd.Function):
+    """features (res5, res4, res3; NCHW) -> 1x1 conv + bias -> GroupNorm(32) -> token buffer [N, sum(HW), C]
+    (msdeformattn.py:215-219,319-323 and the flatten / cat of :66-79)."""
+
+    @staticmethod
+    def forward(ctx, dec, x0, x1, x2, *params):
+        xs = (x0, x1, x2)
+        N = x0.shape[0]
+        shapes = [(x.shape[2], x.shape[3]) for x in xs]
+        starts = np.concatenate([[0], np.cumsum([h * w for h, w in shapes])]).tolist()
+        S, C = starts[-1], dec.input_proj[0][1].num_channels
+        tokens = torch.empty((N, S, C), device=x0.device, dtype=torch.float32)
+        saved = []
+        for idx, x in enumerate(xs):
+            conv, gn = dec.input_proj[idx][0], dec.input_proj[idx][1]
+            xa = K.nchw_to_act(x)
+            y = dec._conv1x1(xa, conv)
+            _, stat = K.groupnorm(y, gn, out=tokens[0, starts[idx]:], out_sample_stride=S * C, out_ld=C, want_stat=True)
+            saved.append((xa, y, stat))
+        ctx.dec, ctx.saved, ctx.starts, ctx.shapes = dec, saved, starts, shapes
+        ctx.in_channels = [x.shape[1] for x in xs]
+        return tokens
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_tokens):
+        dec, starts = ctx.dec, ctx.starts
+        g_tokens = g_tokens.contiguous()
+        N, S, C = g_tokens.shape
+        need = ctx.needs_input_grad            # (dec, x0, x1, x2, w0, b0, gw0, gb0, w1, ...)
+        gx = [None, None, None]
+        gp = []
+        for idx in range(3):
+            conv, gn = dec.input_proj[idx][0], dec.input_proj[idx][1]
+            xa, y, stat = ctx.saved[idx]
+            gptr = ctypes.c_void_p(g_tokens.data_ptr() + 4 * starts[idx] * C)
+            dy, dgam, dbet = K.groupnorm_backward(gptr, C, S * C, y, gn, stat)
+            base = 4 + 4 * idx
+            dw, db, dx = _conv1x1_backward(xa, dy, conv, need[base], need[base + 1], need[1 + idx])
+            if dx is not None:
+                gx[idx] = K.nhwc_to_nchw(dx)[:, :ctx.in_channels[idx]].contiguous()
+            gp += [dw, db, dgam if need[base + 2] else None, dbet if need[base + 3] else None]
+        ctx.saved = None
+        return (None, *gx, *gp)
+
+
+class _FpnFn(torch.autograd.Function):
+    """encoder memory + res2 -> the returned maps (msdeformattn.py:326-358): level split, lateral 1x1 conv + GN, bilinear
+    (align_corners=False) + add, 3x3 conv + GN + ReLU, mask_features 1x1 conv, NHWC -> NCHW."""
+
+    @staticmethod
+    def forward(ctx, dec, shapes, memory, x2, lat_w, lat_gw, lat_gb, out_w, out_gw, out_gb, mask_w, mask_b):
+        lat, outc = dec.lateral_convs[0], dec.output_convs[0]
+        starts = np.concatenate([[0], np.cumsum([h * w for h, w in shapes])]).tolist()
+        memory = memory.contiguous()
+        levels = [K.TokenLevel(memory, starts[i], *shapes[i]) for i in range(3)]
+        xa = K.nchw_to_act(x2)
+        lat_y = dec._conv1x1(xa, lat)
+        cur, lat_stat = K.groupnorm(lat_y, lat.norm, want_stat=True)
+        y = K.upsample_bilinear_add(levels[-1], cur)
+        z = K.conv3x3(y, outc.weight)
+        o, out_stat = K.groupnorm(z, outc.norm, relu=True, want_stat=True)
+        mask = K.nhwc_to_nchw(dec._conv1x1(o, dec.mask_features))
+        ms = [K.nhwc_to_nchw(l) for l in levels]
+        ctx.dec, ctx.shapes, ctx.starts = dec, shapes, starts
+        ctx.saved = (xa, lat_y, lat_stat, y, z, out_stat, o)
+        ctx.mem_shape, ctx.in_channels = tuple(memory.shape), x2.shape[1]
+        return mask, ms[0], ms[1], ms[2]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_mask, g0, g1, g2):
+        dec, shapes, starts = ctx.dec, ctx.shapes, ctx.starts
+        lat, outc = dec.lateral_convs[0], dec.output_convs[0]
+        xa, lat_y, lat_stat, y, z, out_stat, o = ctx.saved
+        need = ctx.needs_input_grad     # (dec, shapes, memory, x2, lat_w, lat_gw, lat_gb, out_w, out_gw, out_gb, mask_w, mask_b)
+        N, S, C = ctx.mem_shape
+        dev = g_mask.device
+        g_mem = torch.empty((N, S, C), device=dev, dtype=torch.float32)
+        for i, g in enumerate((g0, g1, g2)):          # the three returned levels are views of the memory rows
+            gptr = ctypes.c_void_p(g_mem.data_ptr() + 4 * starts[i] * C)
+            if g is None:
+                g_mem[:, starts[i]:starts[i + 1]].zero_()
+            else:
+                K.nchw_into_rows(g, gptr, C, S * C)
+        # mask_features
+        dm = K.nchw_to_act(g_mask, Cp=g_mask.shape[1])
+        d_mask_w, d_mask_b, do = _conv1x1_backward(o, dm, dec.mask_features, need[10], need[11], True)
+        # output conv: GroupNorm + ReLU, then the 3x3 convolution
+        dz, d_out_gw, d_out_gb = K.groupnorm_backward(do.ptr, do.ld, do.H * do.W * do.ld, z, outc.norm, out_stat, relu=True)
+        d_out_w = K.conv3x3_wgrad(y, dz, outc.weight.shape[0], outc.weight.shape[1]) if need[7] else None
+        dyy = K.conv3x3(dz, outc.weight, flip=True)
+        # y = cur + up(level 2): the lateral branch gets dy itself, the finest encoder level its bilinear transpose (added
+        # to the gradient that came in through the returned map)
+        h2, w2 = shapes[2]
+        K.upsample_bilinear_bwd(dyy, ctypes.c_void_p(g_mem.data_ptr() + 4 * starts[2] * C), C, S * C, h2, w2, accumulate=True)
+        dlat, d_lat_gw, d_lat_gb = K.groupnorm_backward(dyy.ptr, dyy.ld, dyy.H * dyy.W * dyy.ld, lat_y, lat.norm, lat_stat)
+        d_lat_w, _, dx2 = _conv1x1_backward(xa, dlat, lat, need[4], False, need[3])
+        gx2 = K.nhwc_to_nchw(dx2)[:, :ctx.in_channels].contiguous() if dx2 is not None else None
+        ctx.saved = None
+        return (None, None, g_mem, gx2, d_lat_w, d_lat_gw if need[5] else None, d_lat_gb if need[6] else None, d_out_w,
+                d_out_gw if need[8] else None, d_out_gb if need[9] else None, d_mask_w, d_mask_b)

@@ -590,13 +590,37 @@ def gen_decoder():
     feats = {k: rng.standard_normal((2, s.channels, H // s.stride, W // s.stride), dtype=np.float32) for k, s in shape.items()}
     with torch.no_grad():
         mask, out0, ms = dec.forward_features({k: torch.from_numpy(v) for k, v in feats.items()})
+    # backward of the shell + encoder: L = <mask, G> + sum_i <ms[i], G_i> with seeded cotangents; parameters and the four
+    # feature maps all receive gradients (the training loop freezes the backbone, train_m2f.py:409-412, but the input
+    # gradients pin the 1x1 data-gradient path too)
+    for p in dec.parameters():
+        p.requires_grad_(True)
+    tf = {k: torch.from_numpy(v).requires_grad_(True) for k, v in feats.items()}
+    mask_g, _, ms_g = dec.forward_features(tf)
+    crng = np.random.default_rng(63)
+    cot = [torch.from_numpy(crng.standard_normal(tuple(t.shape), dtype=np.float32)) for t in (mask_g, *ms_g)]
+    loss = sum((t * c).sum() for t, c in zip((mask_g, *ms_g), cot))
+    loss.backward()
+    grads = {}
+    for k, prm in dec.named_parameters():
+        gk = t2n(prm.grad)
+        grads["gl2_" + k] = np.float64(np.sqrt((gk.astype(np.float64) ** 2).sum()))
+        if gk.size <= 16384:
+            grads["g_" + k] = gk
+        else:
+            flat = gk.reshape(gk.shape[0], -1)
+            grads["gsub_" + k] = flat[::max(1, flat.shape[0] // 32), ::max(1, flat.shape[1] // 64)].copy()
+    for k, t in tf.items():
+        gk = t2n(t.grad)
+        grads["gl2_feat_" + k] = np.float64(np.sqrt((gk.astype(np.float64) ** 2).sum()))
+        grads["gsub_feat_" + k] = gk[:, ::max(1, gk.shape[1] // 32)].copy()
     save("m2f_decoder", names=np.array(list(sd.keys())), seed=np.int64(62), hw=np.array([H, W]),
          offsets_bias=t2n(sd["transformer.encoder.layers.0.self_attn.sampling_offsets.bias"]),
          mask_sub=t2n(mask)[:, ::4], mask_abs_sum=np.float64(np.abs(t2n(mask).astype(np.float64)).sum()),
          out0=t2n(out0), ms1=t2n(ms[1])[:, ::2], ms2_sub=t2n(ms[2])[:, ::4],
-         ms2_abs_sum=np.float64(np.abs(t2n(ms[2]).astype(np.float64)).sum()))
+         ms2_abs_sum=np.float64(np.abs(t2n(ms[2]).astype(np.float64)).sum()), cot_seed=np.int64(63), **grads)
     print(f"   decoder: mask {tuple(mask.shape)} |max| {float(mask.abs().max()):.3g}, out0 {tuple(out0.shape)}, "
-          f"levels {[tuple(m.shape) for m in ms]}")
+          f"levels {[tuple(m.shape) for m in ms]}, {len(grads)} gradient entries")
 
 
 def gen_m2f():
