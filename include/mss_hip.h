@@ -39,6 +39,16 @@ int mss_abi_version(void);
 int mss_msda_forward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                          const float* sampling_loc, const float* attn_weight, int N, int S, int M, int D, int L,
                          int Lq, int P, float* out, void* stream);
+/* Forward through LDS-staged value windows (round 2; replaces the same ms_deform_attn_forward, vision.cpp:18-21 ->
+ * ms_deform_attn_cuda.cu:25-88, for fp32 / D = 32): 64 queries x one head per workgroup, each level's window of value rows
+ * staged once in LDS, corner fetches outside it fall back to the global gather. `host_shapes` is a HOST copy of spatial_shapes
+ * [L][2] (the launch grid depends on it); reference_points NULL: loc / attn are sampling_locations / attention_weights,
+ * else the raw offsets / logits of ops/modules/ms_deform_attn.py:98-109. MSS_ERR_UNSUPPORTED unless D == 32, L <= 8,
+ * L*P <= 20 and value / out are 16-byte aligned. */
+int mss_msda_forward_window_f32(const float* value, const int64_t* host_shapes, const int64_t* level_start_index,
+                                const float* loc_or_offsets, const float* attn_or_logits, const float* reference_points, int N,
+                                int S, int M, int D, int L, int Lq, int P, float* out, void* stream);
+
 int mss_msda_forward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                          const double* sampling_loc, const double* attn_weight, int N, int S, int M, int D, int L,
                          int Lq, int P, double* out, void* stream);

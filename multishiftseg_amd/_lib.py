@@ -62,6 +62,7 @@ SIGNATURES = {
     "mss_msda_backward_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P],
     "mss_msda_backward_f64": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P],
     "mss_msda_forward_fused_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
+    "mss_msda_forward_window_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
     "mss_msda_prepare_f32": [P, P, P, P, I, I, I, I, I, P, P, P],
     "mss_msda_prepare_backward_f32": [P, P, P, P, I, I, I, I, I, P, P, P],
     "mss_conv2d_forward_f32": [POINTER(MssConvArgs), P],

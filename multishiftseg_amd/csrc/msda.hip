@@ -21,6 +21,10 @@
 
 namespace {
 
+constexpr int MSDA_MAX_LP = 20;       // prepare kernels: 256 pairs x 3 x L*P floats of LDS per workgroup (60 KB at 20)
+constexpr int MSDA_WIN_MAXL = 8;      // window forward: levels carried by value in the kernel arguments
+constexpr int MSDA_WIN_ROWS = 320;    // window forward: value rows (128 B each) of one level staged per workgroup (40 KB)
+
 template <typename T> struct Vec4;
 template <> struct Vec4<float> { typedef f32x4 type; };
 
@@ -141,6 +145,239 @@ __global__ __launch_bounds__(256) void msda_fwd_fast_kernel(
     }
   }
   *reinterpret_cast<f32x4*>(out + pair * D + 4 * j) = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward through LDS windows (fp32, D = 32). The fast kernel above sits on the L2 row-gather rate (48 x 128-B rows per
+// (query, head), 16-17 TB/s measured); in the encoder the queries are the pixels of the levels themselves and their
+// samples lie a few pixels around their own position, so neighbouring queries gather the same rows again and again.
+// One workgroup = 64 queries (an 8x8 pixel tile of one level when the queries are the pixel grid, else 64 consecutive
+// queries) x one head. Per level: the bounding box of the tile's samples is reduced in LDS, a window of at most
+// MSDA_WIN_ROWS value rows (the whole box if it fits, else a box of that area around the samples' mean) is staged once
+// with coalesced 128-B loads, and the 4*P corner fetches of every query read LDS; a corner outside the window falls
+// back to the global gather, so the result never depends on where the window lies. Same arithmetic per sample as the
+// fast kernel. Level geometry comes BY VALUE from the host (the grid size depends on it).
+// MEASURED (profiles/r02/m2f/bench_msda_window.jsonl): correct but SLOWER than the gather kernel on MI355X -- 0.66-0.81 ms
+// against 0.46 ms at N = 16 (C4), 0.18-0.22 against 0.107 at C5 -- so it is opt-in (MSS_MSDA_WINDOW=1) and kept as the
+// record of the experiment: 48 LDS b128 reads per (query, head) cost 8 clocks each before bank conflicts (rows of the
+// same parity collide), the per-level barriers and box reductions add to that, and the L2 gather already delivers
+// 17 TB/s = 43 % of the L1 data path; the ceiling of the LDS route is ~2x, the first implementation is 0.7x.
+struct MsdaLevels {
+  int L;
+  int H[MSDA_WIN_MAXL], W[MSDA_WIN_MAXL];
+  int qstart[MSDA_WIN_MAXL];         // first query of the level (grid mode)
+  int tiles_x[MSDA_WIN_MAXL];        // 8x8 tiles per row of the level
+  int tile_start[MSDA_WIN_MAXL + 1]; // prefix sum of the tile counts
+};
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void msda_fwd_window_kernel(
+    const float* __restrict__ value, const int64_t* __restrict__ starts, const float* __restrict__ loc,
+    const float* __restrict__ attn, const float* __restrict__ ref, const MsdaLevels lv, int grid_mode, int ntiles, int S, int M,
+    int Lq, int P, float* __restrict__ out) {
+  constexpr int D = 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int sq[64];
+  __shared__ int sstat[MSDA_WIN_MAXL][8];
+  const int L = lv.L, LP = L * P;
+  float* swin = smem;                       // [MSDA_WIN_ROWS][32]
+  float* sx = swin + MSDA_WIN_ROWS * D;     // [64][LP] w_im
+  float* sy = sx + 64 * LP;                 // h_im
+  float* sa = sy + 64 * LP;                 // attention weight
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int m = b % M;
+  b /= M;
+  const int tile = b % ntiles, n = b / ntiles;
+
+  if (tid < 64) {
+    int q = -1;
+    if (grid_mode) {
+      int lq = 0;
+      while (lq + 1 < L && tile >= lv.tile_start[lq + 1]) ++lq;
+      const int t = tile - lv.tile_start[lq];
+      const int ty = t / lv.tiles_x[lq], tx = t - ty * lv.tiles_x[lq];
+      const int y = ty * 8 + (tid >> 3), x = tx * 8 + (tid & 7);
+      if (y < lv.H[lq] && x < lv.W[lq]) q = lv.qstart[lq] + y * lv.W[lq] + x;
+    } else {
+      q = tile * 64 + tid;
+      if (q >= Lq) q = -1;
+    }
+    sq[tid] = q;
+  }
+  if (tid < L * 8) {
+    const int k = tid & 7;
+    sstat[tid >> 3][k] = (k == 0 || k == 2) ? 0x7fffffff : (k == 1 || k == 3) ? (int)0x80000000 : 0;
+  }
+  __syncthreads();
+
+  // ---- phase 1: the 4 lanes of a query slot turn its L*P raw entries into (w_im, h_im, weight) in LDS
+  {
+    const int slot = tid >> 2, sub = tid & 3;
+    const int q = sq[slot];
+    const long long nq = (long long)n * Lq + max(q, 0);
+    const long long pair = nq * M + m;
+    const float* gl = loc + pair * LP * 2;
+    const float* ga = attn + pair * LP;
+    constexpr int MAXI = (MSDA_MAX_LP + 3) / 4;
+    float lx[MAXI], ly[MAXI], aw[MAXI];
+    float mx = -__builtin_huge_valf();
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+      const int k = sub + 4 * u;
+      if (k < LP) {
+        lx[u] = gl[2 * k], ly[u] = gl[2 * k + 1], aw[u] = ga[k];
+        mx = fmaxf(mx, aw[u]);
+      }
+    }
+    if (FUSED) {
+      mx = fmaxf(mx, __shfl_xor(mx, 1));
+      mx = fmaxf(mx, __shfl_xor(mx, 2));
+      float part = 0.f;
+#pragma unroll
+      for (int u = 0; u < MAXI; ++u)
+        if (sub + 4 * u < LP) {
+          aw[u] = expf(aw[u] - mx);
+          part += aw[u];
+        }
+      part += __shfl_xor(part, 1);
+      part += __shfl_xor(part, 2);
+      const float inv = 1.f / part;
+#pragma unroll
+      for (int u = 0; u < MAXI; ++u) {
+        const int k = sub + 4 * u;
+        if (k < LP) {
+          const int l = k / P;
+          aw[u] *= inv;
+          lx[u] = ref[(nq * L + l) * 2] + lx[u] / (float)lv.W[l];
+          ly[u] = ref[(nq * L + l) * 2 + 1] + ly[u] / (float)lv.H[l];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+      const int k = sub + 4 * u;
+      if (k < LP) {
+        const int l = k / P;
+        sx[slot * LP + k] = q >= 0 ? lx[u] * lv.W[l] - 0.5f : -8.f;
+        sy[slot * LP + k] = q >= 0 ? ly[u] * lv.H[l] - 0.5f : -8.f;
+        sa[slot * LP + k] = q >= 0 ? aw[u] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int g = tid >> 3, j = tid & 7;
+  const size_t row_stride = (size_t)M * D;
+  const float* vbase = value + (size_t)n * S * row_stride + (size_t)m * D + 4 * j;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int q0 = sq[g], q1 = sq[g + 32];
+
+  for (int l = 0; l < L; ++l) {
+    const int H = lv.H[l], W = lv.W[l];
+    // ---- bounding box and mean of the tile's samples on this level
+    {
+      int lo_h = 0x7fffffff, hi_h = (int)0x80000000, lo_w = 0x7fffffff, hi_w = (int)0x80000000, cnt = 0;
+      float sh = 0.f, sw = 0.f;
+      for (int i = tid; i < 64 * P; i += 256) {
+        const int slot = i / P, pt = i - slot * P;
+        const float w_im = sx[slot * LP + l * P + pt], h_im = sy[slot * LP + l * P + pt];
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+          const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im);
+          lo_h = min(lo_h, max(h0, 0)), hi_h = max(hi_h, min(h0 + 1, H - 1));
+          lo_w = min(lo_w, max(w0, 0)), hi_w = max(hi_w, min(w0 + 1, W - 1));
+          sh += h_im, sw += w_im, ++cnt;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        lo_h = min(lo_h, __shfl_xor(lo_h, o)), hi_h = max(hi_h, __shfl_xor(hi_h, o));
+        lo_w = min(lo_w, __shfl_xor(lo_w, o)), hi_w = max(hi_w, __shfl_xor(hi_w, o));
+        cnt += __shfl_xor(cnt, o), sh += __shfl_xor(sh, o), sw += __shfl_xor(sw, o);
+      }
+      if ((tid & 63) == 0 && cnt > 0) {
+        atomicMin(&sstat[l][0], lo_h), atomicMax(&sstat[l][1], hi_h);
+        atomicMin(&sstat[l][2], lo_w), atomicMax(&sstat[l][3], hi_w);
+        atomicAdd(&sstat[l][4], cnt);
+        atomicAdd(reinterpret_cast<float*>(&sstat[l][5]), sh), atomicAdd(reinterpret_cast<float*>(&sstat[l][6]), sw);
+      }
+    }
+    __syncthreads();
+    // ---- the window (block-uniform)
+    int wh0 = 0, ww0 = 0, nh = 0, nw = 0;
+    {
+      const int cnt = sstat[l][4];
+      if (cnt > 0) {
+        const int lo_h = sstat[l][0], hi_h = sstat[l][1], lo_w = sstat[l][2], hi_w = sstat[l][3];
+        const int bh = hi_h - lo_h + 1, bw = hi_w - lo_w + 1;
+        nh = bh, nw = bw, wh0 = lo_h, ww0 = lo_w;
+        if (bh * bw > MSDA_WIN_ROWS) {
+          const float f = sqrtf((float)MSDA_WIN_ROWS / ((float)bh * (float)bw));
+          nh = min(bh, max(2, (int)(bh * f)));
+          nw = min(bw, MSDA_WIN_ROWS / nh);
+          nh = min(bh, MSDA_WIN_ROWS / nw);
+          const float mh = __int_as_float(sstat[l][5]) / cnt, mw = __int_as_float(sstat[l][6]) / cnt;
+          wh0 = min(max((int)floorf(mh + 1.f) - nh / 2, lo_h), hi_h - nh + 1);
+          ww0 = min(max((int)floorf(mw + 1.f) - nw / 2, lo_w), hi_w - nw + 1);
+        }
+      }
+    }
+    const float* vl = vbase + (size_t)starts[l] * row_stride;
+    {
+      const int rows = nh * nw;
+      constexpr int UN = MSDA_WIN_ROWS / 32;
+      f32x4 t[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int r = g + 32 * u;
+        if (r < rows) {
+          const int hy = r / nw, wx = r - hy * nw;
+          t[u] = *reinterpret_cast<const f32x4*>(vl + (size_t)((wh0 + hy) * W + ww0 + wx) * row_stride);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int r = g + 32 * u;
+        if (r < rows) *reinterpret_cast<f32x4*>(swin + r * D + 4 * j) = t[u];
+      }
+    }
+    __syncthreads();
+    // ---- sampling: the thread's two queries, P points each. (A branch-free variant -- LDS read with a clamped index plus
+    // a buffer load pushed out of range for in-window corners -- was 3x slower: the out-of-range buffer loads still
+    // occupy the address path, 2.04 ms against 0.66 ms at N = 16.)
+    auto fetch = [&](int hc, int wc) -> f32x4 {
+      const int dh = hc - wh0, dw = wc - ww0;
+      if ((unsigned)dh < (unsigned)nh && (unsigned)dw < (unsigned)nw)
+        return *reinterpret_cast<const f32x4*>(swin + (dh * nw + dw) * D + 4 * j);
+      return *reinterpret_cast<const f32x4*>(vl + (size_t)(hc * W + wc) * row_stride);
+    };
+    auto sample = [&](int slot, f32x4& acc) {
+      for (int pt = 0; pt < P; ++pt) {
+        const float w_im = sx[slot * LP + l * P + pt], h_im = sy[slot * LP + l * P + pt];
+        const float aw = sa[slot * LP + l * P + pt];
+        const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+        if (!inside) continue;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h0 = (int)hf, w0 = (int)wf;
+        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+        const bool okh0 = h0 >= 0, okh1 = h0 + 1 <= H - 1, okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
+        const int h0c = max(h0, 0), h1c = min(h0 + 1, H - 1), w0c = max(w0, 0), w1c = min(w0 + 1, W - 1);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 v1 = fetch(h0c, w0c), v2 = fetch(h0c, w1c), v3 = fetch(h1c, w0c), v4 = fetch(h1c, w1c);
+        v1 = (okh0 && okw0) ? v1 : z;
+        v2 = (okh0 && okw1) ? v2 : z;
+        v3 = (okh1 && okw0) ? v3 : z;
+        v4 = (okh1 && okw1) ? v4 : z;
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+        acc += aw * val;
+      }
+    };
+    if (q0 >= 0) sample(g, acc0);
+    if (q1 >= 0) sample(g + 32, acc1);
+  }
+  if (q0 >= 0) *reinterpret_cast<f32x4*>(out + (((long long)n * Lq + q0) * M + m) * D + 4 * j) = acc0;
+  if (q1 >= 0) *reinterpret_cast<f32x4*>(out + (((long long)n * Lq + q1) * M + m) * D + 4 * j) = acc1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -513,7 +750,6 @@ __global__ __launch_bounds__(MSDA_LDS_NT) void msda_bwd_value_lds_kernel(
 // One thread per (n, q, m). Backward: d_logit = attn * (g_attn - sum(attn * g_attn)), d_offset = g_loc / (W_l, H_l).
 // A workgroup stages the contiguous logits / offsets of its 256 pairs through LDS (coalesced loads and stores; a
 // thread then owns one pair's row: stride L*P and 2*L*P floats, odd multiples of 4 banks for the usual 12 / 24).
-constexpr int MSDA_MAX_LP = 20;       // 256 pairs x 3 x L*P floats of LDS per workgroup (60 KB at 20)
 __global__ __launch_bounds__(256) void msda_prepare_kernel(const float* __restrict__ offsets, const float* __restrict__ logits,
                                                            const float* __restrict__ ref, const int64_t* __restrict__ shapes,
                                                            long long npairs, int M, int L, int P, float* __restrict__ loc,
@@ -618,6 +854,38 @@ int msda_forward_fast(const float* value, const int64_t* shapes, const int64_t* 
   else
     hipLaunchKernelGGL((msda_fwd_fast_kernel<LPH, false>), dim3((unsigned)nblocks), dim3(256), smem, stream, value, shapes,
                        starts, loc, attn, ref, npairs, S, M, L, Lq, P, out);
+  return mss_launch_status();
+}
+
+int msda_forward_window(const float* value, const int64_t* starts, const float* loc, const float* attn, const float* ref,
+                        const int64_t* host_shapes, int N, int S, int M, int L, int Lq, int P, float* out, hipStream_t stream) {
+  MsdaLevels lv;
+  lv.L = L;
+  long long sum = 0;
+  int tiles = 0;
+  for (int l = 0; l < L; ++l) {
+    const long long h = host_shapes[2 * l], w = host_shapes[2 * l + 1];
+    if (h <= 0 || w <= 0 || h > 32767 || w > 32767) return MSS_ERR_UNSUPPORTED;
+    lv.H[l] = (int)h, lv.W[l] = (int)w;
+    lv.qstart[l] = (int)sum;
+    lv.tiles_x[l] = (int)((w + 7) / 8);
+    lv.tile_start[l] = tiles;
+    tiles += (int)(((h + 7) / 8) * ((w + 7) / 8));
+    sum += h * w;
+  }
+  lv.tile_start[L] = tiles;
+  for (int l = L; l < MSDA_WIN_MAXL; ++l) lv.H[l] = lv.W[l] = lv.qstart[l] = lv.tiles_x[l] = 0, lv.tile_start[l + 1] = tiles;
+  const int grid_mode = sum == (long long)Lq;          // the queries are the pixels of the levels (encoder self-attention)
+  const int ntiles = grid_mode ? tiles : (Lq + 63) / 64;
+  const long long nblocks = (long long)N * ntiles * M;
+  if (nblocks > 0x7fffffffll) return MSS_ERR_UNSUPPORTED;
+  const size_t smem = ((size_t)MSDA_WIN_ROWS * 32 + (size_t)3 * 64 * L * P) * sizeof(float);
+  if (ref)
+    hipLaunchKernelGGL(msda_fwd_window_kernel<true>, dim3((unsigned)nblocks), dim3(256), smem, stream, value, starts, loc, attn, ref,
+                       lv, grid_mode, ntiles, S, M, Lq, P, out);
+  else
+    hipLaunchKernelGGL(msda_fwd_window_kernel<false>, dim3((unsigned)nblocks), dim3(256), smem, stream, value, starts, loc, attn, ref,
+                       lv, grid_mode, ntiles, S, M, Lq, P, out);
   return mss_launch_status();
 }
 
@@ -734,6 +1002,23 @@ int mss_msda_forward_fused_f32(const float* value, const int64_t* spatial_shapes
   if (D == 64 && smem_per_lp * 4 <= 65536)
     return msda_forward_fast<16>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s);
   return MSS_ERR_UNSUPPORTED;
+}
+
+// forward through LDS windows (msda_fwd_window_kernel): `host_shapes` is a HOST copy of spatial_shapes [L][2]; reference_points
+// NULL = sampling_loc / attn_weight given (the op), else raw offsets / logits (the fused form). fp32, D = 32, L <= 8,
+// L*P <= 20, 16-byte aligned value / out; MSS_ERR_UNSUPPORTED otherwise.
+int mss_msda_forward_window_f32(const float* value, const int64_t* host_shapes, const int64_t* level_start_index,
+                                const float* loc_or_offsets, const float* attn_or_logits, const float* reference_points, int N,
+                                int S, int M, int D, int L, int Lq, int P, float* out, void* stream) {
+  if (!host_shapes) return MSS_ERR_BAD_ARG;
+  int rc = msda_check(value, host_shapes, level_start_index, loc_or_offsets, attn_or_logits, N, S, M, D, L, Lq, P);
+  if (rc) return rc;
+  if ((long long)N * Lq * M == 0) return MSS_OK;
+  if (!out) return MSS_ERR_BAD_ARG;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (!aligned || D != 32 || L > MSDA_WIN_MAXL || L * P > MSDA_MAX_LP) return MSS_ERR_UNSUPPORTED;
+  return msda_forward_window(value, level_start_index, loc_or_offsets, attn_or_logits, reference_points, host_shapes, N, S, M, L,
+                             Lq, P, out, static_cast<hipStream_t>(stream));
 }
 
 int mss_msda_forward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,

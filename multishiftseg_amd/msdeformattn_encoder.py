@@ -142,6 +142,7 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
                          for lvl, p in enumerate(pos_embeds)], 1)
         spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src.device)
+        spatial_shapes._mss_host = [tuple(int(v) for v in hw) for hw in shapes]      # host copy for the window forward's grid
         level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
         valid_ratios = torch.ones((src.shape[0], len(shapes), 2), dtype=torch.float32, device=src.device)
         memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, None)

@@ -319,3 +319,61 @@ def test_install_serves_a_reference_style_caller():
         sys.modules.pop("MultiScaleDeformableAttention", None)
         if had is not None:
             sys.modules["MultiScaleDeformableAttention"] = had
+
+
+def _encoder_like_inputs(rng, N, shapes, M, P, sigma, Lq=None):
+    """value / offsets / logits / reference points of an encoder layer: queries = the pixels of the levels (or Lq random
+    positions), offsets ~ N(0, sigma) pixels."""
+    shp = np.array(shapes, dtype=np.int64)
+    L = len(shapes)
+    S = int(shp.prod(1).sum())
+    value = rng.standard_normal((N, S, M, 32), dtype=np.float32)
+    if Lq is None:
+        ref = np.concatenate([np.stack(np.meshgrid((np.arange(h) + 0.5) / h, (np.arange(w) + 0.5) / w, indexing="ij"), -1)
+                              .reshape(-1, 2)[:, ::-1] for h, w in shapes]).astype(np.float32)
+        ref = np.broadcast_to(ref[None, :, None, :], (N, S, L, 2)).copy()
+        Lq = S
+    else:
+        ref = np.broadcast_to(rng.random((N, Lq, 1, 2), dtype=np.float32), (N, Lq, L, 2)).copy()
+    off = (rng.standard_normal((N, Lq, M, L, P, 2), dtype=np.float32) * sigma).astype(np.float32)
+    lg = rng.standard_normal((N, Lq, M, L * P), dtype=np.float32)
+    starts = np.concatenate([[0], np.cumsum(shp.prod(1))[:-1]]).astype(np.int64)
+    return value, off, lg, ref, shp, starts
+
+
+@pytest.mark.parametrize("N,shapes,M,P,sigma,Lq", [
+    (2, [(22, 22), (44, 44), (88, 88)], 8, 4, 3.0, None),     # C4 geometry, windows clipped to the row budget
+    (1, [(32, 64), (64, 128), (128, 256)], 8, 4, 1.0, None),  # C5 geometry, bounding boxes fit
+    (2, [(9, 13), (5, 6), (17, 3)], 4, 2, 2.0, None),         # ragged levels, tiles hanging over the edges
+    (1, [(22, 22), (44, 44)], 8, 4, 40.0, None),              # offsets all over the map: most fetches take the global path
+    (2, [(12, 20), (6, 10)], 8, 4, 2.0, 777),                 # queries are not the pixel grid: 64 consecutive queries per block
+    (1, [(3, 5)], 1, 1, 0.5, None),                           # one level, one head, one point
+])
+def test_window_forward_equals_gather_forward(monkeypatch, N, shapes, M, P, sigma, Lq):
+    """The LDS-window forward (both the op form and the fused offsets/logits form) against the L2-gather kernels it
+    replaces, and against the numpy oracle on a subset of queries."""
+    from multishiftseg_amd import MultiScaleDeformableAttention as MSDA
+    from multishiftseg_amd.ms_deform_attn import _FusedSampleFn, _PrepareFn
+    rng = np.random.default_rng(23)
+    value, off, lg, ref, shp, starts = _encoder_like_inputs(rng, N, shapes, M, P, sigma, Lq)
+    L = len(shapes)
+    v, o, g_, r = dev(value), dev(off), dev(lg), dev(ref)
+    shp_t, st_t = dev(shp), dev(starts)
+    with torch.no_grad():
+        loc, attn = _PrepareFn.apply(o, g_, r, shp_t)
+        monkeypatch.setenv("MSS_MSDA_WINDOW", "0")
+        want = MSDA.ms_deform_attn_forward(v, shp_t, st_t, loc, attn, 128)
+        want_f = _FusedSampleFn.apply(v, shp_t, st_t, o, g_, r)
+        monkeypatch.setenv("MSS_MSDA_WINDOW", "1")
+        got = MSDA.ms_deform_attn_forward(v, shp_t, st_t, loc, attn, 128)          # host shapes through the cached copy
+        shp_hint = dev(shp)
+        shp_hint._mss_host = [tuple(int(x) for x in hw) for hw in shapes]          # ... and through the caller's hint
+        got_f = _FusedSampleFn.apply(v, shp_hint, st_t, o, g_, r)
+    assert id(shp_t) in MSDA._HOST_SHAPES
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-6 * scale
+    assert (got_f - want_f).abs().max().item() <= 1e-5 * scale
+    qs = rng.choice(loc.shape[1], size=min(64, loc.shape[1]), replace=False)
+    ref_out = omsda.forward(value, shp, starts, loc.cpu().numpy()[:, qs], attn.cpu().numpy()[:, qs])
+    np.testing.assert_allclose(got.cpu().numpy()[:, qs], ref_out, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(got_f.cpu().numpy()[:, qs], ref_out, rtol=1e-4, atol=2e-5)

@@ -21,12 +21,23 @@ for N, shapes in ((1, [(22, 22), (44, 44), (88, 88)]), (16, [(22, 22), (44, 44),
     loc = (ref[:, :, None, :, None, :] + off / shp.flip(-1)[None, None, None, :, None, :].float()).contiguous()
     attn = torch.softmax(lg, -1).view(N, S, 8, 3, 4).contiguous()
     g = torch.randn(N, S, 256, device="cuda")
+    os.environ["MSS_MSDA_WINDOW"] = "0"
     ms_f = timeit(lambda: MSDA.ms_deform_attn_forward(value, shp, starts, loc, attn, 128), iters=20)
     with torch.no_grad():
         ms_ff = timeit(lambda: _FusedSampleFn.apply(value, shp, starts, off, lg, ref), iters=20)
+    os.environ["MSS_MSDA_WINDOW"] = "1"
+    shp._mss_host = shapes
+    win = {}
+    for sigma in (1.0, 3.0, 6.0):        # offsets ~ N(0, sigma) pixels; the other columns use sigma = 3
+        off_s = off * (sigma / 3.0)
+        loc_s = (ref[:, :, None, :, None, :] + off_s / shp.flip(-1)[None, None, None, :, None, :].float()).contiguous()
+        win[f"window_fwd_ms_sigma{sigma:g}"] = round(timeit(lambda: MSDA.ms_deform_attn_forward(value, shp, starts, loc_s, attn, 128), iters=20), 4)
+        with torch.no_grad():
+            win[f"window_fused_ms_sigma{sigma:g}"] = round(timeit(lambda: _FusedSampleFn.apply(value, shp, starts, off_s, lg, ref), iters=20), 4)
     ms_b = timeit(lambda: MSDA.ms_deform_attn_backward(value, shp, starts, loc, attn, g, 128), iters=10)
     byt = 4 * (N * S * 256 + 3 * N * S * 8 * 12 + N * S * 256)
     gather = N * S * 8 * 48 * 128
     print(json.dumps(dict(kernel="msda", N=N, S=S, compulsory_MB=round(byt / 1e6, 1), fwd_ms=round(ms_f, 4), fused_fwd_ms=round(ms_ff, 4),
                           bwd_ms=round(ms_b, 4), fwd_compulsory_GBs=round(byt / ms_f / 1e6, 1), fused_fwd_compulsory_GBs=round(byt / ms_ff / 1e6, 1),
-                          fwd_frac_of_8TBs=round(byt / ms_f / 1e6 / 8000, 3), fwd_L2_gather_GBs=round(gather / ms_f / 1e6, 1))), flush=True)
+                          fwd_frac_of_8TBs=round(byt / ms_f / 1e6 / 8000, 3), fwd_L2_gather_GBs=round(gather / ms_f / 1e6, 1), **win,
+                          window_fwd_compulsory_GBs=round(byt / win['window_fwd_ms_sigma3'] / 1e6, 1))), flush=True)
