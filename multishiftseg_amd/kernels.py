@@ -285,7 +285,7 @@ def pack_weight_wino(w, flip=False, tile=2):
     if flip:
         w = w.detach().flip(2, 3).transpose(0, 1)
     K, C, R, S = w.shape
-    assert R == 3 and S == 3 and C % 16 == 0 and K % 4 == 0 and tile in (2, 4)
+    assert R == 3 and S == 3 and C % 16 == 0 and K % 4 == 0 and tile in (2, 4, 6)
     if w.dtype != torch.float32 or not w.is_cuda:
         raise TypeError("pack_weight_wino needs a float32 CUDA tensor")
     w = w.detach().contiguous()
@@ -301,7 +301,8 @@ def packed_wino(param, flip=False, tile=2):
 
 # measured on MI355X (tools/bench_wino.py): F(2x2) 0.87x at 128 channels, 1.24-1.28x at 256, 1.7-2.1x at >= 512;
 # F(4x4) 1.29x at 128 channels, 2.0x at 256, 2.4-3.4x at >= 512
-WINOGRAD_MIN_CHANNELS = {2: 256, 4: 128}
+WINOGRAD_MIN_CHANNELS = {2: 256, 4: 128, 6: 128}
+WINO_TILE_OF_P = {16: 2, 36: 4, 64: 6}
 
 
 def use_winograd(c_in, k_out, stride, in_affine=None, tile=2):
@@ -317,15 +318,21 @@ def use_winograd(c_in, k_out, stride, in_affine=None, tile=2):
 
 def wino_tile(H, W, dil):
     """Output-tile edge m of F(m x m, 3x3) for a layer: the one with fewer Winograd-domain elements
-    (tiles x (m+2)^2), which decides both the MFMA work and the transform traffic: 2.25 per output pixel
-    for m = 4 against 4 for m = 2, unless the dilation sub-grid is so small that 4x4 tiles are mostly padding
-    (e.g. a 12x16 map at dilation 12). MSS_WINO_TILE=2|4 forces one."""
+    (tiles x (m+2)^2), which decides both the MFMA work and the transform traffic: 1.78 per output pixel for m = 6,
+    2.25 for m = 4, 4 for m = 2, unless the dilation sub-grid is so small that the larger tiles are mostly padding
+    (e.g. a 12x16 map at dilation 12; the 4x8 sub-grids of dilation 36 at 128x256 stay on 4x4 tiles, the 6x11 ones of
+    dilation 24 go from six 4x4 tiles to two 6x6 tiles). m = 6 carries 3x the fp32 rounding error of m = 4 (5.8e-6 vs
+    1.9e-6 of the output per layer, tools/wino_matrices.py), so it must save at least 5 % to be chosen.
+    MSS_WINO_TILE=2|4|6 forces one, MSS_WINO_MAX_TILE=4 keeps the policy off 6x6 tiles."""
     forced = os.environ.get("MSS_WINO_TILE")
     if forced:
         return int(forced)
     hs, ws = -(-H // dil), -(-W // dil)
-    cost = {m: (-(-hs // m)) * (-(-ws // m)) * (m + 2) ** 2 for m in (2, 4)}
-    return 4 if cost[4] < cost[2] else 2
+    cost = {m: (-(-hs // m)) * (-(-ws // m)) * (m + 2) ** 2 for m in (2, 4, 6)}
+    best = 4 if cost[4] < cost[2] else 2
+    if int(os.environ.get("MSS_WINO_MAX_TILE", "6")) >= 6 and cost[6] <= 0.95 * cost[best]:
+        best = 6
+    return best
 
 
 def wino_xt_bytes(N, H, W, C, dil):
@@ -401,7 +408,7 @@ def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=
     N, H, W = x.N, x.H, x.W
     dev = x.buf.device
     if xt is not None:
-        ts = {16: 2, 36: 4}[xt.shape[0]]
+        ts = WINO_TILE_OF_P[xt.shape[0]]
     else:
         ts = tile or wino_tile(H, W, dil)
     P = (ts + 2) ** 2
@@ -431,7 +438,7 @@ def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=
 
 
 def conv3x3_wgrad(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=None):
-    tile = {16: 2, 36: 4}[xt.shape[0]] if xt is not None else wino_tile(x.H, x.W, dil)
+    tile = WINO_TILE_OF_P[xt.shape[0]] if xt is not None else wino_tile(x.H, x.W, dil)
     if use_winograd(C, K, 1, in_affine, tile):
         return conv2d_wgrad_winograd(x, dy, K, C, dil, in_affine, in_relu, xt=xt, tile=tile)
     return conv2d_wgrad(x, dy, K, C, 3, 3, dil=dil, pad=dil, in_affine=in_affine, in_relu=in_relu)

@@ -28,8 +28,10 @@ LOSS_PARAMS = {"ce_weights": [50, 10], "conduct_pixel_selection": True, "selecti
 STAGE2 = ["aspp", "bot_fine", "bot_aspp", "ood_head"]
 ROUTES = {"winograd": {}, "direct3x3": {"MSS_WINOGRAD": "0"},
           "igemm_only": {"MSS_WINOGRAD": "0", "MSS_GEMM": "0", "MSS_STEM_IM2COL": "0"}}
-# the experimental fp32-on-bf16-matrix-cores GEMM has to pass the same reference fixtures to be reported at all
-ROUTES_X = dict(ROUTES, bf16x6={"MSS_GEMM_BF16X6": "1"})
+# "winograd" is the policy's own mix (F(6x6) wherever it saves >= 5 % over F(4x4), else F(4x4) / F(2x2)); winograd_f4 keeps
+# the policy off the 6x6 tiles so that the F(4x4) kernels stay pinned by the same fixtures. The experimental
+# fp32-on-bf16-matrix-cores GEMM has to pass the same reference fixtures to be reported at all
+ROUTES_X = dict(ROUTES, winograd_f4={"MSS_WINO_MAX_TILE": "4"}, bf16x6={"MSS_GEMM_BF16X6": "1"})
 _report = {}
 
 
@@ -49,7 +51,7 @@ class _Env:
         self.env = env
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ("MSS_WINOGRAD", "MSS_GEMM", "MSS_WINO_TILE", "MSS_STEM_IM2COL", "MSS_GEMM_BF16X6")}
+        self.old = {k: os.environ.get(k) for k in ("MSS_WINOGRAD", "MSS_GEMM", "MSS_WINO_TILE", "MSS_WINO_MAX_TILE", "MSS_STEM_IM2COL", "MSS_GEMM_BF16X6")}
         for k in self.old:
             os.environ.pop(k, None)
         os.environ.update(self.env)
@@ -84,7 +86,7 @@ def test_c1_eval_512x1024_vs_torch_oracle(model, deeplab_params):
     from multishiftseg_amd import kernels as K, synth
     from oracle import deepv3_torch
     img = synth.synth_image(21, 1, 512, 1024)
-    assert [K.wino_tile(64, 128, r) for r in (12, 24, 36)] == [4, 4, 2]      # what the policy does at C1
+    assert [K.wino_tile(64, 128, r) for r in (1, 2, 4, 12, 24, 36)] == [6, 6, 4, 6, 6, 2]      # what the policy does at C1
     model.eval()
     with torch.no_grad():
         score, logit = model(torch.from_numpy(img).cuda())
@@ -101,7 +103,8 @@ def test_c1_eval_512x1024_vs_torch_oracle(model, deeplab_params):
 
 @pytest.mark.parametrize("route", list(ROUTES_X))
 def test_eval_golden_592x600(model, route):
-    """Outputs of the reference model itself at a size where F(4x4) is the policy's own choice for dil 12/24/36."""
+    """Outputs of the reference model itself at a size where F(4x4) is the policy's own choice for dil 12/24/36 and
+    F(6x6) for the undilated / dilation-2 layers."""
     from multishiftseg_amd import kernels as K, synth
     g = golden("deepwv3plus_eval_1x592x600")
     n, h, w = (int(v) for v in g["shape"])
@@ -109,7 +112,7 @@ def test_eval_golden_592x600(model, route):
     model.eval()
     with _Env(ROUTES_X[route]):
         if route == "winograd":
-            assert [K.wino_tile(74, 75, r) for r in (12, 24, 36)] == [4, 4, 4]
+            assert [K.wino_tile(74, 75, r) for r in (1, 2, 4, 12, 24, 36)] == [6, 6, 4, 4, 4, 4]
         with torch.no_grad():
             score, logit = model(img)
     logit, score = logit.cpu().numpy(), score.cpu().numpy()
@@ -163,7 +166,7 @@ def test_train_step_golden_2x592x600(deeplab_params, route):
     perms = [torch.from_numpy(g[pre + f"perm{i}"].astype(np.int64)) for i in range(3)]
     with _Env(ROUTES_X[route]):
         if route == "winograd":
-            assert [K.wino_tile(74, 75, r) for r in (12, 24, 36)] == [4, 4, 4]
+            assert [K.wino_tile(74, 75, r) for r in (1, 2, 4, 12, 24, 36)] == [6, 6, 4, 4, 4, 4]
         score, logit = m(img)
         loss = crit(logit, score, target, perms=perms).mean()
         opt.zero_grad()
@@ -236,8 +239,11 @@ def test_three_routes_agree_at_bench_size(deeplab_params, tag, pairs, h, w):
     masks = {"mod6": torch.from_numpy(((rng.random((n, 1024)) >= 0.3) / 0.7).astype(np.float32)),
              "mod7": torch.from_numpy(((rng.random((n, 2048)) >= 0.5) / 0.5).astype(np.float32))}
     h8, w8 = -(-h // 8), -(-w // 8)
-    tiles = [K.wino_tile(h8, w8, r) for r in (12, 24, 36)]
-    assert tiles == [4, 4, 4], tiles                # the whole point: F(4x4) on every ASPP layer, as in the benchmark
+    tiles = [K.wino_tile(h8, w8, r) for r in (1, 2, 4, 12, 24, 36)]
+    # the whole point: the benchmark's own tile mix -- F(6x6) in the trunk, F(6x6) / F(4x4) on the ASPP layers
+    assert tiles == ([6, 6, 6, 6, 6, 4] if tag.startswith("c3") else [6, 6, 6, 4, 4, 4]), tiles
+    gs = golden("deepwv3plus_train_step_2x592x600")
+    sens = {k[len("stage2_gradsens_"):]: float(gs[k]) for k in gs.files if k.startswith("stage2_gradsens_")}
     out = {}
     for route, env in ROUTES.items():
         m.load_state_dict(saved)
@@ -271,12 +277,14 @@ def test_three_routes_agree_at_bench_size(deeplab_params, tag, pairs, h, w):
         for k, v in r["grad_rel_l2"].items():
             # image-pooling branch at 2 images per GPU: BatchNorm over 2 samples is sign(x0 - x1) -- its input gradient
             # is O(eps) and pure rounding noise in ANY implementation (reference gradsens confirms), so only its size is held
-            # Otherwise 6e-3: every route differs from the others by fp32 rounding somewhere in the trunk (Winograd F(4x4)
-            # ~4e-6 relative per layer; the two stem formulations and summation orders ~1e-6), and the REFERENCE's own
-            # gradients respond to a 4e-6 jitter of the trunk outputs with up to 8.4e-3 rel-L2 (bot_fine.weight; gradsens_*
-            # in deepwv3plus_train_step_2x592x600.npz) -- cancellation in sums over 2 M pixels, not a kernel property.
+            # Otherwise max(6e-3, 3 x gradsens): every route differs from the others by fp32 rounding somewhere in the trunk
+            # (Winograd F(6x6) ~1.2e-5 relative per layer, F(4x4) ~4e-6; the two stem formulations and summation orders
+            # ~1e-6), and the REFERENCE's own gradients respond to a 4e-6 jitter of the trunk outputs with up to 8.4e-3
+            # rel-L2 (bot_fine.weight; gradsens_* in deepwv3plus_train_step_2x592x600.npz, measured on the reference by
+            # tools/gen_golden.py) -- cancellation in sums over 2 M pixels, not a kernel property. Measured here: F(4x4)
+            # route 3e-3, F(6x6) route 7e-3 on that one tensor, <= 2e-3 on all others.
             loose = pairs == 1 and k.startswith("aspp.img_conv")
-            if v > (0.5 if loose else 6e-3):
+            if v > (0.5 if loose else max(6e-3, 3 * sens.get(k, 0.0))):
                 bad.append((route, k, v))
     _note(f"three_routes[{tag}]", rep)
     assert not nondet, nondet

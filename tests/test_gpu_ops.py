@@ -230,7 +230,7 @@ def test_m2f_score(K):
     np.testing.assert_allclose(s.cpu().numpy(), om2f.anomaly_score(cls, mask, (64, 96)), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("tile", [2, 4])
+@pytest.mark.parametrize("tile", [2, 4, 6])
 @pytest.mark.parametrize("cin,cout,dil,n,h,w", [(32, 64, 1, 2, 12, 14), (64, 32, 2, 1, 13, 17), (32, 128, 4, 2, 16, 22),
                                                  (48, 64, 1, 1, 7, 9), (64, 64, 4, 1, 5, 6),
                                                  # several channel chunks of the LDS-staged input transform, the last one
@@ -258,7 +258,7 @@ def test_winograd_conv_vs_oracle(K, cin, cout, dil, n, h, w, tile, monkeypatch):
     np.testing.assert_allclose(y2.nchw().cpu().numpy(), nnops.conv2d(x, wt, 1, dil, dil), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("tile", [2, 4])
+@pytest.mark.parametrize("tile", [2, 4, 6])
 @pytest.mark.parametrize("cin,cout,dil,n,h,w", [(32, 64, 1, 2, 12, 14), (64, 32, 2, 1, 13, 17), (48, 36, 12, 2, 16, 22)])
 def test_winograd_wgrad_vs_autograd(K, cin, cout, dil, n, h, w, tile):
     rng = np.random.default_rng(cin * 3 + cout + dil)
@@ -283,7 +283,7 @@ def test_winograd_wgrad_vs_autograd(K, cin, cout, dil, n, h, w, tile):
 
 def test_pack_cache_dies_with_parameter(K):
     """Successive same-shaped parameters (recycled id() and storage address) must never see each other's packs."""
-    for tile in (0, 2, 4):
+    for tile in (0, 2, 4, 6):
         for seed in range(6):
             w = torch.nn.Parameter(torch.full((32, 16, 3, 3), float(seed + 1), device="cuda"))
             pw = K.packed(w) if tile == 0 else K.packed_wino(w, tile=tile)
@@ -334,6 +334,9 @@ def test_m2f_fused_equals_unfused_at_full_size(K):
     (32, 48, 3, 2, 1, 2, 17, 19, False),       # 256x64 tile (K <= 64), stride 2
     (32, 64, 3, 1, 1, 2, 12, 14, True),        # Winograd F(4x4): statistics from the output transform
     (64, 32, 3, 1, 4, 1, 13, 17, True),
+    (32, 64, 3, 1, 1, 2, 12, 14, 6),           # Winograd F(6x6): the LDS output transform's statistics (two tiles per wave at K=64)
+    (64, 32, 3, 1, 2, 1, 13, 17, 6),           # ... four tiles per wave
+    (16, 272, 3, 1, 1, 1, 9, 8, 6),            # ... one tile per wave, two channel groups (the second ragged)
 ])
 def test_batchnorm_statistics_from_the_producing_kernel(K, cin, cout, r, stride, dil, n, h, w, wino):
     """want_stats: the conv epilogue / Winograd output transform leaves per-channel partial sums; bn_fold(train=True)
@@ -345,7 +348,7 @@ def test_batchnorm_statistics_from_the_producing_kernel(K, cin, cout, r, stride,
     oh, ow = K.conv_out_size(h, r, stride, dil, pad), K.conv_out_size(w, r, stride, dil, pad)
     res = K.Act.from_nchw(dev(rng.standard_normal((n, cout, oh, ow), dtype=np.float32)))
     if wino:
-        y = K.conv2d_winograd(x, K.pack_weight_wino(wt, tile=4), dil=dil, res=res, want_stats=True)
+        y = K.conv2d_winograd(x, K.pack_weight_wino(wt, tile=6 if wino == 6 else 4), dil=dil, res=res, want_stats=True)
     else:
         y = K.conv2d(x, K.pack_weight(wt), stride=stride, dil=dil, pad=pad, res=res, want_stats=True)
     assert y.stats is not None
@@ -369,7 +372,7 @@ def test_conv_paths_random_shapes(K):
     sizes, channel counts around the tile edges, every dilation of the network, prologue / residual / ReLU / statistics
     switches -- against torch's CPU convolution."""
     rng = np.random.default_rng(2024)
-    checked = {"gemm_nt": 0, "conv_igemm": 0, "wino2": 0, "wino4": 0}
+    checked = {"gemm_nt": 0, "conv_igemm": 0, "wino2": 0, "wino4": 0, "wino6": 0}
     for case in range(40):
         r = int(rng.choice([1, 3, 3]))
         cin = int(rng.choice([16, 32, 48, 64, 80, 144, 272]))
@@ -405,7 +408,7 @@ def test_conv_paths_random_shapes(K):
         checked["gemm_nt" if (r == 1 and stride == 1 and cout > 64 and cin >= 32) else "conv_igemm"] += 1
         # Winograd path
         if r == 3 and stride == 1 and cout % 4 == 0:
-            for tile in (2, 4):
+            for tile in (2, 4, 6):
                 yw = K.conv2d_winograd(xa, K.pack_weight_wino(dev(wt), tile=tile), dil=dil, in_affine=aff, in_relu=use_aff, res=resa)
                 np.testing.assert_allclose(yw.nchw().cpu().numpy(), ref, rtol=0, atol=tol, err_msg=f"case {case} wino{tile}")
                 checked[f"wino{tile}"] += 1

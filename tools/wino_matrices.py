@@ -1,4 +1,4 @@
-"""Cook-Toom construction of the Winograd F(4x4,3x3) matrices used by csrc/winograd.hip.
+"""Cook-Toom construction of the Winograd F(4x4,3x3) and F(6x6,3x3) matrices used by csrc/winograd.hip.
 
 Interpolation points (0, +-11/16, +-3/2, inf) instead of the textbook (0, +-1, +-2, inf): measured on
 ReLU-like inputs with 512 channels, fp32 rms error 1.6e-6 instead of 3.6e-6 (max 2.4e-6 instead of 9.4e-6).
@@ -6,6 +6,10 @@ A^T = V_m^T, G = D^-1 V_r, B^T = D V_n^-T with V_k the evaluation matrix of degr
 points and D a power-of-two row scaling that keeps the B^T rows near unit magnitude (numerically neutral).
 Prints the C initialisers; `python tools/wino_matrices.py check` also verifies the identity in float64 and
 reports the fp32 error against a direct float64 convolution.
+
+F(6x6,3x3) (`python tools/wino_matrices.py 6 [check]`): points (0, +-1/2, +-1, +-2, inf). A search over ~1500 dyadic
+triples (+-a, +-b, +-c) found nothing better than noise around it (rms 5.7e-6 .. 6.2e-6 of the output at 512 channels,
+against 1.9e-6 for F(4x4) above), so the textbook set with its many +-1 entries stays.
 """
 import sys
 from fractions import Fraction as Fr
@@ -13,6 +17,7 @@ from fractions import Fraction as Fr
 import numpy as np
 
 POINTS = (Fr(0), Fr(11, 16), Fr(-11, 16), Fr(3, 2), Fr(-3, 2))
+POINTS6 = (Fr(0), Fr(1, 2), Fr(-1, 2), Fr(1), Fr(-1), Fr(2), Fr(-2))
 
 
 def matrices(pts=POINTS, m=4, r=3):
@@ -59,22 +64,22 @@ def c_init(name, mat):
     return f"static constexpr float {name}[{len(mat)}][{len(mat[0])}] = {{\n      " + ",\n      ".join(rows) + "};"
 
 
-def check():
-    at, g, bt = (as_np(x) for x in matrices())
+def check(pts=POINTS, m=4):
+    at, g, bt = (as_np(x) for x in matrices(pts, m))
     rng = np.random.default_rng(0)
-    C, T = 512, 48
-    d = np.maximum(rng.standard_normal((T, C, 6, 6)), 0)
+    C, T, n = 512, 48, m + 2
+    d = np.maximum(rng.standard_normal((T, C, n, n)), 0)
     w = rng.standard_normal((C, 3, 3)) / np.sqrt(C * 9)
-    ref = np.zeros((T, 4, 4))
-    for i in range(4):
-        for j in range(4):
+    ref = np.zeros((T, m, m))
+    for i in range(m):
+        for j in range(m):
             ref[:, i, j] = (d[:, :, i:i + 3, j:j + 3] * w).sum((1, 2, 3))
 
     def run(dt):
         a_, g_, b_ = at.astype(dt), g.astype(dt), bt.astype(dt)
         u = np.einsum("ik,ckl,jl->cij", g_, w.astype(dt), g_).astype(dt)
         v = np.einsum("ik,tckl,jl->tcij", b_, d.astype(dt), b_).astype(dt)
-        acc = np.zeros((T, 6, 6), dt)
+        acc = np.zeros((T, n, n), dt)
         for c in range(C):
             acc += u[c] * v[:, c]
         return np.einsum("ik,tkl,jl->tij", a_, acc, a_)
@@ -85,7 +90,8 @@ def check():
 
 
 if __name__ == "__main__":
-    at, g, bt = matrices()
+    pts, m = (POINTS6, 6) if "6" in sys.argv[1:] else (POINTS, 4)
+    at, g, bt = matrices(pts, m)
     print(c_init("Bt", bt)); print(c_init("G", g)); print(c_init("At", at))
     if "check" in sys.argv[1:]:
-        check()
+        check(pts, m)
