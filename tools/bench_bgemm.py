@@ -5,8 +5,12 @@ import torch
 from multishiftseg_amd import kernels as K, _lib
 from multishiftseg_amd._lib import MssConvArgs, call, ptr
 from tools.microbench import timeit
-P = 36
-for (T, C, Ko) in [(65536, 128, 128), (16384, 256, 256), (65536, 256, 256), (65536, 304, 256), (4096, 512, 512), (4096, 512, 1024), (4096, 1024, 2048), (5184, 4096, 256)]:
+# default: the F(4x4) products of the 2x1024x2048 step; or `bench_bgemm.py P,T,C,K [P,T,C,K ...]`
+CASES = [(36, T, C, Ko) for (T, C, Ko) in [(65536, 128, 128), (16384, 256, 256), (65536, 256, 256), (65536, 304, 256), (4096, 512, 512),
+                                            (4096, 512, 1024), (4096, 1024, 2048), (5184, 4096, 256)]]
+if len(sys.argv) > 1:
+    CASES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+for (P, T, C, Ko) in CASES:
     xt = torch.randn(P, T, C, device="cuda")
     Kpad = _lib.value("mss_conv2d_kpad", Ko)
     w = torch.randn(P, Kpad, C, device="cuda")
@@ -20,5 +24,5 @@ for (T, C, Ko) in [(65536, 128, 128), (16384, 256, 256), (65536, 256, 256), (655
     ms = timeit(lambda: call("mss_conv2d_forward_f32", ctypes.byref(a)), iters=10, warm=3)
     fl = 2.0 * P * T * C * Ko
     by = 4.0 * P * T * (C + Ko)
-    print(json.dumps(dict(T=T, C=C, K=Ko, ms=round(ms, 3), tflops=round(fl / ms / 1e9, 1), GBs=round(by / ms / 1e6, 1),
+    print(json.dumps(dict(P=P, T=T, C=C, K=Ko, ms=round(ms, 3), tflops=round(fl / ms / 1e9, 1), GBs=round(by / ms / 1e6, 1),
                           bk=os.environ.get("MSS_CONV_BK", "policy"))), flush=True)
