@@ -314,8 +314,8 @@ def main():
     if wn:
         out["winograd"] = {"algorithmic_tflops": round(wn["flops"] / (wn["ms"] * 1e-3) / 1e12, 1), "layers_per_step":
                            wn["launches"] // max(args.steps, 1), "ms_per_step": round(wn["ms"] / max(args.steps, 1), 2),
-                           "note": "3x3 stride-1 layers with >= 128 channels run as Winograd F(4x4,3x3) (F(2x2,3x3) where 4x4 tiles "
-                                   "would be mostly padding): transforms + 36 (16) batched GEMMs in one gemm_nt launch; TFLOP/s here = dense-conv FLOPs / time (can exceed the MFMA peak), "
+                           "note": "3x3 stride-1 layers with >= 64 channels run as Winograd F(6x6,3x3) (F(4x4) / F(2x2) where the larger tiles "
+                                   "would be mostly padding, kernels.wino_tile): transforms + 64 (36, 16) batched GEMMs in one gemm_nt launch; TFLOP/s here = dense-conv FLOPs / time (can exceed the MFMA peak), "
                                    "while roofline.achieved counts only the FLOPs the MFMA kernel really executes"}
     if wg:
         out["wgrad"] = {"achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
