@@ -707,6 +707,193 @@ __global__ __launch_bounds__(NT, 3) void gemm_tn_wgrad_kernel(const float* __res
   }
 }
 
+// Same products, operands TRANSPOSED ON THE WAY INTO LDS so that the inner loop is the NT GEMM's (gemm.hip): waves 0-1 load
+// A (dY'), waves 2-3 load B (X'); a thread fetches 4 consecutive t rows x 4 channels (each a coalesced 16-byte load), and the
+// 4x4 block leaves for LDS as four ds_write_b128 of [channel][4 consecutive t] -- the transpose is register naming. LDS
+// tiles are [128 channels][16 t + 4] with the NT kernel's chunk rotation, so a lane reads the 4 contraction steps of its
+// channel with ONE ds_read_b128 (8 LDS reads per 32 MFMAs instead of 32 ds_read_b32). Arithmetic: the 16 t of a step are
+// consumed in the order (s, s + 4 | s + 8, s + 12), s = 0..3, instead of (2s, 2s + 1): sums over t are re-associated, results
+// differ from gemm_tn_wgrad_kernel in the last bits and are as deterministic (fixed order).
+constexpr int TN2_LDK = 20;
+// BC: c extent of a tile, 128 (3 workgroups per CU) or 256 (2x2 waves of 64 x 128, 2 workgroups per CU; every thread loads a
+// 4x4 block of B and threads 0-127 one of A as well).
+template <int BC>
+__global__ __launch_bounds__(NT, BC == 256 ? 2 : 3) void gemm_tn2_wgrad_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ dst, int P, int T, int K, int C, long long a_bs,
+    long long b_bs, int Kpad, int Cp, int ktiles, int ctiles, int splits, int t_per_split, long long total) {
+  constexpr int TNJ = BC / 64;                          // 32-column MFMA blocks per wave
+  constexpr bool WIDE = BC == 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                                   // [2][128][20]
+  float* Bs = smem + 2 * 128 * TN2_LDK;               // [2][BC][20]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long stride = gridDim.x;
+  // unit 0: BC = 128: A for waves 0-1, B for waves 2-3; BC = 256: B for every thread. unit 1 (WIDE, threads 0-127): A.
+  const bool u0B = WIDE || tid >= 128;                  // wave-uniform
+  const int cq0 = WIDE ? (tid & 63) : (tid & 31), tg0 = WIDE ? (tid >> 6) : ((tid & 127) >> 5);
+  const int cols0 = u0B ? C : K;
+  const float* const base0 = u0B ? B : A;
+  float* const ldst0 = (u0B ? Bs : As) + (4 * cq0) * TN2_LDK + ((tg0 + cq0) & 3) * 4;
+  const bool has1 = WIDE && tid < 128;                  // wave-uniform
+  const int cq1 = tid & 31, tg1 = (tid >> 5) & 3;
+  float* const ldst1 = As + (4 * cq1) * TN2_LDK + ((tg1 + cq1) & 3) * 4;
+
+  long long ld_w = mss_xcd_remap(blockIdx.x, gridDim.x);
+  const float* ptr0 = base0;
+  const float* ptr1 = A;
+  int ld_t = 0, ld_tend = 0;
+  bool colok0 = false, colok1 = false;
+  auto setup = [&](long long w) {
+    const int ct = (int)(w % ctiles); w /= ctiles;
+    const int kt = (int)(w % ktiles); w /= ktiles;
+    const int p = (int)(w % P);
+    const int sp = (int)(w / P);
+    ld_t = sp * t_per_split;
+    ld_tend = min(T, ld_t + t_per_split);
+    const int col0 = (u0B ? ct * BC : kt * 128) + 4 * cq0;
+    colok0 = col0 < cols0;
+    ptr0 = base0 + (size_t)p * (u0B ? b_bs : a_bs) + (size_t)ld_t * cols0 + (colok0 ? col0 : 0);
+    if (WIDE) {
+      const int col1 = kt * 128 + 4 * cq1;
+      colok1 = col1 < K;
+      ptr1 = A + (size_t)p * a_bs + (size_t)ld_t * K + (colok1 ? col1 : 0);
+    }
+  };
+  f32x4 reg0[4], reg1[WIDE ? 4 : 1];
+  auto issue_loads = [&]() {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * tg0 + e;
+      const bool ok = ld_t + r < ld_tend;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? ptr0 + (size_t)r * cols0 : base0);
+      reg0[e] = (ok && colok0) ? v : z;
+    }
+    if (WIDE && has1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * tg1 + e;
+        const bool ok = ld_t + r < ld_tend;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? ptr1 + (size_t)r * K : A);
+        reg1[WIDE ? e : 0] = (ok && colok1) ? v : z;
+      }
+    }
+  };
+  auto advance = [&]() {
+    ld_t += 16;
+    if (ld_t < ld_tend) {
+      ptr0 += (size_t)16 * cols0;
+      if (WIDE) ptr1 += (size_t)16 * K;
+    } else {
+      ld_w += stride;
+      setup(ld_w < total ? ld_w : ld_w - stride);
+    }
+  };
+  auto finish_store = [&](int buf) {
+    float* d = ldst0 + buf * (u0B ? BC : 128) * TN2_LDK;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const f32x4 w = {reg0[0][e], reg0[1][e], reg0[2][e], reg0[3][e]};     // channel 4 cq + e, t = 4 tg .. 4 tg + 3
+      *reinterpret_cast<f32x4*>(d + e * TN2_LDK) = w;
+    }
+    if (WIDE && has1) {
+      float* d1 = ldst1 + buf * 128 * TN2_LDK;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 w = {reg1[0][e], reg1[WIDE ? 1 : 0][e], reg1[WIDE ? 2 : 0][e], reg1[WIDE ? 3 : 0][e]};
+        *reinterpret_cast<f32x4*>(d1 + e * TN2_LDK) = w;
+      }
+    }
+  };
+  const int frag_row = lane & 31, frag_h = lane >> 5;
+  const int rot = frag_row >> 2;
+  const float* Abase = &As[(wm * 64 + frag_row) * TN2_LDK];
+  const float* Bbase = &Bs[(wn * (BC / 2) + frag_row) * TN2_LDK];
+  const int koff[2] = {((frag_h + rot) & 3) * 4, ((2 + frag_h + rot) & 3) * 4};
+  f32x4 fa[2][2], fb[2][TNJ];
+  auto load_frags = [&](int set, int buf, int kc) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(Abase + (buf * 128 + i * 32) * TN2_LDK + koff[kc]);
+#pragma unroll
+    for (int j = 0; j < TNJ; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(Bbase + (buf * BC + j * 32) * TN2_LDK + koff[kc]);
+  };
+  f32x16 acc[2][TNJ];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TNJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  };
+  auto mfma_chunk = [&](int set) {
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TNJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][s2], fb[set][j][s2], acc[i][j], 0, 0, 0);
+  };
+  auto epilogue = [&](long long w) {
+    const int ct = (int)(w % ctiles); w /= ctiles;
+    const int kt = (int)(w % ktiles); w /= ktiles;      // w = split * P + p: the slab index
+    float* o = dst + (size_t)w * Kpad * Cp;
+    const int colq = lane & 31, rowq = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < TNJ; ++j) {
+      const int col = ct * BC + wn * (BC / 2) + j * 32 + colq;
+      if (col >= Cp) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = kt * 128 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + rowq;
+          if (row < Kpad) o[(size_t)row * Cp + col] = acc[i][j][q];
+        }
+    }
+  };
+
+  long long cur = ld_w;
+  int steps_left;
+  {
+    long long w = cur / ((long long)ktiles * ctiles);
+    const int sp = (int)(w / P);
+    const int t0 = sp * t_per_split;
+    steps_left = (min(T, t0 + t_per_split) - t0 + 15) / 16;
+  }
+  setup(ld_w);
+  issue_loads();
+  finish_store(0);
+  advance();
+  zero_acc();
+  __syncthreads();
+  load_frags(0, 0, 0);
+  int buf = 0;
+  while (true) {
+    issue_loads();                          // step +1, stored in this step
+    load_frags(1, buf, 1);
+    finish_store(buf ^ 1);
+    advance();
+    mfma_chunk(0);
+    __syncthreads();
+    load_frags(0, buf ^ 1, 0);
+    mfma_chunk(1);
+    buf ^= 1;
+    if (--steps_left == 0) {
+      epilogue(cur);
+      cur += stride;
+      if (cur >= total) break;
+      zero_acc();
+      long long w = cur / ((long long)ktiles * ctiles);
+      const int sp = (int)(w / P);
+      const int t0 = sp * t_per_split;
+      steps_left = (min(T, t0 + t_per_split) - t0 + 15) / 16;
+    }
+  }
+}
+
 // dwp[tap][row][col] = sum over splits (ascending) of ws[split][tap][row][col], float4 over col (Cp % 4 == 0)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dwp,
                                                            long long slab4, int splits) {
@@ -778,15 +965,14 @@ int launch_wgrad(MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, 
 // ---- the TN route of the batched (Winograd-domain) weight gradient ----
 struct TnPlan { int ktiles, ctiles, splits, tps; long long total; };
 inline bool tn_eligible(const MssConvArgs& p, int lddy) {
-  static const bool off = getenv("MSS_WGRAD_TN") && atoi(getenv("MSS_WGRAD_TN")) == 0;     // A/B switch
+  const bool off = getenv("MSS_WGRAD_TN") && atoi(getenv("MSS_WGRAD_TN")) == 0;     // A/B switch
   return !off && p.batch > 1 && p.R * p.S == 1 && !p.in_scale && !p.in_relu && p.K % 4 == 0 && p.C % 4 == 0 && p.ldx == p.C &&
          lddy == p.K && p.x_bs % 4 == 0 && p.y_bs % 4 == 0 && p.N == 1 && p.H == 1;
 }
-inline TnPlan tn_plan(const MssConvArgs& p) {
+inline TnPlan tn_plan(const MssConvArgs& p, int bc = TN_BC, int slots = 768) {
   TnPlan pl;
-  pl.ktiles = mss_cdiv(p.K, TN_BK); pl.ctiles = mss_cdiv(p.C, TN_BC);
+  pl.ktiles = mss_cdiv(p.K, TN_BK); pl.ctiles = mss_cdiv(p.C, bc);
   const long long base = (long long)p.batch * pl.ktiles * pl.ctiles;
-  const int slots = 768;
   int max_splits = mss_cdiv(p.M, TN_BT * 8);
   if (max_splits > 64) max_splits = 64;
   if (max_splits < 1) max_splits = 1;
@@ -803,9 +989,25 @@ inline TnPlan tn_plan(const MssConvArgs& p) {
   pl.total = base * pl.splits;
   return pl;
 }
+// MSS_WGRAD_TN: 0 the convolution-loader kernel, 1 gemm_tn_wgrad_kernel, 2 gemm_tn2_wgrad_kernel<128>, 3 (default) tn2 with
+// 256-wide c tiles where they need no pixel split and fill their rounds (C % 256 == 0 and at least 2 rounds of 512 slots),
+// 4 the wide kernel whenever C % 256 == 0 (tests)
+inline int tn_mode() {
+  const char* e = getenv("MSS_WGRAD_TN");
+  return e ? atoi(e) : 3;
+}
+inline bool tn_wide(const MssConvArgs& p) {
+  if (tn_mode() == 4) return p.C % 256 == 0;            // tests: the wide kernel at any size, pixel splits included
+  if (tn_mode() != 3 || p.C % 256) return false;
+  const TnPlan w = tn_plan(p, 256, 512);
+  const double eff = (double)w.total / (double)(((w.total + 511) / 512) * 512);
+  return w.splits == 1 && w.total >= 1024 && eff >= 0.9;
+}
+inline TnPlan tn_plan_for(const MssConvArgs& p) { return tn_wide(p) ? tn_plan(p, 256, 512) : tn_plan(p); }
 int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, float* ws, long long ws_bytes,
                     hipStream_t stream) {
-  const TnPlan pl = tn_plan(p);
+  const bool wide = tn_wide(p);
+  const TnPlan pl = tn_plan_for(p);
   const long long slab = (long long)p.batch * p.Kpad * Cp;
   if (pl.splits > 1 && (!ws || ws_bytes < (long long)pl.splits * slab * 4)) return MSS_ERR_BAD_ARG;
   const size_t smem = (size_t)4 * TN_BT * TN_LD * sizeof(float);
@@ -817,15 +1019,27 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_tn_wgrad_kernel<false>, NT, smem) != hipSuccess || n < 1) n = 3;
     per_cu = n > 3 ? 3 : n;
   }
-  const long long slots = (long long)per_cu * cus;
+  const long long slots = (long long)(wide ? 2 : per_cu) * cus;
   const int grid = (int)(pl.total < slots ? pl.total : slots);
-  const char* e2 = getenv("MSS_WGRAD_TN_AHEAD");
-  if (e2 && atoi(e2) == 2)
-    hipLaunchKernelGGL(gemm_tn_wgrad_kernel<true>, dim3(grid), dim3(NT), smem, stream, dy, p.x, pl.splits > 1 ? ws : dwp, p.batch,
-                       p.M, p.K, p.C, p.y_bs, p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
-  else
-    hipLaunchKernelGGL(gemm_tn_wgrad_kernel<false>, dim3(grid), dim3(NT), smem, stream, dy, p.x, pl.splits > 1 ? ws : dwp, p.batch,
-                       p.M, p.K, p.C, p.y_bs, p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+  float* out = pl.splits > 1 ? ws : dwp;
+  const int mode = tn_mode();
+  if (wide) {
+    const size_t smem2 = (size_t)2 * (128 + 256) * TN2_LDK * sizeof(float);
+    hipLaunchKernelGGL(gemm_tn2_wgrad_kernel<256>, dim3(grid), dim3(NT), smem2, stream, dy, p.x, out, p.batch, p.M, p.K, p.C, p.y_bs,
+                       p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+  } else if (mode >= 2) {
+    const size_t smem2 = (size_t)4 * 128 * TN2_LDK * sizeof(float);
+    hipLaunchKernelGGL(gemm_tn2_wgrad_kernel<128>, dim3(grid), dim3(NT), smem2, stream, dy, p.x, out, p.batch, p.M, p.K, p.C, p.y_bs,
+                       p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+  } else {
+    const char* e2 = getenv("MSS_WGRAD_TN_AHEAD");
+    if (e2 && atoi(e2) == 2)
+      hipLaunchKernelGGL(gemm_tn_wgrad_kernel<true>, dim3(grid), dim3(NT), smem, stream, dy, p.x, out, p.batch, p.M, p.K, p.C, p.y_bs,
+                         p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+    else
+      hipLaunchKernelGGL(gemm_tn_wgrad_kernel<false>, dim3(grid), dim3(NT), smem, stream, dy, p.x, out, p.batch, p.M, p.K, p.C, p.y_bs,
+                         p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+  }
   if (pl.splits > 1) {
     const long long slab4 = slab / 4;
     long long blocks = (slab4 + 255) / 256;
@@ -907,7 +1121,7 @@ long long mss_conv2d_wgrad_workspace_bytes(const MssConvArgs* args, int Cp) {
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return 0;
   if (tn_eligible(p, p.K)) {                 // the caller passes lddy == K on this route (checked again at launch)
-    const TnPlan pl = tn_plan(p);
+    const TnPlan pl = tn_plan_for(p);
     return pl.splits > 1 ? (long long)pl.splits * p.batch * p.Kpad * Cp * 4 : 0;
   }
   if (p.K <= 32) return wgrad_ws_bytes<32, 128, 16>(p, Cp);

@@ -448,3 +448,35 @@ def test_bf16x6_gemm_is_fp32_accurate(K, monkeypatch, rows, c, k, batch):
     e6 = (y6.double() - ref).abs().max().item() / scale
     assert e32 < 2e-6 and e6 < 2e-6 and e6 < 3 * e32 + 2e-7, (e32, e6)
     assert not torch.equal(y32, y6)          # it really is a different evaluation
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "2", "4"])
+@pytest.mark.parametrize("P,T,C,Ko", [(3, 700, 512, 128), (2, 1000, 256, 72), (4, 37, 768, 256)])
+def test_batched_wgrad_routes_vs_float64(K, monkeypatch, mode, P, T, C, Ko):
+    """dU[p] = dY'[p]^T X'[p] (the Winograd-domain weight gradient) on its four kernels -- the convolution-loader kernel (0),
+    the TN kernel (1), the transposing-loader kernel with 128-wide (2) and 256-wide (4) c tiles, ragged T and K, with and
+    without a pixel split -- against a float64 product; and twice with identical bits."""
+    import ctypes
+    from multishiftseg_amd._lib import MssConvArgs, call, ptr
+    monkeypatch.setenv("MSS_WGRAD_TN", mode)
+    torch.manual_seed(P * T + C)
+    xt = torch.randn(P, T, C, device="cuda")
+    dyt = torch.randn(P, T, Ko, device="cuda")
+    kpad = (Ko + 3) // 4 * 4
+    a = MssConvArgs()
+    a.x = ptr(xt)
+    a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
+    a.OH, a.OW, a.K, a.Kpad = 1, T, Ko, kpad
+    a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+    a.batch, a.x_bs, a.y_bs = P, T * C, T * Ko
+    outs = []
+    for _ in range(2):
+        du = torch.full((P, kpad, C), float("nan"), device="cuda")
+        ws, wsb = K._wgrad_workspace(a, C, "cuda")
+        call("mss_conv2d_wgrad_f32", ctypes.byref(a), ptr(dyt), Ko, ptr(du), C, ptr(ws), wsb)
+        outs.append(du)
+    assert torch.equal(outs[0], outs[1])
+    want = torch.einsum("ptk,ptc->pkc", dyt.double(), xt.double())
+    err = (outs[0][:, :Ko].double() - want).abs().max().item()
+    assert err <= 2e-6 * T ** 0.5 * 16, err
+    assert not torch.isnan(outs[0]).any()

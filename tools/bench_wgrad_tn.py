@@ -5,8 +5,8 @@ import torch
 from multishiftseg_amd import kernels as K
 from multishiftseg_amd._lib import MssConvArgs, call, ptr
 from tools.microbench import timeit
-P = 36
-for (T, C, Ko) in [(5184, 4096, 256), (6912, 4096, 256), (65536, 256, 256), (65536, 304, 256)]:
+# (P, T, C, K): ASPP dilation 12 / 24 through F(6x6), dilation 36 through F(4x4), the two decoder convolutions through F(6x6)
+for (P, T, C, Ko) in [(64, 2304, 4096, 256), (36, 5184, 4096, 256), (64, 29412, 256, 256), (64, 29412, 304, 256)]:
     xt = torch.randn(P, T, C, device="cuda")
     dyt = torch.randn(P, T, Ko, device="cuda")
     du = torch.empty(P, Ko, C, device="cuda")
@@ -18,5 +18,5 @@ for (T, C, Ko) in [(5184, 4096, 256), (6912, 4096, 256), (65536, 256, 256), (655
     a.batch, a.x_bs, a.y_bs = P, T * C, T * Ko
     ws, wsb = K._wgrad_workspace(a, C, "cuda")
     ms = timeit(lambda: call("mss_conv2d_wgrad_f32", ctypes.byref(a), ptr(dyt), Ko, ptr(du), C, ptr(ws), wsb), iters=5, warm=2)
-    print(json.dumps(dict(T=T, C=C, K=Ko, ms=round(ms, 3), tflops=round(2.0 * P * T * C * Ko / ms / 1e9, 1), ws_MB=round(wsb / 1e6, 1),
+    print(json.dumps(dict(P=P, T=T, C=C, K=Ko, ms=round(ms, 3), tflops=round(2.0 * P * T * C * Ko / ms / 1e9, 1), ws_MB=round(wsb / 1e6, 1),
                           tn=os.environ.get("MSS_WGRAD_TN", "1"), ahead=os.environ.get("MSS_WGRAD_TN_AHEAD", "1"))), flush=True)
