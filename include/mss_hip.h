@@ -332,7 +332,8 @@ int mss_m2f_fused_score_f32(const float* cls, const float* logit, int B, int Q, 
  *   compact:  one pass over a batch of n pixels: order-preserving u32 keys of the id_in pixels' scores packed
  *             at the front of keys[0..n), those of the id_out pixels at the back; counts (device u64[2], zero on
  *             entry) = {#id_in, #id_out}. No host synchronisation per batch.
- *   sort:     ascending key sort (rocPRIM radix sort), temp sized by mss_oodm_sort_temp_bytes
+ *   sort:     ascending key sort (own 4-pass LSD radix sort, csrc/metric.hip; keys 4-byte aligned, n < 2^32), temp sized
+ *             by mss_oodm_sort_temp_bytes
  *   measures: out[0..2] = {AUROC, AUPRC, FPR@recall_level} (device f64[3]); u2_part / ap_part: device scratch of
  *             mss_oodm_rank_blocks(P) elements each. P, N >= 1 (the host mirror returns None otherwise, as
  *             metric.py:176-180 does). */

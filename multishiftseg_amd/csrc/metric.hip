@@ -4,7 +4,8 @@
 // map to the host, concatenate in NumPy and let sklearn argsort 1e7-1e8 pixels on one core.
 //
 // Exact, not binned: the positive (OOD, label == id_out) and negative (label == id_in) scores are compacted into
-// two arrays of order-preserving 32-bit keys, each array is radix-sorted (rocPRIM device primitive, keys only),
+// two arrays of order-preserving 32-bit keys, each array is radix-sorted (own LSD sort below: 4 passes of 8 bits;
+// the rocPRIM primitive it replaced stays reachable with MSS_OODM_SORT=rocprim for A/B timing only),
 // and every metric is a function of rank counts found by binary search:
 //   AUROC = sum_pos (#neg < s + 1/2 #neg == s) / (P N)              -- the area under sklearn's ROC trapezoids,
 //                                                                       accumulated in 64-bit integers (exact)
@@ -15,6 +16,7 @@
 // -0.0 is folded onto +0.0 first (NumPy compares them equal, so they are one threshold).
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <stdlib.h>
 #include "mss_common.h"
 #include "../../include/mss_hip.h"
 
@@ -178,6 +180,186 @@ inline int grid_for(long long n) {
 
 }  // namespace
 
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// LSD radix sort of 32-bit keys, 8 bits per pass, stable. The array is cut into NC <= 1024 contiguous chunks (whole tiles
+// of 4096 keys); per pass:
+//   rs_hist    : workgroup c histograms the pass digit over chunk c (LDS integer atomics) -> hist[c][256]
+//   rs_scan    : workgroup d turns digit d's column of hist into its exclusive prefix over the chunks + the digit total
+//   rs_scatter : workgroup c walks chunk c tile by tile. Keys are held wave-striped (wave w, round i, lane l <-> key
+//                w*1024 + i*64 + l of the tile); a key's rank among equal digits is found with 8 ballots (the lanes that
+//                agree on every digit bit) + a per-wave running count in LDS; the tile is first laid out digit-sorted in
+//                LDS and then written, so a wave stores runs of consecutive addresses per digit instead of 4-byte
+//                scatters. The running offsets of the chunk live in LDS and advance by the tile's digit counts.
+// Traffic: 12 B per key and pass (histogram read, scatter read + write), no atomics on global memory.
+constexpr int RS_NT = 256, RS_ITEMS = 16, RS_TILE = RS_NT * RS_ITEMS, RS_MAXCHUNKS = 1024;
+
+__global__ __launch_bounds__(RS_NT) void rs_hist_kernel(const uint32_t* __restrict__ keys, long long n, long long chunk, int shift,
+                                                        uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const long long lo = (long long)blockIdx.x * chunk, hi = min(n, lo + chunk);
+  // 16-byte loads from the first aligned key on (the key arrays are slices of the compaction buffer: 4-byte aligned only)
+  const long long mis = (long long)((reinterpret_cast<uintptr_t>(keys) >> 2) & 3);
+  long long lo4 = lo + ((4 - ((mis + lo) & 3)) & 3);
+  if (lo4 > hi) lo4 = hi;
+  for (long long i = lo4 + 4ll * threadIdx.x; i + 3 < hi; i += 4ll * RS_NT) {
+    const uint4 k = *reinterpret_cast<const uint4*>(keys + i);
+    atomicAdd(&h[(k.x >> shift) & 255], 1u);
+    atomicAdd(&h[(k.y >> shift) & 255], 1u);
+    atomicAdd(&h[(k.z >> shift) & 255], 1u);
+    atomicAdd(&h[(k.w >> shift) & 255], 1u);
+  }
+  {
+    const long long tail = lo4 + ((hi - lo4) & ~3ll);       // the last 0..3 keys of the chunk, and its first 0..3
+    if (tail + threadIdx.x < hi) atomicAdd(&h[(keys[tail + threadIdx.x] >> shift) & 255], 1u);
+    if (lo + threadIdx.x < lo4) atomicAdd(&h[(keys[lo + threadIdx.x] >> shift) & 255], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan over the 256 threads of a workgroup (4 waves): shuffles inside a wave, one LDS hop across waves
+__device__ __forceinline__ uint32_t rs_block_excl_scan(uint32_t v, uint32_t* wsum /* [4] shared */, uint32_t* total_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  const uint32_t w0 = wsum[0], w1 = wsum[1], w2 = wsum[2], w3 = wsum[3];
+  const uint32_t base = wave == 0 ? 0u : wave == 1 ? w0 : wave == 2 ? w0 + w1 : w0 + w1 + w2;
+  if (total_out) *total_out = w0 + w1 + w2 + w3;
+  __syncthreads();                                           // wsum may be reused by the caller's next scan
+  return base + inc - v;
+}
+
+// hist[c][d] (counts) -> exclusive prefix over the chunks of digit d, in place, + totals[d]. Workgroup d owns digit d,
+// thread t the chunks 4t .. 4t+3 (nchunks <= 1024).
+__global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ hist, int nchunks, uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wsum[4];
+  const int d = blockIdx.x, t = threadIdx.x;
+  uint32_t v[4], sum = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = 4 * t + j;
+    v[j] = c < nchunks ? hist[(size_t)c * 256 + d] : 0u;
+    sum += v[j];
+  }
+  uint32_t total;
+  uint32_t run = rs_block_excl_scan(sum, wsum, &total);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = 4 * t + j;
+    if (c < nchunks) hist[(size_t)c * 256 + d] = run;
+    run += v[j];
+  }
+  if (t == 0) totals[d] = total;
+}
+
+__global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, long long n,
+                                                           long long chunk, int shift, const uint32_t* __restrict__ offsets,
+                                                           const uint32_t* __restrict__ totals) {
+  __shared__ uint32_t run_off[256];            // global offset of the next key of each digit, for this chunk
+  __shared__ uint32_t wcount[4][256];          // per wave: keys of each digit seen so far in the tile
+  __shared__ uint32_t tile_excl[256];          // exclusive scan of the tile's digit totals
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t sorted[RS_TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1;
+  run_off[tid] = rs_block_excl_scan(totals[tid], wsum, nullptr) + offsets[(size_t)blockIdx.x * 256 + tid];
+  const long long lo = (long long)blockIdx.x * chunk, hi = min(n, lo + chunk);
+  for (long long t0 = lo; t0 < hi; t0 += RS_TILE) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wcount[w][tid] = 0;
+    __syncthreads();
+    uint32_t key[RS_ITEMS];
+    unsigned short rank[RS_ITEMS];             // rank among the wave's keys of the same digit
+    const long long wbase = t0 + (long long)wave * (RS_ITEMS * 64);
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+      const long long g = wbase + i * 64 + lane;
+      key[i] = g < hi ? in[g] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+      const long long g = wbase + i * 64 + lane;
+      const bool valid = g < hi;
+      const unsigned d = (key[i] >> shift) & 255;
+      unsigned long long m = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned long long bal = __ballot((d >> b) & 1);
+        m &= ((d >> b) & 1) ? bal : ~bal;
+      }
+      // m: the valid lanes of this round with my digit (including me when valid)
+      const int leader = __ffsll((long long)m) - 1;
+      uint32_t prev = 0;
+      if (valid && lane == leader) {
+        prev = wcount[wave][d];
+        wcount[wave][d] = prev + (uint32_t)__popcll(m);
+      }
+      prev = __shfl(prev, leader < 0 ? 0 : leader);
+      rank[i] = (unsigned short)(prev + (uint32_t)__popcll(m & lt));
+    }
+    __syncthreads();
+    // digit totals of the tile, their exclusive scan, and the per-wave bases
+    const uint32_t c0 = wcount[0][tid], c1 = wcount[1][tid], c2 = wcount[2][tid], c3 = wcount[3][tid];
+    const uint32_t total = c0 + c1 + c2 + c3;
+    const uint32_t excl = rs_block_excl_scan(total, wsum, nullptr);     // (its barriers also order the reads above)
+    tile_excl[tid] = excl;
+    wcount[0][tid] = excl;                     // reuse: position of wave w's first key of digit tid in the sorted tile
+    wcount[1][tid] = excl + c0;
+    wcount[2][tid] = excl + c0 + c1;
+    wcount[3][tid] = excl + c0 + c1 + c2;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+      const long long g = wbase + i * 64 + lane;
+      if (g < hi) {
+        const unsigned d = (key[i] >> shift) & 255;
+        sorted[wcount[wave][d] + rank[i]] = key[i];
+      }
+    }
+    __syncthreads();
+    const int cnt = (int)min((long long)RS_TILE, hi - t0);
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+      const int j = i * RS_NT + tid;
+      if (j < cnt) {
+        const uint32_t k = sorted[j];
+        const unsigned d = (k >> shift) & 255;
+        out[run_off[d] + (uint32_t)j - tile_excl[d]] = k;
+      }
+    }
+    __syncthreads();
+    run_off[tid] += total;
+  }
+}
+
+struct RsPlan { int nchunks; long long chunk; };
+inline RsPlan rs_plan(long long n) {
+  RsPlan p;
+  long long tiles = (n + RS_TILE - 1) / RS_TILE;
+  if (tiles < 1) tiles = 1;
+  p.nchunks = (int)(tiles < RS_MAXCHUNKS ? tiles : RS_MAXCHUNKS);
+  p.chunk = ((tiles + p.nchunks - 1) / p.nchunks) * RS_TILE;
+  p.nchunks = (int)((n + p.chunk - 1) / p.chunk);
+  if (p.nchunks < 1) p.nchunks = 1;
+  return p;
+}
+inline bool rs_use_rocprim() {
+  const char* e = getenv("MSS_OODM_SORT");
+  return e && e[0] == 'r';
+}
+
+}  // namespace
+
 #define S_(x) static_cast<hipStream_t>(x)
 
 extern "C" {
@@ -195,22 +377,45 @@ int mss_oodm_compact_f32(const float* score, const long long* label, long long n
 }
 
 long long mss_oodm_sort_temp_bytes(long long n) {
-  if (n < 0) return -1;
+  if (n < 0 || n >= (1ll << 32)) return -1;
   size_t bytes = 0;
   const uint32_t* in = nullptr;
   uint32_t* out = nullptr;
-  if (rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n) != hipSuccess) return -1;
-  return (long long)(bytes < 16 ? 16 : bytes);
+  if (rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n) != hipSuccess) return -1;   // A/B route only
+  // own sort: a ping-pong key buffer (16-byte aligned) + the [chunks][256] offset table
+  const long long own = ((n * 4 + 15) & ~15ll) + (long long)(RS_MAXCHUNKS + 1) * 256 * 4;
+  const long long need = own > (long long)bytes ? own : (long long)bytes;
+  return need < 16 ? 16 : need;
 }
 
 int mss_oodm_sort_u32(const unsigned int* keys_in, unsigned int* keys_out, long long n, void* temp, long long temp_bytes,
                       void* stream) {
-  if (n < 0) return MSS_ERR_BAD_ARG;
+  if (n < 0 || n >= (1ll << 32)) return MSS_ERR_BAD_ARG;
   if (n == 0) return MSS_OK;
   if (!keys_in || !keys_out || !temp || keys_in == keys_out) return MSS_ERR_BAD_ARG;
-  size_t bytes = (size_t)temp_bytes;
-  hipError_t e = rocprim::radix_sort_keys(temp, bytes, keys_in, keys_out, (size_t)n, 0, 32, S_(stream));
-  return e == hipSuccess ? mss_launch_status() : (int)e;
+  if (rs_use_rocprim()) {
+    size_t bytes = (size_t)temp_bytes;
+    hipError_t e = rocprim::radix_sort_keys(temp, bytes, keys_in, keys_out, (size_t)n, 0, 32, S_(stream));
+    return e == hipSuccess ? mss_launch_status() : (int)e;
+  }
+  const long long kb = (n * 4 + 15) & ~15ll;
+  if (temp_bytes < kb + (long long)(RS_MAXCHUNKS + 1) * 256 * 4) return MSS_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(keys_in) | reinterpret_cast<uintptr_t>(keys_out) | reinterpret_cast<uintptr_t>(temp)) & 3)
+    return MSS_ERR_BAD_ARG;
+  uint32_t* ping = static_cast<uint32_t*>(temp);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(static_cast<char*>(temp) + kb);
+  uint32_t* totals = hist + (size_t)RS_MAXCHUNKS * 256;
+  const RsPlan pl = rs_plan(n);
+  const uint32_t* src = keys_in;
+  for (int pass = 0; pass < 4; ++pass) {
+    uint32_t* dst = (pass & 1) ? keys_out : ping;           // in -> ping -> out -> ping -> out
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(pl.nchunks), dim3(RS_NT), 0, S_(stream), src, n, pl.chunk, 8 * pass, hist);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, S_(stream), hist, pl.nchunks, totals);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(pl.nchunks), dim3(RS_NT), 0, S_(stream), src, dst, n, pl.chunk, 8 * pass, hist,
+                       totals);
+    src = dst;
+  }
+  return mss_launch_status();
 }
 
 int mss_oodm_rank_blocks(long long P) { return grid_for(P); }

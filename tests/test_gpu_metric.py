@@ -106,3 +106,39 @@ def test_full_size_properties(M):
     d = M.eval_ood_measure(-sc, 1 - lab.clamp(max=2), train_id_in=0, train_id_out=1)   # 255 -> -1.. stays ignored
     np.testing.assert_allclose(d[0], a[0], atol=1e-12)
     assert 0.5 < a[0] < 1 and 0 < a[1] < 1 and 0 < a[2] < 1
+
+
+@pytest.mark.parametrize("n,kind", [(1, "rand"), (5, "rand"), (4095, "rand"), (4096, "rand"), (4097, "dups"), (70001, "rand"),
+                                    (1 << 20, "top"), (5_000_003, "rand"), (4096 * 1024 + 7, "dups"), (40_000_001, "rand")])
+def test_own_radix_sort_equals_torch_sort(monkeypatch, n, kind):
+    """mss_oodm_sort_u32 (own 4-pass LSD sort): sizes around the tile (4096) and chunk boundaries, more tiles than the
+    1024 chunks, all-equal digits in the high bytes ('top': keys below 2^12), heavy duplicates; the rocPRIM A/B route gives
+    the same array."""
+    from multishiftseg_amd import _lib
+    from multishiftseg_amd._lib import call, ptr
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n)
+    if kind == "rand":
+        keys = torch.randint(0, 2 ** 31 - 1, (n,), device="cuda", generator=g, dtype=torch.int64)
+        keys = (keys * 2 + torch.randint(0, 2, (n,), device="cuda", generator=g)).to(torch.int64)
+    elif kind == "dups":
+        keys = torch.randint(0, 37, (n,), device="cuda", generator=g, dtype=torch.int64) * 0x01010101
+    else:
+        keys = torch.randint(0, 4096, (n,), device="cuda", generator=g, dtype=torch.int64)
+    want = torch.sort(keys)[0]
+    k32 = (keys & 0xffffffff).to(torch.int64)
+    k32 = torch.where(k32 >= 2 ** 31, k32 - 2 ** 32, k32).to(torch.int32).contiguous()       # same bits as uint32
+    outs = {}
+    pad = torch.empty(n + 3, dtype=torch.int32, device="cuda")
+    off = n % 4                                          # input slices that are only 4-byte aligned, as the meter's are
+    pad[off:off + n] = k32
+    k32 = pad[off:off + n]
+    for route in ("own", "rocprim"):
+        monkeypatch.setenv("MSS_OODM_SORT", route)
+        out = torch.empty_like(want, dtype=torch.int32)
+        temp = torch.empty(_lib.value("mss_oodm_sort_temp_bytes", n), dtype=torch.uint8, device="cuda")
+        call("mss_oodm_sort_u32", ptr(k32), ptr(out), n, ptr(temp), temp.numel())
+        outs[route] = out
+        got = out.to(torch.int64) & 0xffffffff
+        assert torch.equal(got, want), route
+    assert torch.equal(outs["own"], outs["rocprim"])
