@@ -191,3 +191,20 @@ def test_trunk_gradients_are_refused(model):
     finally:
         for p in model.parameters():
             p.requires_grad_(False)
+
+
+def test_graphed_eval_replays_the_same_forward(model):
+    """trainer.GraphedEval: the eval forward captured into a hipGraph gives bit-identical scores / logits to the eager
+    forward, for several inputs, and refuses another shape."""
+    from multishiftseg_amd import synth
+    from multishiftseg_amd.trainer import GraphedEval, ood_scores
+    model.eval()
+    imgs = [torch.from_numpy(synth.synth_image(s, 1, 96, 160)).cuda() for s in (3, 4, 5)]
+    with torch.no_grad():
+        ge = GraphedEval(model, imgs[0].shape)
+        for img in imgs:
+            want_s, want_l = ood_scores(model, img)
+            got_s, got_l = ge(img)
+            assert torch.equal(got_s, want_s) and torch.equal(got_l, want_l)
+        with pytest.raises(ValueError):
+            ge(torch.zeros(1, 3, 64, 64, device="cuda"))
