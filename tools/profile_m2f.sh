@@ -18,6 +18,7 @@ python3 tools/bench_encoder.py 1 > "$OUT/bench_encoder.jsonl" 2> /dev/null
 python3 tools/bench_encoder.py 16 >> "$OUT/bench_encoder.jsonl" 2> /dev/null
 python3 tools/bench_metric.py > "$OUT/bench_metric.jsonl" 2> /dev/null
 python3 tools/bench_m2f.py > "$OUT/bench_m2f.jsonl" 2> /dev/null
+python3 tools/bench_decoder.py > "$OUT/bench_decoder.jsonl" 2> /dev/null
 python3 - "$OUT" <<'PY'
 import csv, glob, json, os, re, sys
 out = sys.argv[1]
