@@ -43,7 +43,8 @@ static_assert(NKC == 2, "the step body below is written for two 8-k chunks");
 // per wave and barrier instead of 32, a quarter less operand traffic per FLOP and half the per-tile prologue/epilogue
 // share, at 2 workgroups per CU).
 template <bool AFFINE, int VARIANT, int BN>
-__global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvArgs p, long long total_tiles, int tiles_per_batch) {
+__global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvArgs p, long long first_tile, long long total_tiles,
+                                                                        int tiles_per_batch) {
   constexpr int WTN = BN / 2, TN = WTN / 32, B_LD = BN / RPP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                       // [2][BM][LDK]
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
   const float* b_ptr[B_LD];
   const float* s_ptr = p.in_scale;
   const float* h_ptr = p.in_shift;
-  long long ld_tile = mss_xcd_remap(blockIdx.x, gridDim.x);
+  long long ld_tile = first_tile + mss_xcd_remap(blockIdx.x, gridDim.x);   // this launch walks tiles [first_tile, total_tiles)
   int ld_k = 0;
   auto setup = [&](long long t) {
     const int b = (int)(t / tiles_per_batch);
@@ -205,10 +206,12 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
 }
 
 template <bool AFFINE, int VARIANT, int BN>
-int launch_gemm(const MssConvArgs& p, hipStream_t stream) {
+int launch_gemm(const MssConvArgs& p, hipStream_t stream, long long first = 0, long long end = -1) {
   const int batch = p.batch > 1 ? p.batch : 1;
   const int tiles_per_batch = p.mtiles * p.ntiles;
-  const long long total = (long long)tiles_per_batch * batch;
+  if (end < 0) end = (long long)tiles_per_batch * batch;
+  const long long total = end - first;                 // tiles of this launch
+  if (total <= 0) return MSS_OK;
   const size_t smem = (size_t)2 * (BM + BN) * LDK * sizeof(float);
   static int per_cu_max = 0, cus = 256;  // resident workgroups per CU (BN = 128: 4 with 32 KB LDS and <= 128 registers); one static per instantiation
   if (per_cu_max == 0) {
@@ -231,7 +234,7 @@ int launch_gemm(const MssConvArgs& p, hipStream_t stream) {
     const double eff = (double)total / (double)(rounds * g);
     if (eff > best + 0.02) { best = eff; grid = (int)g; }
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<AFFINE, VARIANT, BN>), dim3(grid), dim3(NT), smem, stream, p, total, tiles_per_batch);
+  hipLaunchKernelGGL((gemm_nt_kernel<AFFINE, VARIANT, BN>), dim3(grid), dim3(NT), smem, stream, p, first, end, tiles_per_batch);
   return mss_launch_status();
 }
 
@@ -285,7 +288,26 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
     if (ew < 0.8 && en > ew + 0.15) wide = false;
   }
   if (wide) {
-    p.ntiles = p.K / 256;
+    // Hybrid last round, OPT-IN (MSS_GEMM_TAIL=1): when the wide tiles leave a partial last round that is at most 3/4
+    // full, the whole rounds run on wide tiles and the remainder as twice as many narrow tiles in a second launch --
+    // narrow tile 2w + {0, 1} is wide tile w's left / right half in the same n-fastest order -- e.g. 64 x 15 x 2 = 1920
+    // wide tiles (mod4 through F(6x6)): 3 wide rounds + exactly one round of 768 narrow tiles instead of 3.75 -> 4.
+    // Bit-identical results, but MEASURED +2.5 % isolated and within noise in the step (67.1 vs 67.3 ms of gemm_nt): the
+    // workgroups of a partial round share their CU with fewer others and run faster, so "rounds x round time" overstates
+    // what a partial round costs. Off by default.
+    const char* te = getenv("MSS_GEMM_TAIL");
+    const bool tail_off = !(te && atoi(te) == 1);
+    const long long full = (tiles256 / 512) * 512, rem = tiles256 - full;
+    const int nw = p.K / 256;
+    if (!tail_off && bn == 0 && full > 0 && rem > 0 && rem <= 384) {
+      MssConvArgs q = p;
+      q.ntiles = nw;
+      int rc = p.in_scale ? launch_gemm<true, 2, 256>(q, s, 0, full) : launch_gemm<false, 2, 256>(q, s, 0, full);
+      if (rc) return rc;
+      q.ntiles = 2 * nw;
+      return p.in_scale ? launch_gemm<true, 2, 128>(q, s, 2 * full, 2 * tiles256) : launch_gemm<false, 2, 128>(q, s, 2 * full, 2 * tiles256);
+    }
+    p.ntiles = nw;
     return p.in_scale ? launch_gemm<true, 2, 256>(p, s) : launch_gemm<false, 2, 256>(p, s);
   }
   return p.in_scale ? launch_gemm<true, 2, 128>(p, s) : launch_gemm<false, 2, 128>(p, s);

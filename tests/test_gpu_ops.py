@@ -480,3 +480,42 @@ def test_batched_wgrad_routes_vs_float64(K, monkeypatch, mode, P, T, C, Ko):
     err = (outs[0][:, :Ko].double() - want).abs().max().item()
     assert err <= 2e-6 * T ** 0.5 * 16, err
     assert not torch.isnan(outs[0]).any()
+
+
+@pytest.mark.parametrize("P,T,C,Ko,affine", [(64, 1892, 512, 512, False), (34, 2112, 320, 1024, False), (1, 70000, 512, 256, True)])
+def test_gemm_hybrid_last_round_is_bitwise_the_wide_result(K, monkeypatch, P, T, C, Ko, affine):
+    """Wide-tile GEMMs whose last round would be mostly idle finish on narrow tiles in a second launch (gemm.hip): every
+    output element is the same sum in the same order, so the result equals the all-wide launch bit for bit; a sample of rows
+    is checked against float64."""
+    import ctypes
+    from multishiftseg_amd import _lib
+    from multishiftseg_amd._lib import MssConvArgs, call, ptr
+    torch.manual_seed(T + C)
+    x = torch.randn(P, T, C, device="cuda")
+    kpad = _lib.value("mss_conv2d_kpad", Ko)
+    w = torch.zeros(P, kpad, C, device="cuda")
+    w[:, :Ko] = torch.randn(P, Ko, C, device="cuda") / C ** 0.5
+    sc = torch.rand(C, device="cuda") + 0.5
+    sh = torch.randn(C, device="cuda") * 0.1
+    outs = {}
+    for tail in ("0", "1"):
+        monkeypatch.setenv("MSS_GEMM_TAIL", tail)
+        y = torch.full((P, T, Ko), float("nan"), device="cuda")
+        a = MssConvArgs()
+        a.x, a.w, a.y = ptr(x), ptr(w), ptr(y)
+        a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
+        a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, Ko, kpad, Ko
+        a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+        if P > 1:
+            a.batch, a.x_bs, a.w_bs, a.y_bs = P, T * C, kpad * C, T * Ko
+        if affine:
+            a.in_scale, a.in_shift, a.in_relu = ptr(sc), ptr(sh), 1
+        call("mss_conv2d_forward_f32", ctypes.byref(a))
+        outs[tail] = y
+    assert torch.equal(outs["0"], outs["1"])
+    rows = torch.randint(0, T, (64,), device="cuda")
+    xin = x[:, rows].double()
+    if affine:
+        xin = torch.relu(xin * sc.double() + sh.double())
+    want = torch.einsum("ptc,pkc->ptk", xin, w[:, :Ko].double())
+    assert (outs["1"][:, rows].double() - want).abs().max().item() < 1e-4
