@@ -265,17 +265,24 @@ class DeepWV3Plus(nn.Module):
         dec0 = Act.empty(N, h2, w2, 304, dev)                      # concat [bot_fine(m2), up(bot_aspp)]
         K.upsample_ac(up_small, h2, w2, out=dec0.slice(48, 256))
         K.conv2d(m2, K.packed(self.bot_fine.weight), out=dec0.slice(0, 48))
-        f0 = K.conv3x3(dec0, self.final[0].weight, want_stats=train)
+        # the two decoder convolutions keep their Winograd-domain inputs for the weight gradient too (2.3 + 1.9 GB at
+        # 2x1024x2048; re-transforming costs 0.73 ms each), under the same budget as the ASPP layers
+        dec_xt_bytes = K.wino_xt_bytes(N, h2, w2, 304, 1) + K.wino_xt_bytes(N, h2, w2, 256, 1)
+        keep_dec = keep and xt_bytes + dec_xt_bytes < (40 << 30) and os.environ.get("MSS_KEEP_DEC_XT", "1") != "0"
+        kx0 = {} if (keep_dec and self.final[0].weight.requires_grad) else None
+        kx3 = {} if (keep_dec and self.final[3].weight.requires_grad) else None
+        f0 = K.conv3x3(dec0, self.final[0].weight, want_stats=train, keep_xt=kx0)
         st_f0 = K.bn_fold(self.final[1], f0, train)
-        f1 = K.conv3x3(f0, self.final[3].weight, in_affine=(st_f0.scale, st_f0.shift), in_relu=True, want_stats=train)
+        f1 = K.conv3x3(f0, self.final[3].weight, in_affine=(st_f0.scale, st_f0.shift), in_relu=True, want_stats=train, keep_xt=kx3)
         st_f1 = K.bn_fold(self.final[4], f1, train)
+        final_xt = {0: kx0.get("xt") if kx0 else None, 3: kx3.get("xt") if kx3 else None}
         wh, _ = self._heads_weight()
         dec12 = K.conv2d(f1, wh, in_affine=(st_f1.scale, st_f1.shift), in_relu=True)
         score, logit, _ = K.ood_score(dec12.slice(20, 19), dec12.slice(0, 19), size[0], size[1])
         saved = None
         if keep:
             saved = dict(aspp_xt=aspp_xt, x=x, m2=m2, raw=raw, scale=scale, shift=shift, states=states, pooled_act=pooled_act,
-                         u0_rows=u0_rows, dec0=dec0, f0=f0, st_f0=st_f0, f1=f1, st_f1=st_f1, dec12=dec12, size=size)
+                         u0_rows=u0_rows, dec0=dec0, f0=f0, st_f0=st_f0, f1=f1, st_f1=st_f1, dec12=dec12, size=size, final_xt=final_xt)
         return score, logit, saved
 
     def _head_backward(self, s, dscore, dlogit, needs):
@@ -325,12 +332,12 @@ class DeepWV3Plus(nn.Module):
         grads["final.4.weight"], grads["final.4.bias"] = dg, db
         aff_f0 = (s["st_f0"].scale, s["st_f0"].shift)
         if need["final.3.weight"]:
-            grads["final.3.weight"] = K.conv3x3_wgrad(f0, df1, 256, 256, in_affine=aff_f0, in_relu=True)
+            grads["final.3.weight"] = K.conv3x3_wgrad(f0, df1, 256, 256, in_affine=aff_f0, in_relu=True, xt=s["final_xt"].pop(3, None))
         d_act0 = K.conv3x3(df1, self.final[3].weight, flip=True)
         df0, dg, db = K.bn_relu_backward(d_act0, f0, s["st_f0"], want_param_grads=need["final.1.weight"] or need["final.1.bias"])
         grads["final.1.weight"], grads["final.1.bias"] = dg, db
         if need["final.0.weight"]:
-            grads["final.0.weight"] = K.conv3x3_wgrad(dec0, df0, 256, 304)
+            grads["final.0.weight"] = K.conv3x3_wgrad(dec0, df0, 256, 304, xt=s["final_xt"].pop(0, None))
         if not any(need[n] for n in names if n.startswith(("aspp", "bot_"))):
             return [grads.get(n) if need[n] else None for n in names]
         ddec0 = K.conv3x3(df0, self.final[0].weight, flip=True)

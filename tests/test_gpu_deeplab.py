@@ -208,3 +208,39 @@ def test_graphed_eval_replays_the_same_forward(model):
             assert torch.equal(got_s, want_s) and torch.equal(got_l, want_l)
         with pytest.raises(ValueError):
             ge(torch.zeros(1, 3, 64, 64, device="cuda"))
+
+
+def test_decoder_weight_gradient_from_kept_winograd_input(deeplab_params, monkeypatch):
+    """With `final` trainable the two decoder convolutions keep their Winograd-domain input X' for the weight gradient
+    (MSS_KEEP_DEC_XT=0: transform again): same bits either way, and a non-trivial gradient."""
+    from multishiftseg_amd import synth
+    from multishiftseg_amd.deepv3 import DeepWV3Plus
+    from multishiftseg_amd.loss import RelContrastiveLoss
+    m = DeepWV3Plus(19)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in deeplab_params.items()}, strict=True)
+    m = m.cuda()
+    m.uncertainty_func_init()
+    for n, p in m.named_parameters():
+        p.requires_grad = n.startswith(("final", "ood_head"))
+    m.train()
+    img = torch.from_numpy(synth.synth_image(8, 2, 96, 160)).cuda()
+    tgt = torch.from_numpy(synth.synth_targets(5, 1, 96, 160)).cuda()
+    saved = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(4)
+    m.dropout_masks = {"mod6": torch.from_numpy(((rng.random((2, 1024)) >= 0.3) / 0.7).astype(np.float32)),
+                       "mod7": torch.from_numpy(((rng.random((2, 2048)) >= 0.5) / 0.5).astype(np.float32))}
+    grads = {}
+    for keep in ("1", "0"):
+        monkeypatch.setenv("MSS_KEEP_DEC_XT", keep)
+        m.load_state_dict(saved)
+        for p in m.parameters():
+            p.grad = None
+        crit = RelContrastiveLoss({"ce_weights": [50, 10], "conduct_pixel_selection": True, "selection_ratio": 0.8,
+                                   "inoutaug_contras_margins_tri": [10, 5, 5]}, pairing="device", seed=11)
+        s, l = m(img)
+        crit(l, s, tgt.clone()).mean().backward()
+        grads[keep] = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    assert set(grads["1"]) == set(grads["0"]) and "final.0.weight" in grads["1"] and "final.3.weight" in grads["1"]
+    diffs = {n: (grads["1"][n] - grads["0"][n]).abs().max().item() / (grads["0"][n].abs().max().item() + 1e-30) for n in grads["1"]}
+    assert all(v == 0.0 for v in diffs.values()), diffs
+    assert grads["1"]["final.0.weight"].abs().max().item() > 0

@@ -10,19 +10,30 @@ CASES = [(36, T, C, Ko) for (T, C, Ko) in [(65536, 128, 128), (16384, 256, 256),
                                             (4096, 512, 1024), (4096, 1024, 2048), (5184, 4096, 256)]]
 if len(sys.argv) > 1:
     CASES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+NBUF = int(os.environ.get("MSS_BENCH_NBUF", "1"))      # > 1: rotate over that many distinct X' / Y' buffers (cold caches / TLB, as in the step)
 for (P, T, C, Ko) in CASES:
-    xt = torch.randn(P, T, C, device="cuda")
     Kpad = _lib.value("mss_conv2d_kpad", Ko)
     w = torch.randn(P, Kpad, C, device="cuda")
-    yt = torch.empty(P, T, Ko, device="cuda")
-    a = MssConvArgs()
-    a.x, a.w, a.y = ptr(xt), ptr(w), ptr(yt)
-    a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
-    a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, Ko, Kpad, Ko
-    a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
-    a.batch, a.x_bs, a.w_bs, a.y_bs = P, T * C, Kpad * C, T * Ko
-    ms = timeit(lambda: call("mss_conv2d_forward_f32", ctypes.byref(a)), iters=10, warm=3)
+    sets = []
+    for _ in range(NBUF):
+        xt = torch.randn(P, T, C, device="cuda")
+        yt = torch.empty(P, T, Ko, device="cuda")
+        a = MssConvArgs()
+        a.x, a.w, a.y = ptr(xt), ptr(w), ptr(yt)
+        a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
+        a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, Ko, Kpad, Ko
+        a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+        a.batch, a.x_bs, a.w_bs, a.y_bs = P, T * C, Kpad * C, T * Ko
+        sets.append((a, xt, yt))
+    it = [0]
+
+    def run():
+        a = sets[it[0] % NBUF][0]
+        it[0] += 1
+        call("mss_conv2d_forward_f32", ctypes.byref(a))
+    ms = timeit(run, iters=10, warm=3)
     fl = 2.0 * P * T * C * Ko
     by = 4.0 * P * T * (C + Ko)
-    print(json.dumps(dict(P=P, T=T, C=C, K=Ko, ms=round(ms, 3), tflops=round(fl / ms / 1e9, 1), GBs=round(by / ms / 1e6, 1),
+    print(json.dumps(dict(P=P, T=T, C=C, K=Ko, nbuf=NBUF, ms=round(ms, 3), tflops=round(fl / ms / 1e9, 1), GBs=round(by / ms / 1e6, 1),
                           bk=os.environ.get("MSS_CONV_BK", "policy"))), flush=True)
+    del sets
