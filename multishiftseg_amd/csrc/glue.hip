@@ -381,13 +381,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// y[i] = mult * sum_sp ws[sp][i]: 16 outputs x 16 split lanes per workgroup -- lane l adds the splits l, l + 16, ... in
+// ascending order, the 16 lane sums are added in lane order (fixed tree: bit-reproducible). A Linear's bias gradient
+// (one image of 162 624 rows, 256 channels) has 512 splits of 256 outputs: one thread per output walked them in 129 us.
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, float* __restrict__ y,
                                                            long long NC, int splits, float mult) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= NC) return;
+  __shared__ float red[16][17];
+  const int o = threadIdx.x & 15, l = threadIdx.x >> 4;
+  const long long i = (long long)blockIdx.x * 16 + o;
   float s = 0.f;
-  for (int sp = 0; sp < splits; ++sp) s += ws[(long long)sp * NC + i];
-  y[i] = s * mult;
+  if (i < NC)
+    for (int sp = l; sp < splits; sp += 16) s += ws[(long long)sp * NC + i];
+  red[l][o] = s;
+  __syncthreads();
+  if (l == 0 && i < NC) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][o];
+    y[i] = t * mult;
+  }
 }
 
 struct ColsumPlan { int gx, splits, rps; };
@@ -408,7 +420,7 @@ inline int launch_colsum(const float* x, int ldx, float* y, int N, int HW, int C
   const ColsumPlan pl = colsum_plan(N, HW, C);
   hipLaunchKernelGGL(colsum_kernel, dim3(pl.gx, N, pl.splits), dim3(256), 0, st, x, ldx, ws, HW, C, pl.rps);
   const long long NC = (long long)N * C;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, ws, y, NC, pl.splits,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((NC + 15) / 16)), dim3(256), 0, st, ws, y, NC, pl.splits,
                      mult);
   return mss_launch_status();
 }
