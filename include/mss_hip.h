@@ -108,6 +108,8 @@ typedef struct MssConvArgs {
   float* stats;            /* optional: per-channel partial sums of the OUTPUT for the next layer's train-mode    */
                            /*   BatchNorm, [ceil(M/64)][2][K] floats (row group g: sum, sum of squares of rows      */
                            /*   64g..64g+63); reduce with mss_bn_stats_partials_f32. Not with batch > 1.            */
+  int res_mask;            /* 1: `res` gates instead of adds -- y = res[m*ldres + k] > 0 ? y : 0 -- the ReLU backward of a  */
+                           /*   producer whose stored OUTPUT is `res` (FFN of msdeformattn.py:122-131) fused in the dgrad   */
 } MssConvArgs;
 
 int mss_conv2d_forward_f32(MssConvArgs* args, void* stream);

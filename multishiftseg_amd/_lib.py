@@ -35,6 +35,7 @@ class MssConvArgs(Structure):
         ("M", c_int), ("mtiles", c_int), ("ntiles", c_int),
         ("batch", c_int), ("x_bs", c_longlong), ("w_bs", c_longlong), ("y_bs", c_longlong),
         ("stats", c_void_p),
+        ("res_mask", c_int),
     ]
 
 

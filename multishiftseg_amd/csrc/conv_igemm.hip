@@ -1061,6 +1061,7 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
   if (p.in_scale && ((reinterpret_cast<uintptr_t>(p.in_scale) | reinterpret_cast<uintptr_t>(p.in_shift)) & 15))
     return MSS_ERR_BAD_ARG;
   if (p.batch > 1 && (p.res || p.stats || p.x_bs % 4 || p.w_bs % 4 || p.batch > 65535)) return MSS_ERR_BAD_ARG;
+  if (p.res_mask && !p.res) return MSS_ERR_BAD_ARG;
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return MSS_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -56,7 +56,8 @@ __device__ __forceinline__ void mss_epilogue_store(const f32x16 (&acc)[TM][TN], 
             float* yp = y + (size_t)row0 * ldy + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float val = fmaxf(acc[i][j][r] * osc + osh + rv[r], floor_v);
+              const float lin = acc[i][j][r] * osc + osh;
+              const float val = fmaxf(p.res_mask ? (rv[r] > 0.f ? lin : 0.f) : lin + rv[r], floor_v);
               yp[(size_t)((r & 3) + 8 * (r >> 2)) * ldy] = val;
               ssum += val; ssq += val * val;
             }
@@ -64,7 +65,8 @@ __device__ __forceinline__ void mss_epilogue_store(const f32x16 (&acc)[TM][TN], 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int row = row0 + (r & 3) + 8 * (r >> 2);
-              const float val = fmaxf(acc[i][j][r] * osc + osh + rv[r], floor_v);
+              const float lin = acc[i][j][r] * osc + osh;
+              const float val = fmaxf(p.res_mask ? (rv[r] > 0.f ? lin : 0.f) : lin + rv[r], floor_v);
               if (row < p.M) { y[(size_t)row * ldy + col] = val; ssum += val; ssq += val * val; }
             }
           }

@@ -184,7 +184,7 @@ def conv_out_size(h, r, stride, dil, pad):
     return (h + 2 * pad - dil * (r - 1) - 1) // stride + 1
 
 
-def _conv_args(x, pw, y, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res):
+def _conv_args(x, pw, y, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res, res_mask=False):
     a = MssConvArgs()
     a.x, a.w, a.y = x.ptr, ptr(pw.t), (y.ptr if y is not None else None)
     if in_affine is not None:
@@ -196,6 +196,7 @@ def _conv_args(x, pw, y, stride, dil, pad, in_affine, in_relu, out_affine, out_r
         a.out_scale, a.out_shift = ptr(out_affine[0]), ptr(out_affine[1])
     if res is not None:
         a.res, a.ldres = res.ptr, res.ld
+        a.res_mask = int(res_mask)
     a.N, a.H, a.W, a.C, a.ldx = x.N, x.H, x.W, pw.Cp, x.ld
     a.R, a.S, a.stride, a.dil, a.pad = pw.R, pw.S, stride, dil, pad
     a.K, a.Kpad = pw.K, pw.Kpad
@@ -204,9 +205,10 @@ def _conv_args(x, pw, y, stride, dil, pad, in_affine, in_relu, out_affine, out_r
 
 
 def conv2d(x, pw, stride=1, dil=1, pad=0, in_affine=None, in_relu=False, out_affine=None, out_relu=False, res=None,
-           out=None, want_stats=False):
+           out=None, want_stats=False, res_mask=False):
     """y = epilogue(conv(prologue(x))). x: Act with C == pw.Cp channels visible. want_stats: the epilogue also leaves
-    the per-channel partial sums of y on the returned Act (for the next layer's train-mode BatchNorm)."""
+    the per-channel partial sums of y on the returned Act (for the next layer's train-mode BatchNorm). res_mask: `res`
+    gates the output (y = res > 0 ? y : 0, a ReLU backward) instead of being added."""
     assert x.C == pw.Cp or (x.C >= pw.C and x.C <= pw.Cp and x.c0 + pw.Cp <= x.ld), (x.C, pw.C, pw.Cp)
     OH = conv_out_size(x.H, pw.R, stride, dil, pad)
     OW = conv_out_size(x.W, pw.S, stride, dil, pad)
@@ -219,18 +221,18 @@ def conv2d(x, pw, stride=1, dil=1, pad=0, in_affine=None, in_relu=False, out_aff
             return None if t is None else t[lo:lo + n]
         conv2d(x, pw.tail, stride, dil, pad, in_affine, in_relu,
                None if out_affine is None else (sub(out_affine[0], pw.K, pw.tail.K), sub(out_affine[1], pw.K, pw.tail.K)),
-               out_relu, None if res is None else res.slice(pw.K, pw.tail.K), out=out.slice(pw.K, pw.tail.K))
+               out_relu, None if res is None else res.slice(pw.K, pw.tail.K), out=out.slice(pw.K, pw.tail.K), res_mask=res_mask)
         out_affine = None if out_affine is None else (sub(out_affine[0], 0, pw.K), sub(out_affine[1], 0, pw.K))
         res = None if res is None else res.slice(0, pw.K)
         out_main = out.slice(0, pw.K)
-        _conv_launch(x, pw, out_main, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res)
+        _conv_launch(x, pw, out_main, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res, res_mask=res_mask)
         return out
-    _conv_launch(x, pw, out, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res, want_stats)
+    _conv_launch(x, pw, out, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res, want_stats, res_mask)
     return out
 
 
-def _conv_launch(x, pw, out, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res, want_stats=False):
-    a = _conv_args(x, pw, out, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res)
+def _conv_launch(x, pw, out, OH, OW, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res, want_stats=False, res_mask=False):
+    a = _conv_args(x, pw, out, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res, res_mask)
     a.OH, a.OW, a.ldy = OH, OW, out.ld
     out.stats = None
     if want_stats and out.C == pw.K:

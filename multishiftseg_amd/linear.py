@@ -57,6 +57,59 @@ class _LinearFn(Function):
         return gx, gw, gb, None
 
 
+class _FfnFn(Function):
+    """y = relu(x W1^T + b1) W2^T + b2 (msdeformattn.py:122-124 with Dropout p = 0) as ONE autograd node: the hidden
+    activation is stored once, and its ReLU backward rides in the epilogue of linear2's data-gradient GEMM
+    (MssConvArgs.res_mask: dh = h > 0 ? gy W2 : 0) instead of a compare + a multiply pass over the [rows, d_ffn] tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        f, c = w1.shape
+        x2 = x.contiguous()
+        h = torch.empty(x.shape[:-1] + (f,), device=x.device, dtype=torch.float32)
+        K.conv2d(_rows(x2, c), _packed(w1, False), out_affine=(torch.ones_like(b1), b1.detach()), out_relu=True, out=_rows(h, f))
+        y = torch.empty(x.shape[:-1] + (w2.shape[0],), device=x.device, dtype=torch.float32)
+        K.conv2d(_rows(h, f), _packed(w2, False), out_affine=(torch.ones_like(b2), b2.detach()), out=_rows(y, w2.shape[0]))
+        ctx.save_for_backward(x2, w1, w2, h)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w1, w2, h = ctx.saved_tensors
+        f, c = w1.shape
+        k = w2.shape[0]
+        gy = gy.contiguous()
+        gy_rows, h_rows = _rows(gy, k), _rows(h, f)
+        need = ctx.needs_input_grad
+        gw2 = K.conv2d_wgrad(h_rows, gy_rows, k, f, 1, 1).view(k, f) if need[3] else None
+        gb2 = K.colsum(gy_rows).view(k) if need[4] else None
+        gx = gw1 = gb1 = None
+        if need[0] or need[1] or need[2]:
+            dh = torch.empty_like(h)
+            K.conv2d(gy_rows, _packed(w2, True), out=_rows(dh, f), res=h_rows, res_mask=True)
+            dh_rows = _rows(dh, f)
+            if need[1]:
+                gw1 = K.conv2d_wgrad(_rows(x, c), dh_rows, f, c, 1, 1).view(f, c)
+            if need[2]:
+                gb1 = K.colsum(dh_rows).view(f)
+            if need[0]:
+                gx = torch.empty_like(x)
+                K.conv2d(dh_rows, _packed(w1, True), out=_rows(gx, c))
+        return gx, gw1, gb1, gw2, gb2
+
+
+def ffn_relu(x, lin1, lin2):
+    """lin2(relu(lin1(x))) for two nn.Linear with biases, on the MFMA kernels as one autograd node when the shapes are
+    eligible (else the two `linear` calls)."""
+    (f, c), (k, f2) = lin1.weight.shape, lin2.weight.shape
+    ok = x.is_cuda and x.dtype == torch.float32 and lin1.bias is not None and lin2.bias is not None and f == f2 and \
+        all(v % 16 == 0 for v in (c, f, k)) and f > 64 and k > 64 and c >= 32 and x.numel() // c >= MIN_ROWS
+    if not ok:
+        return linear(linear(x, lin1.weight, lin1.bias, relu=True), lin2.weight, lin2.bias)
+    return _FfnFn.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+
+
 # Rows below which a call goes to the library GEMM instead. Round 1 used 65536 (N = 1 calls are launch-bound and torch's
 # host path is shorter); the default is now 0: every eligible Linear of the MSDeformAttn module / encoder runs on the
 # repository's own MFMA kernels, N = 1 included (MSS_LINEAR_MIN_ROWS restores a gate for A/B measurements).

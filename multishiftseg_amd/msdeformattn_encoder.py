@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import kernels as K
-from .linear import linear
+from .linear import ffn_relu, linear
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -74,11 +74,15 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         # residual add + LayerNorm in one HIP pass (csrc/norm.hip); Dropout is the identity at the reference's p = 0.0
         src = K.add_layernorm(src, self.dropout1(
             self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)), self.norm1)
-        if self.activation is F.relu:            # ReLU rides in the GEMM epilogue
-            hidden = linear(src, self.linear1.weight, self.linear1.bias, relu=True)
+        if self.activation is F.relu and (self.dropout2.p == 0.0 or not self.training):
+            # ReLU rides in the GEMM epilogue, its backward in the epilogue of linear2's data gradient (linear.py)
+            ffn = ffn_relu(src, self.linear1, self.linear2)
         else:
-            hidden = self.activation(linear(src, self.linear1.weight, self.linear1.bias))
-        ffn = linear(self.dropout2(hidden), self.linear2.weight, self.linear2.bias)
+            if self.activation is F.relu:
+                hidden = linear(src, self.linear1.weight, self.linear1.bias, relu=True)
+            else:
+                hidden = self.activation(linear(src, self.linear1.weight, self.linear1.bias))
+            ffn = linear(self.dropout2(hidden), self.linear2.weight, self.linear2.bias)
         return K.add_layernorm(src, self.dropout3(ffn), self.norm2)
 
 
