@@ -23,9 +23,11 @@ class GradAllReduce:
     averaged values are copied back into the gradient tensors autograd is about to hand out.
     """
 
-    def __init__(self, named_params, bucket_bytes=64 << 20, group=None):
+    def __init__(self, named_params, bucket_bytes=64 << 20, group=None, force=False):
+        """force: run the collectives even in a one-rank group (exercises the RCCL path on a single GPU; tests)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.buckets = []       # list of lists of names (fixed at construction: every rank reduces the same layout)
         self.where = {}         # name -> bucket index
         self.shapes = {}        # name -> (shape, dtype, device) for zero-filling a gradient that did not arrive
@@ -51,7 +53,7 @@ class GradAllReduce:
         self.inflight = []      # (flat, [(name, tensor)], work)
 
     def __call__(self, name, grad):
-        if self.world == 1 or name not in self.where:
+        if not self.active or name not in self.where:
             return
         i = self.where[name]
         self.pending[i][name] = grad
@@ -94,7 +96,7 @@ class GradAllReduce:
                 self._launch(i)
 
     def backward_done(self):
-        if self.world == 1:
+        if not self.active:
             return
         self.flush()
         for flat, items, work in self.inflight:

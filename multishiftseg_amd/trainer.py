@@ -10,6 +10,8 @@ Mirrors what matters on the hot path of train_deeplab.py:113-216 and test_deepla
   * per-rank data parallelism instead of nn.DataParallel (multishiftseg_amd/ddp.py).
 Datasets, logging, checkpoint policy and metrics are the reference's harness and stay out of scope.
 """
+import os
+
 import torch
 
 from . import ddp
@@ -60,7 +62,9 @@ class TrainStep:
         named = dict(zip(names, params))
         order = [(n, named[n]) for n in BACKWARD_ORDER if n in named]
         assert len(order) == len(named), sorted(set(named) - set(n for n, _ in order))
-        self.sync = ddp.GradAllReduce(order, bucket_bytes) if torch.distributed.is_initialized() else None
+        # MSS_DDP_FORCE=1: run the collectives in a one-rank group too (the RCCL path on a single GPU; tests)
+        self.sync = ddp.GradAllReduce(order, bucket_bytes, force=os.environ.get("MSS_DDP_FORCE") == "1") \
+            if torch.distributed.is_initialized() else None
         self.model.grad_sink = self.sync
         self.model.train()
 

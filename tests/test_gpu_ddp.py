@@ -88,3 +88,72 @@ def test_two_rank_step_matches_manual_average(stage):
         mean = (local[0][n] + local[1][n]) / 2
         scale = mean.abs().max().item() + 1e-20
         assert (res[0]["grads"][n] - mean).abs().max().item() / scale < 1e-3, n
+
+
+def _rccl_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("MSS_DIST_BACKEND", None)
+    from multishiftseg_amd import ddp
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    assert dist.get_backend() == "nccl"
+    torch.manual_seed(0)
+    params = [(f"p{i}", torch.nn.Parameter(torch.randn(n, device="cuda"))) for i, n in enumerate((1000, 70000, 3, 250000))]
+    sink = ddp.GradAllReduce(params, bucket_bytes=300000, force=True)
+    assert len(sink.buckets) >= 2 and sink.active
+    grads = {n: torch.randn_like(p) for n, p in params}
+    want = {n: g.clone() for n, g in grads.items()}
+    for n, _ in reversed(params):
+        if n != "p2":                          # one gradient never arrives: travels as zeros, flush() sends its bucket
+            sink(n, grads[n])
+    sink.backward_done()
+    torch.cuda.synchronize()
+    ok = all(torch.equal(grads[n], want[n]) for n in grads)         # the mean over one rank is the gradient itself
+    t = torch.full((5,), 3.0, device="cuda")
+    dist.all_reduce(t)
+    out["ok"] = bool(ok) and bool((t == 3.0).all().item()) and sink.comm_stream is not None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_one_rank_runs_the_bucketed_allreduce():
+    """The `nccl` (= RCCL) branch of ddp.GradAllReduce -- side stream, record_stream, async work handles, flush of an
+    unfilled bucket -- on the one GPU this box has: a one-rank group, collectives forced on."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
+    assert dict(out).get("ok") is True
+
+
+def _rccl_step_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", MSS_DDP_FORCE="1")
+    os.environ.pop("MSS_DIST_BACKEND", None)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    res = {}
+    for forced in (True, False):
+        os.environ["MSS_DDP_FORCE"] = "1" if forced else "0"
+        model, step = _build(2)
+        assert (step.sync is not None and step.sync.active) == forced
+        img, tgt, masks = _data(0)
+        model.dropout_masks = masks
+        torch.manual_seed(7)
+        loss = step(img, tgt.clone())
+        res[forced] = (float(loss.detach()), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad})
+    out["ok"] = res[True][0] == res[False][0] and all(torch.equal(res[True][1][n], res[False][1][n]) for n in res[True][1])
+    out["n"] = len(res[True][1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_one_rank_train_step():
+    """A whole stage-2 TrainStep with the gradient all-reduce running over RCCL (one-rank group, forced): bucket launches
+    from inside the backward on the side stream, backward_done, Adam -- identical loss and gradients to the un-synchronised
+    step."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_step_worker, args=(_free_port(), out), nprocs=1, join=True)
+    o = dict(out)
+    assert o.get("ok") is True and o.get("n") == 18
