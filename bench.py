@@ -87,7 +87,8 @@ def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes through torch.distributed.run as a
     CHILD process (never exec: this image forbids replacing a process image once a GPU runtime is loaded, and the
     parent must not touch the GPU at all -- it has not: nothing before this point makes a HIP call), relay what
-    the ranks print (rank 0 prints the one JSON line) and exit with the launcher's status."""
+    rank 0's ONE JSON line on stdout (anything else the ranks or their libraries write to stdout -- e.g. gloo's connection
+    banner -- goes to stderr, so that stdout stays one line) and exit with the launcher's status."""
     import socket
     import subprocess
     with socket.socket() as sk:
@@ -98,7 +99,14 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this host driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
-    return subprocess.call(cmd, env=env)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
 
 
 def launch_check(args):
