@@ -734,10 +734,12 @@ __global__ __launch_bounds__(NT, BC == 256 ? 2 : 3) void gemm_tn2_wgrad_kernel(
   const int cq0 = WIDE ? (tid & 63) : (tid & 31), tg0 = WIDE ? (tid >> 6) : ((tid & 127) >> 5);
   const int cols0 = u0B ? C : K;
   const float* const base0 = u0B ? B : A;
-  float* const ldst0 = (u0B ? Bs : As) + (4 * cq0) * TN2_LDK + ((tg0 + cq0) & 3) * 4;
+  // chunk rotation (r >> 2) + (r >> 4) of row r = 4 cq + e: the 16 lanes of a ds_write_b128 group then cover all 64 banks
+  // (with (r >> 2) alone, rows 16 apart met in the same banks: PMC showed 2/3 of the LDS cycles as bank conflicts)
+  float* const ldst0 = (u0B ? Bs : As) + (4 * cq0) * TN2_LDK + ((tg0 + cq0 + (cq0 >> 2)) & 3) * 4;
   const bool has1 = WIDE && tid < 128;                  // wave-uniform
   const int cq1 = tid & 31, tg1 = (tid >> 5) & 3;
-  float* const ldst1 = As + (4 * cq1) * TN2_LDK + ((tg1 + cq1) & 3) * 4;
+  float* const ldst1 = As + (4 * cq1) * TN2_LDK + ((tg1 + cq1 + (cq1 >> 2)) & 3) * 4;
 
   long long ld_w = mss_xcd_remap(blockIdx.x, gridDim.x);
   const float* ptr0 = base0;
@@ -807,16 +809,18 @@ __global__ __launch_bounds__(NT, BC == 256 ? 2 : 3) void gemm_tn2_wgrad_kernel(
     }
   };
   const int frag_row = lane & 31, frag_h = lane >> 5;
-  const int rot = frag_row >> 2;
+  const int rot = (frag_row >> 2) + (frag_row >> 4);      // + 2 per 32-row block (the block base's (r >> 4) mod 4)
   const float* Abase = &As[(wm * 64 + frag_row) * TN2_LDK];
   const float* Bbase = &Bs[(wn * (BC / 2) + frag_row) * TN2_LDK];
-  const int koff[2] = {((frag_h + rot) & 3) * 4, ((2 + frag_h + rot) & 3) * 4};
+  // logical chunk kc * 2 + frag_h of a row in an even / odd 32-row block
+  const int koff[2][2] = {{((frag_h + rot) & 3) * 4, ((frag_h + rot + 2) & 3) * 4},
+                          {((2 + frag_h + rot) & 3) * 4, ((2 + frag_h + rot + 2) & 3) * 4}};
   f32x4 fa[2][2], fb[2][TNJ];
   auto load_frags = [&](int set, int buf, int kc) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(Abase + (buf * 128 + i * 32) * TN2_LDK + koff[kc]);
+    for (int i = 0; i < 2; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(Abase + (buf * 128 + i * 32) * TN2_LDK + koff[kc][i & 1]);
 #pragma unroll
-    for (int j = 0; j < TNJ; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(Bbase + (buf * BC + j * 32) * TN2_LDK + koff[kc]);
+    for (int j = 0; j < TNJ; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(Bbase + (buf * BC + j * 32) * TN2_LDK + koff[kc][j & 1]);
   };
   f32x16 acc[2][TNJ];
   auto zero_acc = [&]() {
