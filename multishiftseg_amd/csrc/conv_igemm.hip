@@ -741,6 +741,7 @@ __global__ __launch_bounds__(NT, BC == 256 ? 2 : 3) void gemm_tn2_wgrad_kernel(
   const int cq1 = tid & 31, tg1 = (tid >> 5) & 3;
   float* const ldst1 = As + (4 * cq1) * TN2_LDK + ((tg1 + cq1 + (cq1 >> 2)) & 3) * 4;
 
+  const bool edge_free = K % 128 == 0 && C % BC == 0;   // no channel tile hangs over the edge: no per-lane column mask
   long long ld_w = mss_xcd_remap(blockIdx.x, gridDim.x);
   const float* ptr0 = base0;
   const float* ptr1 = A;
@@ -765,6 +766,15 @@ __global__ __launch_bounds__(NT, BC == 256 ? 2 : 3) void gemm_tn2_wgrad_kernel(
   f32x4 reg0[4], reg1[WIDE ? 4 : 1];
   auto issue_loads = [&]() {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (edge_free && ld_t + 16 <= ld_tend) {        // workgroup-uniform: whole 16-row step inside, no ragged channel tile
+#pragma unroll
+      for (int e = 0; e < 4; ++e) reg0[e] = *reinterpret_cast<const f32x4*>(ptr0 + (size_t)(4 * tg0 + e) * cols0);
+      if (WIDE && has1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) reg1[WIDE ? e : 0] = *reinterpret_cast<const f32x4*>(ptr1 + (size_t)(4 * tg1 + e) * K);
+      }
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int r = 4 * tg0 + e;
