@@ -978,15 +978,19 @@ int launch_wgrad(MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, 
 
 // ---- the TN route of the batched (Winograd-domain) weight gradient ----
 struct TnPlan { int ktiles, ctiles, splits, tps; long long total; };
+inline int tn_batch(const MssConvArgs& p) { return p.batch > 1 ? p.batch : 1; }
 inline bool tn_eligible(const MssConvArgs& p, int lddy) {
   const bool off = getenv("MSS_WGRAD_TN") && atoi(getenv("MSS_WGRAD_TN")) == 0;     // A/B switch
-  return !off && p.batch > 1 && p.R * p.S == 1 && !p.in_scale && !p.in_relu && p.K % 4 == 0 && p.C % 4 == 0 && p.ldx == p.C &&
-         lddy == p.K && p.x_bs % 4 == 0 && p.y_bs % 4 == 0 && p.N == 1 && p.H == 1;
+  if (off || p.R * p.S != 1 || p.in_scale || p.in_relu || p.K % 4 || p.C % 4 || p.ldx != p.C || lddy != p.K) return false;
+  if (p.batch > 1) return p.x_bs % 4 == 0 && p.y_bs % 4 == 0 && p.N == 1 && p.H == 1;   // Winograd-domain products
+  // a plain 1x1 / stride-1 layer over dense rows (ASPP 4096 -> 256: 95 -> see DESIGN 3.3): the same GEMM with one position;
+  // narrow outputs (<= 64 channels: bot_fine, the heads) keep conv_wgrad_kernel's 64- / 32-row tiles
+  return p.stride == 1 && p.pad == 0 && p.K >= 128 && p.C >= 128 && p.OH == p.H && p.OW == p.W;
 }
 inline TnPlan tn_plan(const MssConvArgs& p, int bc = TN_BC, int slots = 768) {
   TnPlan pl;
   pl.ktiles = mss_cdiv(p.K, TN_BK); pl.ctiles = mss_cdiv(p.C, bc);
-  const long long base = (long long)p.batch * pl.ktiles * pl.ctiles;
+  const long long base = (long long)tn_batch(p) * pl.ktiles * pl.ctiles;
   int max_splits = mss_cdiv(p.M, TN_BT * 8);
   if (max_splits > 64) max_splits = 64;
   if (max_splits < 1) max_splits = 1;
@@ -1022,7 +1026,9 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
                     hipStream_t stream) {
   const bool wide = tn_wide(p);
   const TnPlan pl = tn_plan_for(p);
-  const long long slab = (long long)p.batch * p.Kpad * Cp;
+  const int P = tn_batch(p);
+  const long long a_bs = p.batch > 1 ? p.y_bs : 0, b_bs = p.batch > 1 ? p.x_bs : 0;
+  const long long slab = (long long)P * p.Kpad * Cp;
   if (pl.splits > 1 && (!ws || ws_bytes < (long long)pl.splits * slab * 4)) return MSS_ERR_BAD_ARG;
   const size_t smem = (size_t)4 * TN_BT * TN_LD * sizeof(float);
   static int per_cu = 0, cus = 256;
@@ -1039,20 +1045,20 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
   const int mode = tn_mode();
   if (wide) {
     const size_t smem2 = (size_t)2 * (128 + 256) * TN2_LDK * sizeof(float);
-    hipLaunchKernelGGL(gemm_tn2_wgrad_kernel<256>, dim3(grid), dim3(NT), smem2, stream, dy, p.x, out, p.batch, p.M, p.K, p.C, p.y_bs,
-                       p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+    hipLaunchKernelGGL(gemm_tn2_wgrad_kernel<256>, dim3(grid), dim3(NT), smem2, stream, dy, p.x, out, P, p.M, p.K, p.C, a_bs,
+                       b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
   } else if (mode >= 2) {
     const size_t smem2 = (size_t)4 * 128 * TN2_LDK * sizeof(float);
-    hipLaunchKernelGGL(gemm_tn2_wgrad_kernel<128>, dim3(grid), dim3(NT), smem2, stream, dy, p.x, out, p.batch, p.M, p.K, p.C, p.y_bs,
-                       p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+    hipLaunchKernelGGL(gemm_tn2_wgrad_kernel<128>, dim3(grid), dim3(NT), smem2, stream, dy, p.x, out, P, p.M, p.K, p.C, a_bs,
+                       b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
   } else {
     const char* e2 = getenv("MSS_WGRAD_TN_AHEAD");
     if (e2 && atoi(e2) == 2)
-      hipLaunchKernelGGL(gemm_tn_wgrad_kernel<true>, dim3(grid), dim3(NT), smem, stream, dy, p.x, out, p.batch, p.M, p.K, p.C, p.y_bs,
-                         p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+      hipLaunchKernelGGL(gemm_tn_wgrad_kernel<true>, dim3(grid), dim3(NT), smem, stream, dy, p.x, out, P, p.M, p.K, p.C, a_bs,
+                         b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
     else
-      hipLaunchKernelGGL(gemm_tn_wgrad_kernel<false>, dim3(grid), dim3(NT), smem, stream, dy, p.x, out, p.batch, p.M, p.K, p.C, p.y_bs,
-                         p.x_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+      hipLaunchKernelGGL(gemm_tn_wgrad_kernel<false>, dim3(grid), dim3(NT), smem, stream, dy, p.x, out, P, p.M, p.K, p.C, a_bs,
+                         b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
   }
   if (pl.splits > 1) {
     const long long slab4 = slab / 4;
@@ -1135,13 +1141,18 @@ long long mss_conv2d_wgrad_workspace_bytes(const MssConvArgs* args, int Cp) {
   MssConvArgs p = *args;
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return 0;
-  if (tn_eligible(p, p.K)) {                 // the caller passes lddy == K on this route (checked again at launch)
+  long long tn_bytes = 0;
+  if (tn_eligible(p, p.K)) {                 // lddy == K is assumed here and checked again at launch
     const TnPlan pl = tn_plan_for(p);
-    return pl.splits > 1 ? (long long)pl.splits * p.batch * p.Kpad * Cp * 4 : 0;
+    tn_bytes = pl.splits > 1 ? (long long)pl.splits * tn_batch(p) * p.Kpad * Cp * 4 : 0;
+    if (p.batch > 1) return tn_bytes;        // Winograd-domain products always have lddy == K
   }
-  if (p.K <= 32) return wgrad_ws_bytes<32, 128, 16>(p, Cp);
-  if (p.K <= 64) return wgrad_ws_bytes<64, 128, 16>(p, Cp);
-  return wgrad_ws_bytes<128, 128, 16>(p, Cp);
+  // a plain 1x1 layer whose dy is a channel slice of a wider buffer falls back to conv_wgrad_kernel at launch: enough for both
+  long long cw;
+  if (p.K <= 32) cw = wgrad_ws_bytes<32, 128, 16>(p, Cp);
+  else if (p.K <= 64) cw = wgrad_ws_bytes<64, 128, 16>(p, Cp);
+  else cw = wgrad_ws_bytes<128, 128, 16>(p, Cp);
+  return cw > tn_bytes ? cw : tn_bytes;
 }
 
 // dwp ([R*S][Kpad][Cp], Kpad >= K, Cp >= C multiples of 4) is fully overwritten (padding = 0); args
