@@ -288,14 +288,15 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
     if (ew < 0.8 && en > ew + 0.15) wide = false;
   }
   if (wide) {
-    // Hybrid last round (MSS_GEMM_TAIL=0 turns it off): when the wide tiles leave a partial last round that is at most 3/4
+    // Hybrid last round, OPT-IN (MSS_GEMM_TAIL=1): when the wide tiles leave a partial last round that is at most 3/4
     // full, the whole rounds run on wide tiles and the remainder as twice as many narrow tiles in a second launch --
     // narrow tile 2w + {0, 1} is wide tile w's left / right half in the same n-fastest order -- e.g. 64 x 15 x 2 = 1920
     // wide tiles (mod4 through F(6x6)): 3 wide rounds + exactly one round of 768 narrow tiles instead of 3.75 -> 4.
     // Bit-identical results. Measured: isolated 0.582 -> 0.558 ms (64 x 1892 x 512 -> 512) and 1.172 -> 1.129 ms (64 x 2112 x
     // 512 -> 1024); in the step 67.3 -> 67.1 ms of gemm_nt (the narrow round is slower per FLOP and costs a second launch).
+    // Off by default: 0.2 ms per step does not pay for one GEMM call becoming two kernel launches in every profile.
     const char* te = getenv("MSS_GEMM_TAIL");
-    const bool tail_off = te && atoi(te) == 0;
+    const bool tail_off = !(te && atoi(te) == 1);
     const long long full = (tiles256 / 512) * 512, rem = tiles256 - full;
     const int nw = p.K / 256;
     if (!tail_off && bn == 0 && full > 0 && rem > 0 && rem <= 384) {
