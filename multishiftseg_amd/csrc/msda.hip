@@ -38,7 +38,7 @@ __device__ __forceinline__ T pair_reduce(T v);     // sum over the LPP lanes of 
 // location arithmetic loc = ref + offset / (W_l, H_l) happen here, on the values the wave has staged in LDS anyway, so
 // the [N,Lq,M,L,P,2] / [N,Lq,M,L,P] tensors (11.7 MB per call at C4, read AND written by a separate kernel) never
 // exist. Same arithmetic as msda_prepare_kernel except the order in which the L*P exponentials are added.
-template <int LPH, bool FUSED>
+template <int LPH, bool FUSED, bool BUF>
 __global__ __launch_bounds__(256) void msda_fwd_fast_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
     const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ ref, long long npairs, int S,
@@ -114,6 +114,45 @@ __global__ __launch_bounds__(256) void msda_fwd_fast_kernel(
   if (!mine) return;
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (BUF) {
+    // PMC showed this kernel issuing 22 VALU instructions per gather (69 % VALU-issue utilisation next to the L2 gather
+    // ceiling; the fused form 89 %): 64-bit address arithmetic per corner and sixteen selects per sample that zero the
+    // out-of-image corners. Here the whole value tensor is ONE buffer resource (host-checked: < 4 GB): a corner is a 32-bit
+    // byte offset, and an out-of-image corner gets an out-of-range offset, for which the hardware returns zeros without a
+    // memory access -- the reference's zero padding, exact even next to non-finite values.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(value), 0, (int)(unsigned)min((unsigned long long)npairs / M / Lq * S * row_stride * 4ull, 0xffffffffull),
+        0x00020000);
+    const unsigned rs4 = (unsigned)(row_stride * sizeof(float));
+    const unsigned lane_off = (unsigned)(((size_t)n * S * row_stride + (size_t)m * D + 4 * j) * sizeof(float));
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const unsigned lvl_off = lane_off + (unsigned)starts[l] * rs4;
+#pragma unroll 4
+      for (int pt = 0; pt < P; ++pt) {
+        const float lx = myloc[(l * P + pt) * 2], ly = myloc[(l * P + pt) * 2 + 1];
+        const float aw = myattn[l * P + pt];
+        const float w_im = lx * W - 0.5f, h_im = ly * H - 0.5f;
+        const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h0 = (int)hf, w0 = (int)wf;
+        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+        const bool okh0 = inside && h0 >= 0, okh1 = inside && h0 + 1 <= H - 1;
+        const bool okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
+        const unsigned o00 = lvl_off + (unsigned)(h0 * W + w0) * rs4;          // garbage when out of image: replaced below
+        const unsigned oob = 0xffffffffu;
+        const f32x4 v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (okh0 && okw0) ? o00 : oob, 0, 0));
+        const f32x4 v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (okh0 && okw1) ? o00 + rs4 : oob, 0, 0));
+        const f32x4 v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (okh1 && okw0) ? o00 + W * rs4 : oob, 0, 0));
+        const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (okh1 && okw1) ? o00 + W * rs4 + rs4 : oob, 0, 0));
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+        acc += aw * val;
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + pair * D + 4 * j) = acc;
+    return;
+  }
   for (int l = 0; l < L; ++l) {
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
     const float* vl = vbase + (size_t)starts[l] * row_stride;
@@ -848,12 +887,15 @@ int msda_forward_fast(const float* value, const int64_t* shapes, const int64_t* 
   const long long npairs = (long long)N * Lq * M;
   const long long nblocks = (npairs + 4 * HPW - 1) / (4 * HPW);
   const size_t smem = (size_t)4 * HPW * L * P * 3 * sizeof(float);
-  if (ref)
-    hipLaunchKernelGGL((msda_fwd_fast_kernel<LPH, true>), dim3((unsigned)nblocks), dim3(256), smem, stream, value, shapes,
-                       starts, loc, attn, ref, npairs, S, M, L, Lq, P, out);
-  else
-    hipLaunchKernelGGL((msda_fwd_fast_kernel<LPH, false>), dim3((unsigned)nblocks), dim3(256), smem, stream, value, shapes,
-                       starts, loc, attn, ref, npairs, S, M, L, Lq, P, out);
+  // buffer-resource addressing (32-bit offsets, hardware zero fill) when the value tensor is below 4 GB; MSS_MSDA_BUF=0: A/B
+  const char* e = getenv("MSS_MSDA_BUF");
+  const bool buf = (unsigned long long)N * S * M * (4 * LPH) * 4ull < 0xffffffffull && !(e && atoi(e) == 0);
+#define MSDA_LAUNCH(FUSED_, BUF_)                                                                                              \
+  hipLaunchKernelGGL((msda_fwd_fast_kernel<LPH, FUSED_, BUF_>), dim3((unsigned)nblocks), dim3(256), smem, stream, value, shapes, \
+                     starts, loc, attn, ref, npairs, S, M, L, Lq, P, out)
+  if (ref) { if (buf) MSDA_LAUNCH(true, true); else MSDA_LAUNCH(true, false); }
+  else { if (buf) MSDA_LAUNCH(false, true); else MSDA_LAUNCH(false, false); }
+#undef MSDA_LAUNCH
   return mss_launch_status();
 }
 
