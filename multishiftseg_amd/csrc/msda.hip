@@ -542,6 +542,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
 // float4 gathers and the per-sample work is 4 dot products over 32 channels (4 FMAs + a 3-step DPP sum in each 8-lane
 // group): everything the two gradients need is linear in p_c = <value_corner_c, grad_out>. Results overwrite the
 // staged loc/attn in LDS and leave with coalesced stores.
+template <bool BUF>
 __global__ __launch_bounds__(256) void msda_bwd_gather_fast_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
     const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ gout, long long npairs, int S,
@@ -576,6 +577,10 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_fast_kernel(
   const float* vbase = value + (size_t)n * S * row_stride + (size_t)m * D + 4 * j;
   const f32x4 go4 = *reinterpret_cast<const f32x4*>(gout + pair * D + 4 * j);
   auto dot8 = [&](f32x4 v) { return mss_sum8(v.x * go4.x + v.y * go4.y + v.z * go4.z + v.w * go4.w); };
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(value), 0, (int)(unsigned)min((unsigned long long)npairs / M / Lq * S * row_stride * 4ull, 0xffffffffull), 0x00020000);
+  const unsigned rs4 = (unsigned)(row_stride * sizeof(float));
+  const unsigned lane_off = (unsigned)(((size_t)n * S * row_stride + (size_t)m * D + 4 * j) * sizeof(float));
   for (int l = 0; l < L; ++l) {
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
     const float* vl = vbase + (size_t)starts[l] * row_stride;
@@ -590,17 +595,26 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_fast_kernel(
       const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
       const bool okh0 = inside && h0 >= 0, okh1 = inside && h0 + 1 <= H - 1;
       const bool okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
-      const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h0 + 1, 0), H - 1);
-      const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w0 + 1, 0), W - 1);
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      f32x4 v1 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h0c * W + w0c) * row_stride);
-      f32x4 v2 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h0c * W + w1c) * row_stride);
-      f32x4 v3 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h1c * W + w0c) * row_stride);
-      f32x4 v4 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h1c * W + w1c) * row_stride);
-      v1 = (okh0 && okw0) ? v1 : z;
-      v2 = (okh0 && okw1) ? v2 : z;
-      v3 = (okh1 && okw0) ? v3 : z;
-      v4 = (okh1 && okw1) ? v4 : z;
+      f32x4 v1, v2, v3, v4;
+      if (BUF) {          // one buffer resource for the value tensor: 32-bit corner offsets, zeros for out-of-image corners
+        const unsigned o00 = lane_off + (unsigned)starts[l] * rs4 + (unsigned)(h0 * W + w0) * rs4, oob = 0xffffffffu;
+        v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (okh0 && okw0) ? o00 : oob, 0, 0));
+        v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (okh0 && okw1) ? o00 + rs4 : oob, 0, 0));
+        v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (okh1 && okw0) ? o00 + W * rs4 : oob, 0, 0));
+        v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (okh1 && okw1) ? o00 + W * rs4 + rs4 : oob, 0, 0));
+      } else {
+        const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h0 + 1, 0), H - 1);
+        const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w0 + 1, 0), W - 1);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        v1 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h0c * W + w0c) * row_stride);
+        v2 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h0c * W + w1c) * row_stride);
+        v3 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h1c * W + w0c) * row_stride);
+        v4 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h1c * W + w1c) * row_stride);
+        v1 = (okh0 && okw0) ? v1 : z;
+        v2 = (okh0 && okw1) ? v2 : z;
+        v3 = (okh1 && okw0) ? v3 : z;
+        v4 = (okh1 && okw1) ? v4 : z;
+      }
       const float p1 = dot8(v1), p2 = dot8(v2), p3 = dot8(v3), p4 = dot8(v4);
       const float s_attn = hh * hw * p1 + hh * lw * p2 + lh * hw * p3 + lh * lw * p4;
       const float s_w = aw * (float)W * (-hh * p1 + hh * p2 - lh * p3 + lh * p4);
@@ -971,10 +985,18 @@ int msda_backward(const T* value, const int64_t* shapes, const int64_t* starts, 
     const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(gout)) & 15) == 0;
     if (aligned && smem <= 65536) {
       const long long nblocks = (npairs + 31) / 32;
-      hipLaunchKernelGGL(msda_bwd_gather_fast_kernel, dim3((unsigned)nblocks), dim3(256), smem, stream,
-                         reinterpret_cast<const float*>(value), shapes, starts, reinterpret_cast<const float*>(loc),
-                         reinterpret_cast<const float*>(attn), reinterpret_cast<const float*>(gout), npairs, S, M, L, Lq, P,
-                         reinterpret_cast<float*>(gloc), reinterpret_cast<float*>(gattn));
+      const char* eb = getenv("MSS_MSDA_BUF");
+      const bool buf = (unsigned long long)N * S * M * D * 4ull < 0xffffffffull && !(eb && atoi(eb) == 0);
+      if (buf)
+        hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<true>, dim3((unsigned)nblocks), dim3(256), smem, stream,
+                           reinterpret_cast<const float*>(value), shapes, starts, reinterpret_cast<const float*>(loc),
+                           reinterpret_cast<const float*>(attn), reinterpret_cast<const float*>(gout), npairs, S, M, L, Lq, P,
+                           reinterpret_cast<float*>(gloc), reinterpret_cast<float*>(gattn));
+      else
+        hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<false>, dim3((unsigned)nblocks), dim3(256), smem, stream,
+                           reinterpret_cast<const float*>(value), shapes, starts, reinterpret_cast<const float*>(loc),
+                           reinterpret_cast<const float*>(attn), reinterpret_cast<const float*>(gout), npairs, S, M, L, Lq, P,
+                           reinterpret_cast<float*>(gloc), reinterpret_cast<float*>(gattn));
     } else {
       const long long nblocks = (npairs + 7) / 8;
       hipLaunchKernelGGL((msda_bwd_kernel<T, 32, false>), dim3((unsigned)nblocks), dim3(256), 0, stream, value, shapes,
