@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MSS_ABI_VERSION 1
+#define MSS_ABI_VERSION 3      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32 */
 int mss_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -56,6 +56,18 @@ int mss_msda_backward_f32(const float* value, const int64_t* spatial_shapes, con
                           const float* sampling_loc, const float* attn_weight, const float* grad_out, int N,
                           int S, int M, int D, int L, int Lq, int P, float* grad_value, float* grad_loc,
                           float* grad_attn, void* stream);
+/* The same ms_deform_attn_backward (vision.cpp:18-21 -> ms_deform_attn_cuda.cu:88-157, kernel family
+ * ms_deform_im2col_cuda.cuh:306-925) with grad_value on the BINNED owner-computes path (round 3): every sample is filed
+ * once under the tile of its level that holds its top-left corner (counting sort on the device), a workgroup per tile sums
+ * its records in 64-bit fixed-point LDS words and stores the tile -- no floating-point atomic, no re-scan, bit-reproducible.
+ * `host_shapes`: HOST copy of spatial_shapes (tile geometry and launch grids depend on it); `workspace`: 256-byte aligned
+ * device scratch of >= mss_msda_backward_workspace_bytes(...) bytes. fp32, D == 32, L <= 8, 16-byte aligned value / grad_out;
+ * otherwise MSS_ERR_UNSUPPORTED (workspace_bytes query: 0) and the caller uses mss_msda_backward_f32. */
+long long mss_msda_backward_workspace_bytes(const int64_t* host_shapes, int N, int M, int D, int L, int Lq, int P);
+int mss_msda_backward_binned_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                 const int64_t* host_shapes, const float* sampling_loc, const float* attn_weight,
+                                 const float* grad_out, int N, int S, int M, int D, int L, int Lq, int P, float* grad_value,
+                                 float* grad_loc, float* grad_attn, void* workspace, long long workspace_bytes, void* stream);
 int mss_msda_backward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                           const double* sampling_loc, const double* attn_weight, const double* grad_out, int N,
                           int S, int M, int D, int L, int Lq, int P, double* grad_value, double* grad_loc,

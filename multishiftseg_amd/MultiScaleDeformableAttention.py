@@ -11,6 +11,7 @@ import sys
 
 import torch
 
+from . import _lib
 from ._lib import call, ptr
 
 _HOST_SHAPES = {}      # id(tensor) -> (tensor, version, ctypes int64 array): host copies of spatial_shapes tensors
@@ -94,6 +95,18 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
     sfx = "f32" if value.dtype == torch.float32 else "f64"
+    # fp32 / D = 32: grad_value on the binned owner-computes path (csrc/msda.hip, round 3) whenever a host copy of the level
+    # sizes is at hand; MSS_MSDA_BWD_BINNED=0 keeps the round-2 kernels (A/B and the second formulation in the tests)
+    if sfx == "f32" and D == 32 and N * Lq > 0 and os.environ.get("MSS_MSDA_BWD_BINNED", "1") != "0" \
+            and value.data_ptr() % 16 == 0 and grad_output.data_ptr() % 16 == 0:
+        hs = host_shapes(spatial_shapes)
+        nbytes = _lib.value("mss_msda_backward_workspace_bytes", hs, N, M, D, L, Lq, P) if hs is not None else 0
+        if nbytes > 0:
+            ws = torch.empty(nbytes, device=value.device, dtype=torch.uint8)
+            call("mss_msda_backward_binned_f32", ptr(value), ptr(spatial_shapes), ptr(level_start_index), hs, ptr(sampling_loc),
+                 ptr(attn_weight), ptr(grad_output), N, S, M, D, L, Lq, P, ptr(grad_value), ptr(grad_loc), ptr(grad_attn), ptr(ws),
+                 nbytes)
+            return [grad_value, grad_loc, grad_attn]
     call(f"mss_msda_backward_{sfx}", ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(sampling_loc),
          ptr(attn_weight), ptr(grad_output), N, S, M, D, L, Lq, P, ptr(grad_value), ptr(grad_loc), ptr(grad_attn))
     return [grad_value, grad_loc, grad_attn]

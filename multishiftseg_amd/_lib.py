@@ -13,6 +13,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so libmss_hip.
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSS_LIB", os.path.join(_HERE, "libmss_hip.so"))   # MSS_LIB: A/B experiments only
 
+MSS_ABI_VERSION = 3          # include/mss_hip.h
 MSS_ERR_BAD_ARG = 1001
 MSS_ERR_UNSUPPORTED = 1002
 
@@ -62,6 +63,8 @@ SIGNATURES = {
     "mss_msda_forward_f64": [P, P, P, P, P, I, I, I, I, I, I, I, P, P],
     "mss_msda_backward_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P],
     "mss_msda_backward_f64": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P],
+    "mss_msda_backward_workspace_bytes": [P, I, I, I, I, I, I],
+    "mss_msda_backward_binned_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, L, P],
     "mss_msda_forward_fused_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
     "mss_msda_forward_window_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
     "mss_msda_prepare_f32": [P, P, P, P, I, I, I, I, I, P, P, P],
@@ -140,12 +143,12 @@ SIGNATURES = {
     "mss_peak_scatter_f32": [P, P, L, I, I, L, P],
 }
 # entry points that return a plain value rather than a status code
-_VALUE_RETURNING = {"mss_abi_version", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
+_VALUE_RETURNING = {"mss_abi_version", "mss_msda_backward_workspace_bytes", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
                     "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts",
                     "mss_conv2d_wgrad_workspace_bytes", "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
                     "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats",
                     "mss_groupnorm_stat_offset", "mss_groupnorm_bwd_workspace_floats"}
-_RETURNS_LONGLONG = {"mss_wino_num_tiles", "mss_oodm_sort_temp_bytes", "mss_conv2d_wgrad_workspace_bytes",
+_RETURNS_LONGLONG = {"mss_msda_backward_workspace_bytes", "mss_wino_num_tiles", "mss_oodm_sort_temp_bytes", "mss_conv2d_wgrad_workspace_bytes",
                      "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
                      "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats",
                      "mss_groupnorm_stat_offset", "mss_groupnorm_bwd_workspace_floats"}
@@ -167,6 +170,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
         fn.restype = c_longlong if name in _RETURNS_LONGLONG else c_int
+    got = lib.mss_abi_version()
+    if got != MSS_ABI_VERSION:
+        raise MssError(f"{LIB_PATH} has ABI version {got}, this package expects {MSS_ABI_VERSION}: rebuild it "
+                       "(`make -C multishiftseg_amd/csrc` or __graft_entry__.build())")
     _lib = lib
     return lib
 

@@ -797,6 +797,295 @@ __global__ __launch_bounds__(MSDA_LDS_NT) void msda_bwd_value_lds_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// grad_value, BINNED owner-computes path (round 3; replaces the re-scanning kernel above whenever the caller can hand over
+// a HOST copy of spatial_shapes). The re-scanning kernel reads every sampling location of a level once per tile of that
+// level (4 / 9 / 36 times at 704^2: 2.4 GB per launch at N = 16, 40 wave-instructions per hit). Here every in-image sample
+// is filed ONCE, as a 16-byte record (query, h_im, w_im, attention weight), under the tile that holds its top-left
+// corner ("home" tile; key = (image, head, tile)) by a counting sort:
+//   msda_bin_count_kernel    per-key record counts (LDS histogram per 4096-sample chunk, one global add per key and chunk)
+//   msda_bin_scan_kernel     exclusive scan -> first record of every key
+//   msda_bin_scatter_kernel  the records, each chunk reserving its run of a key with one global add
+//   msda_bwd_value_binned_kernel  a workgroup takes tiles off a ticket counter (heaviest levels first), accumulates the
+//                            records of its tile in a (BH+1) x (BW+1) LDS window of 64-bit fixed-point words -- the extra
+//                            row / column receives the corners that reach into the next tile -- stores the interior
+//                            with plain stores and the halo row / column / corner into a side buffer
+//   msda_bin_merge_kernel    adds each tile's three incoming halos to its first row / column in a fixed order
+// No floating-point atomic, no memset of grad_value, bit-reproducible (integer sums do not depend on the order the
+// records arrive in, the halo additions have a fixed order). Tile edge per level from the expected records per tile
+// (8 x 8 where a level receives > 94 samples per position ... 16 x 16), so the 22^2 / 44^2 / 88^2 levels of a 704^2 crop
+// give 9 + 9 + 36 tiles of 5.4 k / 5.4 k / 1.3 k records instead of 4 + 9 + 36 of 10 k / 4.5 k / 1.1 k.
+constexpr int MSDA_BIN_MAXL = 8;
+constexpr int MSDA_BIN_WIN = 289;          // window cells: (16 + 1) x (16 + 1)
+constexpr int MSDA_BIN_TARGET = 6000;      // records per tile the tile-size rule aims at
+constexpr int MSDA_BIN_CHUNK = 4096;       // samples per workgroup in the count / scatter kernels
+constexpr int MSDA_BIN_NT = 1024;
+
+struct MsdaBinLevel { int H, W, BH, BW, nr, nc, tile0, halo0; float invBH, invBW; };
+struct MsdaBinGeom { MsdaBinLevel lv[MSDA_BIN_MAXL]; int L, ntiles, halo_cells; };
+
+// host: tile geometry of every level. false: shapes this path does not take.
+static bool msda_bin_geom(const int64_t* hs, int L, int Lq, int P, MsdaBinGeom& g) {
+  if (L < 1 || L > MSDA_BIN_MAXL) return false;
+  g.L = L;
+  int tile0 = 0, halo0 = 0;
+  for (int l = 0; l < L; ++l) {
+    const long long H = hs[2 * l], W = hs[2 * l + 1];
+    if (H < 1 || W < 1 || H > 32767 || W > 32767) return false;
+    const double density = (double)Lq * P / ((double)H * W);
+    const int cells = density * 64 > MSDA_BIN_TARGET ? 64 : (density * 128 > MSDA_BIN_TARGET ? 128 : 256);
+    const int bh0 = cells == 256 ? 16 : 8;
+    int BW = (int)(W < cells / bh0 ? W : cells / bh0);
+    int BH = (int)(H < cells / BW ? H : cells / BW);
+    BW = (int)(W < cells / BH ? W : cells / BH);
+    if (BH >= BW) { const int cap = MSDA_BIN_WIN / (BW + 1) - 1; if (BH > cap) BH = cap; }
+    else          { const int cap = MSDA_BIN_WIN / (BH + 1) - 1; if (BW > cap) BW = cap; }
+    MsdaBinLevel& v = g.lv[l];
+    v.H = (int)H; v.W = (int)W; v.BH = BH; v.BW = BW;
+    v.nr = (int)((H + BH - 1) / BH); v.nc = (int)((W + BW - 1) / BW);
+    v.tile0 = tile0; v.halo0 = halo0;
+    v.invBH = 1.0f / (float)BH; v.invBW = 1.0f / (float)BW;
+    const long long nt = (long long)v.nr * v.nc;
+    if (tile0 + nt > (1 << 20)) return false;
+    tile0 += (int)nt;
+    halo0 += (int)nt * (BH + BW + 1);
+  }
+  for (int l = L; l < MSDA_BIN_MAXL; ++l) g.lv[l] = g.lv[L - 1];
+  g.ntiles = tile0;
+  g.halo_cells = halo0;
+  return true;
+}
+
+// home tile of a sample inside level `v` (h_im / w_im already known to be inside (-1, H) x (-1, W))
+__device__ __forceinline__ int msda_bin_home(const MsdaBinLevel& v, float h_im, float w_im) {
+  const int hc = max((int)floorf(h_im), 0), wc = max((int)floorf(w_im), 0);
+  const int br = (int)(((float)hc + 0.5f) * v.invBH), bc = (int)(((float)wc + 0.5f) * v.invBW);   // exact: hc, wc < 2^15
+  return v.tile0 + br * v.nc + bc;
+}
+
+// MODE 0: count. MODE 1: scatter (cursor[] holds the scan, advanced by every chunk's reservation).
+template <int MODE>
+__global__ __launch_bounds__(MSDA_BIN_NT) void msda_bin_kernel(MsdaBinGeom g, const float* __restrict__ loc,
+                                                              const float* __restrict__ attn, int M, int Lq, int P,
+                                                              int* __restrict__ counts_or_cursor, f32x4* __restrict__ records) {
+  extern __shared__ int hist[];                              // [M][ntiles]
+  __shared__ MsdaBinLevel lv[MSDA_BIN_MAXL];
+  const int tid = threadIdx.x, n = blockIdx.y;
+  if (tid < g.L) lv[tid] = g.lv[tid];
+  const int nkeys = M * g.ntiles;
+  for (int i = tid; i < nkeys; i += MSDA_BIN_NT) hist[i] = 0;
+  __syncthreads();
+  const int L = g.L;
+  const long long per_image = (long long)Lq * M * L * P;
+  const long long s0 = (long long)blockIdx.x * MSDA_BIN_CHUNK;
+  constexpr int IT = MSDA_BIN_CHUNK / MSDA_BIN_NT;
+  int key[IT], rank[IT], rq[IT];
+  float rh[IT], rw[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const long long s = s0 + it * MSDA_BIN_NT + tid;
+    key[it] = -1;
+    if (s < per_image) {
+      const long long gs = (long long)n * per_image + s;
+      const float lx = loc[gs * 2], ly = loc[gs * 2 + 1];
+      const unsigned su = (unsigned)s;                       // per_image < 2^31 (host-checked)
+      const unsigned sp = su / (unsigned)P;
+      const unsigned l = sp % (unsigned)L;
+      const unsigned sm = sp / (unsigned)L;
+      const unsigned m = sm % (unsigned)M;
+      const MsdaBinLevel v = lv[l];
+      const float w_im = __fmaf_rn(lx, (float)v.W, -0.5f), h_im = __fmaf_rn(ly, (float)v.H, -0.5f);   // one rounding in both modes
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)v.H && w_im < (float)v.W) {
+        key[it] = (int)m * g.ntiles + msda_bin_home(v, h_im, w_im);
+        rank[it] = atomicAdd(&hist[key[it]], 1);
+        if (MODE == 1) { rq[it] = (int)(sm / (unsigned)M); rh[it] = h_im; rw[it] = w_im; }
+      }
+    }
+  }
+  __syncthreads();
+  int* gk = counts_or_cursor + (size_t)n * nkeys;
+  if (MODE == 0) {
+    for (int i = tid; i < nkeys; i += MSDA_BIN_NT) {
+      const int c = hist[i];
+      if (c) atomicAdd(gk + i, c);
+    }
+    return;
+  }
+  for (int i = tid; i < nkeys; i += MSDA_BIN_NT) {
+    const int c = hist[i];
+    if (c) hist[i] = atomicAdd(gk + i, c);                   // first record of this chunk's run under key i
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    if (key[it] >= 0) {
+      const long long gs = (long long)n * per_image + s0 + it * MSDA_BIN_NT + tid;
+      f32x4 r;
+      r.x = __int_as_float(rq[it]); r.y = rh[it]; r.z = rw[it]; r.w = attn[gs];
+      records[(size_t)hist[key[it]] + rank[it]] = r;
+    }
+  }
+}
+
+// exclusive scan of counts[nkeys] -> offsets[nkeys + 1] and cursor[nkeys] (one workgroup)
+__global__ __launch_bounds__(1024) void msda_bin_scan_kernel(const int* __restrict__ counts, int nkeys, int* __restrict__ offsets,
+                                                             int* __restrict__ cursor) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int per = (nkeys + 1023) / 1024;
+  const int b = tid * per, e = min(nkeys, b + per);
+  int sum = 0;
+  for (int i = b; i < e; ++i) sum += counts[i];
+  part[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - sum;
+  for (int i = b; i < e; ++i) {
+    offsets[i] = run;
+    cursor[i] = run;
+    run += counts[i];
+  }
+  if (tid == 1023) offsets[nkeys] = part[1023];
+}
+
+template <int UN>
+__global__ __launch_bounds__(MSDA_BIN_NT) void msda_bwd_value_binned_kernel(
+    MsdaBinGeom g, const int64_t* __restrict__ starts, const float* __restrict__ gout, const unsigned* __restrict__ absmax,
+    const f32x4* __restrict__ records, const int* __restrict__ offsets, int* __restrict__ ticket, int S, int M, int Lq, int N,
+    float* __restrict__ gvalue, float* __restrict__ halo) {
+  constexpr int D = 32, NT = MSDA_BIN_NT;
+  extern __shared__ unsigned long long win[];              // [(th + 1) * (tw + 1)][32]
+  __shared__ int s_item;
+  __shared__ MsdaBinLevel slv[MSDA_BIN_MAXL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, d = lane & 31;
+  if (tid < g.L) slv[tid] = g.lv[tid];
+  const int NM = N * M, nitems = g.ntiles * NM;
+  const float bound = __uint_as_float(absmax[0]) * __uint_as_float(absmax[1]);
+  int e = 0;
+  if (bound > 0.f && bound < __builtin_huge_valf()) (void)frexpf(bound, &e);
+  const bool finite = bound < __builtin_huge_valf();
+  const double to_fixed = ldexp(1.0, MSDA_FIXED_BITS - e);
+  const double from_fixed = finite ? ldexp(1.0, e - MSDA_FIXED_BITS) : (double)__builtin_nanf("");
+  const size_t rs = (size_t)M * D;
+  for (;;) {
+    if (tid == 0) s_item = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int item = s_item;
+    if (item >= nitems) break;
+    const int t = item / NM, nm = item - t * NM;            // tile-major: the heaviest (coarsest) levels go first
+    const int n = nm / M, m = nm - n * M;
+    int l = 0;
+    while (l + 1 < g.L && t >= slv[l + 1].tile0) ++l;
+    const MsdaBinLevel v = slv[l];
+    const int tt = t - v.tile0, br = tt / v.nc, bc = tt - br * v.nc;
+    const int r0 = br * v.BH, r1 = min(v.H, r0 + v.BH), c0 = bc * v.BW, c1 = min(v.W, c0 + v.BW);
+    const int th = r1 - r0, tw = c1 - c0, ww = tw + 1;
+    const int wcells = (th + 1) * ww;
+    for (int i = tid; i < wcells * D; i += NT) win[i] = 0ull;
+    __syncthreads();
+    const int key = nm * g.ntiles + t;
+    const int beg = offsets[key], end = offsets[key + 1];
+    const float* go = gout + ((size_t)n * Lq * M + m) * D + d;
+    for (int i0 = beg + wave * 64; i0 < end; i0 += NT) {
+      const int cnt = min(64, end - i0);
+      f32x4 rec = {0.f, 0.f, 0.f, 0.f};
+      if (lane < cnt) rec = records[i0 + lane];
+      for (int k = 0; k < cnt; k += 2 * UN) {
+        int sq[UN];
+        float sh[UN], sw[UN], tgv[UN];
+        bool act[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int src = k + 2 * u + half;
+          act[u] = src < cnt;
+          const int from = src & 63;
+          sq[u] = __shfl(__float_as_int(rec.x), from);
+          sh[u] = __shfl(rec.y, from);
+          sw[u] = __shfl(rec.z, from);
+          tgv[u] = __shfl(rec.w, from);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) tgv[u] *= act[u] ? go[(size_t)sq[u] * rs] : 0.f;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          if (act[u]) {
+            const float hf = floorf(sh[u]), wf = floorf(sw[u]);
+            const int h0 = (int)hf, w0 = (int)wf;
+            const float lh = sh[u] - hf, lw = sw[u] - wf, hh = 1.f - lh, hw = 1.f - lw;
+            const bool r_lo = h0 >= 0, r_hi = h0 + 1 <= v.H - 1, c_lo = w0 >= 0, c_hi = w0 + 1 <= v.W - 1;
+            unsigned long long* base = win + ((h0 - r0) * ww + (w0 - c0)) * D + d;
+            auto fx = [&](float c) {
+              const double tq = fma((double)c, to_fixed, 6755399441055744.0);
+              return (unsigned long long)(__double_as_longlong(tq) - 0x4338000000000000ll);
+            };
+            if (r_lo && c_lo) atomicAdd(base, fx(hh * hw * tgv[u]));
+            if (r_lo && c_hi) atomicAdd(base + D, fx(hh * lw * tgv[u]));
+            if (r_hi && c_lo) atomicAdd(base + ww * D, fx(lh * hw * tgv[u]));
+            if (r_hi && c_hi) atomicAdd(base + ww * D + D, fx(lh * lw * tgv[u]));
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float* gv = gvalue + ((size_t)n * S + (size_t)starts[l]) * rs + (size_t)m * D;
+    for (int i = tid; i < th * tw * D; i += NT) {
+      const int cell = i >> 5, ch = i & 31;
+      const int r = cell / tw, c = cell - r * tw;
+      gv[(size_t)((r0 + r) * v.W + c0 + c) * rs + ch] = (float)((double)(long long)win[(r * ww + c) * D + ch] * from_fixed);
+    }
+    // halo: slots [0, tw] = window row th (the corner last), slots [BW + 1, BW + 1 + th) = window column tw
+    float* hb = halo + ((size_t)nm * g.halo_cells + v.halo0 + (size_t)tt * (v.BH + v.BW + 1)) * D;
+    if (r1 < v.H) {
+      const int ncol = c1 < v.W ? tw + 1 : tw;
+      for (int i = tid; i < ncol * D; i += NT)
+        hb[i] = (float)((double)(long long)win[(th * ww) * D + i] * from_fixed);
+    }
+    if (c1 < v.W) {
+      for (int i = tid; i < th * D; i += NT) {
+        const int r = i >> 5, ch = i & 31;
+        hb[(size_t)(v.BW + 1 + r) * D + ch] = (float)((double)(long long)win[(r * ww + tw) * D + ch] * from_fixed);
+      }
+    }
+  }
+}
+
+// grad_value[first row / first column of every tile] += the halos its upper / left / upper-left neighbours left behind
+__global__ __launch_bounds__(256) void msda_bin_merge_kernel(MsdaBinGeom g, const int64_t* __restrict__ starts, int S, int M,
+                                                            int N, const float* __restrict__ halo, float* __restrict__ gvalue) {
+  constexpr int D = 32;
+  const int item = blockIdx.x, nm = blockIdx.y;
+  int l = 0;
+  while (l + 1 < g.L && item >= g.lv[l + 1].tile0) ++l;
+  const MsdaBinLevel v = g.lv[l];
+  const int tt = item - v.tile0, br = tt / v.nc, bc = tt - br * v.nc;
+  if (br == 0 && bc == 0) return;
+  const int n = nm / M, m = nm - n * M;
+  const int r0 = br * v.BH, r1 = min(v.H, r0 + v.BH), c0 = bc * v.BW, c1 = min(v.W, c0 + v.BW);
+  const int th = r1 - r0, tw = c1 - c0;
+  const int slots = v.BH + v.BW + 1;
+  const size_t rs = (size_t)M * D;
+  const float* hl = halo + ((size_t)nm * g.halo_cells + v.halo0) * D;
+  float* gv = gvalue + ((size_t)n * S + (size_t)starts[l]) * rs + (size_t)m * D;
+  const int ch = threadIdx.x & 31;
+  // cells of the first row (j = 0 .. tw-1), then of the first column below it (j = tw .. tw+th-2)
+  for (int j = threadIdx.x >> 5; j < tw + th - 1; j += 8) {
+    const int r = j < tw ? 0 : j - tw + 1, c = j < tw ? j : 0;
+    float add = 0.f;
+    if (r == 0 && br > 0) add += hl[((size_t)(tt - v.nc) * slots + c) * D + ch];                      // upper tile's row
+    if (c == 0 && bc > 0) add += hl[((size_t)(tt - 1) * slots + v.BW + 1 + r) * D + ch];             // left tile's column
+    if (r == 0 && c == 0 && br > 0 && bc > 0) {
+      // upper-left tile's corner: slot (its width) = BW, it is never a ragged tile
+      add += hl[((size_t)(tt - v.nc - 1) * slots + v.BW) * D + ch];
+    }
+    if ((r == 0 && br > 0) || (c == 0 && bc > 0)) gv[(size_t)((r0 + r) * v.W + c0 + c) * rs + ch] += add;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Operand preparation of the MSDeformAttn module (ops/modules/ms_deform_attn.py:100-109) in one pass:
 //   attn = softmax over the L*P logits of a (query, head);  loc = reference_point[l] + offset / (W_l, H_l)
 // instead of softmax + view + stack + div + add as five elementwise library kernels over the 12-36 values per (q, m).
@@ -1016,6 +1305,85 @@ int msda_backward(const T* value, const int64_t* shapes, const int64_t* starts, 
   return mss_launch_status();
 }
 
+// workspace of the binned backward: [header 64 B: ticket, max|grad_out|, max|attn|][counts][offsets + 1][cursor] | records | halo
+struct MsdaBinWs { size_t counts, offsets, cursor, records, halo, total; long long nkeys; };
+static bool msda_bin_layout(const MsdaBinGeom& g, int N, int M, int L, int Lq, int P, MsdaBinWs& w) {
+  const long long per_image = (long long)Lq * M * L * P;
+  if (per_image >= (1ll << 31) || (long long)N * per_image >= (1ll << 31)) return false;
+  w.nkeys = (long long)N * M * g.ntiles;
+  if (w.nkeys >= (1ll << 28) || (long long)M * g.ntiles * 4 > 60 * 1024) return false;      // LDS histogram of a chunk
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  w.counts = 64;
+  w.offsets = up(w.counts + (size_t)w.nkeys * 4);
+  w.cursor = up(w.offsets + (size_t)(w.nkeys + 1) * 4);
+  w.records = up(w.cursor + (size_t)w.nkeys * 4);
+  w.halo = up(w.records + (size_t)N * per_image * 16);
+  w.total = up(w.halo + (size_t)N * M * g.halo_cells * 32 * 4);
+  return true;
+}
+
+static int msda_backward_binned(const float* value, const int64_t* shapes, const int64_t* starts, const int64_t* host_shapes,
+                                const float* loc, const float* attn, const float* gout, int N, int S, int M, int D, int L,
+                                int Lq, int P, float* gvalue, float* gloc, float* gattn, void* ws, size_t ws_bytes,
+                                hipStream_t stream) {
+  if (!host_shapes) return MSS_ERR_BAD_ARG;
+  int rc = msda_check(value, host_shapes, starts, loc, attn, N, S, M, D, L, Lq, P);
+  if (rc) return rc;
+  const long long npairs = (long long)N * Lq * M;
+  if (npairs == 0 || (long long)N * S == 0) return MSS_ERR_UNSUPPORTED;
+  if (D != 32 || M > 65535 || (long long)Lq * P > (1ll << 22)) return MSS_ERR_UNSUPPORTED;
+  if (!gvalue || !gout || !gloc || !gattn || !ws) return MSS_ERR_BAD_ARG;
+  const size_t smem_gather = (size_t)4 * 8 * L * P * 3 * sizeof(float);
+  if (((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(gout)) & 15) != 0 || smem_gather > 65536) return MSS_ERR_UNSUPPORTED;
+  MsdaBinGeom g;
+  MsdaBinWs w;
+  if (!msda_bin_geom(host_shapes, L, Lq, P, g) || !msda_bin_layout(g, N, M, L, Lq, P, w)) return MSS_ERR_UNSUPPORTED;
+  long long cells = 0;
+  for (int l = 0; l < L; ++l) cells += host_shapes[2 * l] * host_shapes[2 * l + 1];
+  if (cells > S) return MSS_ERR_BAD_ARG;
+  if (ws_bytes < w.total || (reinterpret_cast<uintptr_t>(ws) & 255)) return MSS_ERR_BAD_ARG;
+  char* base = static_cast<char*>(ws);
+  int* ticket = reinterpret_cast<int*>(base);
+  unsigned* absmax = reinterpret_cast<unsigned*>(base) + 1;
+  int* counts = reinterpret_cast<int*>(base + w.counts);
+  int* offsets = reinterpret_cast<int*>(base + w.offsets);
+  int* cursor = reinterpret_cast<int*>(base + w.cursor);
+  f32x4* records = reinterpret_cast<f32x4*>(base + w.records);
+  float* halo = reinterpret_cast<float*>(base + w.halo);
+  hipError_t e = hipMemsetAsync(base, 0, w.counts + (size_t)w.nkeys * 4, stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(msda_absmax_kernel, dim3(1024), dim3(256), 0, stream, gout, npairs * D, attn, npairs * L * P, absmax);
+  const long long per_image = (long long)Lq * M * L * P;
+  const unsigned chunks = (unsigned)((per_image + MSDA_BIN_CHUNK - 1) / MSDA_BIN_CHUNK);
+  const size_t hist_bytes = (size_t)M * g.ntiles * sizeof(int);
+  hipLaunchKernelGGL(msda_bin_kernel<0>, dim3(chunks, (unsigned)N), dim3(MSDA_BIN_NT), hist_bytes, stream, g, loc, attn, M, Lq, P,
+                     counts, records);
+  hipLaunchKernelGGL(msda_bin_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, (int)w.nkeys, offsets, cursor);
+  hipLaunchKernelGGL(msda_bin_kernel<1>, dim3(chunks, (unsigned)N), dim3(MSDA_BIN_NT), hist_bytes, stream, g, loc, attn, M, Lq, P,
+                     cursor, records);
+  const size_t win_bytes = (size_t)MSDA_BIN_WIN * 32 * sizeof(unsigned long long);
+  auto kern = msda_bwd_value_binned_kernel<4>;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes);
+  if (e != hipSuccess) return (int)e;
+  const long long nitems = (long long)g.ntiles * N * M;
+  const unsigned nwg = (unsigned)(nitems < 512 ? nitems : 512);          // two 1024-thread workgroups per CU, 256 CUs
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(MSDA_BIN_NT), win_bytes, stream, g, starts, gout, absmax, records, offsets, ticket, S, M,
+                     Lq, N, gvalue, halo);
+  hipLaunchKernelGGL(msda_bin_merge_kernel, dim3((unsigned)g.ntiles, (unsigned)(N * M)), dim3(256), 0, stream, g, starts, S, M, N,
+                     halo, gvalue);
+  // grad_loc / grad_attn: the gather pass (no atomics)
+  const long long nblocks = (npairs + 31) / 32;
+  const char* eb = getenv("MSS_MSDA_BUF");
+  const bool buf = (unsigned long long)N * S * M * D * 4ull < 0xffffffffull && !(eb && atoi(eb) == 0);
+  if (buf)
+    hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<true>, dim3((unsigned)nblocks), dim3(256), smem_gather, stream, value, shapes, starts,
+                       loc, attn, gout, npairs, S, M, L, Lq, P, gloc, gattn);
+  else
+    hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<false>, dim3((unsigned)nblocks), dim3(256), smem_gather, stream, value, shapes, starts,
+                       loc, attn, gout, npairs, S, M, L, Lq, P, gloc, gattn);
+  return mss_launch_status();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1098,6 +1466,28 @@ int mss_msda_backward_f32(const float* value, const int64_t* spatial_shapes, con
                           float* grad_attn, void* stream) {
   return msda_backward<float>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, N,
                               S, M, D, L, Lq, P, grad_value, grad_loc, grad_attn,
+                              static_cast<hipStream_t>(stream));
+}
+
+// backward with grad_value on the binned owner-computes path (fp32, D = 32, L <= 8): `host_shapes` is a HOST copy of
+// spatial_shapes, `workspace` a 256-byte aligned device buffer of at least mss_msda_backward_workspace_bytes(...) bytes
+// (0: shapes this path does not take -> call mss_msda_backward_f32). MSS_ERR_UNSUPPORTED likewise.
+long long mss_msda_backward_workspace_bytes(const int64_t* host_shapes, int N, int M, int D, int L, int Lq, int P) {
+  MsdaBinGeom g;
+  MsdaBinWs w;
+  if (!host_shapes || D != 32 || N <= 0 || Lq <= 0 || M <= 0 || P <= 0 || M > 65535 || (long long)Lq * P > (1ll << 22)) return 0;
+  if ((size_t)4 * 8 * L * P * 3 * sizeof(float) > 65536) return 0;
+  if (!msda_bin_geom(host_shapes, L, Lq, P, g) || !msda_bin_layout(g, N, M, L, Lq, P, w)) return 0;
+  return (long long)w.total;
+}
+
+int mss_msda_backward_binned_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                 const int64_t* host_shapes, const float* sampling_loc, const float* attn_weight,
+                                 const float* grad_out, int N, int S, int M, int D, int L, int Lq, int P, float* grad_value,
+                                 float* grad_loc, float* grad_attn, void* workspace, long long workspace_bytes, void* stream) {
+  if (!spatial_shapes) return MSS_ERR_BAD_ARG;
+  return msda_backward_binned(value, spatial_shapes, level_start_index, host_shapes, sampling_loc, attn_weight, grad_out, N, S, M, D,
+                              L, Lq, P, grad_value, grad_loc, grad_attn, workspace, (size_t)(workspace_bytes < 0 ? 0 : workspace_bytes),
                               static_cast<hipStream_t>(stream));
 }
 

@@ -343,12 +343,30 @@ def wino_xt_bytes(N, H, W, C, dil):
     return (ts + 2) ** 2 * _lib.value("mss_wino_num_tiles", N, H, W, dil, ts) * C * 4
 
 
+_tile_hook = None
+
+
+def set_tile_hook(fn):
+    """Attribution / test hook (tools/attribute_wino_error.py): fn(info) is asked once per forward 3x3 layer with
+    info = dict(H, W, dil, c_in, k_out, stride, policy_tile) and answers None (keep the policy), 0 (direct implicit
+    GEMM) or a tile edge 2 / 4 / 6. Not consulted for data or weight gradients."""
+    global _tile_hook
+    _tile_hook = fn
+
+
 def conv3x3(x, weight, dil=1, stride=1, in_affine=None, in_relu=False, res=None, out=None, flip=False, keep_xt=None,
             want_stats=False):
     """3x3 convolution with padding = dilation on nn.Conv2d-layout `weight` (flip=True: its data gradient),
     through Winograd when the policy says so, else through the direct implicit GEMM."""
     k_out, c_in = (weight.shape[1], weight.shape[0]) if flip else (weight.shape[0], weight.shape[1])
     tile = wino_tile(x.H, x.W, dil)
+    if _tile_hook is not None and not flip:
+        forced = _tile_hook(dict(H=x.H, W=x.W, dil=dil, c_in=c_in, k_out=k_out, stride=stride, policy_tile=tile))
+        if forced == 0:
+            return conv2d(x, packed(weight, flip), stride=stride, dil=dil, pad=dil, in_affine=in_affine, in_relu=in_relu,
+                          res=res, out=out, want_stats=want_stats)
+        if forced:
+            tile = forced
     if use_winograd(c_in, k_out, stride, in_affine, tile):
         return conv2d_winograd(x, packed_wino(weight, flip, tile), dil=dil, in_affine=in_affine,
                                in_relu=in_relu, res=res, out=out, keep_xt=keep_xt, want_stats=want_stats)

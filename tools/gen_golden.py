@@ -185,7 +185,15 @@ def gen_deeplab(DeepWV3Plus):
     return model
 
 
-def gen_deeplab_big(DeepWV3Plus, n=1, h=592, w=600):
+def margin_bits(logit_n):
+    """Top-2 margin of the reference's logits as three packed bit planes (> 1e-3, > 1e-4, > 1e-5): lets a test count
+    argmax flips over ALL pixels and say how close to a tie the reference itself was where they happen."""
+    top2 = np.partition(logit_n, -2, axis=1)[:, -2:]
+    margin = top2[:, 1] - top2[:, 0]
+    return {f"clear_bits_{tag}": np.packbits(margin > thr) for tag, thr in (("1e3", 1e-3), ("1e4", 1e-4), ("1e5", 1e-5))}
+
+
+def gen_deeplab_big(DeepWV3Plus, n=1, h=592, w=600, score_stride=2, logit_stride=4, all_margins=False):
     """Eval forward at a size where the build's Winograd policy picks F(4x4,3x3) for all three ASPP rates on its own
     (the /8 map is 74x75: 4x4 / 4x4 / 3x3 residue sub-grids at dilation 12 / 24 / 36) and nothing divides evenly
     (296x300 -> 148x150 -> 74x75). Big outputs are stored as strided slices + float64 checksums."""
@@ -197,8 +205,10 @@ def gen_deeplab_big(DeepWV3Plus, n=1, h=592, w=600):
     logit_n, score_n = t2n(logit), t2n(score)
     top2 = np.sort(logit_n, axis=1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 1e-3
-    save(f"deepwv3plus_eval_{n}x{h}x{w}", image_seed=np.int64(3), shape=np.array([n, h, w]),
-         score_sub=score_n[:, ::2, ::2], logit_sub=logit_n[:, :, ::4, ::4], label=logit_n.argmax(1).astype(np.uint8),
+    extra = dict(margin_bits(logit_n), score_stride=np.int64(score_stride), logit_stride=np.int64(logit_stride)) if all_margins else {}
+    save(f"deepwv3plus_eval_{n}x{h}x{w}", image_seed=np.int64(3), shape=np.array([n, h, w]), **extra,
+         score_sub=score_n[:, ::score_stride, ::score_stride], logit_sub=logit_n[:, :, ::logit_stride, ::logit_stride],
+         label=logit_n.argmax(1).astype(np.uint8),
          clear_bits=np.packbits(clear), score_abs_sum=np.float64(np.abs(score_n.astype(np.float64)).sum()),
          logit_abs_sum=np.float64(np.abs(logit_n.astype(np.float64)).sum()),
          logit_row=logit_n[:, :, h // 3], score_row=score_n[:, h // 3])
@@ -206,7 +216,8 @@ def gen_deeplab_big(DeepWV3Plus, n=1, h=592, w=600):
 
 
 def gen_train_step(DeepWV3Plus, ref_loss, pairs=2, h=96, w=128, fixture="deepwv3plus_train_step",
-                   stages=("stage1", "stage2"), fp64_replay=True, score_stride=1, logit_stride=4, truncate_perms=False):
+                   stages=("stage1", "stage2"), fp64_replay=True, score_stride=1, logit_stride=4, truncate_perms=False,
+                   store_labels=False):
     """a-7: one optimizer step of each training stage on a (pairs+pairs)x3xhxw batch (default (2+2)x3x96x128),
     train-mode BN on the frozen trunk, Dropout2d masks and the loss permutations recorded and stored."""
     img = synth.synth_image(2, 2 * pairs, h, w)
@@ -267,6 +278,9 @@ def gen_train_step(DeepWV3Plus, ref_loss, pairs=2, h=96, w=128, fixture="deepwv3
         out[pre + "score_abs_sum"] = np.float64(np.abs(t2n(score).astype(np.float64)).sum())
         out[pre + "logit_abs_sum"] = np.float64(np.abs(t2n(logit).astype(np.float64)).sum())
         out[pre + "target_mut"] = t2n(tgt).astype(np.uint8)
+        if store_labels:
+            out[pre + "label"] = t2n(logit).argmax(1).astype(np.uint8)
+            out.update({pre + k: v for k, v in margin_bits(t2n(logit)).items()})
         out[pre + "drop_mod6"] = masks["mod6"]
         out[pre + "drop_mod7"] = masks["mod7"]
         n_used = min(len(p) for p in perms)        # loss.py:149-156 keeps only the first n = min(set sizes) entries
@@ -784,6 +798,14 @@ def main():
         print("train_big")
         gen_train_step(DeepWV3Plus, ref_loss, pairs=1, h=592, w=600, fixture="deepwv3plus_train_step_2x592x600",
                        stages=("stage2",), fp64_replay=False, score_stride=4, logit_stride=8, truncate_perms=True)
+    # the headline configuration itself (BASELINE config 3, per GPU): about 2 + 10 minutes on 8 cores
+    if "deeplab_c3" in which:
+        print("deeplab_c3"); gen_deeplab_big(DeepWV3Plus, n=1, h=1024, w=2048, score_stride=4, logit_stride=8, all_margins=True)
+    if "train_c3" in which:
+        print("train_c3")
+        gen_train_step(DeepWV3Plus, ref_loss, pairs=1, h=1024, w=2048, fixture="deepwv3plus_train_step_2x1024x2048",
+                       stages=("stage2",), fp64_replay=False, score_stride=8, logit_stride=16, truncate_perms=True,
+                       store_labels=True)
 
 
 if __name__ == "__main__":
