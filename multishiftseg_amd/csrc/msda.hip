@@ -664,6 +664,21 @@ __global__ __launch_bounds__(256) void msda_absmax_kernel(const float* __restric
   }
 }
 
+// one atomicMax per WORKGROUP, and only when it can raise the value (same-address atomics serialise: 8192 of them cost
+// 95 us here). `red`: >= 16 floats of LDS; every thread of the (<= 1024-thread) workgroup calls it.
+__device__ __forceinline__ void msda_block_atomic_max(float m, unsigned* __restrict__ out, float* red) {
+  m = mss_wave_max(m);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mm = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) mm = fmaxf(mm, red[i]);
+    const unsigned bits = __float_as_uint(mm);          // non-negative floats order like their bit patterns
+    if (bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
+  }
+}
+
 struct MsdaTile { int l, H, W, r0, r1, c0, c1; long long start; bool valid; };
 __device__ __forceinline__ MsdaTile msda_find_tile(const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
                                                    int L, int t) {
@@ -824,16 +839,19 @@ struct MsdaBinLevel { int H, W, BH, BW, nr, nc, tile0, halo0; float invBH, invBW
 struct MsdaBinGeom { MsdaBinLevel lv[MSDA_BIN_MAXL]; int L, ntiles, halo_cells; };
 
 // host: tile geometry of every level. false: shapes this path does not take.
-static bool msda_bin_geom(const int64_t* hs, int L, int Lq, int P, MsdaBinGeom& g) {
+static bool msda_bin_geom(const int64_t* hs, int L, int Lq, int P, long long samples, MsdaBinGeom& g) {
   if (L < 1 || L > MSDA_BIN_MAXL) return false;
+  // records per tile to aim at: enough tiles for ~6 workgroups per slot (two slots per CU) on small calls
+  const long long target = samples / 3072 < 750 ? 750 : (samples / 3072 > MSDA_BIN_TARGET ? MSDA_BIN_TARGET : samples / 3072);
   g.L = L;
   int tile0 = 0, halo0 = 0;
   for (int l = 0; l < L; ++l) {
     const long long H = hs[2 * l], W = hs[2 * l + 1];
     if (H < 1 || W < 1 || H > 32767 || W > 32767) return false;
     const double density = (double)Lq * P / ((double)H * W);
-    const int cells = density * 64 > MSDA_BIN_TARGET ? 64 : (density * 128 > MSDA_BIN_TARGET ? 128 : 256);
-    const int bh0 = cells == 256 ? 16 : 8;
+    int cells = 16;                                        // 4x4, 4x8, 8x8, 8x16 or 16x16 positions
+    while (cells < 256 && density * cells < target) cells *= 2;
+    const int bh0 = cells == 256 ? 16 : (cells >= 64 ? 8 : 4);
     int BW = (int)(W < cells / bh0 ? W : cells / bh0);
     int BH = (int)(H < cells / BW ? H : cells / BW);
     BW = (int)(W < cells / BH ? W : cells / BH);
@@ -862,12 +880,19 @@ __device__ __forceinline__ int msda_bin_home(const MsdaBinLevel& v, float h_im, 
   return v.tile0 + br * v.nc + bc;
 }
 
+// A record is 4 dwords: header = kill << 31 | query << 9 | window cell of the top-left corner, then A = attn x (row weight of
+// the corner's row), B = attn x (row weight of the row below) and the column fraction lw: the four contributions are
+// (A, B) x (1 - lw, kill ? 0 : lw). Corners outside the image are folded in here -- a top-left corner in row / column -1
+// moves to row / column 0 of the window and takes the other row's / column's weight, a row or column past the last one
+// gets weight 0 -- so the accumulating kernel adds all four unconditionally.
 // MODE 0: count. MODE 1: scatter (cursor[] holds the scan, advanced by every chunk's reservation).
 template <int MODE>
 __global__ __launch_bounds__(MSDA_BIN_NT) void msda_bin_kernel(MsdaBinGeom g, const float* __restrict__ loc,
                                                               const float* __restrict__ attn, int M, int Lq, int P,
-                                                              int* __restrict__ counts_or_cursor, f32x4* __restrict__ records) {
-  extern __shared__ int hist[];                              // [M][ntiles]
+                                                              int* __restrict__ counts_or_cursor, f32x4* __restrict__ records,
+                                                              unsigned* __restrict__ absmax_attn, const float* __restrict__ gout,
+                                                              long long ngout) {
+  extern __shared__ int hist[];                              // [M][ntiles] + 16 floats for the block maximum
   __shared__ MsdaBinLevel lv[MSDA_BIN_MAXL];
   const int tid = threadIdx.x, n = blockIdx.y;
   if (tid < g.L) lv[tid] = g.lv[tid];
@@ -895,9 +920,10 @@ __global__ __launch_bounds__(MSDA_BIN_NT) void msda_bin_kernel(MsdaBinGeom g, co
       const MsdaBinLevel v = lv[l];
       const float w_im = __fmaf_rn(lx, (float)v.W, -0.5f), h_im = __fmaf_rn(ly, (float)v.H, -0.5f);   // one rounding in both modes
       if (h_im > -1.f && w_im > -1.f && h_im < (float)v.H && w_im < (float)v.W) {
-        key[it] = (int)m * g.ntiles + msda_bin_home(v, h_im, w_im);
+        const int tile = msda_bin_home(v, h_im, w_im);
+        key[it] = (int)m * g.ntiles + tile;
         rank[it] = atomicAdd(&hist[key[it]], 1);
-        if (MODE == 1) { rq[it] = (int)(sm / (unsigned)M); rh[it] = h_im; rw[it] = w_im; }
+        if (MODE == 1) { rq[it] = (int)((sm / (unsigned)M) << 4) | (int)l; rh[it] = h_im; rw[it] = w_im; }
       }
     }
   }
@@ -908,6 +934,24 @@ __global__ __launch_bounds__(MSDA_BIN_NT) void msda_bin_kernel(MsdaBinGeom g, co
       const int c = hist[i];
       if (c) atomicAdd(gk + i, c);
     }
+    // ... and this workgroup's share of max|grad_out| (absmax_attn[-1]; 16-byte aligned, float4 per lane): saves a launch
+    const long long n4 = ngout >> 2, nwg = (long long)gridDim.x * gridDim.y, wg = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    const long long per = (n4 + nwg - 1) / nwg, b4 = wg * per, e4 = min(n4, b4 + per);
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(gout);
+    float mx = 0.f;
+    bool bad = false;
+    for (long long i = b4 + tid; i < e4; i += MSDA_BIN_NT) {
+      const f32x4 x = a4[i];
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
+      bad |= !(x.x - x.x == 0.f) || !(x.y - x.y == 0.f) || !(x.z - x.z == 0.f) || !(x.w - x.w == 0.f);
+    }
+    if (wg == 0 && tid < (int)(ngout & 3)) {
+      const float x = gout[(n4 << 2) + tid];
+      mx = fmaxf(mx, fabsf(x));
+      bad |= !(x - x == 0.f);
+    }
+    if (bad) mx = __builtin_huge_valf();
+    msda_block_atomic_max(mx, absmax_attn - 1, reinterpret_cast<float*>(hist + nkeys));
     return;
   }
   for (int i = tid; i < nkeys; i += MSDA_BIN_NT) {
@@ -915,15 +959,36 @@ __global__ __launch_bounds__(MSDA_BIN_NT) void msda_bin_kernel(MsdaBinGeom g, co
     if (c) hist[i] = atomicAdd(gk + i, c);                   // first record of this chunk's run under key i
   }
   __syncthreads();
+  float amax = 0.f;
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     if (key[it] >= 0) {
       const long long gs = (long long)n * per_image + s0 + it * MSDA_BIN_NT + tid;
+      const float aw = attn[gs];
+      amax = (aw - aw == 0.f) ? fmaxf(amax, fabsf(aw)) : __builtin_huge_valf();     // non-finite poisons the gradient
+      const MsdaBinLevel v = lv[rq[it] & 15];
+      const int q = rq[it] >> 4;
+      const float hf = floorf(rh[it]), wf = floorf(rw[it]);
+      int h0 = (int)hf, w0 = (int)wf;
+      const float lh = rh[it] - hf, lw = rw[it] - wf, hh = 1.f - lh, hw = 1.f - lw;
+      float A, B, lwq;
+      unsigned kill;
+      if (h0 < 0) { A = aw * lh; B = 0.f; h0 = 0; }                       // row -1 is outside: row 0 moves up
+      else { A = aw * hh; B = (h0 + 1 <= v.H - 1) ? aw * lh : 0.f; }
+      if (w0 < 0) { lwq = hw; kill = 1u; w0 = 0; }                        // column 0 takes 1 - (1 - lw)
+      else { lwq = lw; kill = (w0 + 1 <= v.W - 1) ? 0u : 1u; }
+      const int tile = key[it] - (key[it] / g.ntiles) * g.ntiles - v.tile0;
+      const int br = tile / v.nc, bc = tile - br * v.nc;
+      const int r0 = br * v.BH, c0 = bc * v.BW;
+      const int tw = min(v.W, c0 + v.BW) - c0;
+      const int cell = (h0 - r0) * (tw + 1) + (w0 - c0);
       f32x4 r;
-      r.x = __int_as_float(rq[it]); r.y = rh[it]; r.z = rw[it]; r.w = attn[gs];
+      r.x = __uint_as_float((kill << 31) | ((unsigned)q << 9) | (unsigned)cell);
+      r.y = A; r.z = B; r.w = lwq;
       records[(size_t)hist[key[it]] + rank[it]] = r;
     }
   }
+  msda_block_atomic_max(amax, absmax_attn, reinterpret_cast<float*>(hist + nkeys));   // NaN / inf were turned into +inf above
 }
 
 // exclusive scan of counts[nkeys] -> offsets[nkeys + 1] and cursor[nkeys] (one workgroup)
@@ -953,7 +1018,8 @@ __global__ __launch_bounds__(1024) void msda_bin_scan_kernel(const int* __restri
 }
 
 template <int UN>
-__global__ __launch_bounds__(MSDA_BIN_NT) void msda_bwd_value_binned_kernel(
+__global__ __launch_bounds__(MSDA_BIN_NT, 8) void msda_bwd_value_binned_kernel(        // 8 waves / SIMD: two workgroups per CU
+
     MsdaBinGeom g, const int64_t* __restrict__ starts, const float* __restrict__ gout, const unsigned* __restrict__ absmax,
     const f32x4* __restrict__ records, const int* __restrict__ offsets, int* __restrict__ ticket, int S, int M, int Lq, int N,
     float* __restrict__ gvalue, float* __restrict__ halo) {
@@ -961,7 +1027,8 @@ __global__ __launch_bounds__(MSDA_BIN_NT) void msda_bwd_value_binned_kernel(
   extern __shared__ unsigned long long win[];              // [(th + 1) * (tw + 1)][32]
   __shared__ int s_item;
   __shared__ MsdaBinLevel slv[MSDA_BIN_MAXL];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, d = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, d = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid < g.L) slv[tid] = g.lv[tid];
   const int NM = N * M, nitems = g.ntiles * NM;
   const float bound = __uint_as_float(absmax[0]) * __uint_as_float(absmax[1]);
@@ -971,6 +1038,8 @@ __global__ __launch_bounds__(MSDA_BIN_NT) void msda_bwd_value_binned_kernel(
   const double to_fixed = ldexp(1.0, MSDA_FIXED_BITS - e);
   const double from_fixed = finite ? ldexp(1.0, e - MSDA_FIXED_BITS) : (double)__builtin_nanf("");
   const size_t rs = (size_t)M * D;
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(gout), 0, (int)(unsigned)min((unsigned long long)N * Lq * rs * 4ull, 0xffffffffull), 0x00020000);
   for (;;) {
     if (tid == 0) s_item = atomicAdd(ticket, 1);
     __syncthreads();
@@ -988,47 +1057,65 @@ __global__ __launch_bounds__(MSDA_BIN_NT) void msda_bwd_value_binned_kernel(
     for (int i = tid; i < wcells * D; i += NT) win[i] = 0ull;
     __syncthreads();
     const int key = nm * g.ntiles + t;
-    const int beg = offsets[key], end = offsets[key + 1];
-    const float* go = gout + ((size_t)n * Lq * M + m) * D + d;
-    for (int i0 = beg + wave * 64; i0 < end; i0 += NT) {
-      const int cnt = min(64, end - i0);
-      f32x4 rec = {0.f, 0.f, 0.f, 0.f};
-      if (lane < cnt) rec = records[i0 + lane];
-      for (int k = 0; k < cnt; k += 2 * UN) {
-        int sq[UN];
-        float sh[UN], sw[UN], tgv[UN];
-        bool act[UN];
+    const int beg = __builtin_amdgcn_readfirstlane(offsets[key]), end = __builtin_amdgcn_readfirstlane(offsets[key + 1]);
+    auto fx = [&](float c) {
+      const double tq = fma((double)c, to_fixed, 6755399441055744.0);
+      return (unsigned long long)(__double_as_longlong(tq) - 0x4338000000000000ll);
+    };
+    // a wave takes UN records at a time, ONE record per wave-instruction: the record words come through the scalar cache
+    // (wave-uniform address) and are used as scalar operands; lane = column * 32 + channel, so lanes 0-31 add the two
+    // corners of the left column, lanes 32-63 those of the right column, and a wave's 64 LDS words are consecutive
+    unsigned long long* wl = win + lane;
+    unsigned long long* wl2 = wl + ww * D;
+    // grad_out as ONE buffer resource (host-checked: < 4 GB): a row is a scalar byte offset (SGPR), the channel a constant
+    // per-lane offset -- no 64-bit address arithmetic and no address registers per load in flight
+    const unsigned go_nm = (unsigned)(((size_t)n * Lq * M + m) * D * sizeof(float));
+    const unsigned rs4 = (unsigned)(rs * sizeof(float));
+    const unsigned d4 = (unsigned)d * 4u;
+    // A wave owns blocks of 64 consecutive records: lane k fetches record k of the block (one coalesced 1-KB load, the next
+    // block's requested a block ahead), then the block is walked UN records at a time, a record's four words broadcast
+    // with v_readlane (no memory round trip, no LDS) and its grad_out row requested one sub-round ahead. (Fetching the
+    // records through the scalar cache instead serialised on SGPR pressure: 4 us per round of 8 records.)
+    const f32x4 zero_rec = {0.f, 0.f, 0.f, 0.f};               // A = B = 0: adds zeros to cell 0 of query 0
+    auto load_g = [&](const f32x4& rv, int k0, float* gq) {
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          const int src = k + 2 * u + half;
-          act[u] = src < cnt;
-          const int from = src & 63;
-          sq[u] = __shfl(__float_as_int(rec.x), from);
-          sh[u] = __shfl(rec.y, from);
-          sw[u] = __shfl(rec.z, from);
-          tgv[u] = __shfl(rec.w, from);
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) tgv[u] *= act[u] ? go[(size_t)sq[u] * rs] : 0.f;
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          if (act[u]) {
-            const float hf = floorf(sh[u]), wf = floorf(sw[u]);
-            const int h0 = (int)hf, w0 = (int)wf;
-            const float lh = sh[u] - hf, lw = sw[u] - wf, hh = 1.f - lh, hw = 1.f - lw;
-            const bool r_lo = h0 >= 0, r_hi = h0 + 1 <= v.H - 1, c_lo = w0 >= 0, c_hi = w0 + 1 <= v.W - 1;
-            unsigned long long* base = win + ((h0 - r0) * ww + (w0 - c0)) * D + d;
-            auto fx = [&](float c) {
-              const double tq = fma((double)c, to_fixed, 6755399441055744.0);
-              return (unsigned long long)(__double_as_longlong(tq) - 0x4338000000000000ll);
-            };
-            if (r_lo && c_lo) atomicAdd(base, fx(hh * hw * tgv[u]));
-            if (r_lo && c_hi) atomicAdd(base + D, fx(hh * lw * tgv[u]));
-            if (r_hi && c_lo) atomicAdd(base + ww * D, fx(lh * hw * tgv[u]));
-            if (r_hi && c_hi) atomicAdd(base + ww * D + D, fx(lh * lw * tgv[u]));
-          }
-        }
+      for (int u = 0; u < UN; ++u) {
+        const unsigned hd = (unsigned)__builtin_amdgcn_readlane(__float_as_int(rv.x), k0 + u);
+        gq[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, d4, go_nm + ((hd >> 9) & 0x3fffffu) * rs4, 0));
       }
+    };
+    int blk = beg + wave * 64;
+    f32x4 rv = blk + lane < end ? records[blk + lane] : zero_rec;
+    for (; blk < end; blk += (NT / 64) * 64) {
+      const int nb = blk + (NT / 64) * 64;
+      const f32x4 rvn = nb + lane < end ? records[nb + lane] : zero_rec;
+      const int cnt = min(64, end - blk);
+      auto process = [&](int k0, const float* gq) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const unsigned hd = (unsigned)__builtin_amdgcn_readlane(__float_as_int(rv.x), k0 + u);
+          const float A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv.y), k0 + u));
+          const float B = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv.z), k0 + u));
+          const float lwv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv.w), k0 + u));
+          const float lwk = (hd >> 31) ? 0.f : lwv;            // scalar select
+          const float cw = half ? lwk : 1.f - lwv;
+          const float tc = cw * gq[u];
+          const int cell = (int)(hd & 511u) * D;
+          atomicAdd(wl + cell, fx(tc * A));
+          atomicAdd(wl2 + cell, fx(tc * B));
+        }
+      };
+      // two register sets in ping-pong (no copies: a copy would wait for the rows just requested); lanes past the end of
+      // the tile hold zero records, so a sub-round past `cnt` only adds zeros
+      float ga[UN], gb[UN];
+      load_g(rv, 0, ga);
+      for (int k0 = 0; k0 < cnt; k0 += 2 * UN) {
+        load_g(rv, k0 + UN, gb);
+        process(k0, ga);
+        if (k0 + 2 * UN < 64) load_g(rv, k0 + 2 * UN, ga);
+        process(k0 + UN, gb);
+      }
+      rv = rvn;
     }
     __syncthreads();
     float* gv = gvalue + ((size_t)n * S + (size_t)starts[l]) * rs + (size_t)m * D;
@@ -1332,12 +1419,13 @@ static int msda_backward_binned(const float* value, const int64_t* shapes, const
   const long long npairs = (long long)N * Lq * M;
   if (npairs == 0 || (long long)N * S == 0) return MSS_ERR_UNSUPPORTED;
   if (D != 32 || M > 65535 || (long long)Lq * P > (1ll << 22)) return MSS_ERR_UNSUPPORTED;
+  if ((unsigned long long)N * Lq * M * D * 4ull >= 0xffffffffull) return MSS_ERR_UNSUPPORTED;      // grad_out as one buffer resource
   if (!gvalue || !gout || !gloc || !gattn || !ws) return MSS_ERR_BAD_ARG;
   const size_t smem_gather = (size_t)4 * 8 * L * P * 3 * sizeof(float);
   if (((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(gout)) & 15) != 0 || smem_gather > 65536) return MSS_ERR_UNSUPPORTED;
   MsdaBinGeom g;
   MsdaBinWs w;
-  if (!msda_bin_geom(host_shapes, L, Lq, P, g) || !msda_bin_layout(g, N, M, L, Lq, P, w)) return MSS_ERR_UNSUPPORTED;
+  if (!msda_bin_geom(host_shapes, L, Lq, P, (long long)N * Lq * M * L * P, g) || !msda_bin_layout(g, N, M, L, Lq, P, w)) return MSS_ERR_UNSUPPORTED;
   long long cells = 0;
   for (int l = 0; l < L; ++l) cells += host_shapes[2 * l] * host_shapes[2 * l + 1];
   if (cells > S) return MSS_ERR_BAD_ARG;
@@ -1352,17 +1440,16 @@ static int msda_backward_binned(const float* value, const int64_t* shapes, const
   float* halo = reinterpret_cast<float*>(base + w.halo);
   hipError_t e = hipMemsetAsync(base, 0, w.counts + (size_t)w.nkeys * 4, stream);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(msda_absmax_kernel, dim3(1024), dim3(256), 0, stream, gout, npairs * D, attn, npairs * L * P, absmax);
   const long long per_image = (long long)Lq * M * L * P;
   const unsigned chunks = (unsigned)((per_image + MSDA_BIN_CHUNK - 1) / MSDA_BIN_CHUNK);
-  const size_t hist_bytes = (size_t)M * g.ntiles * sizeof(int);
+  const size_t hist_bytes = (size_t)M * g.ntiles * sizeof(int) + 16 * sizeof(float);
   hipLaunchKernelGGL(msda_bin_kernel<0>, dim3(chunks, (unsigned)N), dim3(MSDA_BIN_NT), hist_bytes, stream, g, loc, attn, M, Lq, P,
-                     counts, records);
+                     counts, records, absmax + 1, gout, npairs * D);          // + max|grad_out|
   hipLaunchKernelGGL(msda_bin_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, (int)w.nkeys, offsets, cursor);
   hipLaunchKernelGGL(msda_bin_kernel<1>, dim3(chunks, (unsigned)N), dim3(MSDA_BIN_NT), hist_bytes, stream, g, loc, attn, M, Lq, P,
-                     cursor, records);
+                     cursor, records, absmax + 1, gout, 0ll);       // + max|attn| over the filed samples
   const size_t win_bytes = (size_t)MSDA_BIN_WIN * 32 * sizeof(unsigned long long);
-  auto kern = msda_bwd_value_binned_kernel<4>;
+  auto kern = msda_bwd_value_binned_kernel<8>;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes);
   if (e != hipSuccess) return (int)e;
   const long long nitems = (long long)g.ntiles * N * M;
@@ -1476,8 +1563,9 @@ long long mss_msda_backward_workspace_bytes(const int64_t* host_shapes, int N, i
   MsdaBinGeom g;
   MsdaBinWs w;
   if (!host_shapes || D != 32 || N <= 0 || Lq <= 0 || M <= 0 || P <= 0 || M > 65535 || (long long)Lq * P > (1ll << 22)) return 0;
+  if ((unsigned long long)N * Lq * M * D * 4ull >= 0xffffffffull) return 0;
   if ((size_t)4 * 8 * L * P * 3 * sizeof(float) > 65536) return 0;
-  if (!msda_bin_geom(host_shapes, L, Lq, P, g) || !msda_bin_layout(g, N, M, L, Lq, P, w)) return 0;
+  if (!msda_bin_geom(host_shapes, L, Lq, P, (long long)N * Lq * M * L * P, g) || !msda_bin_layout(g, N, M, L, Lq, P, w)) return 0;
   return (long long)w.total;
 }
 

@@ -27,6 +27,25 @@ _STRUCTURE = [3, 3, 6, 3, 1, 1]
 _CHANNELS = [(128, 128), (256, 256), (512, 512), (512, 1024), (512, 1024, 2048), (1024, 2048, 4096)]
 _ASPP_RATES = (12, 24, 36)   # output_stride 8 doubles (6, 12, 18): deepv3.py:53-54
 
+# Accuracy-aware Winograd tile caps per trunk module (round 3). F(6x6) rounds 3x coarser than F(4x4), and what a layer's
+# rounding does to the logits depends on where the layer sits: measured at 2x3x1024x2048 in train mode against the
+# reference's own outputs (tools/attribute_wino_error.py, profiles/r03/wino_attribution_*.txt), ONE mod2 layer on F(6x6)
+# moves the logits by 3-4e-5 rms (max 2.9e-4), one mod4 layer by 1-2e-5, one mod6/mod7/ASPP/decoder layer by <= 7e-6: the
+# residual stream is small early on and every later BatchNorm re-amplifies what was injected into it. The contributions add
+# in quadrature, so the cap goes where the error per saved millisecond is largest:
+#   fast      every layer on the cheapest tile (the round-2 policy): max |dlogit| 7.1e-4 against the direct kernels
+#   balanced  mod2 + mod3 on F(4x4) (default)
+#   strict    mod2 + mod3 + mod4 on F(4x4)
+_WINO_CAPS = {"fast": {}, "balanced": {"mod2": 4, "mod3": 4}, "strict": {"mod2": 4, "mod3": 4, "mod4": 4}}
+
+
+def wino_cap(module_name):
+    """Largest Winograd output tile the trunk module `module_name` may use (MSS_WINO_ACCURACY=fast|balanced|strict)."""
+    mode = os.environ.get("MSS_WINO_ACCURACY", "balanced")
+    if mode not in _WINO_CAPS:
+        raise ValueError(f"MSS_WINO_ACCURACY={mode!r}: expected one of {sorted(_WINO_CAPS)}")
+    return _WINO_CAPS[mode].get(module_name, 6)
+
 
 def _bnrelu(c):
     return nn.Sequential(nn.BatchNorm2d(c), nn.ReLU(inplace=True))
@@ -180,15 +199,18 @@ class DeepWV3Plus(nn.Module):
             shortcut = a
         d = blk.dilation
         c = blk.convs
+        cap = wino_cap(name)
         if not blk.bottleneck:
             # want_stats: the producing kernel leaves the batch statistics the next train-mode BatchNorm needs
-            o = K.conv3x3(a, c.conv1.weight, dil=d, stride=blk.stride, in_affine=aff1, in_relu=True, want_stats=train)
+            o = K.conv3x3(a, c.conv1.weight, dil=d, stride=blk.stride, in_affine=aff1, in_relu=True, want_stats=train,
+                          max_tile=cap)
             st2 = K.bn_fold(c.bn2[0], o, train)
             return K.conv3x3(o, c.conv2.weight, dil=d, in_affine=self._dropout_affine(st2, blk, name, a.N), in_relu=True,
-                             res=shortcut, want_stats=train)
+                             res=shortcut, want_stats=train, max_tile=cap)
         o = K.conv2d(a, K.packed(c.conv1.weight), stride=blk.stride, in_affine=aff1, in_relu=True, want_stats=train)
         st2 = K.bn_fold(c.bn2[0], o, train)
-        o2 = K.conv3x3(o, c.conv2.weight, dil=d, in_affine=(st2.scale, st2.shift), in_relu=True, want_stats=train)
+        o2 = K.conv3x3(o, c.conv2.weight, dil=d, in_affine=(st2.scale, st2.shift), in_relu=True, want_stats=train,
+                       max_tile=cap)
         st3 = K.bn_fold(c.bn3[0], o2, train)
         return K.conv2d(o2, K.packed(c.conv3.weight), in_affine=self._dropout_affine(st3, blk, name, a.N), in_relu=True,
                         res=shortcut, want_stats=train)

@@ -303,7 +303,7 @@ def packed_wino(param, flip=False, tile=2):
 
 # measured on MI355X (tools/bench_wino.py): F(2x2) 0.87x at 128 channels, 1.24-1.28x at 256, 1.7-2.1x at >= 512;
 # F(4x4) 1.29x at 128 channels, 2.0x at 256, 2.4-3.4x at >= 512; F(6x6): 64 -> 128 at 512x1024 1.50 -> 0.8 ms
-WINOGRAD_MIN_CHANNELS = {2: 256, 4: 128, 6: 64}
+WINOGRAD_MIN_CHANNELS = {2: 256, 4: int(os.environ.get("MSS_WINO_F4_MIN_CHANNELS", "128")), 6: 64}
 WINO_TILE_OF_P = {16: 2, 36: 4, 64: 6}
 
 
@@ -318,21 +318,22 @@ def use_winograd(c_in, k_out, stride, in_affine=None, tile=2):
     return c_in >= lo and k_out >= lo and c_in % 16 == 0 and k_out % 4 == 0
 
 
-def wino_tile(H, W, dil):
+def wino_tile(H, W, dil, max_tile=6):
     """Output-tile edge m of F(m x m, 3x3) for a layer: the one with fewer Winograd-domain elements
     (tiles x (m+2)^2), which decides both the MFMA work and the transform traffic: 1.78 per output pixel for m = 6,
     2.25 for m = 4, 4 for m = 2, unless the dilation sub-grid is so small that the larger tiles are mostly padding
     (e.g. a 12x16 map at dilation 12; the 4x8 sub-grids of dilation 36 at 128x256 stay on 4x4 tiles, the 6x11 ones of
     dilation 24 go from six 4x4 tiles to two 6x6 tiles). m = 6 carries 3x the fp32 rounding error of m = 4 (5.8e-6 vs
-    1.9e-6 of the output per layer, tools/wino_matrices.py), so it must save at least 5 % to be chosen.
-    MSS_WINO_TILE=2|4|6 forces one, MSS_WINO_MAX_TILE=4 keeps the policy off 6x6 tiles."""
+    1.9e-6 of the output per layer, tools/wino_matrices.py), so it must save at least 5 % to be chosen, and the caller
+    caps it (`max_tile`) on the layers whose error the rest of the network amplifies most (deepv3.wino_cap).
+    MSS_WINO_TILE=2|4|6 forces one, MSS_WINO_MAX_TILE=4 keeps the policy off 6x6 tiles everywhere."""
     forced = os.environ.get("MSS_WINO_TILE")
     if forced:
         return int(forced)
     hs, ws = -(-H // dil), -(-W // dil)
     cost = {m: (-(-hs // m)) * (-(-ws // m)) * (m + 2) ** 2 for m in (2, 4, 6)}
     best = 4 if cost[4] < cost[2] else 2
-    if int(os.environ.get("MSS_WINO_MAX_TILE", "6")) >= 6 and cost[6] <= 0.95 * cost[best]:
+    if min(max_tile, int(os.environ.get("MSS_WINO_MAX_TILE", "6"))) >= 6 and cost[6] <= 0.95 * cost[best]:
         best = 6
     return best
 
@@ -355,11 +356,12 @@ def set_tile_hook(fn):
 
 
 def conv3x3(x, weight, dil=1, stride=1, in_affine=None, in_relu=False, res=None, out=None, flip=False, keep_xt=None,
-            want_stats=False):
+            want_stats=False, max_tile=6):
     """3x3 convolution with padding = dilation on nn.Conv2d-layout `weight` (flip=True: its data gradient),
-    through Winograd when the policy says so, else through the direct implicit GEMM."""
+    through Winograd when the policy says so, else through the direct implicit GEMM. max_tile: accuracy cap on the
+    Winograd tile edge for this layer (0: no Winograd at all)."""
     k_out, c_in = (weight.shape[1], weight.shape[0]) if flip else (weight.shape[0], weight.shape[1])
-    tile = wino_tile(x.H, x.W, dil)
+    tile = wino_tile(x.H, x.W, dil, max_tile) if max_tile else 0
     if _tile_hook is not None and not flip:
         forced = _tile_hook(dict(H=x.H, W=x.W, dil=dil, c_in=c_in, k_out=k_out, stride=stride, policy_tile=tile))
         if forced == 0:
@@ -367,7 +369,7 @@ def conv3x3(x, weight, dil=1, stride=1, in_affine=None, in_relu=False, res=None,
                           res=res, out=out, want_stats=want_stats)
         if forced:
             tile = forced
-    if use_winograd(c_in, k_out, stride, in_affine, tile):
+    if tile and use_winograd(c_in, k_out, stride, in_affine, tile):
         return conv2d_winograd(x, packed_wino(weight, flip, tile), dil=dil, in_affine=in_affine,
                                in_relu=in_relu, res=res, out=out, keep_xt=keep_xt, want_stats=want_stats)
     return conv2d(x, packed(weight, flip), stride=stride, dil=dil, pad=dil, in_affine=in_affine, in_relu=in_relu, res=res,

@@ -32,6 +32,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fixture", default="deepwv3plus_train_step_2x1024x2048")
     ap.add_argument("--tiles", default="policy,4")
+    ap.add_argument("--totals-only", action="store_true", help="only the direct / policy / policy<=4 rows")
+    ap.add_argument("--tag", default="")
     args = ap.parse_args()
     g = np.load(os.path.join(ROOT, "tests", "golden", args.fixture + ".npz"))
     pairs, h, w = (int(v) for v in g["shape"])
@@ -98,7 +100,7 @@ def main():
              f"policy   vs reference: {report['policy']['vs_reference']}  vs direct: {report['policy']['vs_direct']}",
              f"policy<=4 vs reference: {report['policy_max_tile_4']['vs_reference']}  vs direct: {report['policy_max_tile_4']['vs_direct']}",
              "", f"{'#':>2} {'HxW':>10} {'dil':>3} {'Cin':>5} {'Cout':>5} {'tile':>4} | {'max|dlogit|':>11} {'rms':>9} {'flips':>6} | F(4x4): {'max':>9} {'rms':>9}"]
-    for i, info in enumerate(layers):
+    for i, info in enumerate([] if args.totals_only else layers):
         ent = dict(info, index=i)
         if not K.use_winograd(info["c_in"], info["k_out"], info["stride"], None, info["policy_tile"]):
             ent["winograd"] = False
@@ -118,8 +120,10 @@ def main():
                      f"         {b.get('max_abs_logit_diff', 0):9.2e} {b.get('rms_logit_diff', 0):9.2e}")
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    json.dump(report, open(os.path.join(out, "wino_attribution.json"), "w"), indent=1)
-    open(os.path.join(out, "wino_attribution.txt"), "w").write("\n".join(lines) + "\n")
+    report["policy_tiles"] = [info["policy_tile"] for info in layers]
+    lines.insert(1, f"MSS_WINO_ACCURACY={os.environ.get('MSS_WINO_ACCURACY', 'balanced')}; policy tiles per forward 3x3 layer: {report['policy_tiles']}")
+    json.dump(report, open(os.path.join(out, f"wino_attribution{args.tag}.json"), "w"), indent=1)
+    open(os.path.join(out, f"wino_attribution{args.tag}.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
 
