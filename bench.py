@@ -14,8 +14,11 @@ has the same amount of work (weak scaling); `value` is whole-job images/s. Input
 the device before the timed region; weights are synthetic (multishiftseg_amd.synth), fp32 throughout.
 
 One JSON line on rank 0 carries the step metric, the fp32-MFMA roofline of the dominant kernel
-(gemm_nt / conv_igemm, timed live with HIP events on the launch stream), the OOD-score Mpix/s of the eval path,
-and -- at N=1 -- a CPU baseline (the numpy oracle, bounded sample).
+(gemm_nt / conv_igemm: HIP events on the launch stream around every launch, in a SECOND pass of K steps right after the
+timed region so that the ~110 event records per step are not charged to `value`), `parity` (the default route against the
+reference's own outputs at this very configuration, argmax flips over all pixels), the OOD-score Mpix/s of the eval path
+(eager, score-only, hipGraph), at N = 1 the Mask2Former legs (`m2f`: MSDeformAttn op, pixel decoder, fused score, metric
+sweep) and a CPU baseline (stock-torch restatements on the host's cores, bounded samples), at N > 1 `comm`.
 """
 import argparse
 import json
@@ -83,30 +86,96 @@ def cpu_baseline(bench_hw):
                 c1_numpy_vs_torch_max_abs_logit_diff=agree, bench_fwd_s=t_big, bench_hw=[H, W], host=_host_info())
 
 
+def cpu_baseline_msda():
+    """SURVEY 8(d) "MSDA: grid_sample-based restatement at C4": the forward of the op at N = 1, Lq = S = 10 164 (levels
+    22^2 / 44^2 / 88^2, 8 heads x 32 channels, 4 points) composed from stock torch CPU ops the way the reference's own CPU path
+    composes it (oracle/msda.py:forward_sampled <- ops/functions/ms_deform_attn_func.py:52-72); 1 warm-up + 3 runs, median."""
+    import statistics
+    from oracle import msda as omsda
+    rng = np.random.default_rng(0)
+    shapes = np.array([(22, 22), (44, 44), (88, 88)], dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(shapes.prod(1))[:-1]]).astype(np.int64)
+    S = int(shapes.prod(1).sum())
+    value = rng.standard_normal((1, S, 8, 32), dtype=np.float32)
+    loc = rng.random((1, S, 8, 3, 4, 2), dtype=np.float32)
+    attn = rng.random((1, S, 8, 3, 4), dtype=np.float32)
+    attn /= attn.sum((-1, -2), keepdims=True)
+    runs = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        omsda.forward_sampled(value, shapes, starts, loc, attn)
+        if i:
+            runs.append(time.perf_counter() - t0)
+    return {"forward_c4_n1_s": round(statistics.median(runs), 4), "runs_s": [round(r, 4) for r in runs], "tokens": S,
+            "kind": "port", "threads": torch.get_num_threads(),
+            "sample": "MSDeformAttn forward, N=1, 10 164 queries x 8 heads x 12 samples, stock torch grid_sample composition"}
+
+
+def parity_check(model, H, W, pairs):
+    """The default route of THIS process against the reference's own outputs at THIS configuration (fixture generated by
+    importing the reference: tools/gen_golden.py train_c3 -> tests/golden/deepwv3plus_train_step_2x1024x2048.npz; data only):
+    train-mode forward with the fixture's Dropout2d masks; max |error| on the stored strided logit / score slices and argmax
+    flips against the reference's full label map over ALL pixels. Running statistics are restored afterwards."""
+    path = os.path.join(ROOT, "tests", "golden", f"deepwv3plus_train_step_{2 * pairs}x{H}x{W}.npz")
+    if not os.path.exists(path):
+        return None
+    from multishiftseg_amd import synth
+    g = np.load(path)
+    pre = "stage2_"
+    dev = next(model.parameters()).device
+    saved = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    was = model.training
+    try:
+        model.train()
+        model.dropout_masks = {"mod6": torch.from_numpy(g[pre + "drop_mod6"]), "mod7": torch.from_numpy(g[pre + "drop_mod7"])}
+        img = torch.from_numpy(synth.synth_image(int(g["image_seed"]), 2 * pairs, H, W)).to(dev)
+        with torch.no_grad():
+            score, logit = model(img)
+        ss, ls = int(g["score_stride"]), int(g["logit_stride"])
+        flip = logit.argmax(1).to(torch.uint8) != torch.from_numpy(g[pre + "label"]).to(dev)
+        clear = torch.from_numpy(np.unpackbits(g[pre + "clear_bits_1e3"])[:flip.numel()].reshape(tuple(flip.shape)).astype(bool)).to(dev)
+        return {"against": "reference outputs (tests/golden/" + os.path.basename(path) + ", train-mode forward, reference Dropout2d masks)",
+                "max_abs_logit_err": float((logit[:, :, ::ls, ::ls] - torch.from_numpy(g[pre + "logit_sub"]).to(dev)).abs().max()),
+                "max_abs_score_err": float((score[:, ::ss, ::ss] - torch.from_numpy(g[pre + "score"]).to(dev)).abs().max()),
+                "compared": f"every {ls}th logit / {ss}th score in each direction", "tolerance": 1e-3,
+                "argmax_flips_all_pixels": int(flip.sum()), "pixels": int(flip.numel()),
+                "argmax_flips_where_reference_margin_gt_1e-3": int((flip & clear).sum()),
+                "wino_accuracy": os.environ.get("MSS_WINO_ACCURACY", "strict")}
+    finally:
+        model.dropout_masks = None
+        model.load_state_dict(saved)
+        model.train(was)
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes through torch.distributed.run as a
     CHILD process (never exec: this image forbids replacing a process image once a GPU runtime is loaded, and the
     parent must not touch the GPU at all -- it has not: nothing before this point makes a HIP call), relay what
     rank 0's ONE JSON line on stdout (anything else the ranks or their libraries write to stdout -- e.g. gloo's connection
     banner -- goes to stderr, so that stdout stays one line) and exit with the launcher's status."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own c10d rendezvous on a port IT picks and binds (no bind-close-rebind race)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this host driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    relayed = 0
     for line in proc.stdout:
         if line.startswith('{"metric"'):
             sys.stdout.write(line)
             sys.stdout.flush()
+            relayed += 1
         else:
             sys.stderr.write(line)
-    return proc.wait()
+    rc = proc.wait()
+    if rc == 0 and relayed != 1:
+        sys.stderr.write(f"bench.py: the ranks exited 0 but rank 0 printed {relayed} result lines\n")
+        return 1
+    if rc != 0:
+        sys.stderr.write(f"bench.py: torch.distributed.run exited with status {rc}; no result line is valid\n")
+    return rc
 
 
 def launch_check(args):
@@ -124,11 +193,9 @@ def launch_check(args):
     sync = ddp.GradAllReduce(named, bucket_bytes=(48 << 20) if device.type == "cuda" else (1 << 19))
 
     def one_step(k):
-        grads = [(n, torch.full((sz,), float(rank + 1 + k), device=device)) for n, sz in sizes]
-        for n, g in grads:
-            sync(n, g)
+        grads = [(n, sync(n, torch.full((sz,), float(rank + 1 + k), device=device))) for n, sz in sizes]
         sync.backward_done()
-        return grads
+        return [(n, g if g is not None else torch.full((sz,), float(rank + 1 + k), device=device)) for (n, g), (_, sz) in zip(grads, sizes)]
 
     def sync_dev():
         if device.type == "cuda":
@@ -183,6 +250,8 @@ def main():
                     help="local: per-rank loss (no loss collectives); global: reference semantics over all ranks' pairs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ood", action="store_true")
+    ap.add_argument("--no-m2f", action="store_true", help="skip the Mask2Former legs (`m2f`, N=1 only, ~40 s)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the live check against the reference fixture (`parity`)")
     ap.add_argument("--no-experimental", action="store_true",
                     help="skip the extra, separately reported run with MSS_GEMM_BF16X6=1 (N=1 only; never part of `value`)")
     args = ap.parse_args()
@@ -229,8 +298,6 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    prof = K.ConvProfile()
-    K.set_conv_profile(prof)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -241,12 +308,49 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    K.set_conv_profile(None)
     loss_val = float(loss.detach())
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # second, UNTIMED pass of the same K steps with a HIP event pair around every MFMA launch (the roofline leg)
+    prof = K.ConvProfile()
+    K.set_conv_profile(prof)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    elapsed_profiled = time.perf_counter() - t1
+    K.set_conv_profile(None)
+
+    comm = None
+    if world > 1:
+        # exposed communication = step(N) - the same step with the collectives switched off (everything else -- scaling into
+        # the flat buffers, stream waits -- still runs): a fresh TrainStep under MSS_DDP_NO_COMM=1, same inputs
+        os.environ["MSS_DDP_NO_COMM"] = "1"
+        try:
+            step_nc = TrainStep(model, crit, stage=args.stage)
+            for _ in range(max(1, args.warmup)):
+                step_nc(img, target0.clone())
+            dist.barrier()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                step_nc(img, target0.clone())
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_nc = torch.tensor([time.perf_counter() - t2], device=device, dtype=torch.float64)
+            dist.all_reduce(t_nc, op=dist.ReduceOp.MAX)
+            sync = step.sync
+            comm = {"gradient_bytes_per_step": sync.bytes_per_step, "buckets": len(sync.buckets),
+                    "bucket_bytes": [4 * n for n in sync.sizes], "backend": dist.get_backend(),
+                    "ms_per_step_without_collectives": round(1e3 * float(t_nc) / args.steps, 3),
+                    "exposed_ms_per_step": round(1e3 * (elapsed - float(t_nc)) / args.steps, 3),
+                    "note": "exposed = ms_per_step - the same step with the all-reduces skipped (MSS_DDP_NO_COMM=1), max over ranks"}
+        finally:
+            os.environ.pop("MSS_DDP_NO_COMM", None)
 
     if rank != 0:
         if world > 1:
@@ -285,6 +389,8 @@ def main():
                    "rccl_ranks": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else 0),
                    "loss_pairing": "device", "loss_sync": args.loss_sync, "loss": round(loss_val, 4)},
         "roofline": {"bound": "mfma", "kernel": dom + "_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+                     "measured": f"HIP events on the launch stream around every launch, second (untimed) pass of the same {args.steps} steps "
+                                 f"({1e3 * elapsed_profiled / args.steps:.2f} ms/step with the event records)",
                      "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": round(alg_bytes / max(conv["launches"], 1)),
@@ -298,6 +404,13 @@ def main():
                                            "launches_per_step": v["launches"] // max(args.steps, 1),
                                            "avg_launch_ms": round(v["ms"] / max(v["launches"], 1), 4),
                                            "kernel_ms_per_step": round(v["ms"] / max(args.steps, 1), 2)} for k, v in kinds.items()}
+    if comm is not None:
+        out["comm"] = comm
+    if not args.no_parity and args.workload == "c3":
+        try:
+            out["parity"] = parity_check(model, H, W, pairs)
+        except Exception as exc:        # never lose the measurement to the checker
+            out["parity"] = {"error": repr(exc)}
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
     # they cannot be collected from inside this process); the summary of the last such run is kept in profiles/
     tpath = os.path.join(ROOT, "profiles", "conv_traffic_latest.json")
@@ -308,8 +421,10 @@ def main():
             out["roofline"]["traffic"] = round(fam["hbm_bytes_per_launch"] if fam else tj["hbm_bytes_per_launch"])
             # the same counters as a rate over this run's measured launch time (8000 GB/s HBM peak for comparison)
             out["roofline"]["memory_side_GBs"] = round(out["roofline"]["traffic"] / (out["roofline"]["avg_launch_ms"] * 1e-3) / 1e9, 1)
-            out["roofline"]["traffic_note"] = ("bytes per launch, L2-memory-side (Infinity-Cache hits included), from "
-                                               "profiles/conv_traffic_latest.json: " + tj["correction"])
+            out["roofline"]["traffic_source"] = "from_profile"
+            out["roofline"]["traffic_note"] = ("NOT measured in this run: bytes per launch, L2-memory-side (Infinity-Cache hits included), from "
+                                               "the rocprofv3 --pmc passes kept in profiles/conv_traffic_latest.json (tree "
+                                               + str(tj.get("git_commit", "unknown")) + "): " + tj["correction"])
         except Exception:
             pass
     try:
@@ -382,19 +497,51 @@ def main():
         e.record()
         torch.cuda.synchronize()
         kl_ms = s.elapsed_time(e) / 20
+        from multishiftseg_amd.trainer import GraphedEval
+
+        def time_eval(fn, n=5):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            tt = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - tt) / n
+        dt_so = time_eval(lambda: ood_scores(model, e_img, score_only=True))
+        ge = GraphedEval(model, e_img.shape, score_only=True)
+        dt_graph = time_eval(lambda: ge(e_img))
+        del ge
         out["ood_score"] = {"end_to_end_mpix_s": round(H * W / dt / 1e6, 3), "end_to_end_ms": round(dt * 1e3, 2),
+                            "score_only_mpix_s": round(H * W / dt_so / 1e6, 3), "score_only_ms": round(dt_so * 1e3, 2),
+                            "score_only_hipgraph_mpix_s": round(H * W / dt_graph / 1e6, 3), "score_only_hipgraph_ms": round(dt_graph * 1e3, 2),
+                            "note": "end_to_end: eval forward -> (score, logits), eager; score_only: what test_deeplab.py:92-96 consumes; "
+                                    "hipgraph: the same forward captured once and replayed (trainer.GraphedEval)",
                             "tail_kernel_mpix_s": round(H * W / (k_ms * 1e-3) / 1e6, 1),
                             "tail_kernel_GBs": round(23.0 * H * W / (k_ms * 1e-3) / 1e9, 1),
                             "tail_kernel_with_logits_us": round(kl_ms * 1e3, 1),
                             "tail_kernel_with_logits_GBs": round(118.0 * H * W / (kl_ms * 1e-3) / 1e9, 1), "hbm_peak_GBs": 8000,
                             "image": f"1x3x{H}x{W}"}
 
+    if world == 1 and not args.no_m2f:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import m2f_legs
+            out["m2f"] = m2f_legs.measure()
+            if cpu is not None:
+                cm = cpu_baseline_msda()
+                gpu_ms = out["m2f"]["msda"]["c4_n1"]["forward_ms"]
+                cm["gpu_forward_ms"] = gpu_ms
+                out["m2f"]["msda"]["cpu_baseline"] = cm
+        except Exception as exc:
+            out["m2f"] = {"error": repr(exc)}
+
     if cpu is not None:
         ratio = STAGE2_STEP_OVER_FWD if args.stage == 2 else 1.0
         out["cpu_baseline"] = {
             "value": round(1.0 / (cpu["bench_fwd_s"] * ratio), 6), "unit": "images/s", "cores": cpu["host"]["torch_threads"],
-            "kind": "port",
-            "sample": f"stock torch CPU ops composing the same graph (oracle/deepv3_torch.py): ONE eval forward of a 1x3x{H}x{W} image "
+            "kind": "port", "extrapolated": True,
+            "sample": f"EXTRAPOLATED, not a timed CPU train step: stock torch CPU ops composing the same graph (oracle/deepv3_torch.py): ONE eval forward of a 1x3x{H}x{W} image "
                       f"({cpu['bench_fwd_s']:.2f} s) x the stage-{args.stage} step/forward FLOP ratio {ratio} (SURVEY 8d) -> train images/s; "
                       "C1 (1x3x512x1024 eval forward + OOD score): 1 warm-up + 3 runs, median, in `c1`",
             "c1": {"image": "1x3x512x1024", "torch_runs_s": cpu["c1_runs_s"], "torch_median_s": round(cpu["c1_median_s"], 3),

@@ -16,24 +16,32 @@ import torch.distributed as dist
 class GradAllReduce:
     """Bucketed, overlapped gradient averaging. Use as ``model.grad_sink``.
 
-    ``order``: parameter names in the order the backward produces them (heads first, ASPP last);
-    consecutive names are grouped into buckets of at most ``bucket_bytes``. A bucket is flattened
-    and all-reduced when its last gradient arrives. ``backward_done`` (called by the model at the
-    end of its backward) makes the compute stream wait for the communication stream, then the
-    averaged values are copied back into the gradient tensors autograd is about to hand out.
+    ``named_params``: (name, parameter) in the order the backward produces the gradients (heads first, ASPP last);
+    consecutive names are grouped into buckets of at most ``bucket_bytes``. Every bucket owns ONE persistent flat buffer:
+    a gradient is scaled by 1/world straight into its slice the moment it exists (one pass), the bucket is all-reduced IN
+    PLACE on a side stream as soon as it is complete, and what autograd receives is the slice itself -- no concatenation,
+    no division pass, no copy back (round 2 made three passes over the 123 MB of stage 2).
+
+    The sequence of collectives never depends on which gradients a rank produced: buckets are launched strictly in index
+    order (a complete bucket waits for its incomplete predecessors until ``backward_done``), every bucket is launched
+    every step, and a gradient that did not arrive travels as zeros and still receives the average (it is assigned to
+    ``param.grad`` of a parameter that requires grad) -- ranks can therefore never pair collectives of different sizes.
     """
 
     def __init__(self, named_params, bucket_bytes=64 << 20, group=None, force=False):
-        """force: run the collectives even in a one-rank group (exercises the RCCL path on a single GPU; tests)."""
+        """force: run the collectives even in a one-rank group (exercises the RCCL path on a single GPU; tests).
+        MSS_DDP_NO_COMM=1 (bench / tests only): everything but the collective itself -- the exposed-communication probe."""
+        import os
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
+        self.no_comm = os.environ.get("MSS_DDP_NO_COMM") == "1"
         self.buckets = []       # list of lists of names (fixed at construction: every rank reduces the same layout)
-        self.where = {}         # name -> bucket index
-        self.shapes = {}        # name -> (shape, dtype, device) for zero-filling a gradient that did not arrive
+        self.where = {}         # name -> (bucket index, offset, numel)
+        self.params = {}        # name -> parameter
         cur, cur_bytes = [], 0
         for name, p in named_params:
-            self.shapes[name] = (tuple(p.shape), p.dtype, p.device)
+            self.params[name] = p
             nbytes = p.numel() * p.element_size()
             if cur and cur_bytes + nbytes > bucket_bytes:
                 self.buckets.append(cur)
@@ -42,79 +50,91 @@ class GradAllReduce:
             cur_bytes += nbytes
         if cur:
             self.buckets.append(cur)
+        self.sizes = []
         for i, b in enumerate(self.buckets):
+            off = 0
             for n in b:
-                self.where[n] = i
+                self.where[n] = (i, off, self.params[n].numel())
+                off += self.params[n].numel()
+            self.sizes.append(off)
+        self.flat = [None] * len(self.buckets)          # persistent, allocated on first use
         self.comm_stream = None
+        self.bytes_per_step = sum(self.sizes) * 4
         self._reset()
 
     def _reset(self):
-        self.pending = [dict() for _ in self.buckets]
-        self.inflight = []      # (flat, [(name, tensor)], work)
+        self.arrived = [set() for _ in self.buckets]
+        self.next_bucket = 0
+        self.inflight = []      # (bucket index, work)
+
+    def _buffer(self, i):
+        if self.flat[i] is None:
+            p = self.params[self.buckets[i][0]]
+            self.flat[i] = torch.zeros(self.sizes[i], dtype=p.dtype, device=p.device)
+        return self.flat[i]
 
     def __call__(self, name, grad):
+        """Returns the tensor to hand to autograd in place of `grad` (a view of the bucket's flat buffer, holding the
+        average once backward_done() has returned), or None when this sink does not handle `name`."""
         if not self.active or name not in self.where:
-            return
-        i = self.where[name]
-        self.pending[i][name] = grad
-        if len(self.pending[i]) == len(self.buckets[i]):
-            self._launch(i)
+            return None
+        i, off, n = self.where[name]
+        view = self._buffer(i)[off:off + n].view(grad.shape)
+        torch.mul(grad, 1.0 / self.world, out=view)
+        self.arrived[i].add(name)
+        while self.next_bucket < len(self.buckets) and len(self.arrived[self.next_bucket]) == len(self.buckets[self.next_bucket]):
+            self._launch(self.next_bucket)
+            self.next_bucket += 1
+        return view
 
     def _launch(self, i):
-        # a gradient that is absent this step (parameter frozen after construction, unused branch) travels as zeros
-        # so that the message layout never depends on which gradients a rank happened to produce
-        items = []
-        for n in self.buckets[i]:
-            g = self.pending[i].get(n)
-            if g is None:
-                shape, dtype, dev = self.shapes[n]
-                g = torch.zeros(shape, dtype=dtype, device=dev)
-                items.append((n, g, False))
-            else:
-                items.append((n, g, True))
-        self.pending[i] = {}
-        if items[0][1].is_cuda:
+        flat = self._buffer(i)
+        for n in self.buckets[i]:                     # a gradient that is absent this step travels as zeros
+            if n not in self.arrived[i]:
+                _, off, cnt = self.where[n]
+                flat[off:off + cnt].zero_()
+        if self.no_comm:
+            self.inflight.append((i, None))
+            return
+        if flat.is_cuda:
             if self.comm_stream is None:
                 self.comm_stream = torch.cuda.Stream()
-            flat = torch.cat([g.reshape(-1) for _, g, _ in items])
-            flat.div_(self.world)
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 work = dist.all_reduce(flat, group=self.group, async_op=True)
-            flat.record_stream(self.comm_stream)
         else:
-            flat = torch.cat([g.reshape(-1) for _, g, _ in items])
-            flat.div_(self.world)
             work = dist.all_reduce(flat, group=self.group, async_op=True)
-        self.inflight.append((flat, items, work))
+        self.inflight.append((i, work))
 
     def flush(self):
-        """Launch buckets that never filled (some of their parameters produced no gradient this step). The bucket
-        layout itself is never changed."""
-        for i, pend in enumerate(self.pending):
-            if pend:
-                self._launch(i)
+        """Launch, in index order, every bucket that has not been launched yet (some gradient of it, or of a predecessor,
+        did not arrive this step)."""
+        while self.next_bucket < len(self.buckets):
+            self._launch(self.next_bucket)
+            self.next_bucket += 1
 
     def backward_done(self):
         if not self.active:
             return
         self.flush()
-        for flat, items, work in self.inflight:
-            work.wait()          # CUDA: makes the current stream wait for the collective, no host block
-            off = 0
-            for _, g, present in items:
-                n = g.numel()
-                if present:
-                    g.copy_(flat[off:off + n].view_as(g))
-                off += n
+        for i, work in self.inflight:
+            if work is not None:
+                work.wait()      # CUDA: makes the current stream wait for the collective, no host block
+            for n in self.buckets[i]:
+                if n not in self.arrived[i]:
+                    p = self.params[n]
+                    if p.requires_grad:           # no local gradient this step, but the other ranks' average is this rank's too
+                        _, off, cnt = self.where[n]
+                        p.grad = self.flat[i][off:off + cnt].view(p.shape).clone()
         self._reset()
 
     def abort(self):
         """The backward is unwinding from an exception: start no further collective (the other ranks may never reach
         theirs), wait for the ones already in flight and forget this step's gradients."""
-        for _, _, work in self.inflight:
+        for _, work in self.inflight:
             try:
-                work.wait()
+                if work is not None:
+                    work.wait()
             except Exception:
                 pass
         self._reset()

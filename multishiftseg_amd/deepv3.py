@@ -28,20 +28,23 @@ _CHANNELS = [(128, 128), (256, 256), (512, 512), (512, 1024), (512, 1024, 2048),
 _ASPP_RATES = (12, 24, 36)   # output_stride 8 doubles (6, 12, 18): deepv3.py:53-54
 
 # Accuracy-aware Winograd tile caps per trunk module (round 3). F(6x6) rounds 3x coarser than F(4x4), and what a layer's
-# rounding does to the logits depends on where the layer sits: measured at 2x3x1024x2048 in train mode against the
-# reference's own outputs (tools/attribute_wino_error.py, profiles/r03/wino_attribution_*.txt), ONE mod2 layer on F(6x6)
-# moves the logits by 3-4e-5 rms (max 2.9e-4), one mod4 layer by 1-2e-5, one mod6/mod7/ASPP/decoder layer by <= 7e-6: the
-# residual stream is small early on and every later BatchNorm re-amplifies what was injected into it. The contributions add
-# in quadrature, so the cap goes where the error per saved millisecond is largest:
-#   fast      every layer on the cheapest tile (the round-2 policy): max |dlogit| 7.1e-4 against the direct kernels
-#   balanced  mod2 + mod3 on F(4x4) (default)
-#   strict    mod2 + mod3 + mod4 on F(4x4)
+# rounding does to the logits depends on where the layer sits. Measured at 2x3x1024x2048 in train mode against the
+# reference's own outputs (tools/attribute_wino_error.py, profiles/r03/wino_attribution_*.txt): ONE mod2 layer on F(6x6)
+# moves the logits by 3-4e-5 rms (max 2.9e-4), one mod3 layer by 2e-5, one mod4 layer by 1-2e-5, a mod5..mod7 / ASPP /
+# decoder layer by <= 1.2e-5 -- the residual stream is small early on and every later BatchNorm re-amplifies what was
+# injected into it. Contributions add in quadrature, so the cap goes where the error per saved millisecond is largest
+# (max |dlogit| against the direct kernels / against the reference, argmax flips of 4.2 M pixels, step time, same box):
+#   fast      every layer on the cheapest tile (the round-2 policy)     7.1e-4 / 5.6e-4   691 flips   107.96 ms
+#   balanced  mod2 + mod3 on F(4x4)                                       3.3e-4 / 2.7e-4   382         109.34 ms
+#   strict    mod2 + mod3 + mod4 on F(4x4)  (DEFAULT)                     2.4e-4 / 1.7e-4   243         109.70 ms
+# (the direct kernels themselves: - / 7.7e-5, 118 flips; every layer on F(4x4): 1.6e-4 / 1.3e-4, 184 flips, ~118 ms.)
+# mod4 costs next to nothing on F(4x4): its F(6x6) products have 1892 rows = 3.75 rounds of GEMM tiles.
 _WINO_CAPS = {"fast": {}, "balanced": {"mod2": 4, "mod3": 4}, "strict": {"mod2": 4, "mod3": 4, "mod4": 4}}
 
 
 def wino_cap(module_name):
     """Largest Winograd output tile the trunk module `module_name` may use (MSS_WINO_ACCURACY=fast|balanced|strict)."""
-    mode = os.environ.get("MSS_WINO_ACCURACY", "balanced")
+    mode = os.environ.get("MSS_WINO_ACCURACY", "strict")
     if mode not in _WINO_CAPS:
         raise ValueError(f"MSS_WINO_ACCURACY={mode!r}: expected one of {sorted(_WINO_CAPS)}")
     return _WINO_CAPS[mode].get(module_name, 6)
@@ -149,6 +152,9 @@ class DeepWV3Plus(nn.Module):
         self.grad_sink = None
         # test hook: {"mod6": [N,1024], "mod7": [N,2048]} pre-scaled Dropout2d masks
         self.dropout_masks = None
+        # eval only: forward returns (anomaly_score, None) and skips the 160 MB upsampled logit volume -- what the
+        # reference's test loop consumes (test_deeplab.py:92-96 keeps anomaly_score only)
+        self.score_only = False
 
     # ---- reference API ---------------------------------------------------------------------
     def energy_func(self, logit):
@@ -245,7 +251,7 @@ class DeepWV3Plus(nn.Module):
             self._heads_cache = (key, K.pack_weight(wh), K.pack_weight(wh, flip=True))
         return self._heads_cache[1], self._heads_cache[2]
 
-    def _head_forward(self, x, m2, size, keep=False):
+    def _head_forward(self, x, m2, size, keep=False, want_logit=True):
         train = self.training
         N, h8, w8 = x.N, x.H, x.W
         h2, w2 = m2.H, m2.W
@@ -300,7 +306,8 @@ class DeepWV3Plus(nn.Module):
         final_xt = {0: kx0.get("xt") if kx0 else None, 3: kx3.get("xt") if kx3 else None}
         wh, _ = self._heads_weight()
         dec12 = K.conv2d(f1, wh, in_affine=(st_f1.scale, st_f1.shift), in_relu=True)
-        score, logit, _ = K.ood_score(dec12.slice(20, 19), dec12.slice(0, 19), size[0], size[1])
+        score, logit, _ = K.ood_score(dec12.slice(20, 19), dec12.slice(0, 19) if want_logit else None, size[0], size[1],
+                                      want_logit=want_logit)
         saved = None
         if keep:
             saved = dict(aspp_xt=aspp_xt, x=x, m2=m2, raw=raw, scale=scale, shift=shift, states=states, pooled_act=pooled_act,
@@ -314,9 +321,11 @@ class DeepWV3Plus(nn.Module):
 
         class _Grads(dict):
             def __setitem__(self, k, v):
-                dict.__setitem__(self, k, v)
                 if sink is not None and v is not None and need.get(k):
-                    sink(k, v)
+                    r = sink(k, v)             # a sink may hand back the tensor autograd should get (ddp: its flat-buffer slice)
+                    if r is not None:
+                        v = r
+                dict.__setitem__(self, k, v)
         grads = _Grads()
         try:
             out = self._head_backward_impl(s, dscore, dlogit, names, need, grads)
@@ -411,5 +420,5 @@ class DeepWV3Plus(nn.Module):
             score, logit = _HeadFn.apply(self, x, m2, size, *params)
         else:
             with torch.no_grad():
-                score, logit, _ = self._head_forward(x, m2, size)
+                score, logit, _ = self._head_forward(x, m2, size, want_logit=self.training or not self.score_only)
         return score, logit

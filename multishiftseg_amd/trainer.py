@@ -79,13 +79,16 @@ class TrainStep:
 
 
 @torch.no_grad()
-def ood_scores(model, img):
-    """test_deeplab.py:86-90: eval-mode forward -> (anomaly_score, logit)."""
-    was = model.training
+def ood_scores(model, img, score_only=False):
+    """test_deeplab.py:86-90: eval-mode forward -> (anomaly_score, logit). score_only: (anomaly_score, None), the form the
+    reference's evaluation actually consumes (test_deeplab.py:92-96) -- the upsampled logit volume is never written."""
+    was, was_so = model.training, model.score_only
     model.eval()
+    model.score_only = bool(score_only)
     try:
         return model(img)
     finally:
+        model.score_only = was_so
         model.train(was)
 
 
@@ -93,26 +96,40 @@ class GraphedEval:
     """The eval forward (test_deeplab.py:86-90: image -> (anomaly_score, logit)) captured ONCE into a hipGraph and replayed:
     ~350 kernel launches per image become one graph launch, which removes the host launch path from the OOD-score
     throughput (the kernels take raw pointers and sizes, allocate nothing themselves and never synchronise, so the whole
-    forward is capturable; scratch tensors come from the graph's private pool). Fixed input shape; weights are read
-    through their pointers at replay time, so in-place weight updates are seen, re-packed forms (Winograd-domain /
-    MFMA layouts, cached per parameter version) are NOT -- call refresh() after changing weights."""
+    forward is capturable; scratch tensors come from the graph's private pool). Fixed input shape.
 
-    def __init__(self, model, shape, warmup=2):
-        self.model, self.shape = model, tuple(shape)
+    What a replay reads by raw pointer, and who keeps it alive: BatchNorm buffers and parameters (the model), and the
+    PACKED copies of every conv weight (MFMA / Winograd-domain layouts, made during the warm-up outside the graph's pool):
+    this object holds references to exactly the packed tensors that were current at capture (`_keep`), so a later re-pack by
+    an eager forward cannot free them under the graph. Packed copies do NOT follow in-place weight updates, so every call
+    compares each parameter's (version, data_ptr) with the capture-time signature and re-captures on any change
+    (optimizer step, load_state_dict, .to()); refresh() forces it."""
+
+    def __init__(self, model, shape, warmup=2, score_only=False):
+        self.model, self.shape, self.score_only = model, tuple(shape), bool(score_only)
         self.static_in = torch.zeros(self.shape, device="cuda", dtype=torch.float32)
+        self.captures = 0
         self._capture(warmup)
+
+    def _signature(self):
+        return [(p._version, p.data_ptr()) for p in self.model.parameters()] + \
+               [(b._version, b.data_ptr()) for b in self.model.buffers() if b.dtype.is_floating_point]
 
     def _capture(self, warmup):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                 # warm-up off the capture: packs weights, fills one-time caches
             for _ in range(warmup):
-                ood_scores(self.model, self.static_in)
+                ood_scores(self.model, self.static_in, self.score_only)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.static_out = ood_scores(self.model, self.static_in)
+            self.static_out = ood_scores(self.model, self.static_in, self.score_only)
+        # own what the graph reads: the packed forms current right now (+ the fused heads weight of the model)
+        self._keep = [dict(p.__dict__.get("_mss_packed", {})) for p in self.model.parameters()] + [self.model._heads_cache]
+        self._sig = self._signature()
+        self.captures += 1
 
     def refresh(self):
         self._capture(1)
@@ -120,6 +137,8 @@ class GraphedEval:
     def __call__(self, img):
         if tuple(img.shape) != self.shape:
             raise ValueError(f"GraphedEval was captured for {self.shape}, got {tuple(img.shape)}")
+        if self._signature() != self._sig:            # weights or BatchNorm buffers changed since the capture
+            self._capture(1)
         self.static_in.copy_(img)
         self.graph.replay()
         return self.static_out

@@ -87,3 +87,25 @@ def backward(value, shapes, starts, loc, attn, grad_out):
         grad_loc[:, :, :, l, :, 0] = np.where(inside, W * (gw * tgv).sum(-1), 0)       # .cuh:162
         grad_loc[:, :, :, l, :, 1] = np.where(inside, H * (gh * tgv).sum(-1), 0)       # .cuh:163
     return grad_value, grad_loc, grad_attn
+
+
+def forward_sampled(value, shapes, starts, loc, attn):
+    """The same result as `forward`, on stock torch CPU ops the way the reference's CPU path gets it
+    (`ms_deform_attn_core_pytorch`, ops/functions/ms_deform_attn_func.py:52-72): every level's [N*M, D, H, W] map is
+    re-sampled bilinearly (zero padding, align_corners=False, grid = 2*loc - 1) at each query's P locations; here the
+    level's attention weights are applied and accumulated level by level instead of stacking all L*P samples first.
+    bench.py's MSDA `cpu_baseline` times this on the GPU host (threads = torch.get_num_threads()). numpy in / out."""
+    import torch
+    from torch.nn.functional import grid_sample
+    v, lc, at = (torch.from_numpy(np.ascontiguousarray(a)) for a in (value, loc, attn))
+    N, S, M, D = v.shape
+    Lq, L, P = lc.shape[1], lc.shape[3], lc.shape[4]
+    acc = torch.zeros((N * M, D, Lq), dtype=v.dtype)
+    for l in range(L):
+        H, W, s0 = int(shapes[l][0]), int(shapes[l][1]), int(starts[l])
+        level_map = v[:, s0:s0 + H * W].permute(0, 2, 3, 1).reshape(N * M, D, H, W)
+        grid = (2 * lc[:, :, :, l] - 1).permute(0, 2, 1, 3, 4).reshape(N * M, Lq, P, 2)
+        sampled = grid_sample(level_map, grid, mode="bilinear", padding_mode="zeros", align_corners=False)   # [N*M, D, Lq, P]
+        weights = at[:, :, :, l].permute(0, 2, 1, 3).reshape(N * M, 1, Lq, P)
+        acc += (sampled * weights).sum(-1)
+    return acc.view(N, M * D, Lq).permute(0, 2, 1).contiguous().numpy()

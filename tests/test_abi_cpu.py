@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     extra = [n for n in exported if n not in names]
     assert not extra, f"exported but not declared in mss_hip.h: {extra}"
     handle = lib.load()
-    assert handle.mss_abi_version() == 1
+    assert handle.mss_abi_version() == lib.MSS_ABI_VERSION == int(re.search(r"#define MSS_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "mss_hip.h")).read()).group(1))
     assert lib.value("mss_conv2d_kpad", 19) == 64 and lib.value("mss_conv2d_kpad", 304) == 384
 
 

@@ -25,51 +25,58 @@ def _worker(rank, world, port, out):
     torch.manual_seed(0)
     shapes = {"ood_head.weight": (19, 256, 1, 1), "bot_fine.weight": (48, 128, 1, 1), "aspp.features.1.0.weight": (8, 16, 3, 3),
               "aspp.features.1.1.bias": (8,)}
-    params = [(n, torch.zeros(s)) for n, s in shapes.items()]
+    params = [(n, torch.zeros(s, requires_grad=True)) for n, s in shapes.items()]
     sync = ddp.GradAllReduce(params, bucket_bytes=30000)          # forces several buckets
     assert len(sync.buckets) >= 2
     grads = {n: torch.full(s, float(rank + 1)) + torch.arange(int(torch.tensor(s).prod())).reshape(s) for n, s in shapes.items()}
     expect = {n: (sum(torch.full(s, float(k + 1)) for k in range(world)) / world
                   + torch.arange(int(torch.tensor(s).prod())).reshape(s)) for n, s in shapes.items()}
-    for n in shapes:                                              # arrival order = backward order
-        sync(n, grads[n])
+    # the sink hands back what autograd should receive: the gradient's slice of the bucket's persistent flat buffer,
+    # holding the average once backward_done() has returned
+    got = {n: sync(n, grads[n]) for n in shapes}                  # arrival order = backward order
     sync.backward_done()
-    ok = all(torch.allclose(grads[n], expect[n]) for n in shapes)
-    # second step reuses the object
-    for n in shapes:
-        grads[n].fill_(float(rank))
-        sync(n, grads[n])
+    ok = all(torch.allclose(got[n], expect[n]) for n in shapes)
+    ok = ok and all(got[n].data_ptr() != grads[n].data_ptr() for n in shapes)
+    flat_ptrs = [f.data_ptr() for f in sync.flat]
+    # second step reuses the object AND its buffers
+    got = {n: sync(n, torch.full(shapes[n], float(rank))) for n in shapes}
     sync.backward_done()
-    ok = ok and all(torch.allclose(grads[n], torch.full_like(grads[n], (world - 1) / 2)) for n in shapes)
+    ok = ok and all(torch.allclose(got[n], torch.full_like(got[n], (world - 1) / 2)) for n in shapes)
+    ok = ok and flat_ptrs == [f.data_ptr() for f in sync.flat]
     # a parameter that never arrives (frozen later) must not dead-lock the bucket
     sync2 = ddp.GradAllReduce(params, bucket_bytes=1 << 30)
-    g = torch.full((19, 256, 1, 1), float(rank))
-    sync2("ood_head.weight", g)
+    g = sync2("ood_head.weight", torch.full((19, 256, 1, 1), float(rank)))
     sync2.backward_done()
     ok = ok and torch.allclose(g, torch.full_like(g, (world - 1) / 2))
-    # a gradient absent in one step and present in the next: the bucket layout must not have been rewritten, and ranks
-    # that disagree on which gradients exist still exchange messages of the same size (absent = zeros)
+    # a gradient produced by ONE rank only: same message sizes on both ranks (absent = zeros), and the rank without a local
+    # gradient still receives the average (as param.grad)
     layout = [list(b) for b in sync2.buckets]
-    g1 = torch.full((19, 256, 1, 1), float(rank + 1))
-    g2 = torch.full((48, 128, 1, 1), 10.0 * (rank + 1))
-    sync2("ood_head.weight", g1)
-    if rank == 0:
-        sync2("bot_fine.weight", g2)          # only rank 0 produced this one
+    pd = dict(params)
+    pd["bot_fine.weight"].grad = None
+    g1 = sync2("ood_head.weight", torch.full((19, 256, 1, 1), float(rank + 1)))
+    g2 = sync2("bot_fine.weight", torch.full((48, 128, 1, 1), 10.0)) if rank == 0 else None
     sync2.backward_done()
     ok = ok and sync2.buckets == layout
     ok = ok and torch.allclose(g1, torch.full_like(g1, (1 + world) / 2))
     if rank == 0:
         ok = ok and torch.allclose(g2, torch.full_like(g2, 10.0 / world))
+    else:
+        ok = ok and pd["bot_fine.weight"].grad is not None and torch.allclose(pd["bot_fine.weight"].grad, torch.full((48, 128, 1, 1), 10.0 / world))
+    # ranks that produce their gradients in DIFFERENT orders (rank 1 delivers the last bucket first) still issue the
+    # collectives in bucket order: no hang, no mis-paired sizes
+    sync3 = ddp.GradAllReduce(params, bucket_bytes=30000)
+    order = list(shapes) if rank == 0 else list(reversed(list(shapes)))
+    got = {n: sync3(n, torch.full(shapes[n], float(rank + 1))) for n in order}
+    sync3.backward_done()
+    ok = ok and all(torch.allclose(got[n], torch.full_like(got[n], (1 + world) / 2)) for n in shapes)
     # an exception during the backward starts no collective and leaves the object reusable
     g3 = torch.full((19, 256, 1, 1), 7.0)
     sync2("ood_head.weight", g3)
     sync2.abort()
-    ok = ok and not any(sync2.pending) and not sync2.inflight and torch.allclose(g3, torch.full_like(g3, 7.0))
-    for n in shapes:
-        grads[n].fill_(float(rank))
-        sync2(n, grads[n])
+    ok = ok and not any(sync2.arrived) and sync2.next_bucket == 0 and not sync2.inflight and torch.allclose(g3, torch.full_like(g3, 7.0))
+    got = {n: sync2(n, torch.full(shapes[n], float(rank))) for n in shapes}
     sync2.backward_done()
-    ok = ok and all(torch.allclose(grads[n], torch.full_like(grads[n], (world - 1) / 2)) for n in shapes)
+    ok = ok and all(torch.allclose(got[n], torch.full_like(got[n], (world - 1) / 2)) for n in shapes)
     out[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()

@@ -10,12 +10,12 @@ from conftest import golden
 SHAPE = {"res2": (256, 4), "res3": (512, 8), "res4": (1024, 16), "res5": (2048, 32)}
 
 
-def build():
+def build(fixture="m2f_decoder", layers=2):
     from multishiftseg_amd import synth
     from multishiftseg_amd.msdeformattn_decoder import MSDeformAttnPixelDecoder, ShapeSpec
-    g = golden("m2f_decoder")
+    g = golden(fixture)
     dec = MSDeformAttnPixelDecoder({k: ShapeSpec(*v) for k, v in SHAPE.items()}, transformer_dropout=0.0, transformer_nheads=8,
-                                   transformer_dim_feedforward=1024, transformer_enc_layers=2, conv_dim=256, mask_dim=256, norm="GN",
+                                   transformer_dim_feedforward=1024, transformer_enc_layers=layers, conv_dim=256, mask_dim=256, norm="GN",
                                    transformer_in_features=["res3", "res4", "res5"], common_stride=4).eval()
     sd = dec.state_dict()
     assert list(sd.keys()) == [str(n) for n in g["names"]]              # parameter names and order = the reference's
@@ -55,6 +55,31 @@ def test_decoder_forward_features_golden():
     np.testing.assert_allclose(mask.cpu().numpy()[:, ::4], g["mask_sub"], rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(mask.double().abs().sum().item(), float(g["mask_abs_sum"]), rtol=1e-4)
     np.testing.assert_allclose(ms[2].double().abs().sum().item(), float(g["ms2_abs_sum"]), rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["m2f_decoder_704", "m2f_decoder_1024x2048"])
+def test_decoder_forward_features_fullsize_golden(fixture):
+    """Row a-11 at the BASELINE sizes: forward_features with the shipped depth (6 encoder layers) on
+    the feature pyramid of one 704x704 crop (C4: 10 164 tokens) and of one 1024x2048 image (C5: 43 008 tokens) against the
+    reference class's own outputs (tools/gen_golden.py decoder_704 / decoder_c5): strided slices, one full row, float64
+    checksums of every returned map. Bound: 2e-3 of each map's largest magnitude (fp32 through 6 x (MSDA + 6 Linears + 2 LN))."""
+    dec, g = build(fixture, layers=int(golden(fixture)["layers"]))
+    dec = dec.cuda()
+    n, H, W = (int(v) for v in g["nhw"])
+    rng = np.random.default_rng(int(g["seed"]))
+    feats = {k: torch.from_numpy(rng.standard_normal((n, c, H // s, W // s), dtype=np.float32)).cuda() for k, (c, s) in SHAPE.items()}
+    with torch.no_grad():
+        mask, out0, ms = dec.forward_features(feats)
+    amax = [float(v) for v in g["absmax"]]
+    got = {"mask_sub": mask[:, ::8, ::4, ::4], "out0_sub": out0[:, ::4], "ms1_sub": ms[1][:, ::8, ::2, ::2], "ms2_sub": ms[2][:, ::8, ::4, ::4],
+           "mask_row": mask[:, :, mask.shape[2] // 3]}
+    scale = {"mask_sub": amax[0], "mask_row": amax[0], "out0_sub": amax[1], "ms1_sub": amax[2], "ms2_sub": amax[3]}
+    for k, t in got.items():
+        err = float((t.cpu() - torch.from_numpy(g[k])).abs().max())
+        assert err < 2e-3 * scale[k], (fixture, k, err, scale[k])
+    for k, t in {"mask": mask, "out0": out0, "ms1": ms[1], "ms2": ms[2]}.items():
+        np.testing.assert_allclose(t.double().abs().sum().item(), float(g[k + "_abs_sum"]), rtol=1e-4, err_msg=k)
 
 
 @pytest.mark.gpu

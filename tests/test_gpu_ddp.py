@@ -104,12 +104,14 @@ def _rccl_worker(rank, port, out):
     assert len(sink.buckets) >= 2 and sink.active
     grads = {n: torch.randn_like(p) for n, p in params}
     want = {n: g.clone() for n, g in grads.items()}
-    for n, _ in reversed(params):
+    got = {}
+    for n, _ in reversed(params):              # delivered in reverse bucket order: launches still go out in bucket order
         if n != "p2":                          # one gradient never arrives: travels as zeros, flush() sends its bucket
-            sink(n, grads[n])
+            got[n] = sink(n, grads[n])
     sink.backward_done()
     torch.cuda.synchronize()
-    ok = all(torch.equal(grads[n], want[n]) for n in grads)         # the mean over one rank is the gradient itself
+    ok = all(torch.equal(got[n], want[n]) for n in got)             # the mean over one rank is the gradient itself
+    ok = ok and dict(params)["p2"].grad is not None and not dict(params)["p2"].grad.any()
     t = torch.full((5,), 3.0, device="cuda")
     dist.all_reduce(t)
     out["ok"] = bool(ok) and bool((t == 3.0).all().item()) and sink.comm_stream is not None

@@ -208,6 +208,31 @@ def test_graphed_eval_replays_the_same_forward(model):
             assert torch.equal(got_s, want_s) and torch.equal(got_l, want_l)
         with pytest.raises(ValueError):
             ge(torch.zeros(1, 3, 64, 64, device="cuda"))
+        # score-only form (what test_deeplab.py:92-96 consumes): same scores, no logit volume, eager and graphed
+        s_only, none = ood_scores(model, imgs[1], score_only=True)
+        assert none is None and torch.equal(s_only, ood_scores(model, imgs[1])[0])
+        ge_s = GraphedEval(model, imgs[0].shape, score_only=True)
+        got_s, got_none = ge_s(imgs[2])
+        assert got_none is None and torch.equal(got_s, ood_scores(model, imgs[2])[0])
+        # a weight update after the capture: the replay must neither read freed packed copies nor serve
+        # the old weights -- the signature check re-captures
+        saved = model.aspp.features[1][0].weight.detach().clone()
+        saved_rm = model.final[1].running_mean.detach().clone()
+        try:
+            before = ge.captures
+            with torch.no_grad():
+                model.aspp.features[1][0].weight.mul_(1.5)
+                model.final[1].running_mean.add_(0.25)
+            ood_scores(model, imgs[0])                       # an eager forward re-packs and drops the old packed tensors
+            torch.cuda.empty_cache()
+            want_s, want_l = ood_scores(model, imgs[1])
+            got_s, got_l = ge(imgs[1])
+            assert ge.captures == before + 1
+            assert torch.equal(got_s, want_s) and torch.equal(got_l, want_l)
+        finally:
+            with torch.no_grad():
+                model.aspp.features[1][0].weight.copy_(saved)
+                model.final[1].running_mean.copy_(saved_rm)
 
 
 def test_decoder_weight_gradient_from_kept_winograd_input(deeplab_params, monkeypatch):

@@ -31,7 +31,9 @@ ROUTES = {"winograd": {}, "direct3x3": {"MSS_WINOGRAD": "0"},
 # "winograd" is the policy's own mix (F(6x6) wherever it saves >= 5 % over F(4x4), else F(4x4) / F(2x2)); winograd_f4 keeps
 # the policy off the 6x6 tiles so that the F(4x4) kernels stay pinned by the same fixtures. The experimental
 # fp32-on-bf16-matrix-cores GEMM has to pass the same reference fixtures to be reported at all
-ROUTES_X = dict(ROUTES, winograd_f4={"MSS_WINO_MAX_TILE": "4"}, bf16x6={"MSS_GEMM_BF16X6": "1"})
+# winograd_fast is the round-2 policy (no accuracy caps: F(6x6) wherever it is cheapest), still a supported switch
+ROUTES_X = dict(ROUTES, winograd_f4={"MSS_WINO_MAX_TILE": "4"}, winograd_fast={"MSS_WINO_ACCURACY": "fast"},
+                bf16x6={"MSS_GEMM_BF16X6": "1"})
 _report = {}
 
 
@@ -51,7 +53,8 @@ class _Env:
         self.env = env
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ("MSS_WINOGRAD", "MSS_GEMM", "MSS_WINO_TILE", "MSS_WINO_MAX_TILE", "MSS_STEM_IM2COL", "MSS_GEMM_BF16X6")}
+        self.old = {k: os.environ.get(k) for k in ("MSS_WINOGRAD", "MSS_GEMM", "MSS_WINO_TILE", "MSS_WINO_MAX_TILE", "MSS_STEM_IM2COL", "MSS_GEMM_BF16X6",
+                                                          "MSS_WINO_ACCURACY")}
         for k in self.old:
             os.environ.pop(k, None)
         os.environ.update(self.env)
@@ -139,14 +142,22 @@ def _grad_close(got, ref, name, noise, sens, lo=2e-3):
     return rel, bound
 
 
-@pytest.mark.parametrize("route", list(ROUTES_X))
-def test_train_step_golden_2x592x600(deeplab_params, route):
-    """One stage-2 optimizer step of the reference on a (1+1)x3x592x600 batch -- the per-GPU batch shape of C3 -- with
-    its Dropout2d masks and loss permutations injected. In the default route every ASPP layer runs F(4x4) and its weight
-    gradient consumes the X' kept by the forward."""
+def _flip_report(logit, g, pre, n, h, w):
+    """argmax flips against the reference's label map over ALL pixels, split by how close to a tie the reference was."""
+    ref = torch.from_numpy(g[pre + "label"]).to(logit.device)
+    flip = (logit.argmax(1).to(torch.uint8) != ref).cpu().numpy()
+    out = {"pixels": int(flip.size), "flips_all_pixels": int(flip.sum())}
+    for tag in ("1e3", "1e4", "1e5"):
+        clear = np.unpackbits(g[pre + "clear_bits_" + tag])[:n * h * w].reshape(n, h, w).astype(bool)
+        out[f"flips_where_ref_margin_gt_{tag}"] = int((flip & clear).sum())
+        out[f"ref_pixels_with_margin_gt_{tag}"] = int(clear.sum())
+    return out
+
+
+def _train_step_vs_golden(deeplab_params, fixture, route, tile_check, out_bound):
     from multishiftseg_amd import kernels as K, synth
     from multishiftseg_amd.loss import RelContrastiveLoss
-    g = golden("deepwv3plus_train_step_2x592x600")
+    g = golden(fixture)
     pairs, h, w = (int(v) for v in g["shape"])
     ss, ls = int(g["score_stride"]), int(g["logit_stride"])
     pre = "stage2_"
@@ -166,7 +177,8 @@ def test_train_step_golden_2x592x600(deeplab_params, route):
     perms = [torch.from_numpy(g[pre + f"perm{i}"].astype(np.int64)) for i in range(3)]
     with _Env(ROUTES_X[route]):
         if route == "winograd":
-            assert [K.wino_tile(74, 75, r) for r in (1, 2, 4, 12, 24, 36)] == [6, 6, 4, 4, 4, 4]
+            h8, w8 = -(-h // 8), -(-w // 8)
+            assert [K.wino_tile(h8, w8, r) for r in (1, 2, 4, 12, 24, 36)] == tile_check
         score, logit = m(img)
         loss = crit(logit, score, target, perms=perms).mean()
         opt.zero_grad()
@@ -174,15 +186,16 @@ def test_train_step_golden_2x592x600(deeplab_params, route):
         opt.step()
     e_s = float(np.abs(score.detach().cpu().numpy()[:, ::ss, ::ss] - g[pre + "score"]).max())
     e_l = float(np.abs(logit.detach().cpu().numpy()[:, :, ::ls, ::ls] - g[pre + "logit_sub"]).max())
-    assert e_s < 1e-3 and e_l < 1e-3, (e_s, e_l)
-    np.testing.assert_allclose(loss.item(), float(g[pre + "loss"]), rtol=1e-4)
+    rep = {"score_err": e_s, "logit_err": e_l, "grads": {}}
+    if pre + "label" in g.files:
+        rep["argmax"] = _flip_report(logit.detach(), g, pre, 2 * pairs, h, w)
+    np.testing.assert_allclose(np.abs(logit.detach().double()).sum().item(), float(g[pre + "logit_abs_sum"]), rtol=1e-5)
+    np.testing.assert_allclose(np.abs(score.detach().double()).sum().item(), float(g[pre + "score_abs_sum"]), rtol=1e-5)
     mism = float((target.cpu().numpy().astype(np.uint8) != g[pre + "target_mut"]).mean())
-    assert mism < 1e-4
+    rep["target_mismatch"] = mism
+    rep["loss"], rep["loss_ref"] = loss.item(), float(g[pre + "loss"])
     sd = m.state_dict()
-    for k in [k for k in g.files if k.startswith(pre + "rs_")]:
-        np.testing.assert_allclose(sd[k[len(pre) + 3:]].cpu().numpy(), g[k], rtol=1e-3, atol=1e-4, err_msg=k)
     pd = dict(m.named_parameters())
-    rep = {"score_err": e_s, "logit_err": e_l, "target_mismatch": mism, "grads": {}}
     bad = []
     for k in [k for k in g.files if k.startswith(pre + "grad_") and not k.startswith((pre + "grad_sub_", pre + "grad_l2_"))]:
         name = k[len(pre) + 5:]
@@ -201,8 +214,61 @@ def test_train_step_golden_2x592x600(deeplab_params, route):
         rep["grads"][name] = {"rel_l2_slice": rel, "bound": bound, "gradsens": sens, "l2": l2, "l2_ref": float(g[k])}
         if rel > bound or abs(l2 / float(g[k]) - 1) > max(2e-3, 3 * sens):
             bad.append((name, rel, bound, l2, float(g[k])))
-    _note(f"train_step_2x592x600[{route}]", rep)
+    _note(f"{fixture}[{route}]", rep)
+    assert e_s < out_bound and e_l < out_bound, (e_s, e_l)
+    np.testing.assert_allclose(loss.item(), float(g[pre + "loss"]), rtol=1e-4)
+    assert mism < 1e-4
+    for k in [k for k in g.files if k.startswith(pre + "rs_")]:
+        np.testing.assert_allclose(sd[k[len(pre) + 3:]].cpu().numpy(), g[k], rtol=1e-3, atol=1e-4, err_msg=k)
     assert not bad, bad
+    return rep
+
+
+@pytest.mark.parametrize("route", list(ROUTES_X))
+def test_train_step_golden_2x592x600(deeplab_params, route):
+    """One stage-2 optimizer step of the reference on a (1+1)x3x592x600 batch -- the per-GPU batch shape of C3 -- with
+    its Dropout2d masks and loss permutations injected. In the default route every ASPP layer runs F(4x4) and its weight
+    gradient consumes the X' kept by the forward."""
+    _train_step_vs_golden(deeplab_params, "deepwv3plus_train_step_2x592x600", route, [6, 6, 4, 4, 4, 4], 1e-3)
+
+
+# ---------------------------------------------------------------------- the headline configuration vs the REFERENCE
+def test_eval_golden_c3_1x1024x2048(model):
+    """BASELINE's metric resolution, eval mode (test_deeplab.py:86-96): outputs of the reference model itself
+    (tools/gen_golden.py deeplab_c3) against the DEFAULT route. Bound 5e-4 = half the 1e-3 bar; argmax flips counted over
+    ALL pixels, none allowed where the reference's own top-2 margin exceeds the bar."""
+    from multishiftseg_amd import synth
+    g = golden("deepwv3plus_eval_1x1024x2048")
+    n, h, w = (int(v) for v in g["shape"])
+    ss, ls = int(g["score_stride"]), int(g["logit_stride"])
+    img = torch.from_numpy(synth.synth_image(int(g["image_seed"]), n, h, w)).cuda()
+    model.eval()
+    with _Env({}):
+        with torch.no_grad():
+            score, logit = model(img)
+    e_l = float((logit[:, :, ::ls, ::ls].cpu() - torch.from_numpy(g["logit_sub"])).abs().max())
+    e_s = float((score[:, ::ss, ::ss].cpu() - torch.from_numpy(g["score_sub"])).abs().max())
+    rep = {"max_abs_logit_err": e_l, "max_abs_score_err": e_s, "argmax": _flip_report(logit, g, "", n, h, w)}
+    _note("eval_c3_1x1024x2048[default]", rep)
+    assert e_l < 5e-4 and e_s < 5e-4, rep
+    assert float((logit[:, :, h // 3].cpu() - torch.from_numpy(g["logit_row"])).abs().max()) < 5e-4
+    assert float((score[:, h // 3].cpu() - torch.from_numpy(g["score_row"])).abs().max()) < 5e-4
+    np.testing.assert_allclose(logit.double().abs().sum().item(), float(g["logit_abs_sum"]), rtol=1e-5)
+    np.testing.assert_allclose(score.double().abs().sum().item(), float(g["score_abs_sum"]), rtol=1e-5)
+    assert rep["argmax"]["flips_where_ref_margin_gt_1e3"] == 0, rep
+
+
+def test_train_step_golden_c3_2x1024x2048(deeplab_params):
+    """THE headline configuration (BASELINE config 3, per GPU: one orig+aug pair of 1024x2048, stage 2, train-mode BN /
+    Dropout2d): one optimizer step of the reference itself (train_deeplab.py:189-204 with lib/loss.py:34-156; fixture from
+    tools/gen_golden.py train_c3) against the DEFAULT route bench.py times. Logits and scores within 5e-4 of the reference
+    (half the bar), loss, target mutation, running statistics, every stage-2 gradient; argmax flips over ALL 4.2 M pixels
+    are counted and none is allowed where the reference's top-2 margin exceeds 1e-3."""
+    rep = _train_step_vs_golden(deeplab_params, "deepwv3plus_train_step_2x1024x2048", "winograd", [6, 6, 6, 6, 6, 4], 5e-4)
+    assert rep["argmax"]["flips_where_ref_margin_gt_1e3"] == 0, rep["argmax"]
+    # flips can only sit on pixels the reference itself decided by less than the fp32 noise of ANY implementation:
+    # the direct-kernel route flips 118 of 4.2 M (profiles/r03/wino_attribution_*.txt)
+    assert rep["argmax"]["flips_all_pixels"] < 1e-4 * rep["argmax"]["pixels"], rep["argmax"]
 
 
 def _stage2_step(m, img, target, masks, seed):
@@ -222,9 +288,11 @@ def _stage2_step(m, img, target, masks, seed):
     return score.detach(), logit.detach(), float(loss), grads, tgt
 
 
-@pytest.mark.parametrize("tag,pairs,h,w", [("c3_2x1024x2048", 1, 1024, 2048), ("c2_16x700x700", 8, 700, 700)])
+@pytest.mark.parametrize("tag,pairs,h,w", [("c3_2x1024x2048", 1, 1024, 2048), ("c2_16x700x700", 8, 700, 700),
+                                            ("c2_16x768x768", 8, 768, 768)])
 def test_three_routes_agree_at_bench_size(deeplab_params, tag, pairs, h, w):
-    """The configurations bench.py measures. Same weights, inputs, Dropout2d masks and device-side pair sampling on the
+    """The configurations bench.py measures (c2 both as exps/DeepLab.yaml crops it, 700^2, and as BASELINE words it,
+    768^2). Same weights, inputs, Dropout2d masks and device-side pair sampling on the
     three routes; running statistics are restored between runs so every route sees the same BatchNorm buffers."""
     from multishiftseg_amd import kernels as K, synth
     m = _new_model(deeplab_params)
@@ -270,7 +338,7 @@ def test_three_routes_agree_at_bench_size(deeplab_params, tag, pairs, h, w):
         for k, gr in grads.items():
             r["grad_rel_l2"][k] = _rel_l2(gr, ref[3][k])
         rep[route] = r
-        if e_s > 1e-3 or e_l > 1e-3:
+        if e_s > 5e-4 or e_l > 5e-4:          # half the 1e-3 bar, between any two routes
             bad.append((route, "outputs", e_s, e_l))
         if abs(loss / ref[2] - 1) > 1e-4:
             bad.append((route, "loss", loss, ref[2]))

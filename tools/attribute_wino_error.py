@@ -121,7 +121,7 @@ def main():
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     report["policy_tiles"] = [info["policy_tile"] for info in layers]
-    lines.insert(1, f"MSS_WINO_ACCURACY={os.environ.get('MSS_WINO_ACCURACY', 'balanced')}; policy tiles per forward 3x3 layer: {report['policy_tiles']}")
+    lines.insert(1, f"MSS_WINO_ACCURACY={os.environ.get('MSS_WINO_ACCURACY', 'strict')}; policy tiles per forward 3x3 layer: {report['policy_tiles']}")
     json.dump(report, open(os.path.join(out, f"wino_attribution{args.tag}.json"), "w"), indent=1)
     open(os.path.join(out, f"wino_attribution{args.tag}.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))

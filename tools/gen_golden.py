@@ -637,6 +637,33 @@ def gen_decoder():
           f"levels {[tuple(m.shape) for m in ms]}, {len(grads)} gradient entries")
 
 
+def gen_decoder_fullsize(tag="m2f_decoder_704", n=1, H=704, W=704, layers=6):
+    """a-11 at BASELINE config 4's size: the reference's MSDeformAttnPixelDecoder.forward_features with the SHIPPED depth
+    (6 encoder layers, anomaly_ft.yaml:27-31) on the feature maps of a 704x704 crop (levels 22^2 / 44^2 / 88^2, 10 164
+    tokens). Forward only; big outputs as strided slices + float64 checksums. ~1 minute on 8 cores."""
+    Dec, ShapeSpec = import_reference_decoder()
+    torch.manual_seed(61)
+    shape = {"res2": ShapeSpec(256, 4), "res3": ShapeSpec(512, 8), "res4": ShapeSpec(1024, 16), "res5": ShapeSpec(2048, 32)}
+    dec = Dec(shape, transformer_dropout=0.0, transformer_nheads=8, transformer_dim_feedforward=1024, transformer_enc_layers=layers,
+              conv_dim=256, mask_dim=256, norm="GN", transformer_in_features=["res3", "res4", "res5"], common_stride=4).eval()
+    sd = {}
+    for k, v in dec.state_dict().items():
+        sd[k] = v.clone() if k.endswith("sampling_offsets.bias") else \
+            torch.from_numpy(synth.gen_tensor(10, "m2fdec." + k, tuple(v.shape), gain=1.0))
+    dec.load_state_dict(sd)
+    rng = np.random.default_rng(64)
+    feats = {k: rng.standard_normal((n, s.channels, H // s.stride, W // s.stride), dtype=np.float32) for k, s in shape.items()}
+    with torch.no_grad():
+        mask, out0, ms = dec.forward_features({k: torch.from_numpy(v) for k, v in feats.items()})
+    absum = lambda t: np.float64(np.abs(t2n(t).astype(np.float64)).sum())
+    save(tag, names=np.array(list(sd.keys())), seed=np.int64(64), nhw=np.array([n, H, W]), layers=np.int64(layers),
+         mask_sub=t2n(mask)[:, ::8, ::4, ::4], mask_abs_sum=absum(mask), mask_row=t2n(mask)[:, :, mask.shape[2] // 3],
+         out0_sub=t2n(out0)[:, ::4], out0_abs_sum=absum(out0), ms1_sub=t2n(ms[1])[:, ::8, ::2, ::2], ms1_abs_sum=absum(ms[1]),
+         ms2_sub=t2n(ms[2])[:, ::8, ::4, ::4], ms2_abs_sum=absum(ms[2]),
+         absmax=np.array([float(t.abs().max()) for t in (mask, out0, ms[1], ms[2])]))
+    print(f"   {tag}: mask {tuple(mask.shape)} |max| {float(mask.abs().max()):.3g}, levels {[tuple(m.shape) for m in ms]}")
+
+
 def gen_m2f():
     """train_m2f.py:387-407 cannot be imported (detectron2 absent); its five lines of torch
     arithmetic are evaluated here verbatim on random inputs."""
@@ -781,6 +808,10 @@ def main():
         print("encoder"); gen_encoder()
     if "decoder" in which:
         print("decoder"); gen_decoder()
+    if "decoder_704" in which:           # minutes: only on request
+        print("decoder_704"); gen_decoder_fullsize()
+    if "decoder_c5" in which:
+        print("decoder_c5"); gen_decoder_fullsize("m2f_decoder_1024x2048", 1, 1024, 2048)
     if "datapath" in which:
         print("datapath"); gen_datapath()
     if "loss" in which:

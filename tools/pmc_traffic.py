@@ -43,7 +43,7 @@ def main():
     cands = [k for k in ("gemm_nt_kernel", "conv_igemm_kernel") if k in fams] or list(fams)
     dom = max(cands, key=lambda k: fams[k]["launches"] * fams[k]["hbm_bytes_per_launch"])
     c = fams[dom]
-    out = {"kernel": dom,
+    out = {"kernel": dom, "git_commit": os.environ.get("MSS_TREE", "unknown"),
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1 "
                      "--no-cpu-baseline --no-ood`, summarised by tools/pmc_traffic.py",
            "launches": c["launches"], "fetch_size_avg_KB": c["fetch_size_avg_KB"], "write_size_avg_KB": c["write_size_avg_KB"],
