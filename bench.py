@@ -296,6 +296,13 @@ def main():
     def one_step():
         return step(img, target0.clone())      # the loss mutates its targets; a loader would hand over fresh ones
 
+    parity = None
+    if rank == 0 and not args.no_parity and args.workload == "c3":
+        try:                        # before any optimizer step: the weights are still the ones the fixture was made with
+            parity = parity_check(model, H, W, pairs)
+        except Exception as exc:    # never lose the measurement to the checker
+            parity = {"error": repr(exc)}
+
     for _ in range(args.warmup):
         one_step()
     if world > 1:
@@ -406,11 +413,8 @@ def main():
                                            "kernel_ms_per_step": round(v["ms"] / max(args.steps, 1), 2)} for k, v in kinds.items()}
     if comm is not None:
         out["comm"] = comm
-    if not args.no_parity and args.workload == "c3":
-        try:
-            out["parity"] = parity_check(model, H, W, pairs)
-        except Exception as exc:        # never lose the measurement to the checker
-            out["parity"] = {"error": repr(exc)}
+    if parity is not None:
+        out["parity"] = parity
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
     # they cannot be collected from inside this process); the summary of the last such run is kept in profiles/
     tpath = os.path.join(ROOT, "profiles", "conv_traffic_latest.json")

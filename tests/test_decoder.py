@@ -23,7 +23,8 @@ def build(fixture="m2f_decoder", layers=2):
     for k, v in sd.items():
         new[k] = v.clone() if k.endswith("sampling_offsets.bias") else \
             torch.from_numpy(synth.gen_tensor(10, "m2fdec." + k, tuple(v.shape), gain=1.0))
-    np.testing.assert_allclose(new["transformer.encoder.layers.0.self_attn.sampling_offsets.bias"].numpy(), g["offsets_bias"], atol=1e-6)
+    if "offsets_bias" in g.files:
+        np.testing.assert_allclose(new["transformer.encoder.layers.0.self_attn.sampling_offsets.bias"].numpy(), g["offsets_bias"], atol=1e-6)
     dec.load_state_dict(new)
     return dec, g
 

@@ -189,8 +189,8 @@ def _train_step_vs_golden(deeplab_params, fixture, route, tile_check, out_bound)
     rep = {"score_err": e_s, "logit_err": e_l, "grads": {}}
     if pre + "label" in g.files:
         rep["argmax"] = _flip_report(logit.detach(), g, pre, 2 * pairs, h, w)
-    np.testing.assert_allclose(np.abs(logit.detach().double()).sum().item(), float(g[pre + "logit_abs_sum"]), rtol=1e-5)
-    np.testing.assert_allclose(np.abs(score.detach().double()).sum().item(), float(g[pre + "score_abs_sum"]), rtol=1e-5)
+    np.testing.assert_allclose(logit.detach().double().abs().sum().item(), float(g[pre + "logit_abs_sum"]), rtol=1e-5)
+    np.testing.assert_allclose(score.detach().double().abs().sum().item(), float(g[pre + "score_abs_sum"]), rtol=1e-5)
     mism = float((target.cpu().numpy().astype(np.uint8) != g[pre + "target_mut"]).mean())
     rep["target_mismatch"] = mism
     rep["loss"], rep["loss_ref"] = loss.item(), float(g[pre + "loss"])
