@@ -151,7 +151,11 @@ class MSDeformAttn(nn.Module):
                 input_padding_mask=None):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
-        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        host = getattr(input_spatial_shapes, "_mss_host", None)
+        if host is not None:                    # level sizes known on the host: no device read (keeps the forward capturable)
+            assert sum(int(h) * int(w) for h, w in host) == Len_in
+        elif not (input_flatten.is_cuda and torch.cuda.is_current_stream_capturing()):
+            assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in      # ms_deform_attn.py:93
         value = linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))

@@ -97,7 +97,8 @@ class MSDeformAttnTransformerEncoder(nn.Module):
         """Pixel centres ((x+0.5)/W, (y+0.5)/H) of every query's own level, shared by all target
         levels (msdeformattn.py:140-153) -> [N, sum(HW), L, 2]."""
         pts = []
-        for lvl, (h, w) in enumerate(spatial_shapes.tolist()):
+        host = getattr(spatial_shapes, "_mss_host", None)          # known on the host: no device read (hipGraph capture)
+        for lvl, (h, w) in enumerate(host if host is not None else spatial_shapes.tolist()):
             ys = (torch.arange(h, dtype=torch.float32, device=device) + 0.5)
             xs = (torch.arange(w, dtype=torch.float32, device=device) + 0.5)
             gy, gx = torch.meshgrid(ys, xs, indexing="ij")
@@ -145,9 +146,19 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         writes its GroupNorm outputs there directly)."""
         pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
                          for lvl, p in enumerate(pos_embeds)], 1)
-        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src.device)
-        spatial_shapes._mss_host = [tuple(int(v) for v in hw) for hw in shapes]      # host copy for the window forward's grid
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
-        valid_ratios = torch.ones((src.shape[0], len(shapes), 2), dtype=torch.float32, device=src.device)
+        # the op's index tensors depend on the level sizes only: built once per (sizes, batch, device) -- also what makes the
+        # forward capturable into a hipGraph (no host-to-device copy of the shape list inside the capture)
+        key = (tuple(tuple(int(v) for v in hw) for hw in shapes), int(src.shape[0]), str(src.device))
+        cache = self.__dict__.setdefault("_index_cache", {})
+        ent = cache.get(key)
+        if ent is None:
+            spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src.device)
+            spatial_shapes._mss_host = [tuple(int(v) for v in hw) for hw in shapes]  # host copy: launch grids, tile geometry
+            level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+            valid_ratios = torch.ones((src.shape[0], len(shapes), 2), dtype=torch.float32, device=src.device)
+            if len(cache) >= 8:
+                cache.clear()
+            ent = cache[key] = (spatial_shapes, level_start_index, valid_ratios)
+        spatial_shapes, level_start_index, valid_ratios = ent
         memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, None)
         return memory, spatial_shapes, level_start_index

@@ -71,9 +71,15 @@ class TrainStep:
     def __call__(self, img, target):
         """img [2p,3,H,W] laid out [orig...; aug...], target int64 [2p,H,W] (mutated by the loss)."""
         score, logit = self.model(img)
-        loss = self.criterion(logit, score, target).mean()
         self.optimizer.zero_grad()
-        loss.backward()
+        if hasattr(self.criterion, "value_and_grads") and logit.requires_grad:
+            # the fused loss hands out its value AND both gradients; d(loss.mean())/d(loss) = 1 (train_deeplab.py:198-202),
+            # so they go to autograd as they are -- no `grad * 1` pass over the 318 MB logit gradient
+            loss, dlogit, dscore = self.criterion.value_and_grads(logit, score, target)
+            torch.autograd.backward((score, logit), (dscore, dlogit))
+        else:
+            loss = self.criterion(logit, score, target).mean()
+            loss.backward()
         self.optimizer.step()
         return loss
 

@@ -89,15 +89,10 @@ def backward(value, shapes, starts, loc, attn, grad_out):
     return grad_value, grad_loc, grad_attn
 
 
-def forward_sampled(value, shapes, starts, loc, attn):
-    """The same result as `forward`, on stock torch CPU ops the way the reference's CPU path gets it
-    (`ms_deform_attn_core_pytorch`, ops/functions/ms_deform_attn_func.py:52-72): every level's [N*M, D, H, W] map is
-    re-sampled bilinearly (zero padding, align_corners=False, grid = 2*loc - 1) at each query's P locations; here the
-    level's attention weights are applied and accumulated level by level instead of stacking all L*P samples first.
-    bench.py's MSDA `cpu_baseline` times this on the GPU host (threads = torch.get_num_threads()). numpy in / out."""
+def _forward_sampled_t(v, shapes, starts, lc, at):
+    """torch tensors in / out; differentiable (see backward_sampled)."""
     import torch
     from torch.nn.functional import grid_sample
-    v, lc, at = (torch.from_numpy(np.ascontiguousarray(a)) for a in (value, loc, attn))
     N, S, M, D = v.shape
     Lq, L, P = lc.shape[1], lc.shape[3], lc.shape[4]
     acc = torch.zeros((N * M, D, Lq), dtype=v.dtype)
@@ -107,5 +102,29 @@ def forward_sampled(value, shapes, starts, loc, attn):
         grid = (2 * lc[:, :, :, l] - 1).permute(0, 2, 1, 3, 4).reshape(N * M, Lq, P, 2)
         sampled = grid_sample(level_map, grid, mode="bilinear", padding_mode="zeros", align_corners=False)   # [N*M, D, Lq, P]
         weights = at[:, :, :, l].permute(0, 2, 1, 3).reshape(N * M, 1, Lq, P)
-        acc += (sampled * weights).sum(-1)
-    return acc.view(N, M * D, Lq).permute(0, 2, 1).contiguous().numpy()
+        acc = acc + (sampled * weights).sum(-1)
+    return acc.view(N, M * D, Lq).permute(0, 2, 1).contiguous()
+
+
+def backward_sampled(value, shapes, starts, loc, attn, grad_out):
+    """(grad_value, grad_loc, grad_attn) as torch autograd derives them from the grid_sample composition -- how the
+    reference's own test obtains its comparison gradients (ops/test.py:66-81 runs gradcheck on the op; its fixtures in
+    tests/golden/msda_*.npz are autograd of ms_deform_attn_core_pytorch). Seconds at the BASELINE sizes, where the
+    np.add.at restatement above takes minutes: used by the full-size GPU parity tests."""
+    import torch
+    v, lc, at = (torch.from_numpy(np.ascontiguousarray(a)).requires_grad_(True) for a in (value, loc, attn))
+    out = _forward_sampled_t(v, shapes, starts, lc, at)
+    out.backward(torch.from_numpy(np.ascontiguousarray(grad_out)))
+    return v.grad.numpy(), lc.grad.numpy(), at.grad.numpy()
+
+
+def forward_sampled(value, shapes, starts, loc, attn):
+    """The same result as `forward`, on stock torch CPU ops the way the reference's CPU path gets it
+    (`ms_deform_attn_core_pytorch`, ops/functions/ms_deform_attn_func.py:52-72): every level's [N*M, D, H, W] map is
+    re-sampled bilinearly (zero padding, align_corners=False, grid = 2*loc - 1) at each query's P locations; here the
+    level's attention weights are applied and accumulated level by level instead of stacking all L*P samples first.
+    bench.py's MSDA `cpu_baseline` times this on the GPU host (threads = torch.get_num_threads()). numpy in / out."""
+    import torch
+    v, lc, at = (torch.from_numpy(np.ascontiguousarray(a)) for a in (value, loc, attn))
+    with torch.no_grad():
+        return _forward_sampled_t(v, shapes, starts, lc, at).numpy()

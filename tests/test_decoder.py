@@ -84,6 +84,33 @@ def test_decoder_forward_features_fullsize_golden(fixture):
 
 
 @pytest.mark.gpu
+def test_graphed_features_replays_the_same_forward():
+    """GraphedFeatures: forward_features captured into ONE hipGraph gives the eager forward's bits, for several inputs, and
+    re-captures after a weight update."""
+    from multishiftseg_amd.msdeformattn_decoder import GraphedFeatures
+    dec, g = build()
+    dec = dec.cuda()
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    rng = np.random.default_rng(5)
+    mk = lambda: {k: torch.from_numpy(rng.standard_normal((1, c, 96 // s, 160 // s), dtype=np.float32)).cuda() for k, (c, s) in SHAPE.items()}
+    feats = [mk() for _ in range(3)]
+    gf = GraphedFeatures(dec, feats[0])
+    for f in feats:
+        with torch.no_grad():
+            want = dec.forward_features(f)
+        got = gf(f)
+        assert torch.equal(got[0], want[0]) and all(torch.equal(a, b) for a, b in zip(got[2], want[2]))
+    with torch.no_grad():
+        dec.mask_features.weight.mul_(1.25)
+        want = dec.forward_features(feats[1])
+    got = gf(feats[1])
+    assert gf.captures == 2 and torch.equal(got[0], want[0])
+    with pytest.raises(ValueError):
+        gf({k: v[:, :, :2] for k, v in feats[0].items()})
+
+
+@pytest.mark.gpu
 def test_groupnorm_layernorm_upsample_ops_vs_oracle():
     from multishiftseg_amd import kernels as K
     from oracle import nnops

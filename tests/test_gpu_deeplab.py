@@ -235,6 +235,43 @@ def test_graphed_eval_replays_the_same_forward(model):
                 model.final[1].running_mean.copy_(saved_rm)
 
 
+def test_train_step_fused_loss_gradients_equal_the_autograd_route(deeplab_params):
+    """TrainStep feeds RelContrastiveLoss.value_and_grads straight into autograd (no `grad * 1` pass over the logit gradient):
+    same loss, same parameter gradients, bit for bit, as `criterion(...).mean().backward()` (train_deeplab.py:198-202)."""
+    from multishiftseg_amd import synth
+    from multishiftseg_amd.deepv3 import DeepWV3Plus
+    from multishiftseg_amd.loss import RelContrastiveLoss
+    from multishiftseg_amd.trainer import LOSS_PARAMS, TrainStep
+    m = DeepWV3Plus(19)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in deeplab_params.items()}, strict=True)
+    m = m.cuda()
+    m.uncertainty_func_init()
+    saved = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    img = torch.from_numpy(synth.synth_image(8, 2, 96, 160)).cuda()
+    tgt = torch.from_numpy(synth.synth_targets(5, 1, 96, 160)).cuda()
+    rng = np.random.default_rng(4)
+    masks = {"mod6": torch.from_numpy(((rng.random((2, 1024)) >= 0.3) / 0.7).astype(np.float32)),
+             "mod7": torch.from_numpy(((rng.random((2, 2048)) >= 0.5) / 0.5).astype(np.float32))}
+    step = TrainStep(m, RelContrastiveLoss(LOSS_PARAMS, pairing="device", seed=3), stage=2)
+    m.dropout_masks = masks
+    t1 = tgt.clone()
+    loss_a = step(img, t1)
+    grads_a = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+    m.load_state_dict(saved)
+    for p in m.parameters():
+        p.grad = None
+    crit = RelContrastiveLoss(LOSS_PARAMS, pairing="device", seed=3)
+    t2 = tgt.clone()
+    score, logit = m(img)
+    loss_b = crit(logit, score, t2).mean()
+    loss_b.backward()
+    assert torch.equal(loss_a.detach(), loss_b.detach()) and torch.equal(t1, t2)
+    assert len(grads_a) == 18
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            assert torch.equal(p.grad, grads_a[n]), n
+
+
 def test_decoder_weight_gradient_from_kept_winograd_input(deeplab_params, monkeypatch):
     """With `final` trainable the two decoder convolutions keep their Winograd-domain input X' for the weight gradient
     (MSS_KEEP_DEC_XT=0: transform again): same bits either way, and a non-trivial gradient."""

@@ -86,6 +86,41 @@ def test_production_shapes_vs_oracle(F, N, shapes):
     np.testing.assert_allclose(a.grad.cpu().numpy(), ga, rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("tag,N,shapes", [("c4", 1, [(22, 22), (44, 44), (88, 88)]), ("c4_n2", 2, [(22, 22), (44, 44), (88, 88)]),
+                                          ("c5", 1, [(32, 64), (64, 128), (128, 256)])])
+def test_full_size_every_query_vs_oracle(F, tag, N, shapes):
+    """at the BASELINE token counts (C4: 10 164, C5: 43 008) EVERY output element and EVERY gradient
+    element against the oracle -- forward, fused forward and the backward on its default (binned owner-computes) route;
+    comparator: the grid_sample composition and its autograd (oracle/msda.py:forward_sampled / backward_sampled, pinned to the
+    reference's fixtures by tests/test_oracle_golden.py). Locations as the encoder makes them (pixel centres + N(0, 3 px))
+    with a share pushed over the borders."""
+    from multishiftseg_amd import MultiScaleDeformableAttention as MSDA
+    rng = np.random.default_rng(len(tag) + N)
+    shp = np.array(shapes, dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(shp.prod(1))[:-1]]).astype(np.int64)
+    S, L = int(shp.prod(1).sum()), len(shapes)
+    ref = np.concatenate([np.stack(np.meshgrid((np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h), -1).reshape(-1, 2) for h, w in shapes])
+    off = rng.standard_normal((N, S, 8, L, 4, 2)).astype(np.float32) * 3
+    off[:, ::17] *= 12                                                   # every 17th query samples far away / outside
+    loc = (ref[None, :, None, None, None, :] + off / shp[None, None, None, :, None, ::-1]).astype(np.float32)
+    attn = rng.random((N, S, 8, L, 4), dtype=np.float32)
+    attn /= attn.sum((-1, -2), keepdims=True)
+    value = rng.standard_normal((N, S, 8, 32), dtype=np.float32)
+    gout = rng.standard_normal((N, S, 256), dtype=np.float32)
+    t = {k: torch.from_numpy(v).cuda() for k, v in dict(value=value, loc=loc, attn=attn, gout=gout).items()}
+    ts, tst = torch.from_numpy(shp).cuda(), torch.from_numpy(starts).cuda()
+    out = MSDA.ms_deform_attn_forward(t["value"], ts, tst, t["loc"], t["attn"], 128)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(t["value"], ts, tst, t["loc"], t["attn"], t["gout"], 128)
+    want = omsda.forward_sampled(value, shp, starts, loc, attn)
+    wv, wl, wa = omsda.backward_sampled(value, shp, starts, loc, attn, gout)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(gv.cpu().numpy(), wv, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(ga.cpu().numpy(), wa, rtol=1e-3, atol=1e-4)
+    # grad_loc = level size x a difference of corner values: compare relative to its own scale
+    scale = float(np.abs(wl).max())
+    assert float(np.abs(gl.cpu().numpy() - wl).max()) < 2e-5 * scale + 1e-3
+
+
 def test_full_size_properties(F):
     """Full C4 size (N=16, Lq=S=10164): linearity in value and in the attention weights, and the
     adjoint identity <out, g> == <value, grad_value> (the op is linear in value)."""

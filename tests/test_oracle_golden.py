@@ -73,6 +73,11 @@ def test_msda(tag):
     np.testing.assert_allclose(ga, g["grad_attn"], **tol)
     # the grid_sample-style composition bench.py times as the MSDA CPU baseline
     np.testing.assert_allclose(msda.forward_sampled(g["value"], g["shapes"], g["starts"], g["loc"], g["attn"]), g["out"], **tol)
+    # ... and its autograd, the comparator of the full-size GPU tests
+    sv, sl, sa = msda.backward_sampled(g["value"], g["shapes"], g["starts"], g["loc"], g["attn"], g["grad_out"])
+    np.testing.assert_allclose(sv, g["grad_value"], **tol)
+    np.testing.assert_allclose(sl, g["grad_loc"], **(tol if f64 else dict(rtol=1e-3, atol=1e-4)))
+    np.testing.assert_allclose(sa, g["grad_attn"], **tol)
 
 
 def test_m2f_score():

@@ -100,6 +100,16 @@ def decoder_leg():
             (mask.sum() + sum(m.sum() for m in ms)).backward()
         b = timeit(fb, iters=5, warm=3)
         out[tag] = {"forward_ms": round(f, 2), "forward_backward_ms": round(b, 2), "images_per_s_fwd_bwd": round(N / b * 1e3, 1)}
+        if N == 1:
+            try:                                          # the inference form: the same forward as ONE hipGraph launch
+                from multishiftseg_amd.msdeformattn_decoder import GraphedFeatures
+                for p in dec.parameters():
+                    p.grad = None
+                gf = GraphedFeatures(dec, feats)
+                out[tag]["forward_hipgraph_ms"] = round(timeit(lambda: gf(feats), iters=10, warm=2), 3)
+                del gf
+            except Exception as exc:
+                out[tag]["forward_hipgraph_error"] = repr(exc)[:200]
         del feats
     return out
 
