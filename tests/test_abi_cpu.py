@@ -39,6 +39,26 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert lib.value("mss_conv2d_kpad", 19) == 64 and lib.value("mss_conv2d_kpad", 304) == 384
 
 
+def test_msda_binned_workspace_query_is_host_only(lib):
+    """mss_msda_backward_workspace_bytes is pure host arithmetic (tile geometry from a HOST copy of spatial_shapes): 16 bytes per
+    sample + halos + counters for the shapes the binned path takes, 0 for the ones it does not."""
+    import ctypes
+
+    def q(shapes, N, M, D, Lq, P):
+        flat = [int(v) for hw in shapes for v in hw]
+        return lib.value("mss_msda_backward_workspace_bytes", (ctypes.c_int64 * len(flat))(*flat), N, M, D, len(shapes), Lq, P)
+    c4 = [(22, 22), (44, 44), (88, 88)]
+    n16 = q(c4, 16, 8, 32, 10164, 4)
+    samples = 16 * 10164 * 8 * 3 * 4
+    assert 16 * samples < n16 < 16 * samples * 1.25                 # records dominate; halos + counters < 25 % on top
+    assert q(c4, 1, 8, 32, 10164, 4) < n16 // 8
+    assert q([(1, 300), (300, 1), (17, 17), (5, 3)], 2, 8, 32, 257, 4) > 0      # thin / tiny levels are taken
+    assert q(c4, 16, 8, 64, 10164, 4) == 0                         # D != 32
+    assert q([(4, 4)] * 9, 1, 8, 32, 144, 4) == 0                   # more than 8 levels
+    assert q(c4, 0, 8, 32, 10164, 4) == 0 and q(c4, 1, 8, 32, 0, 4) == 0
+    assert q([(0, 5)], 1, 8, 32, 10, 4) == 0                        # degenerate level
+
+
 def test_struct_layout_matches_header(lib):
     """sizeof(MssConvArgs)/sizeof(MssRclArgs) as the C compiler sees them."""
     import ctypes
