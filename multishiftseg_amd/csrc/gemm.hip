@@ -58,13 +58,35 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
   const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
 
   // ---- loader state: the K-step the next issue_loads() fetches ----
+  // VARIANT 3 (r03): 32-bit byte offsets from the (uniform) operand bases instead of 64-bit pointers, the offsets of the
+  // workgroup's NEXT tile kept beside the current ones, and a branch-free advance() (a select on "this was the tile's last
+  // K-step"): the K-step body becomes ONE basic block, which is what lets the requests below interleave the loader's
+  // instructions with the MFMAs instead of leaving them in a clump in front of them (a 32x32x2 f32 MFMA holds the pipe for
+  // 64 cycles; in variant 2 this wave issues ~45 other instructions with no MFMA in flight every K-step).
   const float* a_ptr[A_LD];
   const float* b_ptr[B_LD];
+  unsigned a_off[A_LD], b_off[B_LD], a_nxt[A_LD], b_nxt[B_LD], s_off = 0, s_nxt = 0;
   const float* s_ptr = p.in_scale;
   const float* h_ptr = p.in_shift;
   long long ld_tile = first_tile + mss_xcd_remap(blockIdx.x, gridDim.x);   // this launch walks tiles [first_tile, total_tiles)
   int ld_k = 0;
+  auto setup_off = [&](long long t, unsigned* ao, unsigned* bo, unsigned& so) {
+    const int b = (int)(t / tiles_per_batch);
+    const int v = (int)(t - (long long)b * tiles_per_batch);
+    const int mt = v / p.ntiles, nt = v - mt * p.ntiles;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      int row = mt * BM + row0 + j * RPP;
+      row = row < p.M ? row : p.M - 1;
+      ao[j] = (unsigned)(((size_t)b * p.x_bs + (size_t)row * p.ldx + chunk * 4) * sizeof(float));
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j)
+      bo[j] = (unsigned)(((size_t)b * p.w_bs + (size_t)(nt * BN + row0 + j * RPP) * p.C + chunk * 4) * sizeof(float));
+    if (AFFINE) so = (unsigned)(((size_t)((mt * BM) / p.H) * p.in_ss_stride + chunk * 4) * sizeof(float));
+  };
   auto setup = [&](long long t) {
+    if (VARIANT == 3) { setup_off(t, a_off, b_off, s_off); return; }
     const int b = (int)(t / tiles_per_batch);
     const int v = (int)(t - (long long)b * tiles_per_batch);
     const int mt = v / p.ntiles, nt = v - mt * p.ntiles;
@@ -84,8 +106,25 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
       h_ptr = p.in_shift + so;
     }
   };
+  auto setup_next = [&]() {              // offsets of the tile the loader enters after its current one (past the end: the same)
+    const long long t = ld_tile + stride;
+    setup_off(t < total_tiles ? t : ld_tile, a_nxt, b_nxt, s_nxt);
+  };
   f32x4 areg[A_LD], breg[B_LD], sreg, hreg;
   auto issue_loads = [&]() {
+    if (VARIANT == 3) {
+      const char* xb = reinterpret_cast<const char*>(p.x);
+      const char* wb = reinterpret_cast<const char*>(p.w);
+#pragma unroll
+      for (int j = 0; j < A_LD; ++j) areg[j] = *reinterpret_cast<const f32x4*>(xb + a_off[j]);
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j) breg[j] = *reinterpret_cast<const f32x4*>(wb + b_off[j]);
+      if (AFFINE) {
+        sreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in_scale) + s_off);
+        hreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in_shift) + s_off);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) areg[j] = *reinterpret_cast<const f32x4*>(a_ptr[j]);
 #pragma unroll
@@ -96,6 +135,16 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
     }
   };
   auto advance = [&]() {                 // next K-step of this tile, else first K-step of this workgroup's next tile
+    if (VARIANT == 3) {
+      const bool wrap = ++ld_k == n_it;
+#pragma unroll
+      for (int j = 0; j < A_LD; ++j) a_off[j] = wrap ? a_nxt[j] : a_off[j] + BK * (unsigned)sizeof(float);
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j) b_off[j] = wrap ? b_nxt[j] : b_off[j] + BK * (unsigned)sizeof(float);
+      if (AFFINE) s_off = wrap ? s_nxt : s_off + BK * (unsigned)sizeof(float);
+      ld_k = wrap ? 0 : ld_k;
+      return;
+    }
     if (++ld_k < n_it) {
 #pragma unroll
       for (int j = 0; j < A_LD; ++j) a_ptr[j] += BK;
@@ -165,21 +214,33 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
 
   long long cur = ld_tile;               // tile being multiplied (the launch guarantees cur < total_tiles)
   setup(ld_tile);
+  if (VARIANT == 3) setup_next();
   issue_loads();
   finish_store(0);
   advance();
-  if (VARIANT == 2) { issue_loads(); advance(); }      // registers now hold K-step 1
+  if (VARIANT >= 2) { issue_loads(); advance(); }      // registers now hold K-step 1
   zero_acc();
   __syncthreads();
   load_frags(0, 0, 0);
   int buf = 0, k = 0;
   while (true) {
-    if (VARIANT == 2) {
+    if (VARIANT >= 2) {
       load_frags(1, buf, 1);
       finish_store(buf ^ 1);             // K-step k+1, requested during step k-1
       issue_loads();                     // K-step k+2 (possibly of the next tile) into the registers just drained
       advance();
       mfma_chunk(0);
+      if (VARIANT == 3) {
+        // one fragment read / LDS write / global load / pair of VALU-SALU behind each of the first MFMAs of the chunk
+#pragma unroll
+        for (int i = 0; i < TM + TN; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+        for (int i = 0; i < A_LD + B_LD; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+#pragma unroll
+        for (int i = 0; i < A_LD + B_LD; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
+#pragma unroll
+        for (int i = 0; i < 4 * TM * TN - (TM + TN) - 2 * (A_LD + B_LD); ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x6, 2, 0); }
+      }
       __syncthreads();
       load_frags(0, buf ^ 1, 0);
       mfma_chunk(1);
@@ -201,8 +262,187 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
       if (cur >= total_tiles) break;
       zero_acc();
       k = 0;
+      if (VARIANT == 3) {                // the loader entered tile `cur` at least one K-step ago (n_it >= 3): prepare the one after it
+        ld_tile = cur;
+        setup_next();
+      }
     }
   }
+}
+
+// EXPERIMENT (r03, MSS_GEMM_WP=1): the same 128x256 tile with WAVE-PRIVATE operand staging and no workgroup barrier. Each of
+// the four waves stages the 64 A rows and 128 B rows of its own 64x128 sub-tile in its own LDS region (every operand row is
+// therefore staged twice per workgroup: twice the L2 -> LDS traffic, 96 KB of LDS, ONE workgroup per CU = one wave per SIMD
+// with up to 512 registers), orders its ds_write / ds_read through the LDS pipe's in-order execution, and never waits for
+// another wave. Tests whether the 13 % between this inner loop and the register-only MFMA loop is barrier skew.
+// MODE (ablation, results are garbage for MODE > 0): 1 = no global loads / LDS writes inside the loop (operands frozen on the
+// first K-step), 2 = additionally no fragment reads (register-only MFMA loop + epilogue), 3 = as 2 with all-zero operands
+// (separates what the instruction stream costs from what the data costs: clocks under load depend on operand toggling).
+template <int MODE>
+__global__ __launch_bounds__(NT, 1) void gemm_nt_wp_kernel(MssConvArgs p, long long first_tile, long long total_tiles,
+                                                           int tiles_per_batch) {
+  constexpr int BN = 256, WTN = 128, TN = 4, AR = 64, BR = 128, A_P = AR / 16, B_P = BR / 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* As = smem + wave * (2 * (AR + BR) * LDK);   // [2][AR][LDK]
+  float* Bs = As + 2 * AR * LDK;                     // [2][BR][LDK]
+  const int chunk = lane & 3, lrow = lane >> 2;      // 16 rows x 4 chunks per pass
+  const int wchunk = (chunk + (lrow >> 2)) & 3;      // rows lrow + 16 j: the same rotation for every pass
+  const int n_it = p.C / BK;
+  const long long stride = gridDim.x;
+  const float* a_ptr[A_P];
+  const float* b_ptr[B_P];
+  long long ld_tile = first_tile + mss_xcd_remap(blockIdx.x, gridDim.x);
+  int ld_k = 0;
+  auto setup = [&](long long t) {
+    const int b = (int)(t / tiles_per_batch);
+    const int v = (int)(t - (long long)b * tiles_per_batch);
+    const int mt = v / p.ntiles, nt = v - mt * p.ntiles;
+#pragma unroll
+    for (int j = 0; j < A_P; ++j) {
+      int row = mt * BM + wm * AR + lrow + j * 16;
+      row = row < p.M ? row : p.M - 1;
+      a_ptr[j] = p.x + (size_t)b * p.x_bs + (size_t)row * p.ldx + chunk * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < B_P; ++j)
+      b_ptr[j] = p.w + (size_t)b * p.w_bs + (size_t)(nt * BN + wn * BR + lrow + j * 16) * p.C + chunk * 4;
+  };
+  // DEPTH register sets: the loader runs DEPTH + 1 K-steps ahead (set s holds the K-step that is stored s steps from now)
+  constexpr int DEPTH = 2;          // the main loop below is written out for 2
+  f32x4 areg[DEPTH][A_P], breg[DEPTH][B_P];
+  auto issue_loads = [&](int set) {
+#pragma unroll
+    for (int j = 0; j < A_P; ++j) areg[set][j] = *reinterpret_cast<const f32x4*>(a_ptr[j]);
+#pragma unroll
+    for (int j = 0; j < B_P; ++j) breg[set][j] = *reinterpret_cast<const f32x4*>(b_ptr[j]);
+  };
+  auto advance = [&]() {
+    if (++ld_k < n_it) {
+#pragma unroll
+      for (int j = 0; j < A_P; ++j) a_ptr[j] += BK;
+#pragma unroll
+      for (int j = 0; j < B_P; ++j) b_ptr[j] += BK;
+    } else {
+      ld_k = 0;
+      ld_tile += stride;
+      setup(ld_tile < total_tiles ? ld_tile : ld_tile - stride);
+    }
+  };
+  auto finish_store = [&](int buf, int set) {
+#pragma unroll
+    for (int j = 0; j < A_P; ++j)
+      *reinterpret_cast<f32x4*>(&As[(buf * AR + lrow + j * 16) * LDK + wchunk * 4]) = areg[set][j];
+#pragma unroll
+    for (int j = 0; j < B_P; ++j)
+      *reinterpret_cast<f32x4*>(&Bs[(buf * BR + lrow + j * 16) * LDK + wchunk * 4]) = breg[set][j];
+  };
+  const int frag_row = lane & 31, frag_h = lane >> 5;
+  const int rot = frag_row >> 2;
+  const float* Abase = &As[frag_row * LDK];
+  const float* Bbase = &Bs[frag_row * LDK];
+  const int koff[2] = {((frag_h + rot) & 3) * 4, ((2 + frag_h + rot) & 3) * 4};
+  f32x4 fa[2][TM], fb[2][TN];
+  auto load_frags = [&](int set, int buf, int kc) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      fa[set][i] = *reinterpret_cast<const f32x4*>(Abase + (buf * AR + i * 32) * LDK + koff[kc]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      fb[set][j] = *reinterpret_cast<const f32x4*>(Bbase + (buf * BR + j * 32) * LDK + koff[kc]);
+  };
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  auto mfma_chunk = [&](int set) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][s], fb[set][j][s], acc[i][j], 0, 0, 0);
+  };
+  auto epilogue = [&](long long t) {
+    const int b = (int)(t / tiles_per_batch);
+    const int v = (int)(t - (long long)b * tiles_per_batch);
+    const int mt = v / p.ntiles, nt = v - mt * p.ntiles;
+    mss_epilogue_store<TM, TN>(acc, p, p.y + (size_t)b * p.y_bs, mt * BM + wm * WTM, nt * BN + wn * WTN, lane);
+  };
+  long long cur = ld_tile;
+  setup(ld_tile);
+  issue_loads(0);
+  finish_store(0, 0);
+  advance();
+  issue_loads(0);                        // K-step 1
+  advance();
+  issue_loads(1);                        // K-step 2
+  advance();
+  zero_acc();
+  load_frags(0, 0, 0);
+  if (MODE >= 2) load_frags(1, 0, 1);
+  if (MODE == 3) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[s2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[s2][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  int buf = 0, k = 0;
+  auto step = [&](int set) {             // set: the register set holding K-step k+1; it is refilled with K-step k+3
+    if (MODE < 2) load_frags(1, buf, 1);
+    if (MODE < 1) {
+      finish_store(buf ^ 1, set);
+      issue_loads(set);
+      advance();
+    }
+    mfma_chunk(0);
+    if (MODE < 2) load_frags(0, buf ^ 1, 0);   // the wave's own ds_writes above are ahead of these reads in the (in-order) LDS pipe
+    mfma_chunk(1);
+    buf ^= 1;
+  };
+  auto tile_end = [&]() -> bool {         // true: this workgroup has no tile left
+    if (++k < n_it) return false;
+    epilogue(cur);
+    cur += stride;
+    if (cur >= total_tiles) return true;
+    zero_acc();
+    k = 0;
+    return false;
+  };
+  while (true) {                         // unrolled by the number of register sets: no register copies, no dynamic indexing
+    step(0);
+    if (tile_end()) break;
+    step(1);
+    if (tile_end()) break;
+  }
+}
+
+template <int MODE>
+static int launch_gemm_wp(const MssConvArgs& p, hipStream_t stream) {
+  const int batch = p.batch > 1 ? p.batch : 1;
+  const int tiles_per_batch = p.mtiles * p.ntiles;
+  const long long total = (long long)tiles_per_batch * batch;
+  if (total <= 0) return MSS_OK;
+  const size_t smem = (size_t)4 * 2 * (64 + 128) * LDK * sizeof(float);      // 96 KB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wp_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const long long g = total < 256 ? total : 256;
+  hipLaunchKernelGGL(gemm_nt_wp_kernel<MODE>, dim3((unsigned)g), dim3(NT), smem, stream, p, 0ll, total, tiles_per_batch);
+  return mss_launch_status();
 }
 
 template <bool AFFINE, int VARIANT, int BN>
@@ -265,9 +505,17 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
   }
   // measured (tools/bench_bgemm.py, tools/bench_1x1.py, r02): variant 2 is +3-7 % on every shape (C = 128: 82.7 -> 86.9,
   // 512: 127 -> 132, 1024 -> 2048: 132 -> 136 TFLOP/s; 1x1 2048 -> 4096 with prologue/residual/statistics: 123 -> 128)
-  int variant = 2;
+  // r03: variant 3 (32-bit offsets, branch-free advance, loader instructions interleaved with the MFMAs) is +1.5-5 % on the long
+  // reductions and +12-18 % on the short ones (C = 128 / 256 / 512 products: 86 -> 102, 99 -> 116, 118 -> 132 TFLOP/s; 1x1
+  // 2048 -> 4096: 138 -> 145), bit-identical results (tools/bench_gemm_variant.py); shapes it does not take fall back to 2
+  int variant = 3;
   { const char* e = getenv("MSS_GEMM_VARIANT"); if (e) variant = atoi(e); }
   if (variant == 1) return p.in_scale ? launch_gemm<true, 1, 128>(p, s) : launch_gemm<false, 1, 128>(p, s);
+  // variant 3 addresses its operands with 32-bit byte offsets and needs >= 3 K-steps per tile (see the kernel)
+  const long long nb3 = p.batch > 1 ? p.batch : 1;
+  const bool v3 = variant == 3 && p.C / BK >= 3 &&
+                  (unsigned long long)((nb3 - 1) * p.x_bs + (long long)p.M * p.ldx) * 4ull < 0xffffffffull &&
+                  (unsigned long long)((nb3 - 1) * p.w_bs + (long long)p.Kpad * p.C) * 4ull < 0xffffffffull;
   if (variant == 0) return p.in_scale ? launch_gemm<true, 0, 128>(p, s) : launch_gemm<false, 0, 128>(p, s);
   // 256-wide tiles when the output channels split evenly, the reduction is long enough and there is work for two rounds of
   // the 512 slots (MSS_GEMM_BN=128|256 forces one). Measured (tools/bench_bgemm.py, bench_1x1.py): 1x1 2048 -> 4096
@@ -308,7 +556,16 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
       return p.in_scale ? launch_gemm<true, 2, 128>(q, s, 2 * full, 2 * tiles256) : launch_gemm<false, 2, 128>(q, s, 2 * full, 2 * tiles256);
     }
     p.ntiles = nw;
+    if (v3) return p.in_scale ? launch_gemm<true, 3, 256>(p, s) : launch_gemm<false, 3, 256>(p, s);
+    {
+      const char* we = getenv("MSS_GEMM_WP");          // experiment: wave-private staging, no workgroup barrier (non-affine only)
+      if (we && atoi(we) == 1 && !p.in_scale) return launch_gemm_wp<0>(p, s);
+      if (we && atoi(we) == 2 && !p.in_scale) return launch_gemm_wp<1>(p, s);
+      if (we && atoi(we) == 3 && !p.in_scale) return launch_gemm_wp<2>(p, s);
+      if (we && atoi(we) == 4 && !p.in_scale) return launch_gemm_wp<3>(p, s);
+    }
     return p.in_scale ? launch_gemm<true, 2, 256>(p, s) : launch_gemm<false, 2, 256>(p, s);
   }
+  if (v3) return p.in_scale ? launch_gemm<true, 3, 128>(p, s) : launch_gemm<false, 3, 128>(p, s);
   return p.in_scale ? launch_gemm<true, 2, 128>(p, s) : launch_gemm<false, 2, 128>(p, s);
 }
