@@ -523,7 +523,7 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
   int bn = 0;
   { const char* e = getenv("MSS_GEMM_BN"); if (e) bn = atoi(e); }
   const long long tiles256 = (long long)p.mtiles * (p.K / 256) * (p.batch > 1 ? p.batch : 1);
-  bool wide = p.K % 256 == 0 && (bn == 256 || (bn == 0 && tiles256 >= 1024 && p.C >= 300));
+  bool wide = p.K % 256 == 0 && (bn == 256 || (bn == 0 && tiles256 >= 1024 && p.C >= 256));
   if (wide && bn == 0) {
     // ... unless the last round of wide tiles is mostly idle while the narrow tiles fill theirs: 64 x 18 x 1 wide tiles (ASPP
     // dilation 12 / 24 through F(6x6): 2304 tiles x 4096 -> 256) are 2.25 rounds of the 512 slots but exactly 3 rounds of the
