@@ -556,7 +556,6 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
       return p.in_scale ? launch_gemm<true, 2, 128>(q, s, 2 * full, 2 * tiles256) : launch_gemm<false, 2, 128>(q, s, 2 * full, 2 * tiles256);
     }
     p.ntiles = nw;
-    if (v3) return p.in_scale ? launch_gemm<true, 3, 256>(p, s) : launch_gemm<false, 3, 256>(p, s);
     {
       const char* we = getenv("MSS_GEMM_WP");          // experiment: wave-private staging, no workgroup barrier (non-affine only)
       if (we && atoi(we) == 1 && !p.in_scale) return launch_gemm_wp<0>(p, s);
@@ -564,6 +563,7 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
       if (we && atoi(we) == 3 && !p.in_scale) return launch_gemm_wp<2>(p, s);
       if (we && atoi(we) == 4 && !p.in_scale) return launch_gemm_wp<3>(p, s);
     }
+    if (v3) return p.in_scale ? launch_gemm<true, 3, 256>(p, s) : launch_gemm<false, 3, 256>(p, s);
     return p.in_scale ? launch_gemm<true, 2, 256>(p, s) : launch_gemm<false, 2, 256>(p, s);
   }
   if (v3) return p.in_scale ? launch_gemm<true, 3, 128>(p, s) : launch_gemm<false, 3, 128>(p, s);
