@@ -519,3 +519,65 @@ def test_gemm_hybrid_last_round_is_bitwise_the_wide_result(K, monkeypatch, P, T,
         xin = torch.relu(xin * sc.double() + sh.double())
     want = torch.einsum("ptc,pkc->ptk", xin, w[:, :Ko].double())
     assert (outs["1"][:, rows].double() - want).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("P,T,C,Ko,affine,extras", [
+    (36, 4000, 128, 128, False, False),      # narrow tile, 8 K-steps per tile, ragged last row tile
+    (64, 1892, 512, 512, False, False),      # wide tile, partial last round
+    (5, 3000, 48, 256, False, False),        # 3 K-steps per tile: the shortest reduction variant 3 takes
+    (1, 70000, 512, 256, True, True),        # BatchNorm + ReLU prologue, residual, ReLU epilogue, statistics
+    (1, 5000, 304, 304, True, False),        # C = 304, 304 = 256 + 48 output channels (narrow tail launch)
+])
+def test_gemm_variant3_is_bitwise_variant2(K, monkeypatch, P, T, C, Ko, affine, extras):
+    """gemm.hip variant 3 (round 3: 32-bit operand offsets, branch-free advance, loader instructions interleaved with the MFMAs)
+    changes the SCHEDULE only: every output element is the same fmaf chain as in variant 2, so outputs and the BatchNorm partial
+    sums are equal bit for bit; a sample of rows is checked against float64."""
+    import ctypes
+    from multishiftseg_amd import _lib
+    from multishiftseg_amd._lib import MssConvArgs, call, ptr
+    torch.manual_seed(T + C)
+    x = torch.randn(P, T, C, device="cuda")
+    kpad = _lib.value("mss_conv2d_kpad", Ko)
+    w = torch.zeros(P, kpad, C, device="cuda")
+    w[:, :Ko] = torch.randn(P, Ko, C, device="cuda") / C ** 0.5
+    sc = torch.rand(C, device="cuda") + 0.5
+    sh = torch.randn(C, device="cuda") * 0.1
+    res = torch.randn(P, T, Ko, device="cuda")
+    outs, stats = {}, {}
+    for var in ("2", "3"):
+        monkeypatch.setenv("MSS_GEMM_VARIANT", var)
+        y = torch.full((P, T, Ko), float("nan"), device="cuda")
+        st = torch.full((-(-T // 64), 2, Ko), float("nan"), device="cuda")
+        a = MssConvArgs()
+        a.x, a.w, a.y = ptr(x), ptr(w), ptr(y)
+        a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
+        a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, Ko, kpad, Ko
+        a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+        if P > 1:
+            a.batch, a.x_bs, a.w_bs, a.y_bs = P, T * C, kpad * C, T * Ko
+        if affine:
+            a.in_scale, a.in_shift, a.in_relu = ptr(sc), ptr(sh), 1
+        if extras:
+            a.res, a.ldres, a.out_relu, a.stats = ptr(res), Ko, 1, ptr(st)
+        if Ko % 128 and Ko > 128:               # as kernels.conv2d does: 256 + 48 -> a narrow tail launch on the rest
+            a.K = Ko - Ko % 128
+            call("mss_conv2d_forward_f32", ctypes.byref(a))
+            a.K, a.Kpad = Ko % 128, kpad - (Ko - Ko % 128)
+            a.w = ctypes.c_void_p(w.data_ptr() + 4 * (Ko - Ko % 128) * C)
+            a.y = ctypes.c_void_p(y.data_ptr() + 4 * (Ko - Ko % 128))
+            if P > 1:
+                pytest.skip("tail split of a batched call needs per-batch weight strides the test does not model")
+        call("mss_conv2d_forward_f32", ctypes.byref(a))
+        outs[var], stats[var] = y, st
+    assert torch.equal(outs["2"], outs["3"])
+    assert not torch.isnan(outs["3"]).any()
+    if extras:
+        assert torch.equal(stats["2"], stats["3"])
+    rows = torch.randint(0, T, (64,), device="cuda")
+    xin = x[:, rows].double()
+    if affine:
+        xin = torch.relu(xin * sc.double() + sh.double())
+    want = torch.einsum("ptc,pkc->ptk", xin, w[:, :Ko].double())
+    if extras:
+        want = torch.relu(want + res[:, rows].double())
+    assert (outs["3"][:, rows].double() - want).abs().max().item() < 1e-4
