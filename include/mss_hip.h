@@ -289,7 +289,8 @@ int mss_rcl_select_hist_f32(const float* ce_aug, long long n, const uint32_t* se
 int mss_rcl_select_pick_f32(uint32_t* sel, uint32_t* hist_ws, int shift, void* stream);
 /* pass2 (selection mode only; a no-op when a->select == 0): the AUGMENTED half of dlogit (NCHW, assigned; may be
  * NULL) = grad_scale * d loss / d logit for the selected pixels and 0 for the others, target mutation, counters[7..8].
- * The original half was written by pass1. */
+ * The original half was written by pass1, unscaled: grad_scale must be 1 (MSS_ERR_BAD_ARG otherwise; scale the loss
+ * gradient downstream). */
 int mss_rcl_pass2_f32(const MssRclArgs* a, const float* lse, const float* ce_aug, const uint8_t* kind,
                       uint32_t* sel, double* counters, float grad_scale, float* dlogit, void* stream);
 /* row-major ordered compaction of pixel indices into the three sets of loss.py:122-124

@@ -829,6 +829,7 @@ int mss_rcl_pass2_f32(const MssRclArgs* a, const float* lse, const float* ce_aug
   int rc = rcl_check(a);
   if (rc) return rc;
   if (!lse || !ce_aug || !kind || !sel || !counters) return MSS_ERR_BAD_ARG;
+  if (grad_scale != 1.f) return MSS_ERR_BAD_ARG;   // pass 1 writes its half of dlogit unscaled: one scale for both halves
   if (!a->select) return MSS_OK;       // nothing left to do: pass 1 wrote the whole gradient
   const long long n_aug = (long long)(a->B - a->B / 2) * a->H * a->W;
   const bool v4 = rcl_vec4(a) && ((reinterpret_cast<uintptr_t>(lse) | reinterpret_cast<uintptr_t>(ce_aug) |
