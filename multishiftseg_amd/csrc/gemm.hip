@@ -505,9 +505,9 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
   }
   // measured (tools/bench_bgemm.py, tools/bench_1x1.py, r02): variant 2 is +3-7 % on every shape (C = 128: 82.7 -> 86.9,
   // 512: 127 -> 132, 1024 -> 2048: 132 -> 136 TFLOP/s; 1x1 2048 -> 4096 with prologue/residual/statistics: 123 -> 128)
-  // r03: variant 3 (32-bit offsets, branch-free advance, loader instructions interleaved with the MFMAs) is +1.5-5 % on the long
-  // reductions and +12-18 % on the short ones (C = 128 / 256 / 512 products: 86 -> 102, 99 -> 116, 118 -> 132 TFLOP/s; 1x1
-  // 2048 -> 4096: 138 -> 145), bit-identical results (tools/bench_gemm_variant.py); shapes it does not take fall back to 2
+  // r03: variant 3 (32-bit offsets, branch-free advance, loader instructions interleaved with the MFMAs) is +4-6 % from C = 256 up
+  // (36 x 16384 x 256 -> 256: 125 -> 130, 512 -> 512: 128 -> 136, 1024 -> 2048: 133 -> 140, 1x1 2048 -> 4096: 139 -> 146 TFLOP/s) and
+  // +0.5 % at C = 128, bit-identical results (tools/bench_gemm_variant.py, alternating A/B); shapes it does not take fall back to 2
   int variant = 3;
   { const char* e = getenv("MSS_GEMM_VARIANT"); if (e) variant = atoi(e); }
   if (variant == 1) return p.in_scale ? launch_gemm<true, 1, 128>(p, s) : launch_gemm<false, 1, 128>(p, s);
