@@ -925,7 +925,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < slab4;
        i += (long long)gridDim.x * blockDim.x) {
     f32x4 a = w4[i];
-    for (int sp = 1; sp < splits; ++sp) a += w4[(long long)sp * slab4 + i];
+    int sp = 1;
+    for (; sp + 8 <= splits; sp += 8) {        // eight loads in flight, added in split order (the sum is bit-reproducible)
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = w4[(long long)(sp + u) * slab4 + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; sp < splits; ++sp) a += w4[(long long)sp * slab4 + i];
     d4[i] = a;
   }
 }
@@ -1001,7 +1009,10 @@ inline TnPlan tn_plan(const MssConvArgs& p, int bc = TN_BC, int slots = 768) {
   pl.ktiles = mss_cdiv(p.K, TN_BK); pl.ctiles = mss_cdiv(p.C, bc);
   const long long base = (long long)tn_batch(p) * pl.ktiles * pl.ctiles;
   int max_splits = mss_cdiv(p.M, TN_BT * 8);
-  if (max_splits > 64) max_splits = 64;
+  // one position with few output tiles and very many rows (the decoder's Linear layers: 162 624 tokens x 256 -> 256 is 4 tiles):
+  // 64 splits would fill a third of the slots
+  const int cap = p.batch > 1 ? 64 : 256;
+  if (max_splits > cap) max_splits = cap;
   if (max_splits < 1) max_splits = 1;
   int splits = 1;
   double best = 0.0;

@@ -482,6 +482,22 @@ def test_batched_wgrad_routes_vs_float64(K, monkeypatch, mode, P, T, C, Ko):
     assert not torch.isnan(outs[0]).any()
 
 
+@pytest.mark.parametrize("T,C,Ko", [(162624, 256, 256), (50001, 256, 192), (40000, 1024, 256)])
+def test_linear_wgrad_many_rows_vs_float64(K, T, C, Ko):
+    """The decoder's Linear weight gradients: ONE position, a handful of output tiles and very many rows (16 x 10 164 tokens), i.e.
+    up to 192 row splits on the TN kernel (the cap was 64: a third of the slots) summed by the ordered reduction; against a
+    float64 product on a sample of rows of dW, and twice with identical bits."""
+    torch.manual_seed(T + C)
+    x = torch.randn(T, C, device="cuda")
+    dy = torch.randn(T, Ko, device="cuda")
+    outs = [K.conv2d_wgrad(K.Act(x.view(1, 1, T, C)), K.Act(dy.view(1, 1, T, Ko)), Ko, C, 1, 1).view(Ko, C) for _ in range(2)]
+    assert torch.equal(outs[0], outs[1])
+    rows = torch.arange(0, Ko, 7, device="cuda")
+    want = dy[:, rows].double().t() @ x.double()
+    err = (outs[0][rows].double() - want).abs().max().item()
+    assert err <= 2e-6 * T ** 0.5 * 16, err
+
+
 @pytest.mark.parametrize("P,T,C,Ko,affine", [(64, 1892, 512, 512, False), (34, 2112, 320, 1024, False), (1, 70000, 512, 256, True)])
 def test_gemm_hybrid_last_round_is_bitwise_the_wide_result(K, monkeypatch, P, T, C, Ko, affine):
     """Wide-tile GEMMs whose last round would be mostly idle finish on narrow tiles in a second launch (gemm.hip): every
