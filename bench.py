@@ -444,6 +444,12 @@ def main():
                            "note": "3x3 stride-1 layers with >= 64 channels run as Winograd F(6x6,3x3) (F(4x4) / F(2x2) where the larger tiles "
                                    "would be mostly padding, kernels.wino_tile): transforms + 64 (36, 16) batched GEMMs in one gemm_nt launch; TFLOP/s here = dense-conv FLOPs / time (can exceed the MFMA peak), "
                                    "while roofline.achieved counts only the FLOPs the MFMA kernel really executes"}
+    wt = summ.get("wino_transform")
+    if wt:
+        out["winograd"]["transforms"] = {
+            "ms_per_step": round(wt["ms"] / max(args.steps, 1), 2), "launches_per_step": wt["launches"] // max(args.steps, 1),
+            "algorithmic_GBs": round(wt["flops"] / (wt["ms"] * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(wt["flops"] / (wt["ms"] * 1e-3) / 8e12, 4),
+            "note": "input / output / grad-output transforms (HBM-bound): bytes = the NHWC tensor once + the (m+2)^2-position tensor once"}
     if wg:
         out["wgrad"] = {"achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                         "kernel_ms_per_step": round(wg["ms"] / max(args.steps, 1), 2)}

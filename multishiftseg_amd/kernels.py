@@ -392,7 +392,8 @@ def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=N
         xt = torch.empty((P, T, C), device=dev, dtype=torch.float32)
         sc, sh = in_affine if in_affine is not None else (None, None)
         assert sc is None or sc.dim() == 1
-        call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ts, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
+        with _Timed("wino_transform", 4.0 * (N * H * W * C + P * T * C), ("input", N, H, W, C, dil, ts)):   # "flops" = algorithmic BYTES
+            call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ts, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
         yt = torch.empty((P, T, K), device=dev, dtype=torch.float32)
         a = MssConvArgs()
         a.x, a.w, a.y = ptr(xt), ptr(ww.t), ptr(yt)
@@ -418,8 +419,9 @@ def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=N
         if want_stats and out.C == K:
             out.stats = torch.empty((_lib.value("mss_wino_output_stats_parts", N, H, W, K, dil, ts), 2, K), device=dev,
                                     dtype=torch.float32)
-        call("mss_wino_output_transform_f32", ptr(yt), N, H, W, K, dil, ts, res.ptr if res is not None else None,
-             res.ld if res is not None else 0, out.ptr, out.ld, ptr(out.stats))
+        with _Timed("wino_transform", 4.0 * (P * T * K + N * H * W * K * (2 if res is not None else 1)), ("output", N, H, W, K, dil, ts)):
+            call("mss_wino_output_transform_f32", ptr(yt), N, H, W, K, dil, ts, res.ptr if res is not None else None,
+                 res.ld if res is not None else 0, out.ptr, out.ld, ptr(out.stats))
     return out
 
 
@@ -440,10 +442,12 @@ def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=
         if xt is None:
             xt = torch.empty((P, T, C), device=dev, dtype=torch.float32)
             sc, sh = in_affine if in_affine is not None else (None, None)
-            call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ts, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
+            with _Timed("wino_transform", 4.0 * (N * H * W * C + P * T * C), ("input", N, H, W, C, dil, ts)):
+                call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ts, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
         assert tuple(xt.shape) == (P, T, C)
         dyt = torch.empty((P, T, K), device=dev, dtype=torch.float32)
-        call("mss_wino_grad_output_transform_f32", dy.ptr, dy.ld, N, H, W, K, dil, ts, ptr(dyt))
+        with _Timed("wino_transform", 4.0 * (N * H * W * K + P * T * K), ("grad_output", N, H, W, K, dil, ts)):
+            call("mss_wino_grad_output_transform_f32", dy.ptr, dy.ld, N, H, W, K, dil, ts, ptr(dyt))
         du = torch.empty((P, Kpad, Cp), device=dev, dtype=torch.float32)     # fully overwritten by the kernel
         a = MssConvArgs()
         a.x = ptr(xt)

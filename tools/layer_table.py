@@ -22,8 +22,8 @@ s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 s.record(); step(img, tgt.clone()); e.record(); torch.cuda.synchronize()
 K.set_conv_profile(None)
 rows = prof.per_launch()
-tot = sum(r[2] for r in rows)
+tot = sum(r[2] for r in rows if r[0] != "wino_transform")     # (the transforms are inside their layer's conv_winograd row)
 print(f"step {s.elapsed_time(e):.1f} ms; MFMA kernels {tot:.1f} ms in {len(rows)} launches")
-print(f"{'kind':11s} {'N,H,W,C,K,R,stride,dil':34s} {'ms':>8s} {'TF/s':>7s} {'%step':>6s}")
+print(f"{'kind':11s} {'N,H,W,C,K,R,stride,dil':34s} {'ms':>8s} {'TF/s':>7s} {'%step':>6s}   (wino_transform rows: (which, N, H, W, channels, dil, tile), TB/s of algorithmic bytes)")
 for kind, tag, ms, tf in rows:
     print(f"{kind:11s} {str(tag):34s} {ms:8.3f} {tf:7.1f} {100*ms/s.elapsed_time(e):6.2f}")
