@@ -543,16 +543,21 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
     // Bit-identical results. Measured: isolated 0.582 -> 0.558 ms (64 x 1892 x 512 -> 512) and 1.172 -> 1.129 ms (64 x 2112 x
     // 512 -> 1024); in the step 67.3 -> 67.1 ms of gemm_nt (the narrow round is slower per FLOP and costs a second launch).
     // Off by default: 0.2 ms per step does not pay for one GEMM call becoming two kernel launches in every profile.
+    // r03: a default rule for nearly-empty last rounds (rem <= 128; only one-image eval products qualify) measured +-0 on the eval
+    // forward (42.15 -> 42.15 ms): it stays opt-in. The two launches use the variant-3 kernels where the shape allows.
     const char* te = getenv("MSS_GEMM_TAIL");
-    const bool tail_off = !(te && atoi(te) == 1);
+    const int tail_mode = te ? atoi(te) : -1;
     const long long full = (tiles256 / 512) * 512, rem = tiles256 - full;
     const int nw = p.K / 256;
-    if (!tail_off && bn == 0 && full > 0 && rem > 0 && rem <= 384) {
+    const long long rem_max = tail_mode == 1 ? 384 : 0;
+    if (bn == 0 && full > 0 && rem > 0 && rem <= rem_max) {
       MssConvArgs q = p;
       q.ntiles = nw;
-      int rc = p.in_scale ? launch_gemm<true, 2, 256>(q, s, 0, full) : launch_gemm<false, 2, 256>(q, s, 0, full);
+      int rc = v3 ? (p.in_scale ? launch_gemm<true, 3, 256>(q, s, 0, full) : launch_gemm<false, 3, 256>(q, s, 0, full))
+                  : (p.in_scale ? launch_gemm<true, 2, 256>(q, s, 0, full) : launch_gemm<false, 2, 256>(q, s, 0, full));
       if (rc) return rc;
       q.ntiles = 2 * nw;
+      if (v3) return p.in_scale ? launch_gemm<true, 3, 128>(q, s, 2 * full, 2 * tiles256) : launch_gemm<false, 3, 128>(q, s, 2 * full, 2 * tiles256);
       return p.in_scale ? launch_gemm<true, 2, 128>(q, s, 2 * full, 2 * tiles256) : launch_gemm<false, 2, 128>(q, s, 2 * full, 2 * tiles256);
     }
     p.ntiles = nw;
