@@ -414,11 +414,12 @@ class DeepWV3Plus(nn.Module):
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         if torch.is_grad_enabled():
             self._check_trunk_frozen()
-        with torch.no_grad():
-            x, m2 = self._run_trunk(inp)
-        if want_grad:
-            score, logit = _HeadFn.apply(self, x, m2, size, *params)
-        else:
+        with K.batched_counters():
             with torch.no_grad():
-                score, logit, _ = self._head_forward(x, m2, size, want_logit=self.training or not self.score_only)
+                x, m2 = self._run_trunk(inp)
+            if want_grad:
+                score, logit = _HeadFn.apply(self, x, m2, size, *params)
+            else:
+                with torch.no_grad():
+                    score, logit, _ = self._head_forward(x, m2, size, want_logit=self.training or not self.score_only)
         return score, logit

@@ -547,8 +547,34 @@ def bn_fold(bn, x=None, train=False, M=None, x_rows=None):
          ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None, ptr(st.scale),
          ptr(st.shift), ptr(st.save_mean), ptr(st.save_invstd))
     if track and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        if _nbt_pending is not None:
+            _nbt_pending.append(bn.num_batches_tracked)      # one launch for all layers of a forward (43 tiny kernels otherwise)
+        else:
+            bn.num_batches_tracked += 1
     return st
+
+
+_nbt_pending = None
+
+
+class batched_counters:
+    """with batched_counters(): every train-mode bn_fold inside defers its `num_batches_tracked += 1`; they are applied by ONE
+    multi-tensor add on exit (nn.BatchNorm2d's counter, F.batch_norm's bookkeeping: same values, 1 launch instead of one per layer)."""
+
+    def __enter__(self):
+        global _nbt_pending
+        self.prev, _nbt_pending = _nbt_pending, []
+        return self
+
+    def __exit__(self, *exc):
+        global _nbt_pending
+        pending, _nbt_pending = _nbt_pending, self.prev
+        if pending:
+            if self.prev is not None:
+                self.prev.extend(pending)
+            else:
+                torch._foreach_add_(pending, 1)
+        return False
 
 
 def bn_relu_backward(dy, x, st, relu=True, want_param_grads=False, x_rows=None, dy_rows=None):

@@ -84,6 +84,9 @@ def test_train_step_golden(deeplab_params, stage, names, lr):
     mism = (target.cpu().numpy().astype(np.uint8) != g[pre + "target_mut"]).mean()
     assert mism < 1e-3          # selection threshold ties / 1e-6 CE differences may move a handful of pixels
     sd = m.state_dict()
+    for k, v in deeplab_params.items():      # train-mode BN on every layer, frozen or not: each counter moved by exactly one
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(np.asarray(v)) + 1, k
     for k in [k for k in g.files if k.startswith(pre + "rs_")]:
         np.testing.assert_allclose(sd[k[len(pre) + 3:]].cpu().numpy(), g[k], rtol=1e-3, atol=1e-4, err_msg=k)
     pd = dict(m.named_parameters())

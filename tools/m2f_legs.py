@@ -22,6 +22,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
+L2_GATHER_GBS = 18800.0     # MI355X_MICROARCH.md "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served from the XCDs' L2
 C4 = [(22, 22), (44, 44), (88, 88)]
 C5 = [(32, 64), (64, 128), (128, 256)]
 
@@ -76,6 +77,7 @@ def msda_leg(N, shapes):
             "forward_compulsory_MB": round(fwd_b / 1e6, 1), "forward_GBs": round(fwd_b / f / 1e6, 1),
             "forward_frac_of_hbm_peak": round(fwd_b / f / 1e6 / HBM_PEAK_GBS, 4),
             "forward_L2_row_gather_GBs": round(gather / f / 1e6, 1),
+            "forward_frac_of_L2_gather_ceiling": round(gather / f / 1e6 / L2_GATHER_GBS, 3),
             "backward_algorithmic_MB": round(bwd_b / 1e6, 1), "backward_GBs": round(bwd_b / b / 1e6, 1),
             "backward_frac_of_hbm_peak": round(bwd_b / b / 1e6 / HBM_PEAK_GBS, 4)}
 
@@ -156,7 +158,8 @@ def metric_leg(images=64, h=1024, w=2048):
 def measure():
     out = {"msda": {"c4_n1": msda_leg(1, C4), "c4_n16": msda_leg(16, C4), "c5_n1": msda_leg(1, C5),
                     "roofline_note": "HBM bound on the compulsory bytes of SURVEY 8(d) (8 TB/s); the forward is a row gather served "
-                                     "by L2 (48 x 128 B per (query, head)), its rate is forward_L2_row_gather_GBs"},
+                                     "by L2 (48 x 128 B per (query, head)), its rate is forward_L2_row_gather_GBs; the chip's measured ceiling "
+                                     "for L2-resident row gathers is 16.8-18.8 TB/s (MI355X_MICROARCH.md, Indexed rows): forward_frac_of_L2_gather_ceiling"},
            "pixel_decoder_forward_features": decoder_leg(), "fused_score": fused_score_leg(), "metric_sweep": metric_leg()}
     torch.cuda.empty_cache()
     return out
