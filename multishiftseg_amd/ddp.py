@@ -28,8 +28,11 @@ class GradAllReduce:
     ``param.grad`` of a parameter that requires grad) -- ranks can therefore never pair collectives of different sizes.
     """
 
-    def __init__(self, named_params, bucket_bytes=64 << 20, group=None, force=False):
-        """force: run the collectives even in a one-rank group (exercises the RCCL path on a single GPU; tests).
+    def __init__(self, named_params, bucket_bytes=64 << 20, group=None, force=False, close_after_bytes=16 << 20):
+        """close_after_bytes: a gradient at least this large closes its bucket, i.e. its all-reduce starts the moment it exists
+        instead of waiting for the small gradients behind it (stage 2: the three 37.7 MB ASPP weight gradients each end a bucket
+        and travel beside the next branch's GEMMs; the last bucket is the 8 MB of the two small branches).
+        force: run the collectives even in a one-rank group (exercises the RCCL path on a single GPU; tests).
         MSS_DDP_NO_COMM=1 (bench / tests only): everything but the collective itself -- the exposed-communication probe."""
         import os
         self.group = group
@@ -48,6 +51,9 @@ class GradAllReduce:
                 cur, cur_bytes = [], 0
             cur.append(name)
             cur_bytes += nbytes
+            if close_after_bytes and nbytes >= close_after_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
         if cur:
             self.buckets.append(cur)
         self.sizes = []

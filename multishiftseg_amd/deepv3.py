@@ -382,6 +382,41 @@ class DeepWV3Plus(nn.Module):
             if any(need[n] for n in names if n.startswith("aspp")):
                 d_act = K.conv2d(d_up, K.packed(self.bot_aspp.weight, flip=True))
                 states = s["states"]
+                # the three dilated branches first (37.7 MB of gradient each), the two 4 MB branches last: under data parallelism the
+                # all-reduce of each large gradient runs beside the next branch's weight-gradient GEMMs and only a small bucket
+                # is left after the last kernel of the backward (trainer.BACKWARD_ORDER lists the gradients in this order)
+                for i in (3, 2, 1, 0):
+                    p = f"aspp.features.{i}"
+                    sl = raw.slice(256 * (i + 1), 256)
+                    want = need[p + ".1.weight"] or need[p + ".1.bias"]
+                    draw, dg, db = K.bn_relu_backward(d_act.slice(256 * (i + 1), 256), sl, states[i + 1], want_param_grads=want)
+                    grads[p + ".1.weight"], grads[p + ".1.bias"] = dg, db
+                    if need[p + ".0.weight"]:
+                        if i == 0:
+                            grads[p + ".0.weight"] = K.conv2d_wgrad(x, draw, 256, 4096, 1, 1)
+                        else:
+                            grads[p + ".0.weight"] = K.conv3x3_wgrad(x, draw, 256, 4096, dil=_ASPP_RATES[i - 1],
+                                                                     xt=s["aspp_xt"].pop(i, None))
+                # image-pooling branch: the broadcast's transpose is a column sum
+                dv = K.colsum(d_act.slice(0, 256))
+                want = need["aspp.img_conv.1.weight"] or need["aspp.img_conv.1.bias"]
+                du0, dg, db = K.bn_relu_backward(None, None, states[0], want_param_grads=want, x_rows=s["u0_rows"], dy_rows=dv)
+                grads["aspp.img_conv.1.weight"], grads["aspp.img_conv.1.bias"] = dg, db
+                if need["aspp.img_conv.0.weight"]:
+                    grads["aspp.img_conv.0.weight"] = K.conv2d_wgrad(s["pooled_act"], Act(du0.view(N, 1, 1, 256)), 256,
+                                                                     4096, 1, 1)
+        return [grads.get(n) if need[n] else None for n in names]
+        ddec0 = K.conv3x3(df0, self.final[0].weight, flip=True)
+        if need["bot_fine.weight"]:
+            grads["bot_fine.weight"] = K.conv2d_wgrad(m2, ddec0.slice(0, 48), 48, 128, 1, 1)
+        if any(need[n] for n in names if n.startswith(("aspp", "bot_aspp"))):
+            d_up = K.upsample_ac_bwd(ddec0.slice(48, 256), h8, w8)
+            aff = (s["scale"], s["shift"])
+            if need["bot_aspp.weight"]:
+                grads["bot_aspp.weight"] = K.conv2d_wgrad(raw, d_up, 256, 1280, 1, 1, in_affine=aff, in_relu=True)
+            if any(need[n] for n in names if n.startswith("aspp")):
+                d_act = K.conv2d(d_up, K.packed(self.bot_aspp.weight, flip=True))
+                states = s["states"]
                 # image-pooling branch: the broadcast's transpose is a column sum
                 dv = K.colsum(d_act.slice(0, 256))
                 want = need["aspp.img_conv.1.weight"] or need["aspp.img_conv.1.bias"]

@@ -23,11 +23,12 @@ WEIGHT_DECAY = 1.0e-4                                                           
 LOSS_PARAMS = {"ce_weights": [50, 10], "conduct_pixel_selection": True, "selection_ratio": 0.8,
                "inoutaug_contras_margins_tri": [10, 5, 5]}                               # exps/DeepLab.yaml:28-35
 
-# order in which DeepWV3Plus._head_backward produces gradients (heads first, ASPP last)
+# order in which DeepWV3Plus._head_backward produces gradients: heads first, then the three dilated ASPP branches (37.7 MB
+# each), the 1x1 and image-pooling branches (4 MB each) last, so that the bucket left after the last kernel is small
 BACKWARD_ORDER = ["ood_head.weight", "final.6.weight", "final.4.weight", "final.4.bias", "final.3.weight",
-                  "final.1.weight", "final.1.bias", "final.0.weight", "bot_fine.weight", "bot_aspp.weight",
-                  "aspp.img_conv.1.weight", "aspp.img_conv.1.bias", "aspp.img_conv.0.weight"] + \
-    [f"aspp.features.{i}.{s}" for i in range(4) for s in ("1.weight", "1.bias", "0.weight")]
+                  "final.1.weight", "final.1.bias", "final.0.weight", "bot_fine.weight", "bot_aspp.weight"] + \
+    [f"aspp.features.{i}.{s}" for i in (3, 2, 1, 0) for s in ("1.weight", "1.bias", "0.weight")] + \
+    ["aspp.img_conv.1.weight", "aspp.img_conv.1.bias", "aspp.img_conv.0.weight"]
 
 
 def configure_trainable_params(model, patterns):

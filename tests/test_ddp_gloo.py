@@ -114,6 +114,24 @@ def test_trainer_stage_sets():
     assert not any(p.requires_grad for n, p in m.named_parameters() if n.startswith("mod"))
 
 
+def test_stage2_bucket_layout_leaves_a_small_tail():
+    """Stage 2 under data parallelism: the gradients are produced heads -> dilated ASPP branches -> the two 4 MB branches, every
+    37.7 MB branch gradient closes its bucket (its all-reduce starts beside the next branch's GEMMs) and what is left after the
+    last kernel of the backward is the small bucket only. Layout logic only: no process group needed."""
+    from multishiftseg_amd import ddp
+    from multishiftseg_amd.deepv3 import DeepWV3Plus
+    from multishiftseg_amd.trainer import BACKWARD_ORDER, STAGE_TRAINABLE, configure_trainable_params
+    with torch.device("meta"):
+        m = DeepWV3Plus(19)
+    params, names = configure_trainable_params(m, STAGE_TRAINABLE[2])
+    named = dict(zip(names, params))
+    sync = ddp.GradAllReduce([(n, named[n]) for n in BACKWARD_ORDER if n in named], 64 << 20)
+    assert sum(sync.sizes) == 30749952 and len(sync.buckets) == 4
+    assert [b[-1] for b in sync.buckets[:3]] == [f"aspp.features.{i}.0.weight" for i in (3, 2, 1)]
+    assert 4 * sync.sizes[-1] < (9 << 20) and sync.buckets[-1][-1] == "aspp.img_conv.0.weight"
+    assert [n for b in sync.buckets for n in b] == [n for n in BACKWARD_ORDER if n in named]
+
+
 def test_bench_self_launch_gloo():
     """`python bench.py --gpus 2` without a launcher starts two fresh rank processes itself (torch.distributed.run as a
     child, never exec) and relays ONE JSON line from rank 0. launchcheck is the model-free workload that runs on CPU."""
