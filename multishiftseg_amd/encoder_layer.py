@@ -1,0 +1,188 @@
+"""One autograd node per deformable-attention encoder layer (msdeformattn.py:92-131 with Dropout p = 0):
+
+    q    = src + pos
+    attn = output_proj( MSDeformAttn-sample( value_proj(src), sampling_offsets(q), attention_weights(q) ) )
+    s1   = LayerNorm1(src + attn)
+    out  = LayerNorm2(s1 + linear2(relu(linear1(s1))))
+
+Same kernels and the same arithmetic as the layer composed from `linear`, `_FusedSampleFn` and `add_layernorm` (the tests
+compare the two bit for bit in the forward and to rounding in the backward); what the single node buys is the BACKWARD:
+composed from separate nodes, autograd sums the gradients of every tensor with several consumers (src: query, value
+projection, residual; q: two projections; s1: FFN, residual) with one elementwise pass each over [N, S, 256] -- four to five
+166 MB passes per layer at 16 x 10 164 tokens. Here those sums ride in the residual input of the data-gradient GEMMs'
+epilogues (`MssConvArgs.res`), and one explicit add per layer is left (a GEMM epilogue takes one residual).
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import MultiScaleDeformableAttention as MSDA
+from . import _lib
+from . import kernels as K
+from ._lib import call, ptr
+from .linear import _packed, _rows
+
+
+def _gemm(x, weight, bias=None, relu=False, res=None, res_mask=False, flip=False):
+    """x [..., c] -> [..., k] with weight [k, c] (flip: x [..., k] -> [..., c], the data gradient), epilogue bias / ReLU /
+    residual add (or ReLU-backward gate) on the fp32 MFMA GEMM."""
+    k, c = weight.shape
+    cin, cout = (k, c) if flip else (c, k)
+    out = torch.empty(x.shape[:-1] + (cout,), device=x.device, dtype=torch.float32)
+    aff = (torch.ones_like(bias), bias.detach()) if bias is not None else None
+    K.conv2d(_rows(x, cin), _packed(weight, flip), out_affine=aff, out_relu=relu, out=_rows(out, cout),
+             res=_rows(res, cout) if res is not None else None, res_mask=res_mask)
+    return out
+
+
+def _wgrad(x, gy, weight):
+    k, c = weight.shape
+    return K.conv2d_wgrad(_rows(x, c), _rows(gy, k), k, c, 1, 1).view(k, c)
+
+
+def _bgrad(gy, k):
+    return K.colsum(_rows(gy, k)).view(k)
+
+
+def _layernorm(x, res, weight, bias, eps):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    stat = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    call("mss_add_layernorm_f32", ptr(x), ptr(res), rows, C, ptr(weight), ptr(bias), float(eps), ptr(y), ptr(stat))
+    return y, stat
+
+
+def _layernorm_bwd(gy, x, res, stat, weight):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dz = torch.empty_like(x)
+    dg, db = torch.empty_like(weight), torch.empty_like(weight)
+    ws = torch.empty(_lib.value("mss_add_layernorm_bwd_workspace_floats", rows, C), device=x.device, dtype=torch.float32)
+    call("mss_add_layernorm_bwd_f32", ptr(gy), ptr(x), ptr(res), ptr(stat), rows, C, ptr(weight), ptr(dz), ptr(dg), ptr(db), ptr(ws))
+    return dz, dg, db
+
+
+# positions of the parameters in _EncoderLayerFn.apply's argument list (after src, pos, ref, shapes, starts, geometry)
+_PARAMS = ("off_w", "off_b", "att_w", "att_b", "val_w", "val_b", "out_w", "out_b", "n1_w", "n1_b",
+           "l1_w", "l1_b", "l2_w", "l2_b", "n2_w", "n2_b")
+
+
+class _EncoderLayerFn(Function):
+    @staticmethod
+    def forward(ctx, src, pos, ref, shapes, starts, geom, *params):
+        p = dict(zip(_PARAMS, params))
+        M, L, P, eps1, eps2 = geom
+        N, S, C = src.shape
+        D = C // M
+        src = src.contiguous()
+        q = src + pos
+        value = _gemm(src, p["val_w"], p["val_b"])
+        offs = _gemm(q, p["off_w"], p["off_b"])
+        logits = _gemm(q, p["att_w"], p["att_b"])
+        ref = ref.contiguous().float()
+        samp = torch.empty((N, S, C), device=src.device, dtype=torch.float32)
+        call("mss_msda_forward_fused_f32", ptr(value), ptr(shapes), ptr(starts), ptr(offs), ptr(logits), ptr(ref),
+             N, S, M, D, L, S, P, ptr(samp))
+        attn = _gemm(samp, p["out_w"], p["out_b"])
+        s1, stat1 = _layernorm(src, attn, p["n1_w"], p["n1_b"], eps1)
+        h = _gemm(s1, p["l1_w"], p["l1_b"], relu=True)
+        f = _gemm(h, p["l2_w"], p["l2_b"])
+        out, stat2 = _layernorm(s1, f, p["n2_w"], p["n2_b"], eps2)
+        ctx.geom = geom
+        ctx.shapes_host = getattr(shapes, "_mss_host", None)
+        ctx.save_for_backward(src, q, ref, shapes, starts, value, offs, logits, samp, attn, stat1, s1, h, f, stat2, *params)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        src, q, ref, shapes, starts, value, offs, logits, samp, attn, stat1, s1, h, f, stat2 = ctx.saved_tensors[:15]
+        p = dict(zip(_PARAMS, ctx.saved_tensors[15:]))
+        need = dict(zip(("src", "pos") + (None,) * 4 + _PARAMS, ctx.needs_input_grad))
+        M, L, P, _, _ = ctx.geom
+        N, S, C = src.shape
+        D = C // M
+        if ctx.shapes_host is not None:
+            shapes._mss_host = ctx.shapes_host          # the host copy of the level sizes travels with the tensor object only
+        g = {}
+        # ---- LayerNorm2 and the FFN: d(s1) = g2 + dh W1 rides in the last data-gradient GEMM's residual input
+        g2, g["n2_w"], g["n2_b"] = _layernorm_bwd(gout.contiguous(), s1, f, stat2, p["n2_w"])
+        if need["l2_w"]:
+            g["l2_w"] = _wgrad(h, g2, p["l2_w"])
+        if need["l2_b"]:
+            g["l2_b"] = _bgrad(g2, C)
+        dh = _gemm(g2, p["l2_w"], res=h, res_mask=True, flip=True)            # ReLU backward in the epilogue
+        if need["l1_w"]:
+            g["l1_w"] = _wgrad(s1, dh, p["l1_w"])
+        if need["l1_b"]:
+            g["l1_b"] = _bgrad(dh, dh.shape[-1])
+        ds1 = _gemm(dh, p["l1_w"], res=g2, flip=True)
+        del dh, g2
+        # ---- LayerNorm1 and the attention output projection
+        g1, g["n1_w"], g["n1_b"] = _layernorm_bwd(ds1, src, attn, stat1, p["n1_w"])
+        del ds1
+        if need["out_w"]:
+            g["out_w"] = _wgrad(samp, g1, p["out_w"])
+        if need["out_b"]:
+            g["out_b"] = _bgrad(g1, C)
+        dsamp = _gemm(g1, p["out_w"], flip=True)
+        # ---- the sampling op: locations / weights rebuilt by the one-pass prepare kernel (bit-identical to the forward's)
+        offs6 = offs.view(N, S, M, L, P, 2)
+        loc = torch.empty_like(offs6)
+        aw = torch.empty((N, S, M, L, P), device=src.device, dtype=torch.float32)
+        call("mss_msda_prepare_f32", ptr(offs6), ptr(logits), ptr(ref), ptr(shapes), N, S, M, L, P, ptr(loc), ptr(aw))
+        gvalue, gloc, gaw = MSDA.ms_deform_attn_backward(value.view(N, S, M, D), shapes, starts, loc, aw, dsamp, 128)
+        del dsamp, loc
+        goff = torch.empty_like(offs6)
+        glog = torch.empty((N, S, M, L * P), device=src.device, dtype=torch.float32)
+        call("mss_msda_prepare_backward_f32", ptr(aw), ptr(gaw), ptr(gloc), ptr(shapes), N, S, M, L, P, ptr(goff), ptr(glog))
+        del gloc, gaw, aw
+        goff, glog, gvalue = goff.view(N, S, -1), glog.view(N, S, -1), gvalue.view(N, S, C)
+        # ---- the three input projections: d(q) = goff Woff + glog Watt (chained through the residual input), d(src) = g1 + gvalue Wv + d(q)
+        if need["off_w"]:
+            g["off_w"] = _wgrad(q, goff, p["off_w"])
+        if need["off_b"]:
+            g["off_b"] = _bgrad(goff, goff.shape[-1])
+        if need["att_w"]:
+            g["att_w"] = _wgrad(q, glog, p["att_w"])
+        if need["att_b"]:
+            g["att_b"] = _bgrad(glog, glog.shape[-1])
+        if need["val_w"]:
+            g["val_w"] = _wgrad(src, gvalue, p["val_w"])
+        if need["val_b"]:
+            g["val_b"] = _bgrad(gvalue, C)
+        dq = dsrc = None
+        if need["src"] or need["pos"]:
+            dq = _gemm(glog, p["att_w"], res=_gemm(goff, p["off_w"], flip=True), flip=True)
+        if need["src"]:
+            dsrc = _gemm(gvalue, p["val_w"], res=g1, flip=True)
+            dsrc += dq
+        return (dsrc, dq if need["pos"] else None, None, None, None, None) + tuple(g.get(n) if need[n] else None for n in _PARAMS)
+
+
+def eligible(layer, src, pos, reference_points, spatial_shapes, padding_mask):
+    """The shapes the fused node takes: the pixel decoder's (fp32, 2-d reference points, 8 heads x 32 channels, <= 20 samples per
+    head, ReLU FFN, no dropout, no padding mask). Everything else runs as the composition of the separate nodes."""
+    import torch.nn.functional as F
+    a = layer.self_attn
+    C = src.shape[-1]
+    return (src.is_cuda and src.dtype == torch.float32 and pos is not None and pos.shape == src.shape and padding_mask is None
+            and reference_points.shape[-1] == 2 and not reference_points.requires_grad and spatial_shapes.dtype == torch.int64
+            and C == a.d_model and C % 256 == 0 and C <= 1024 and C // a.n_heads == 32 and a.n_levels * a.n_points <= 20
+            and a.n_heads * a.n_levels * a.n_points > 64 and (a.n_heads * a.n_levels * a.n_points) % 16 == 0
+            and layer.activation is F.relu and (not layer.training or (layer.dropout1.p == 0.0 and layer.dropout2.p == 0.0 and layer.dropout3.p == 0.0))
+            and layer.linear1.bias is not None and layer.linear2.bias is not None and layer.linear1.out_features % 16 == 0
+            and layer.norm1.elementwise_affine and layer.norm1.bias is not None and layer.norm2.elementwise_affine and layer.norm2.bias is not None
+            and not MSDA.use_window(src.new_empty((1, 1, a.n_heads, 32)), a.n_levels, a.n_points))
+
+
+def encoder_layer(layer, src, pos, reference_points, spatial_shapes, level_start_index):
+    a = layer.self_attn
+    geom = (a.n_heads, a.n_levels, a.n_points, layer.norm1.eps, layer.norm2.eps)
+    return _EncoderLayerFn.apply(
+        src, pos, reference_points, spatial_shapes.contiguous(), level_start_index.contiguous(), geom,
+        a.sampling_offsets.weight, a.sampling_offsets.bias, a.attention_weights.weight, a.attention_weights.bias,
+        a.value_proj.weight, a.value_proj.bias, a.output_proj.weight, a.output_proj.bias,
+        layer.norm1.weight, layer.norm1.bias, layer.linear1.weight, layer.linear1.bias,
+        layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias)

@@ -15,11 +15,13 @@ ratios are 1 and are folded away here.
 """
 import copy
 import math
+import os
 
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import encoder_layer
 from . import kernels as K
 from .linear import ffn_relu, linear
 from .ms_deform_attn import MSDeformAttn
@@ -70,6 +72,10 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        if os.environ.get("MSS_ENCODER_FUSED", "1") != "0" and \
+                encoder_layer.eligible(self, src, pos, reference_points, spatial_shapes, padding_mask):
+            # the whole layer as ONE autograd node: same kernels, the backward's gradient sums in GEMM epilogues (encoder_layer.py)
+            return encoder_layer.encoder_layer(self, src, pos, reference_points, spatial_shapes, level_start_index)
         q = src if pos is None else src + pos
         # residual add + LayerNorm in one HIP pass (csrc/norm.hip); Dropout is the identity at the reference's p = 0.0
         src = K.add_layernorm(src, self.dropout1(
