@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MSS_ABI_VERSION 3      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32 */
+#define MSS_ABI_VERSION 4      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32 */
 int mss_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -371,6 +371,11 @@ int mss_add_layernorm_f32(const float* x, const float* res, long long rows, int 
 long long mss_add_layernorm_bwd_workspace_floats(long long rows, int C);
 int mss_add_layernorm_bwd_f32(const float* gy, const float* x, const float* res, const float* stat, long long rows, int C,
                               const float* gamma, float* dz, float* dgamma, float* dbeta, float* ws, void* stream);
+/* the same, and dzsum [C] = per-channel sums of dz: the bias gradient of the Linear whose output was `res`
+ * (msdeformattn.py:116-131: output_proj / linear2) without another pass over [rows][C]. ws: 3/2 of the floats above. */
+int mss_add_layernorm_bwd_sum_f32(const float* gy, const float* x, const float* res, const float* stat, long long rows, int C,
+                                  const float* gamma, float* dz, float* dgamma, float* dbeta, float* dzsum, float* ws,
+                                  void* stream);
 /* nn.GroupNorm(groups, C) on NHWC x [N][HW][C] (pixel stride ldx, sample stride x_sample_stride floats), optional ReLU,
  * output with its own pixel / sample strides (e.g. straight into the encoder's token buffer [N][sum HW][C]).
  * C/groups a multiple of 4, C <= 1024. ws: scratch of mss_groupnorm_workspace_floats floats. Deterministic. */

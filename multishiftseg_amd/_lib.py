@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so libmss_hip.
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSS_LIB", os.path.join(_HERE, "libmss_hip.so"))   # MSS_LIB: A/B experiments only
 
-MSS_ABI_VERSION = 3          # include/mss_hip.h
+MSS_ABI_VERSION = 4          # include/mss_hip.h
 MSS_ERR_BAD_ARG = 1001
 MSS_ERR_UNSUPPORTED = 1002
 
@@ -128,6 +128,7 @@ SIGNATURES = {
     "mss_add_layernorm_f32": [P, P, L, I, P, P, F, P, P, P],
     "mss_add_layernorm_bwd_workspace_floats": [L, I],
     "mss_add_layernorm_bwd_f32": [P, P, P, P, L, I, P, P, P, P, P, P],
+    "mss_add_layernorm_bwd_sum_f32": [P, P, P, P, L, I, P, P, P, P, P, P, P],
     "mss_groupnorm_workspace_floats": [I, I, I, I],
     "mss_groupnorm_nhwc_f32": [P, I, L, I, I, I, I, P, P, F, I, P, I, L, P, P],
     "mss_groupnorm_stat_offset": [I, I, I],

@@ -51,18 +51,21 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
 
 // backward: dz = rstd * (g*gamma - mean_C(g*gamma) - xhat * mean_C(g*gamma*xhat)), the same for x and res; per-workgroup
 // partial sums of (g*xhat | g) per channel go to part[block][2][C] and are added in block order by ln_param_grad_kernel.
-template <int Q>
+// SUM: the workgroup also leaves the per-channel sums of dz (part[block][3][C]): the bias gradient of the Linear that produced
+// `res` (d bias = column sums of the gradient of its output = dz), without another pass over the [rows, C] tensor.
+template <int Q, bool SUM = false>
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                 const float* __restrict__ res, const float* __restrict__ stat,
                                                                 long long rows, int C, const float* __restrict__ gamma,
                                                                 float* __restrict__ dz, float* __restrict__ part,
                                                                 int rows_per_block) {
-  __shared__ f32x4 red[2][4][64 * Q];
+  constexpr int NP = SUM ? 3 : 2;
+  __shared__ f32x4 red[NP][4][64 * Q];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  f32x4 dg[Q], db[Q], gm[Q];
+  f32x4 dg[Q], db[Q], gm[Q], dzs[Q];
 #pragma unroll
   for (int k = 0; k < Q; ++k) {
-    dg[k] = f32x4{0.f, 0.f, 0.f, 0.f}; db[k] = dg[k];
+    dg[k] = f32x4{0.f, 0.f, 0.f, 0.f}; db[k] = dg[k]; dzs[k] = dg[k];
     gm[k] = ld4(gamma + (lane + 64 * k) * 4);
   }
   const long long r0 = (long long)blockIdx.x * rows_per_block;
@@ -89,19 +92,25 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
       const int c = (lane + 64 * k) * 4;
-      st4(dz + row * C + c, rstd * (g[k] * gm[k] - m1 - xh[k] * m2));
+      const f32x4 d = rstd * (g[k] * gm[k] - m1 - xh[k] * m2);
+      st4(dz + row * C + c, d);
+      if (SUM) dzs[k] += d;
     }
   }
 #pragma unroll
-  for (int k = 0; k < Q; ++k) { red[0][wave][lane + 64 * k] = dg[k]; red[1][wave][lane + 64 * k] = db[k]; }
+  for (int k = 0; k < Q; ++k) {
+    red[0][wave][lane + 64 * k] = dg[k]; red[1][wave][lane + 64 * k] = db[k];
+    if (SUM) red[NP - 1][wave][lane + 64 * k] = dzs[k];
+  }
   __syncthreads();
   if (wave == 0) {
-    float* o = part + (size_t)blockIdx.x * 2 * C;
+    float* o = part + (size_t)blockIdx.x * NP * C;
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
       const int i = lane + 64 * k;
       st4(o + i * 4, ((red[0][0][i] + red[0][1][i]) + red[0][2][i]) + red[0][3][i]);
       st4(o + C + i * 4, ((red[1][0][i] + red[1][1][i]) + red[1][2][i]) + red[1][3][i]);
+      if (SUM) st4(o + 2 * C + i * 4, ((red[NP - 1][0][i] + red[NP - 1][1][i]) + red[NP - 1][2][i]) + red[NP - 1][3][i]);
     }
   }
 }
@@ -273,8 +282,12 @@ long long mss_add_layernorm_bwd_workspace_floats(long long rows, int C) {
   return blocks * 2 * C;
 }
 
-int mss_add_layernorm_bwd_f32(const float* gy, const float* x, const float* res, const float* stat, long long rows, int C,
-                              const float* gamma, float* dz, float* dgamma, float* dbeta, float* ws, void* stream) {
+}  // extern "C"
+
+namespace {
+template <bool SUM>
+int launch_add_layernorm_bwd(const float* gy, const float* x, const float* res, const float* stat, long long rows, int C,
+                             const float* gamma, float* dz, float* dgamma, float* dbeta, float* dzsum, float* ws, void* stream) {
   if (!gy || !x || !stat || !gamma || !dz || !ws || rows < 0) return MSS_ERR_BAD_ARG;
   if (rows == 0) return MSS_OK;
   if (C % 256 || C > 1024) return MSS_ERR_UNSUPPORTED;
@@ -284,15 +297,32 @@ int mss_add_layernorm_bwd_f32(const float* gy, const float* x, const float* res,
   blocks = (rows + rpb - 1) / rpb;
   const dim3 grid((unsigned)blocks);
   switch (C / 256) {
-    case 1: hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
-    case 2: hipLaunchKernelGGL(add_layernorm_bwd_kernel<2>, grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
-    case 3: hipLaunchKernelGGL(add_layernorm_bwd_kernel<3>, grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
-    default: hipLaunchKernelGGL(add_layernorm_bwd_kernel<4>, grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
+    case 1: hipLaunchKernelGGL((add_layernorm_bwd_kernel<1, SUM>), grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
+    case 2: hipLaunchKernelGGL((add_layernorm_bwd_kernel<2, SUM>), grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
+    case 3: hipLaunchKernelGGL((add_layernorm_bwd_kernel<3, SUM>), grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
+    default: hipLaunchKernelGGL((add_layernorm_bwd_kernel<4, SUM>), grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
   }
-  // part is [block][2][C]: rows of dgamma at stride 2C from offset 0, rows of dbeta from offset C
-  if (dgamma) hipLaunchKernelGGL(ordered_colsum_kernel, dim3((C + 3) / 4), dim3(256), 0, S_(stream), ws, (int)blocks, C, 2ll * C, dgamma);
-  if (dbeta) hipLaunchKernelGGL(ordered_colsum_kernel, dim3((C + 3) / 4), dim3(256), 0, S_(stream), ws + C, (int)blocks, C, 2ll * C, dbeta);
+  // part is [block][NP][C]: rows of dgamma at stride NP*C from offset 0, rows of dbeta from offset C, of sum(dz) from 2C
+  const long long st = (SUM ? 3ll : 2ll) * C;
+  if (dgamma) hipLaunchKernelGGL(ordered_colsum_kernel, dim3((C + 3) / 4), dim3(256), 0, S_(stream), ws, (int)blocks, C, st, dgamma);
+  if (dbeta) hipLaunchKernelGGL(ordered_colsum_kernel, dim3((C + 3) / 4), dim3(256), 0, S_(stream), ws + C, (int)blocks, C, st, dbeta);
+  if (SUM && dzsum) hipLaunchKernelGGL(ordered_colsum_kernel, dim3((C + 3) / 4), dim3(256), 0, S_(stream), ws + 2 * C, (int)blocks, C, st, dzsum);
   return mss_launch_status();
+}
+}  // namespace
+
+extern "C" {
+
+int mss_add_layernorm_bwd_f32(const float* gy, const float* x, const float* res, const float* stat, long long rows, int C,
+                              const float* gamma, float* dz, float* dgamma, float* dbeta, float* ws, void* stream) {
+  return launch_add_layernorm_bwd<false>(gy, x, res, stat, rows, C, gamma, dz, dgamma, dbeta, nullptr, ws, stream);
+}
+
+// the same with dzsum [C] = per-channel sums of dz (ws: 3/2 of mss_add_layernorm_bwd_workspace_floats)
+int mss_add_layernorm_bwd_sum_f32(const float* gy, const float* x, const float* res, const float* stat, long long rows, int C,
+                                  const float* gamma, float* dz, float* dgamma, float* dbeta, float* dzsum, float* ws, void* stream) {
+  if (!dzsum) return MSS_ERR_BAD_ARG;
+  return launch_add_layernorm_bwd<true>(gy, x, res, stat, rows, C, gamma, dz, dgamma, dbeta, dzsum, ws, stream);
 }
 
 // GroupNorm over NHWC x [N][HW][C] (pixel stride ldx, sample stride x_sample_stride floats): y = (x - mean[n,g]) *

@@ -54,13 +54,31 @@ def _layernorm(x, res, weight, bias, eps):
 
 
 def _layernorm_bwd(gy, x, res, stat, weight):
+    """-> dz, dgamma, dbeta, column sums of dz (= the bias gradient of the Linear that produced `res`: no colsum pass over dz)."""
     C = x.shape[-1]
     rows = x.numel() // C
     dz = torch.empty_like(x)
-    dg, db = torch.empty_like(weight), torch.empty_like(weight)
-    ws = torch.empty(_lib.value("mss_add_layernorm_bwd_workspace_floats", rows, C), device=x.device, dtype=torch.float32)
-    call("mss_add_layernorm_bwd_f32", ptr(gy), ptr(x), ptr(res), ptr(stat), rows, C, ptr(weight), ptr(dz), ptr(dg), ptr(db), ptr(ws))
-    return dz, dg, db
+    dg, db, dzsum = torch.empty_like(weight), torch.empty_like(weight), torch.empty_like(weight)
+    ws = torch.empty(_lib.value("mss_add_layernorm_bwd_workspace_floats", rows, C) // 2 * 3, device=x.device, dtype=torch.float32)
+    call("mss_add_layernorm_bwd_sum_f32", ptr(gy), ptr(x), ptr(res), ptr(stat), rows, C, ptr(weight), ptr(dz), ptr(dg), ptr(db),
+         ptr(dzsum), ptr(ws))
+    return dz, dg, db, dzsum
+
+
+def _gemm_with_colsum(x, weight, res, res_mask, flip):
+    """_gemm whose epilogue also leaves the column sums of its OUTPUT (MssConvArgs.stats: per-64-row partial sums written by the
+    producing kernel, added in float64 by the BatchNorm-statistics reduction) -- the bias gradient of the layer below, without
+    re-reading the [rows, d_ffn] tensor."""
+    k, c = weight.shape
+    cin, cout = (k, c) if flip else (c, k)
+    out = torch.empty(x.shape[:-1] + (cout,), device=x.device, dtype=torch.float32)
+    o = K.conv2d(_rows(x, cin), _packed(weight, flip), out=_rows(out, cout), res=_rows(res, cout) if res is not None else None,
+                 res_mask=res_mask, want_stats=True)
+    if o.stats is None:
+        return out, _bgrad(out, cout)
+    accum = K._col_accum(o.stats.shape[0], cout, x.device)
+    call("mss_bn_stats_partials_f32", ptr(o.stats), o.stats.shape[0], cout, ptr(accum))
+    return out, accum[:cout].float()
 
 
 # positions of the parameters in _EncoderLayerFn.apply's argument list (after src, pos, ref, shapes, starts, geometry)
@@ -107,25 +125,24 @@ class _EncoderLayerFn(Function):
             shapes._mss_host = ctx.shapes_host          # the host copy of the level sizes travels with the tensor object only
         g = {}
         # ---- LayerNorm2 and the FFN: d(s1) = g2 + dh W1 rides in the last data-gradient GEMM's residual input
-        g2, g["n2_w"], g["n2_b"] = _layernorm_bwd(gout.contiguous(), s1, f, stat2, p["n2_w"])
+        # (three of the six bias gradients come out of kernels that run anyway: linear2's and output_proj's are the column sums of
+        # the LayerNorm backward's dz, linear1's the column sums of the ReLU-gated data-gradient GEMM's output)
+        g2, g["n2_w"], g["n2_b"], g["l2_b"] = _layernorm_bwd(gout.contiguous(), s1, f, stat2, p["n2_w"])
         if need["l2_w"]:
             g["l2_w"] = _wgrad(h, g2, p["l2_w"])
-        if need["l2_b"]:
-            g["l2_b"] = _bgrad(g2, C)
-        dh = _gemm(g2, p["l2_w"], res=h, res_mask=True, flip=True)            # ReLU backward in the epilogue
+        if need["l1_b"]:
+            dh, g["l1_b"] = _gemm_with_colsum(g2, p["l2_w"], res=h, res_mask=True, flip=True)   # ReLU backward in the epilogue
+        else:
+            dh = _gemm(g2, p["l2_w"], res=h, res_mask=True, flip=True)
         if need["l1_w"]:
             g["l1_w"] = _wgrad(s1, dh, p["l1_w"])
-        if need["l1_b"]:
-            g["l1_b"] = _bgrad(dh, dh.shape[-1])
         ds1 = _gemm(dh, p["l1_w"], res=g2, flip=True)
         del dh, g2
         # ---- LayerNorm1 and the attention output projection
-        g1, g["n1_w"], g["n1_b"] = _layernorm_bwd(ds1, src, attn, stat1, p["n1_w"])
+        g1, g["n1_w"], g["n1_b"], g["out_b"] = _layernorm_bwd(ds1, src, attn, stat1, p["n1_w"])
         del ds1
         if need["out_w"]:
             g["out_w"] = _wgrad(samp, g1, p["out_w"])
-        if need["out_b"]:
-            g["out_b"] = _bgrad(g1, C)
         dsamp = _gemm(g1, p["out_w"], flip=True)
         # ---- the sampling op: locations / weights rebuilt by the one-pass prepare kernel (bit-identical to the forward's)
         offs6 = offs.view(N, S, M, L, P, 2)
