@@ -274,11 +274,21 @@ class DeepWV3Plus(nn.Module):
         K.broadcast_rows(u0_rows, raw.slice(0, 256))
         states.append(st)
         xt_bytes = sum(K.wino_xt_bytes(N, h8, w8, 4096, r) for r in _ASPP_RATES)
+        # two dilated branches whose Winograd-domain products have the same shape share ONE GEMM launch when that fills the chip
+        # better (the one-image eval forward: dilations 12 and 24, kernels.conv3x3_pair_tile); never when X' is kept for a backward
+        pair_tile = 0 if keep else K.conv3x3_pair_tile(x, asp.features[1][0].weight, asp.features[2][0].weight, *_ASPP_RATES[:2])
         for i, feat in enumerate(asp.features):
             rate = 1 if i == 0 else _ASPP_RATES[i - 1]
             sl = raw.slice(256 * (i + 1), 256)
             if i == 0:
                 K.conv2d(x, K.packed(feat[0].weight), out=sl, want_stats=train)
+            elif pair_tile and i in (1, 2):
+                if i == 1:
+                    K.conv3x3_pair(x, feat[0].weight, asp.features[2][0].weight, _ASPP_RATES[0], _ASPP_RATES[1], sl,
+                                   raw.slice(256 * 3, 256), pair_tile, want_stats=train)
+                    pair_slices = {1: sl, 2: raw.slice(256 * 3, 256)}
+                sl = pair_slices[i]              # carries the statistics the producing transform left (train-mode BatchNorm)
+                aspp_xt[i] = None
             else:
                 # keep the Winograd-domain input X' for this layer's weight gradient when the three of them fit
                 # comfortably (2.25-4x the 4096-channel map each: 10.6 GB in all at 2x1024x2048)

@@ -425,6 +425,89 @@ def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=N
     return out
 
 
+def packed_wino_pair(p1, p2, tile):
+    """The Winograd-domain forms of two same-shaped 3x3 weights in ONE buffer [2P][Kpad][C] (P = (tile+2)^2), for
+    conv3x3_pair. Cached on p1 until either parameter changes; the halves are also installed as the two parameters' own
+    packed forms (views of the buffer), so the single-layer path does not keep a second copy."""
+    key = (p1._version, p1.data_ptr(), p2._version, p2.data_ptr())
+    cache = p1.__dict__.setdefault("_mss_packed", {})
+    ent = cache.get(("wino_pair", tile))
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    assert p1.shape == p2.shape and p1.shape[2:] == (3, 3)
+    K, C = p1.shape[0], p1.shape[1]
+    P = (tile + 2) ** 2
+    Kpad = _lib.value("mss_conv2d_kpad", K)
+    t = torch.empty((2 * P, Kpad, C), device=p1.device, dtype=torch.float32)
+    for j, p in enumerate((p1, p2)):
+        w = p.detach().contiguous()
+        call("mss_wino_pack_weights_f32", ptr(w), ptr(t[j * P:(j + 1) * P]), K, C, Kpad, C, tile)
+        p.__dict__.setdefault("_mss_packed", {})[("wino", False, tile)] = (p._version, p.data_ptr(), WinoWeight(t[j * P:(j + 1) * P], K, C, Kpad, C, tile))
+    ww = WinoWeight(t, K, C, Kpad, C, tile)
+    cache[("wino_pair", tile)] = (key, ww)
+    return ww
+
+
+def conv3x3_pair_tile(x, w1, w2, dil1, dil2):
+    """Tile edge when two 3x3 / stride-1 layers on the SAME input (ASPP's dilated branches) can share one batched GEMM launch
+    and it pays, else 0: same Winograd tile and tile count, K a multiple of 128, and the joint launch fills its rounds of
+    workgroup slots better than each alone -- the one-image eval forward: 64 x 1152 x 4096 -> 256 is 1152 narrow tiles = 1.5
+    rounds of 768 slots (106 TFLOP/s), the pair exactly 3 (MSS_WINO_PAIR=0 switches it off)."""
+    if os.environ.get("MSS_WINO_PAIR", "1") == "0" or _tile_hook is not None or w1.shape != w2.shape:
+        return 0
+    k, c = w1.shape[0], w1.shape[1]
+    t1, t2 = wino_tile(x.H, x.W, dil1), wino_tile(x.H, x.W, dil2)
+    if t1 != t2 or not t1 or not use_winograd(c, k, 1, None, t1) or k % 128:
+        return 0
+    T1 = _lib.value("mss_wino_num_tiles", x.N, x.H, x.W, dil1, t1)
+    if T1 != _lib.value("mss_wino_num_tiles", x.N, x.H, x.W, dil2, t1):
+        return 0
+    P = (t1 + 2) ** 2
+
+    def eff(positions):                 # the better of the wide (k / 256 column tiles, 512 slots) and narrow (k / 128, 768) launches
+        best = 0.0
+        for bn, slots in ((256, 512), (128, 768)):
+            if k % bn == 0:
+                tiles = positions * -(-T1 // 128) * (k // bn)
+                best = max(best, tiles / (-(-tiles // slots) * slots))
+        return best
+    return t1 if eff(2 * P) > eff(P) + 0.1 else 0
+
+
+def conv3x3_pair(x, w1, w2, dil1, dil2, out1, out2, tile, want_stats=False):
+    """conv3x3(x, w1, dil1) -> out1 and conv3x3(x, w2, dil2) -> out2 with the 2 x (tile+2)^2 Winograd-domain products in ONE
+    gemm_nt launch (see conv3x3_pair_tile). Same transforms, same products, same results as the two separate calls."""
+    ww = packed_wino_pair(w1, w2, tile)
+    N, H, W, C, Ko = x.N, x.H, x.W, ww.C, ww.K
+    P = (tile + 2) ** 2
+    dev = x.buf.device
+    T = _lib.value("mss_wino_num_tiles", N, H, W, dil1, tile)
+    with _Timed("conv_winograd", 2 * 2.0 * N * H * W * Ko * C * 9, (N, H, W, C, 2 * Ko, 3, 1, (dil1, dil2))):
+        xt = torch.empty((2 * P, T, C), device=dev, dtype=torch.float32)
+        for j, d in enumerate((dil1, dil2)):
+            with _Timed("wino_transform", 4.0 * (N * H * W * C + P * T * C), ("input", N, H, W, C, d, tile)):
+                call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, d, tile, None, None, 0, ptr(xt[j * P:(j + 1) * P]))
+        yt = torch.empty((2 * P, T, Ko), device=dev, dtype=torch.float32)
+        a = MssConvArgs()
+        a.x, a.w, a.y = ptr(xt), ptr(ww.t), ptr(yt)
+        a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
+        a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, Ko, ww.Kpad, Ko
+        a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+        a.batch, a.x_bs, a.w_bs, a.y_bs = 2 * P, T * C, ww.Kpad * ww.Cp, T * Ko
+        with _Timed(_fwd_kind(a), 2.0 * 2 * P * T * C * Ko, (2 * P, 1, T, C, Ko, 1, 1, 1)):
+            call("mss_conv2d_forward_f32", ctypes.byref(a))
+        del xt
+        for j, (d, out) in enumerate(((dil1, out1), (dil2, out2))):
+            out.stats = None
+            if want_stats and out.C == Ko:
+                out.stats = torch.empty((_lib.value("mss_wino_output_stats_parts", N, H, W, Ko, d, tile), 2, Ko), device=dev,
+                                        dtype=torch.float32)
+            with _Timed("wino_transform", 4.0 * (P * T * Ko + N * H * W * Ko), ("output", N, H, W, Ko, d, tile)):
+                call("mss_wino_output_transform_f32", ptr(yt[j * P:(j + 1) * P]), N, H, W, Ko, d, tile, None, 0, out.ptr, out.ld,
+                     ptr(out.stats))
+    return out1, out2
+
+
 def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=None, tile=None):
     """[K,C,3,3] weight gradient of a 3x3 / stride-1 / padding = dilation conv in the Winograd domain:
     dU[p] = dY'[p]^T X'[p] ((m+2)^2 batched MFMA products over tiles, 2.25x / 4x fewer FLOPs than the 9-tap

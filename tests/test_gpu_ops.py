@@ -482,6 +482,37 @@ def test_batched_wgrad_routes_vs_float64(K, monkeypatch, mode, P, T, C, Ko):
     assert not torch.isnan(outs[0]).any()
 
 
+def test_winograd_pair_equals_two_separate_layers(K, monkeypatch):
+    """kernels.conv3x3_pair: two dilated 3x3 layers on the same input with their 2 x 64 Winograd-domain products in ONE gemm_nt
+    launch (the eval forward's ASPP branches) -- every output element is the same sum in the same order as in the separate
+    calls: bit-identical, BatchNorm partial sums included; and the rule takes the pair at the one-image ASPP shape only."""
+    torch.manual_seed(5)
+    x = K.Act(torch.randn(1, 24, 24, 64, device="cuda"))
+    w1 = torch.nn.Parameter(torch.randn(128, 64, 3, 3, device="cuda") * 0.05)
+    w2 = torch.nn.Parameter(torch.randn(128, 64, 3, 3, device="cuda") * 0.05)
+    a1, a2 = K.Act.empty(1, 24, 24, 128, "cuda"), K.Act.empty(1, 24, 24, 128, "cuda")
+    K.conv2d_winograd(x, K.pack_weight_wino(w1.detach(), tile=6), dil=1, out=a1, want_stats=True)
+    K.conv2d_winograd(x, K.pack_weight_wino(w2.detach(), tile=6), dil=2, out=a2, want_stats=True)
+    b1, b2 = K.Act.empty(1, 24, 24, 128, "cuda"), K.Act.empty(1, 24, 24, 128, "cuda")
+    K.conv3x3_pair(x, w1, w2, 1, 2, b1, b2, 6, want_stats=True)
+    assert torch.equal(a1.buf, b1.buf) and torch.equal(a2.buf, b2.buf)
+    assert torch.equal(a1.stats, b1.stats) and torch.equal(a2.stats, b2.stats)
+    # the halves of the pair buffer serve the single-layer path too (no second packed copy), and follow a weight update
+    assert K.packed_wino(w1, False, 6).t.data_ptr() == K.packed_wino_pair(w1, w2, 6).t.data_ptr()
+    with torch.no_grad():
+        w2.mul_(2.0)
+    K.conv3x3_pair(x, w1, w2, 1, 2, b1, b2, 6)
+    assert torch.equal(a1.buf, b1.buf) and torch.allclose(2 * a2.buf, b2.buf, rtol=1e-6, atol=1e-6)
+    wa = torch.empty(256, 4096, 3, 3, device="meta")
+    class Shape:            # geometry only: the rule never touches data
+        def __init__(self, n): self.N, self.H, self.W = n, 128, 256
+    assert K.conv3x3_pair_tile(Shape(1), wa, wa, 12, 24) == 6
+    assert K.conv3x3_pair_tile(Shape(2), wa, wa, 12, 24) == 0      # 2304 tiles per position: three full rounds already
+    assert K.conv3x3_pair_tile(Shape(1), wa, wa, 12, 36) == 0      # different tile sizes / tile counts
+    monkeypatch.setenv("MSS_WINO_PAIR", "0")
+    assert K.conv3x3_pair_tile(Shape(1), wa, wa, 12, 24) == 0
+
+
 @pytest.mark.parametrize("T,C,Ko", [(162624, 256, 256), (50001, 256, 192), (40000, 1024, 256)])
 def test_linear_wgrad_many_rows_vs_float64(K, T, C, Ko):
     """The decoder's Linear weight gradients: ONE position, a handful of output tiles and very many rows (16 x 10 164 tokens), i.e.
