@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MSS_ABI_VERSION 4      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32 */
+#define MSS_ABI_VERSION 4      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32 */
 int mss_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -174,6 +174,10 @@ int mss_nchw_to_nhwc_pad_f32(const float* x, float* y, int N, int C, int H, int 
  * out [N,H,W,32] NHWC with channel j = c*9 + r*3 + s holding img[n][c][y+r-1][x+s-1] (zero padding), 27..31 zero: the
  * column order of weight.reshape(64, 27). The 1x1 convolution of that tensor with the reshaped weight IS conv1. */
 int mss_im2col3x3_c3_f32(const float* img, float* out, int N, int H, int W, void* stream);
+/* The stem in ONE kernel (csrc/stem.hip): y [N][OH][OW][64] NHWC (pixel stride ldy >= 64) = MaxPool2d(3, stride 2, padding 1) of
+ * conv3x3(img [N][3][H][W] NCHW, w [64][3][3][3], padding 1, no bias) -- mod1.conv1 + pool2 of the trunk (wider_resnet.py:343-345,
+ * 353-355; no BatchNorm between them). OH = (H-1)/2 + 1, OW = (W-1)/2 + 1. The full-resolution 64-channel map is never stored. */
+int mss_stem_conv_pool_f32(const float* img, const float* w, float* y, int ldy, int N, int H, int W, void* stream);
 
 /* BatchNorm2d pieces (mynn.py:8-12 Norm2d = nn.BatchNorm2d, eps 1e-5, momentum 0.1).
  * stats: per-channel batch mean and biased variance of an NHWC tensor (M pixels). `accum` is a scratch of

@@ -78,6 +78,7 @@ SIGNATURES = {
     "mss_conv2d_unpack_wgrad_f32": [P, P, I, I, I, I, I, I, I, P],
     "mss_nchw_to_nhwc_pad_f32": [P, P, I, I, I, I, I, P],
     "mss_im2col3x3_c3_f32": [P, P, I, I, I, P],
+    "mss_stem_conv_pool_f32": [P, P, P, I, I, I, I, P],
     "mss_bn_stats_nhwc_f32": [P, L, I, I, P, P],
     "mss_bn_finalize_train_f32": [P, L, I, P, P, F, F, P, P, P, P, P, P, P],
     "mss_bn_fold_eval_f32": [P, P, P, P, F, I, P, P, P],

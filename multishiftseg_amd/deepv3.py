@@ -222,7 +222,12 @@ class DeepWV3Plus(nn.Module):
                         res=shortcut, want_stats=train)
 
     def _run_trunk(self, inp):
-        if os.environ.get("MSS_STEM_IM2COL", "1") != "0":
+        fused_stem = os.environ.get("MSS_STEM_FUSED", "1") != "0"
+        if fused_stem:
+            # mod1.conv1 + pool2 in one kernel (csrc/stem.hip): image in, pooled 64-channel map out; MSS_STEM_FUSED=0 keeps the
+            # two routes below + the separate pool (independent second formulations, compared in the tests)
+            a = K.stem_conv_pool(inp, self.mod1.conv1.weight)
+        elif os.environ.get("MSS_STEM_IM2COL", "1") != "0":
             # 3 -> 64 stem as a dense K = 27 (32) GEMM on explicit 3x3 patches; MSS_STEM_IM2COL=0: the implicit-GEMM
             # kernel on the image padded to 16 channels (K = 144, 13/16 zeros) -- kept as the independent second route
             a = K.conv2d(K.stem_im2col(inp), K.packed_stem(self.mod1.conv1.weight))
@@ -231,7 +236,7 @@ class DeepWV3Plus(nn.Module):
         m2 = None
         for mod_id in range(6):
             name = f"mod{mod_id + 2}"
-            if mod_id < 2:
+            if mod_id < 2 and not (fused_stem and mod_id == 0):
                 a = K.maxpool3s2(a)
             for blk in getattr(self, name):
                 a = self._run_block(blk, a, name)

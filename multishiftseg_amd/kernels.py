@@ -572,6 +572,19 @@ def stem_im2col(img):
     return out
 
 
+def stem_conv_pool(img, weight):
+    """[N,3,H,W] NCHW image, mod1.conv1.weight [64,3,3,3] -> Act [N,(H-1)//2+1,(W-1)//2+1,64] = MaxPool2d(3,2,1)(conv3x3(img)) in
+    ONE kernel (csrc/stem.hip): the full-resolution 64-channel map never exists."""
+    n, c, h, w = img.shape
+    if c != 3 or tuple(weight.shape) != (64, 3, 3, 3):
+        raise ValueError(f"the fused stem expects a 3-channel image and a [64,3,3,3] weight, got {tuple(img.shape)} / {tuple(weight.shape)}")
+    img = img.contiguous()
+    wt = weight.detach().contiguous()
+    out = Act.empty(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, 64, img.device)
+    call("mss_stem_conv_pool_f32", ptr(img), ptr(wt), out.ptr, out.ld, n, h, w)
+    return out
+
+
 def packed_stem(param):
     """mod1.conv1.weight [64,3,3,3] as the 1x1 weight [64,32,1,1] that matches stem_im2col's channel order."""
     def make():

@@ -482,6 +482,26 @@ def test_batched_wgrad_routes_vs_float64(K, monkeypatch, mode, P, T, C, Ko):
     assert not torch.isnan(outs[0]).any()
 
 
+@pytest.mark.parametrize("n,h,w", [(1, 64, 128), (2, 37, 53), (1, 1, 1), (1, 2, 33), (3, 90, 150), (1, 70, 1000), (1, 33, 2048)])
+def test_fused_stem_conv_pool(K, n, h, w):
+    """csrc/stem.hip: conv3x3(3 -> 64, padding 1) + MaxPool2d(3, 2, 1) in one kernel (wave per pooled row, MFMA from registers,
+    pooling in the accumulator layout) against (a) the two-kernel path of this repository (im2col + K = 32 GEMM, then the pool
+    kernel) and (b) torch in float64; odd and tiny sizes, widths beyond one segment, every border case of both paddings."""
+    torch.manual_seed(n * h + w)
+    img = torch.randn(n, 3, h, w, device="cuda")
+    wt = torch.nn.Parameter(torch.randn(64, 3, 3, 3, device="cuda") * 0.2)
+    got = K.stem_conv_pool(img, wt)
+    two = K.maxpool3s2(K.conv2d(K.stem_im2col(img), K.packed_stem(wt)))
+    assert (got.N, got.H, got.W, got.C) == (two.N, two.H, two.W, two.C) == (n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, 64)
+    want = torch.nn.functional.max_pool2d(torch.nn.functional.conv2d(img.double(), wt.detach().double(), padding=1), 3, 2, 1)
+    g = got.nchw().double()
+    assert torch.isfinite(g).all()
+    err, err2 = (g - want).abs().max().item(), (two.nchw().double() - want).abs().max().item()
+    assert err <= 2e-6 * max(1.0, want.abs().max().item()), (err, err2)
+    # the same products in the same K-order as the GEMM of the two-kernel path: the same numbers
+    assert torch.equal(got.nchw(), two.nchw()), (got.nchw() - two.nchw()).abs().max().item()
+
+
 def test_winograd_pair_equals_two_separate_layers(K, monkeypatch):
     """kernels.conv3x3_pair: two dilated 3x3 layers on the same input with their 2 x 64 Winograd-domain products in ONE gemm_nt
     launch (the eval forward's ASPP branches) -- every output element is the same sum in the same order as in the separate
