@@ -445,6 +445,35 @@ static int launch_gemm_wp(const MssConvArgs& p, hipStream_t stream) {
   return mss_launch_status();
 }
 
+// A handful of rows (ASPP's image-pooling branch: [N, 4096] x [4096 -> 256], deepv3.py:84-88): one MFMA tile would walk the whole
+// reduction alone (256 K-steps on one or two of 256 CUs: 0.25 ms for 4 MB of weights). Here a WAVE owns one output channel: its
+// weight row streams through the lanes in 16-byte pieces, the <= 8 input rows come from cache, one wave reduction per row.
+template <int MAXM>
+__global__ __launch_bounds__(256) void gemm_few_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                            float* __restrict__ y, int ldy, int M, int C, int K) {
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= K) return;
+  float acc[MAXM];
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) acc[m] = 0.f;
+  const float* wr = w + (size_t)k * C;
+  for (int c = lane * 4; c < C; c += 256) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m)
+      if (m < M) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * ldx + c);
+        acc[m] += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
+      }
+  }
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) {
+    const float s = mss_wave_sum(acc[m]);
+    if (m < M && lane == 0) y[(size_t)m * ldy + k] = s;
+  }
+}
+
 template <bool AFFINE, int VARIANT, int BN>
 int launch_gemm(const MssConvArgs& p, hipStream_t stream, long long first = 0, long long end = -1) {
   const int batch = p.batch > 1 ? p.batch : 1;
@@ -493,6 +522,13 @@ bool mss_gemm_nt_eligible(const MssConvArgs& p) {
 
 // Returns -1 when the shape is not handled here (the implicit-GEMM kernel takes it).
 int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
+  if (p.R * p.S == 1 && p.stride == 1 && p.pad == 0 && p.H == p.OH && p.W == p.OW && p.M > 0 && p.M <= 8 && p.batch <= 1 && p.C % 4 == 0 &&
+      p.ldx % 4 == 0 && !p.in_scale && !p.in_relu && !p.out_scale && !p.out_relu && !p.res && !p.stats &&
+      ((reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.w)) & 15) == 0) {
+    hipLaunchKernelGGL(gemm_few_rows_kernel<8>, dim3((p.K + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), p.x, p.ldx, p.w,
+                       p.y, p.ldy, p.M, p.C, p.K);
+    return mss_launch_status();
+  }
   if (!mss_gemm_nt_eligible(p)) return -1;
   p.H = (p.in_scale && p.in_ss_stride) ? p.OH * p.OW : (p.M > 0 ? p.M : 1);   // rows per affine group
   p.mtiles = mss_cdiv(p.M, BM);
