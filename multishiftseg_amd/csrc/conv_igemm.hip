@@ -23,6 +23,7 @@
 
 int mss_gemm_nt_dispatch(MssConvArgs p, void* stream);   // gemm.hip: persistent GEMM for the 1x1 / stride-1 shapes
 bool mss_gemm_nt_eligible(const MssConvArgs& p);
+bool mss_gemm_few_rows(const MssConvArgs& p);
 
 namespace {
 
@@ -1131,7 +1132,9 @@ int mss_conv2d_forward_route(const MssConvArgs* args) {
   MssConvArgs p = *args;
   p.M = p.N * p.OH * p.OW;
   const char* e = getenv("MSS_GEMM");
-  return (!e || atoi(e)) && mss_gemm_nt_eligible(p) ? 1 : 0;
+  if (!(!e || atoi(e))) return 0;
+  if (mss_gemm_few_rows(p)) return 2;                  // (0 implicit-GEMM kernel, 1 gemm_nt_kernel, 2 gemm_few_rows_kernel)
+  return mss_gemm_nt_eligible(p) ? 1 : 0;
 }
 
 // Kpad the packed layout must use for a conv with K output channels (multiple of the N tile).

@@ -177,7 +177,7 @@ def _fwd_kind(a):
     """Profiling label of a forward launch: which of the two MFMA kernels the C side picks."""
     if _profile is None:
         return "conv_igemm"
-    return "gemm_nt" if _lib.value("mss_conv2d_forward_route", ctypes.byref(a)) else "conv_igemm"
+    return ("conv_igemm", "gemm_nt", "gemm_few_rows")[_lib.value("mss_conv2d_forward_route", ctypes.byref(a))]
 
 
 def conv_out_size(h, r, stride, dil, pad):
