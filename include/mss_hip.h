@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-#define MSS_ABI_VERSION 4      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32 */
+#define MSS_ABI_VERSION 4      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
+                                  mss_wino_input_transform_bnbwd_f32 */
 int mss_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -156,6 +157,13 @@ long long mss_wino_num_tiles(int N, int H, int W, int dil, int tile);
 int mss_wino_pack_weights_f32(const float* w, float* u, int K, int C, int Kpad, int Cp, int tile, void* stream);
 int mss_wino_input_transform_f32(const float* x, int ldx, int N, int H, int W, int C, int dil, int tile,
                                  const float* scale, const float* shift, int relu, float* xt, void* stream);
+/* The same X', but of dx = the train-mode BatchNorm+ReLU backward of the gradient dy w.r.t. the layer input x2, computed on the fly
+ * (the arithmetic of mss_bn_relu_bwd_apply_f32): the data-gradient convolution behind a BatchNorm backward never materialises dx.
+ * scale / shift: the forward's folded affine; mean / invstd: its saved batch statistics; accum: [2C] doubles of
+ * mss_bn_relu_bwd_reduce_f32 over the same (dy, x2). MSS_ERR_UNSUPPORTED where the LDS-staged transform is not taken. */
+int mss_wino_input_transform_bnbwd_f32(const float* dy, int lddy, const float* x2, int ldx2, int N, int H, int W, int C, int dil,
+                                       int tile, const float* scale, const float* shift, const float* mean, const float* invstd,
+                                       const double* accum, int relu, float* xt, void* stream);
 int mss_wino_output_transform_f32(const float* yt, int N, int H, int W, int K, int dil, int tile, const float* res,
                                   int ldres, float* y, int ldy, float* stats, void* stream);
 /* stats (optional): [mss_wino_output_stats_parts(...)][2][K] partial sums / sums of squares of y, as MssConvArgs.stats */

@@ -115,6 +115,7 @@ SIGNATURES = {
     "mss_wino_num_tiles": [I, I, I, I, I],
     "mss_wino_pack_weights_f32": [P, P, I, I, I, I, I, P],
     "mss_wino_input_transform_f32": [P, I, I, I, I, I, I, I, P, P, I, P, P],
+    "mss_wino_input_transform_bnbwd_f32": [P, I, P, I, I, I, I, I, I, I, P, P, P, P, P, I, P, P],
     "mss_wino_output_transform_f32": [P, I, I, I, I, I, I, P, I, P, I, P, P],
     "mss_wino_output_stats_parts": [I, I, I, I, I, I],
     "mss_bn_stats_partials_f32": [P, L, I, P, P],
@@ -198,6 +199,11 @@ def call(name, *args):
     if rc != 0:
         kind = {MSS_ERR_BAD_ARG: "bad argument", MSS_ERR_UNSUPPORTED: "unsupported shape"}.get(rc, "hipError_t")
         raise MssError(f"{name} failed with code {rc} ({kind})")
+
+
+def status(name, *args):
+    """As call(), but hands the status code back instead of raising (callers that have a fallback for MSS_ERR_UNSUPPORTED)."""
+    return getattr(load(), name)(*args, stream_ptr())
 
 
 def value(name, *args):

@@ -374,19 +374,34 @@ class DeepWV3Plus(nn.Module):
             return [grads.get(n) for n in names]
         _, wh_flip = self._heads_weight()
         d_act1 = K.conv2d(ddec12, wh_flip)
-        df1, dg, db = K.bn_relu_backward(d_act1, f1, s["st_f1"], want_param_grads=need["final.4.weight"] or need["final.4.bias"])
-        grads["final.4.weight"], grads["final.4.bias"] = dg, db
+        # Neither stage of exps/DeepLab.yaml trains `final`: the gradient w.r.t. a BatchNorm's input then has ONE consumer, the data
+        # gradient of the 3x3 layer in front of it, and the BatchNorm backward's apply pass rides in that convolution's Winograd
+        # input transform (kernels.conv3x3_dgrad_after_bn: df1 / df0 are never written). With `final` trainable: the separate steps.
         aff_f0 = (s["st_f0"].scale, s["st_f0"].shift)
-        if need["final.3.weight"]:
-            grads["final.3.weight"] = K.conv3x3_wgrad(f0, df1, 256, 256, in_affine=aff_f0, in_relu=True, xt=s["final_xt"].pop(3, None))
-        d_act0 = K.conv3x3(df1, self.final[3].weight, flip=True)
-        df0, dg, db = K.bn_relu_backward(d_act0, f0, s["st_f0"], want_param_grads=need["final.1.weight"] or need["final.1.bias"])
-        grads["final.1.weight"], grads["final.1.bias"] = dg, db
-        if need["final.0.weight"]:
-            grads["final.0.weight"] = K.conv3x3_wgrad(dec0, df0, 256, 304, xt=s["final_xt"].pop(0, None))
-        if not any(need[n] for n in names if n.startswith(("aspp", "bot_"))):
-            return [grads.get(n) if need[n] else None for n in names]
-        ddec0 = K.conv3x3(df0, self.final[0].weight, flip=True)
+        if need["final.4.weight"] or need["final.4.bias"] or need["final.3.weight"]:
+            df1, dg, db = K.bn_relu_backward(d_act1, f1, s["st_f1"], want_param_grads=need["final.4.weight"] or need["final.4.bias"])
+            grads["final.4.weight"], grads["final.4.bias"] = dg, db
+            if need["final.3.weight"]:
+                grads["final.3.weight"] = K.conv3x3_wgrad(f0, df1, 256, 256, in_affine=aff_f0, in_relu=True, xt=s["final_xt"].pop(3, None))
+            d_act0 = K.conv3x3(df1, self.final[3].weight, flip=True)
+            del df1
+        else:
+            d_act0 = K.conv3x3_dgrad_after_bn(d_act1, f1, s["st_f1"], self.final[3].weight)
+        del d_act1
+        upstream = any(need[n] for n in names if n.startswith(("aspp", "bot_")))
+        if need["final.1.weight"] or need["final.1.bias"] or need["final.0.weight"]:
+            df0, dg, db = K.bn_relu_backward(d_act0, f0, s["st_f0"], want_param_grads=need["final.1.weight"] or need["final.1.bias"])
+            grads["final.1.weight"], grads["final.1.bias"] = dg, db
+            if need["final.0.weight"]:
+                grads["final.0.weight"] = K.conv3x3_wgrad(dec0, df0, 256, 304, xt=s["final_xt"].pop(0, None))
+            if not upstream:
+                return [grads.get(n) if need[n] else None for n in names]
+            ddec0 = K.conv3x3(df0, self.final[0].weight, flip=True)
+            del df0
+        else:
+            if not upstream:
+                return [grads.get(n) if need[n] else None for n in names]
+            ddec0 = K.conv3x3_dgrad_after_bn(d_act0, f0, s["st_f0"], self.final[0].weight)
         if need["bot_fine.weight"]:
             grads["bot_fine.weight"] = K.conv2d_wgrad(m2, ddec0.slice(0, 48), 48, 128, 1, 1)
         if any(need[n] for n in names if n.startswith(("aspp", "bot_aspp"))):

@@ -394,34 +394,45 @@ def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=N
         assert sc is None or sc.dim() == 1
         with _Timed("wino_transform", 4.0 * (N * H * W * C + P * T * C), ("input", N, H, W, C, dil, ts)):   # "flops" = algorithmic BYTES
             call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ts, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
-        yt = torch.empty((P, T, K), device=dev, dtype=torch.float32)
-        a = MssConvArgs()
-        a.x, a.w, a.y = ptr(xt), ptr(ww.t), ptr(yt)
-        a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
-        a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, K, ww.Kpad, K
-        a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
-        a.batch, a.x_bs, a.w_bs, a.y_bs = P, T * C, ww.Kpad * ww.Cp, T * K
-        rem = K % 128
-        split = K - rem if (K > 128 and 0 < rem <= 64) else 0     # e.g. 304 = 256 + 48: narrow tail on the 64-wide tile
+        return _wino_gemm_and_output(xt, ww, N, H, W, dil, res, out, keep_xt, want_stats)
+
+
+def _wino_gemm_and_output(xt, ww, N, H, W, dil, res, out, keep_xt, want_stats):
+    """Steps 2 and 3 of the Winograd convolution on a transformed input X' [P][T][C]: the batched MFMA products and the output
+    transform (+ residual, + BatchNorm partial sums)."""
+    C, K, ts = ww.C, ww.K, ww.tile
+    P, T = xt.shape[0], xt.shape[1]
+    dev = xt.device
+    if out is None:
+        out = Act.empty(N, H, W, K, dev)
+    yt = torch.empty((P, T, K), device=dev, dtype=torch.float32)
+    a = MssConvArgs()
+    a.x, a.w, a.y = ptr(xt), ptr(ww.t), ptr(yt)
+    a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
+    a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, K, ww.Kpad, K
+    a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+    a.batch, a.x_bs, a.w_bs, a.y_bs = P, T * C, ww.Kpad * ww.Cp, T * K
+    rem = K % 128
+    split = K - rem if (K > 128 and 0 < rem <= 64) else 0     # e.g. 304 = 256 + 48: narrow tail on the 64-wide tile
+    if split:
+        a.K = split
+    with _Timed(_fwd_kind(a), 2.0 * P * T * C * K, (P, 1, T, C, K, 1, 1, 1)):   # the MFMA work actually executed
+        call("mss_conv2d_forward_f32", ctypes.byref(a))
         if split:
-            a.K = split
-        with _Timed(_fwd_kind(a), 2.0 * P * T * C * K, (P, 1, T, C, K, 1, 1, 1)):   # the MFMA work actually executed
+            a.K, a.Kpad = rem, ww.Kpad - split
+            a.w = ctypes.c_void_p(ww.t.data_ptr() + 4 * split * ww.Cp)
+            a.y = ctypes.c_void_p(yt.data_ptr() + 4 * split)
             call("mss_conv2d_forward_f32", ctypes.byref(a))
-            if split:
-                a.K, a.Kpad = rem, ww.Kpad - split
-                a.w = ctypes.c_void_p(ww.t.data_ptr() + 4 * split * ww.Cp)
-                a.y = ctypes.c_void_p(yt.data_ptr() + 4 * split)
-                call("mss_conv2d_forward_f32", ctypes.byref(a))
-        if keep_xt is not None:
-            keep_xt["xt"] = xt
-        del xt
-        out.stats = None
-        if want_stats and out.C == K:
-            out.stats = torch.empty((_lib.value("mss_wino_output_stats_parts", N, H, W, K, dil, ts), 2, K), device=dev,
-                                    dtype=torch.float32)
-        with _Timed("wino_transform", 4.0 * (P * T * K + N * H * W * K * (2 if res is not None else 1)), ("output", N, H, W, K, dil, ts)):
-            call("mss_wino_output_transform_f32", ptr(yt), N, H, W, K, dil, ts, res.ptr if res is not None else None,
-                 res.ld if res is not None else 0, out.ptr, out.ld, ptr(out.stats))
+    if keep_xt is not None:
+        keep_xt["xt"] = xt
+    del xt
+    out.stats = None
+    if want_stats and out.C == K:
+        out.stats = torch.empty((_lib.value("mss_wino_output_stats_parts", N, H, W, K, dil, ts), 2, K), device=dev,
+                                dtype=torch.float32)
+    with _Timed("wino_transform", 4.0 * (P * T * K + N * H * W * K * (2 if res is not None else 1)), ("output", N, H, W, K, dil, ts)):
+        call("mss_wino_output_transform_f32", ptr(yt), N, H, W, K, dil, ts, res.ptr if res is not None else None,
+             res.ld if res is not None else 0, out.ptr, out.ld, ptr(out.stats))
     return out
 
 
@@ -702,6 +713,39 @@ def bn_relu_backward(dy, x, st, relu=True, want_param_grads=False, x_rows=None, 
     call("mss_bn_relu_bwd_apply_f32", dyp, lddy, xp, ldx, dxp, lddx, M, C, None, ptr(st.scale), ptr(st.shift),
          ptr(st.save_mean), ptr(st.save_invstd), int(relu), ptr(accum), ptr(dgamma), ptr(dbeta))
     return dx, dgamma, dbeta
+
+
+def conv3x3_dgrad_after_bn(dy, x, st, weight, relu=True):
+    """conv3x3(bn_relu_backward(dy, x, st)[0], weight, flip=True) -- the data gradient of the 3x3 layer in FRONT of a train-mode
+    BatchNorm+ReLU -- with the BatchNorm backward's apply pass folded into the Winograd input transform of that convolution
+    (mss_wino_input_transform_bnbwd_f32): the gradient w.r.t. the BatchNorm input is never written or read back. Falls back to the
+    two separate steps where the fused transform does not apply (eval-mode statistics, non-Winograd or small shapes,
+    MSS_BNBWD_FUSED=0). Same arithmetic per element, so the two routes agree bit for bit."""
+    k_out, c_in = weight.shape[1], weight.shape[0]
+    tile = wino_tile(x.H, x.W, 1)
+    fused = (st.train and os.environ.get("MSS_BNBWD_FUSED", "1") != "0" and _tile_hook is None and tile >= 4
+             and use_winograd(c_in, k_out, 1, None, tile) and dy.C == c_in and x.C == c_in)
+    if fused:
+        N, H, W, C = x.N, x.H, x.W, c_in
+        dev = x.buf.device
+        accum = _col_accum(x.M, C, dev)
+        call("mss_bn_relu_bwd_reduce_f32", dy.ptr, dy.ld, x.ptr, x.ld, x.M, C, ptr(st.scale), ptr(st.shift), ptr(st.save_mean),
+             ptr(st.save_invstd), int(relu), ptr(accum))
+        ww = packed_wino(weight, True, tile)
+        P = (tile + 2) ** 2
+        T = _lib.value("mss_wino_num_tiles", N, H, W, 1, tile)
+        with _Timed("conv_winograd", 2.0 * N * H * W * k_out * C * 9, (N, H, W, C, k_out, 3, 1, 1)):
+            xt = torch.empty((P, T, C), device=dev, dtype=torch.float32)
+            with _Timed("wino_transform", 4.0 * (2 * N * H * W * C + P * T * C), ("input+bn_bwd", N, H, W, C, 1, tile)):
+                rc = _lib.status("mss_wino_input_transform_bnbwd_f32", dy.ptr, dy.ld, x.ptr, x.ld, N, H, W, C, 1, tile, ptr(st.scale),
+                                 ptr(st.shift), ptr(st.save_mean), ptr(st.save_invstd), ptr(accum), int(relu), ptr(xt))
+            if rc == 0:
+                return _wino_gemm_and_output(xt, ww, N, H, W, 1, None, None, None, False)
+            if rc != _lib.MSS_ERR_UNSUPPORTED:
+                raise _lib.MssError(f"mss_wino_input_transform_bnbwd_f32 failed with code {rc}")
+            del xt
+    dx, _, _ = bn_relu_backward(dy, x, st, relu=relu)
+    return conv3x3(dx, weight, flip=True)
 
 
 def maxpool3s2(x):

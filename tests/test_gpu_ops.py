@@ -516,6 +516,38 @@ def test_few_rows_1x1_route(K, m, c, k):
     assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())    # fp32 accumulation over up to 4096 terms
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 40, 56, 128, 128), (1, 96, 96, 256, 304), (2, 24, 24, 128, 256), (1, 7, 9, 128, 128)])
+def test_dgrad_after_bn_fused_equals_separate_steps(K, monkeypatch, n, h, w, cin, cout):
+    """kernels.conv3x3_dgrad_after_bn: the train-mode BatchNorm+ReLU backward's apply pass inside the Winograd input transform of the
+    data-gradient convolution in front of it (mss_wino_input_transform_bnbwd_f32) against the two separate steps -- the same
+    arithmetic per element, so bit for bit -- and against torch's float64 autograd of conv -> BatchNorm(train) -> ReLU."""
+    torch.manual_seed(n * h + cin)
+    wt = torch.nn.Parameter(torch.randn(cin, cout, 3, 3, device="cuda") * 0.05)      # forward layer: cout -> cin channels
+    bn = torch.nn.BatchNorm2d(cin).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+    xin = torch.randn(n, cout, h, w, device="cuda")
+    x = K.conv3x3(K.Act.from_nchw(xin), wt, want_stats=True)                          # BN input [n,h,w,cin]
+    st = K.bn_fold(bn, x, train=True)
+    dy = K.Act.from_nchw(torch.randn(n, cin, h, w, device="cuda"))
+    monkeypatch.setenv("MSS_BNBWD_FUSED", "0")
+    sep = K.conv3x3_dgrad_after_bn(dy, x, st, wt)
+    monkeypatch.setenv("MSS_BNBWD_FUSED", "1")
+    fus = K.conv3x3_dgrad_after_bn(dy, x, st, wt)
+    assert torch.equal(sep.buf, fus.buf)
+    # float64 reference ON THE SAME BatchNorm input (the fp32 values of x: a ReLU mask decided by a differently rounded x would
+    # flip at the elements within 1e-5 of zero and dominate the comparison): BN(train) -> ReLU backward, then the convolution's
+    bnd = torch.nn.BatchNorm2d(cin).cuda().double().train()
+    with torch.no_grad():
+        bnd.weight.copy_(bn.weight.double()); bnd.bias.copy_(bn.bias.double())
+    xq = x.nchw().double().requires_grad_(True)
+    torch.relu(bnd(xq)).backward(dy.nchw().double())
+    xd = xin.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xd, wt.detach().double(), padding=1).backward(xq.grad)
+    rel = (fus.nchw().double() - xd.grad).norm().item() / xd.grad.norm().item()
+    assert rel <= 2e-4, rel
+
+
 def test_winograd_pair_equals_two_separate_layers(K, monkeypatch):
     """kernels.conv3x3_pair: two dilated 3x3 layers on the same input with their 2 x 64 Winograd-domain products in ONE gemm_nt
     launch (the eval forward's ASPP branches) -- every output element is the same sum in the same order as in the separate
