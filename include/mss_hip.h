@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define MSS_ABI_VERSION 4      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
-                                  mss_wino_input_transform_bnbwd_f32 */
+                                  mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32 */
 int mss_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -164,6 +164,11 @@ int mss_wino_input_transform_f32(const float* x, int ldx, int N, int H, int W, i
 int mss_wino_input_transform_bnbwd_f32(const float* dy, int lddy, const float* x2, int ldx2, int N, int H, int W, int C, int dil,
                                        int tile, const float* scale, const float* shift, const float* mean, const float* invstd,
                                        const double* accum, int relu, float* xt, void* stream);
+/* The same X' for the decoder's first 3x3 layer, whose input is a concat (deepv3.py:269-275): channels [0, c_split) from `a`, the
+ * rest = the align_corners=True bilinear upsample of `small` [N][IH][IW][C - c_split] to H x W, interpolated inside the transform
+ * (the full-resolution upsampled map is never stored). MSS_ERR_UNSUPPORTED where the LDS-staged transform is not taken. */
+int mss_wino_input_transform_upcat_f32(const float* a, int lda, int c_split, const float* small, int ld_small, int IH, int IW, int N,
+                                       int H, int W, int C, int tile, float* xt, void* stream);
 int mss_wino_output_transform_f32(const float* yt, int N, int H, int W, int K, int dil, int tile, const float* res,
                                   int ldres, float* y, int ldy, float* stats, void* stream);
 /* stats (optional): [mss_wino_output_stats_parts(...)][2][K] partial sums / sums of squares of y, as MssConvArgs.stats */

@@ -116,6 +116,7 @@ SIGNATURES = {
     "mss_wino_pack_weights_f32": [P, P, I, I, I, I, I, P],
     "mss_wino_input_transform_f32": [P, I, I, I, I, I, I, I, P, P, I, P, P],
     "mss_wino_input_transform_bnbwd_f32": [P, I, P, I, I, I, I, I, I, I, P, P, P, P, P, I, P, P],
+    "mss_wino_input_transform_upcat_f32": [P, I, I, P, I, I, I, I, I, I, I, I, P, P],
     "mss_wino_output_transform_f32": [P, I, I, I, I, I, I, P, I, P, I, P, P],
     "mss_wino_output_stats_parts": [I, I, I, I, I, I],
     "mss_bn_stats_partials_f32": [P, L, I, P, P],

@@ -58,3 +58,22 @@ __device__ __forceinline__ float mss_wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
 }
+
+// ---- bilinear, align_corners=True: same arithmetic as ATen's upsample_bilinear2d (area_pixel_compute_source_index with
+// align_corners): src = scale*dst, i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1-l1.
+struct Tap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Tap ac_tap(int o, float scale, int in) {
+  Tap t;
+  // ATen rounds scale * o to fp32 first (area_pixel_compute_source_index) and subtracts afterwards. Under the default
+  // -ffp-contract=fast the product would be fused into the subtraction below (fma(scale, o, -i0): more accurate, but
+  // it moves the weights by up to 3e-5 at o ~ 700 and the interpolated values by 2e-4); the empty asm pins the rounded
+  // product in a register (__fmul_rn is a plain multiply in HIP and does not prevent the contraction)
+  float src = scale * (float)o;
+  asm volatile("" : "+v"(src));
+  t.i0 = (int)src;
+  t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+static inline float mss_ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }

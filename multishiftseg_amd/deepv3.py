@@ -305,16 +305,25 @@ class DeepWV3Plus(nn.Module):
             scale[256 * i:256 * (i + 1)].copy_(s.scale)
             shift[256 * i:256 * (i + 1)].copy_(s.shift)
         up_small = K.conv2d(raw, K.packed(self.bot_aspp.weight), in_affine=(scale, shift), in_relu=True)
-        dec0 = Act.empty(N, h2, w2, 304, dev)                      # concat [bot_fine(m2), up(bot_aspp)]
-        K.upsample_ac(up_small, h2, w2, out=dec0.slice(48, 256))
-        K.conv2d(m2, K.packed(self.bot_fine.weight), out=dec0.slice(0, 48))
+        # dec0 = concat [bot_fine(m2), up(bot_aspp)]: when nothing needs it as a tensor (final.0 is not trained in either stage of
+        # exps/DeepLab.yaml, so no weight gradient reads it), the x4 bilinear upsample is interpolated inside final.0's Winograd
+        # input transform and the 1 GB map is never stored (kernels.conv3x3_on_upsampled_concat)
+        dec0 = f0 = None
+        if not (keep and self.final[0].weight.requires_grad):
+            f0 = K.conv3x3_on_upsampled_concat(K.conv2d(m2, K.packed(self.bot_fine.weight)), up_small, self.final[0].weight,
+                                               want_stats=train)
+        if f0 is None:
+            dec0 = Act.empty(N, h2, w2, 304, dev)
+            K.upsample_ac(up_small, h2, w2, out=dec0.slice(48, 256))
+            K.conv2d(m2, K.packed(self.bot_fine.weight), out=dec0.slice(0, 48))
         # the two decoder convolutions keep their Winograd-domain inputs for the weight gradient too (2.3 + 1.9 GB at
         # 2x1024x2048; re-transforming costs 0.73 ms each), under the same budget as the ASPP layers
         dec_xt_bytes = K.wino_xt_bytes(N, h2, w2, 304, 1) + K.wino_xt_bytes(N, h2, w2, 256, 1)
         keep_dec = keep and xt_bytes + dec_xt_bytes < (40 << 30) and os.environ.get("MSS_KEEP_DEC_XT", "1") != "0"
         kx0 = {} if (keep_dec and self.final[0].weight.requires_grad) else None
         kx3 = {} if (keep_dec and self.final[3].weight.requires_grad) else None
-        f0 = K.conv3x3(dec0, self.final[0].weight, want_stats=train, keep_xt=kx0)
+        if f0 is None:
+            f0 = K.conv3x3(dec0, self.final[0].weight, want_stats=train, keep_xt=kx0)
         st_f0 = K.bn_fold(self.final[1], f0, train)
         f1 = K.conv3x3(f0, self.final[3].weight, in_affine=(st_f0.scale, st_f0.shift), in_relu=True, want_stats=train, keep_xt=kx3)
         st_f1 = K.bn_fold(self.final[4], f1, train)
@@ -435,38 +444,6 @@ class DeepWV3Plus(nn.Module):
                 if need["aspp.img_conv.0.weight"]:
                     grads["aspp.img_conv.0.weight"] = K.conv2d_wgrad(s["pooled_act"], Act(du0.view(N, 1, 1, 256)), 256,
                                                                      4096, 1, 1)
-        return [grads.get(n) if need[n] else None for n in names]
-        ddec0 = K.conv3x3(df0, self.final[0].weight, flip=True)
-        if need["bot_fine.weight"]:
-            grads["bot_fine.weight"] = K.conv2d_wgrad(m2, ddec0.slice(0, 48), 48, 128, 1, 1)
-        if any(need[n] for n in names if n.startswith(("aspp", "bot_aspp"))):
-            d_up = K.upsample_ac_bwd(ddec0.slice(48, 256), h8, w8)
-            aff = (s["scale"], s["shift"])
-            if need["bot_aspp.weight"]:
-                grads["bot_aspp.weight"] = K.conv2d_wgrad(raw, d_up, 256, 1280, 1, 1, in_affine=aff, in_relu=True)
-            if any(need[n] for n in names if n.startswith("aspp")):
-                d_act = K.conv2d(d_up, K.packed(self.bot_aspp.weight, flip=True))
-                states = s["states"]
-                # image-pooling branch: the broadcast's transpose is a column sum
-                dv = K.colsum(d_act.slice(0, 256))
-                want = need["aspp.img_conv.1.weight"] or need["aspp.img_conv.1.bias"]
-                du0, dg, db = K.bn_relu_backward(None, None, states[0], want_param_grads=want, x_rows=s["u0_rows"], dy_rows=dv)
-                grads["aspp.img_conv.1.weight"], grads["aspp.img_conv.1.bias"] = dg, db
-                if need["aspp.img_conv.0.weight"]:
-                    grads["aspp.img_conv.0.weight"] = K.conv2d_wgrad(s["pooled_act"], Act(du0.view(N, 1, 1, 256)), 256,
-                                                                     4096, 1, 1)
-                for i in range(4):
-                    p = f"aspp.features.{i}"
-                    sl = raw.slice(256 * (i + 1), 256)
-                    want = need[p + ".1.weight"] or need[p + ".1.bias"]
-                    draw, dg, db = K.bn_relu_backward(d_act.slice(256 * (i + 1), 256), sl, states[i + 1], want_param_grads=want)
-                    grads[p + ".1.weight"], grads[p + ".1.bias"] = dg, db
-                    if need[p + ".0.weight"]:
-                        if i == 0:
-                            grads[p + ".0.weight"] = K.conv2d_wgrad(x, draw, 256, 4096, 1, 1)
-                        else:
-                            grads[p + ".0.weight"] = K.conv3x3_wgrad(x, draw, 256, 4096, dil=_ASPP_RATES[i - 1],
-                                                                     xt=s["aspp_xt"].pop(i, None))
         return [grads.get(n) if need[n] else None for n in names]
 
     # ---- forward -------------------------------------------------------------------------------------

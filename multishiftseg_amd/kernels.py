@@ -715,6 +715,33 @@ def bn_relu_backward(dy, x, st, relu=True, want_param_grads=False, x_rows=None, 
     return dx, dgamma, dbeta
 
 
+def conv3x3_on_upsampled_concat(a, small, weight, want_stats=False):
+    """conv3x3(concat([a, upsample_ac(small -> a.H x a.W)], channels), weight) -- the decoder's first 3x3 layer on dec0 =
+    cat(bot_fine(m2), Upsample(bot_aspp(...))) (deepv3.py:269-275) -- with the bilinear upsample interpolated inside the Winograd
+    input transform (mss_wino_input_transform_upcat_f32): the full-resolution upsampled map is never written or read.
+    Returns None where that transform does not apply (non-Winograd or small shapes, MSS_UPCAT_FUSED=0): the caller builds the concat."""
+    k_out, c_in = weight.shape[0], weight.shape[1]
+    N, H, W = a.N, a.H, a.W
+    tile = wino_tile(H, W, 1)
+    if not (os.environ.get("MSS_UPCAT_FUSED", "1") != "0" and _tile_hook is None and tile >= 4 and a.C + small.C == c_in and a.C % 4 == 0
+            and small.N == N and use_winograd(c_in, k_out, 1, None, tile)):
+        return None
+    dev = a.buf.device
+    ww = packed_wino(weight, False, tile)
+    P = (tile + 2) ** 2
+    T = _lib.value("mss_wino_num_tiles", N, H, W, 1, tile)
+    with _Timed("conv_winograd", 2.0 * N * H * W * k_out * c_in * 9, (N, H, W, c_in, k_out, 3, 1, 1)):
+        xt = torch.empty((P, T, c_in), device=dev, dtype=torch.float32)
+        with _Timed("wino_transform", 4.0 * (N * H * W * a.C + small.M * small.C + P * T * c_in), ("input+upsample", N, H, W, c_in, 1, tile)):
+            rc = _lib.status("mss_wino_input_transform_upcat_f32", a.ptr, a.ld, a.C, small.ptr, small.ld, small.H, small.W, N, H, W, c_in,
+                             tile, ptr(xt))
+        if rc == _lib.MSS_ERR_UNSUPPORTED:
+            return None
+        if rc != 0:
+            raise _lib.MssError(f"mss_wino_input_transform_upcat_f32 failed with code {rc}")
+        return _wino_gemm_and_output(xt, ww, N, H, W, 1, None, None, None, want_stats)
+
+
 def conv3x3_dgrad_after_bn(dy, x, st, weight, relu=True):
     """conv3x3(bn_relu_backward(dy, x, st)[0], weight, flip=True) -- the data gradient of the 3x3 layer in FRONT of a train-mode
     BatchNorm+ReLU -- with the BatchNorm backward's apply pass folded into the Winograd input transform of that convolution

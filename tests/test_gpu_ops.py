@@ -548,6 +548,32 @@ def test_dgrad_after_bn_fused_equals_separate_steps(K, monkeypatch, n, h, w, cin
     assert rel <= 2e-4, rel
 
 
+@pytest.mark.parametrize("n,ih,iw,scale_up,ca,cs,k", [(2, 12, 20, 4, 48, 256, 256), (1, 32, 64, 4, 48, 80, 64), (1, 15, 19, 3, 16, 112, 128)])
+def test_conv_on_upsampled_concat_fused_equals_separate_steps(K, monkeypatch, n, ih, iw, scale_up, ca, cs, k):
+    """kernels.conv3x3_on_upsampled_concat: the decoder's first 3x3 layer on cat(a, Upsample(small)) with the align_corners=True
+    bilinear upsample interpolated inside the Winograd input transform, against upsample + concat + conv3x3 of this repository
+    (same arithmetic: equal to rounding of the interpolation's fused multiply-adds) and against torch in float64."""
+    torch.manual_seed(n + ih + cs)
+    h, w = (ih - 1) * scale_up + 1 + 3, (iw - 1) * scale_up + 1 + 1          # not an exact multiple: generic align_corners geometry
+    a = K.Act.from_nchw(torch.randn(n, ca, h, w, device="cuda"))
+    small = K.Act.from_nchw(torch.randn(n, cs, ih, iw, device="cuda"))
+    wt = torch.nn.Parameter(torch.randn(k, ca + cs, 3, 3, device="cuda") * 0.05)
+    fus = K.conv3x3_on_upsampled_concat(a, small, wt, want_stats=True)
+    assert fus is not None
+    cat = K.Act.empty(n, h, w, ca + cs, "cuda")
+    cat.slice(0, ca).buf[..., cat.c0:cat.c0 + ca] = a.buf[..., :ca]
+    K.upsample_ac(small, h, w, out=cat.slice(ca, cs))
+    sep = K.conv3x3(cat, wt, want_stats=True)
+    d = (fus.nchw() - sep.nchw()).abs().max().item()
+    assert d <= 2e-6 * sep.nchw().abs().max().item(), d
+    up = torch.nn.functional.interpolate(small.nchw().double(), size=(h, w), mode="bilinear", align_corners=True)
+    want = torch.nn.functional.conv2d(torch.cat((a.nchw().double(), up), 1), wt.detach().double(), padding=1)
+    rel = (fus.nchw().double() - want).norm().item() / want.norm().item()
+    assert rel <= 5e-5, rel
+    monkeypatch.setenv("MSS_UPCAT_FUSED", "0")
+    assert K.conv3x3_on_upsampled_concat(a, small, wt) is None
+
+
 def test_winograd_pair_equals_two_separate_layers(K, monkeypatch):
     """kernels.conv3x3_pair: two dilated 3x3 layers on the same input with their 2 x 64 Winograd-domain products in ONE gemm_nt
     launch (the eval forward's ASPP branches) -- every output element is the same sum in the same order as in the separate
