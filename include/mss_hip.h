@@ -22,7 +22,8 @@ extern "C" {
 #endif
 
 #define MSS_ABI_VERSION 4      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
-                                  mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32 */
+                                  mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32,
+                                  mss_bn_fold_train_from_partials_f32 */
 int mss_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -210,6 +211,12 @@ int mss_bn_stats_nhwc_f32(const float* x, long long M, int C, int ldx, double* a
 int mss_bn_finalize_train_f32(const double* accum, long long M, int C, const float* gamma, const float* beta,
                               float eps, float momentum, float* running_mean, float* running_var, float* scale,
                               float* shift, float* save_mean, float* save_invstd, void* stream);
+/* mss_bn_stats_partials_f32 + mss_bn_finalize_train_f32 in two launches instead of three (bit-identical results): the train-mode fold
+ * of a BatchNorm whose producer left partial sums. M = rows covered by the partial sums. */
+int mss_bn_fold_train_from_partials_f32(const float* partials, long long nparts, int C, double* accum, long long M,
+                                        const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                        float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
+                                        void* stream);
 /* eval mode: scale/shift from the running statistics. */
 int mss_bn_fold_eval_f32(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, int C, float* scale, float* shift, void* stream);

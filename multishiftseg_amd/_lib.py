@@ -81,6 +81,7 @@ SIGNATURES = {
     "mss_stem_conv_pool_f32": [P, P, P, I, I, I, I, P],
     "mss_bn_stats_nhwc_f32": [P, L, I, I, P, P],
     "mss_bn_finalize_train_f32": [P, L, I, P, P, F, F, P, P, P, P, P, P, P],
+    "mss_bn_fold_train_from_partials_f32": [P, L, I, P, L, P, P, F, F, P, P, P, P, P, P, P],
     "mss_bn_fold_eval_f32": [P, P, P, P, F, I, P, P, P],
     "mss_affine_relu_nhwc_f32": [P, I, P, I, L, I, P, P, I, P],
     "mss_bn_relu_bwd_reduce_f32": [P, I, P, I, L, I, P, P, P, P, I, P, P],

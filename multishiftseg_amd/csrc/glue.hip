@@ -226,6 +226,60 @@ __global__ void bn_finalize_train_kernel(const double* __restrict__ accum, long 
   }
 }
 
+// col_reduce_final_kernel + bn_finalize_train_kernel in one launch (the BatchNorm of a layer whose producer left partial sums: 40
+// of the 43 train-mode folds of a step): a workgroup adds the partial rows of TWO channels' sum and sum-of-squares columns in the
+// same fixed order and finishes those two channels.
+__global__ __launch_bounds__(256) void bn_final_finalize_kernel(double* __restrict__ accum, int nparts, long long M, int C,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float eps, float momentum, float* running_mean, float* running_var,
+                                                                float* scale, float* shift, float* save_mean, float* save_invstd) {
+  const double* __restrict__ part = accum + 2 * C;
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int ch = blockIdx.x * 2 + (cl & 1);
+  const int col = (cl >> 1) * C + ch;                  // cl 0, 1: the two channels' sums; 2, 3: their sums of squares
+  double s = 0.0;
+  if (ch < C) {
+    for (int r0 = rl; r0 < nparts; r0 += 64 * 16) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int r = r0 + 64 * u;
+        v[u] = r < nparts ? part[(size_t)r * 2 * C + col] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+#pragma unroll
+  for (int half = 32; half >= 1; half >>= 1) {
+    if (rl < half) red[threadIdx.x] += red[threadIdx.x + 4 * half];
+    __syncthreads();
+  }
+  if (threadIdx.x < 2 && ch < C) {
+    const int c = ch;
+    const double sum = red[threadIdx.x], sumsq = red[threadIdx.x + 2];
+    accum[c] = sum; accum[C + c] = sumsq;
+    const double mean = sum / (double)M;
+    double var = sumsq / (double)M - mean * mean;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_invstd) save_invstd[c] = invstd;
+    if (running_mean) {
+      const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
 __global__ void bn_fold_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
                                     float* scale, float* shift) {
@@ -1084,6 +1138,20 @@ int mss_bn_stats_partials_f32(const float* partials, long long nparts, int C, do
   const dim3 grid = col_reduce_grid(nparts, C);
   hipLaunchKernelGGL(bn_stats_partials_kernel, grid, dim3(256), 0, S_(stream), partials, nparts, C, accum);
   hipLaunchKernelGGL(col_reduce_final_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, S_(stream), accum, (int)grid.y, 2 * C);
+  return mss_launch_status();
+}
+
+// mss_bn_stats_partials_f32 + mss_bn_finalize_train_f32 in two launches instead of three (same sums in the same order, same
+// arithmetic: bit-identical). accum as for mss_bn_stats_partials_f32; M = the number of rows the partial sums cover.
+int mss_bn_fold_train_from_partials_f32(const float* partials, long long nparts, int C, double* accum, long long M,
+                                        const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                        float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
+                                        void* stream) {
+  if (!partials || !accum || !scale || !shift || C % 4 || nparts <= 0 || M <= 0) return MSS_ERR_BAD_ARG;
+  const dim3 grid = col_reduce_grid(nparts, C);
+  hipLaunchKernelGGL(bn_stats_partials_kernel, grid, dim3(256), 0, S_(stream), partials, nparts, C, accum);
+  hipLaunchKernelGGL(bn_final_finalize_kernel, dim3((C + 1) / 2), dim3(256), 0, S_(stream), accum, (int)grid.y, M, C, gamma, beta, eps,
+                     momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
   return mss_launch_status();
 }
 

@@ -639,8 +639,22 @@ def bn_fold(bn, x=None, train=False, M=None, x_rows=None):
     elif x.stats is not None and x.stats.shape[2] == C and x.C == C:   # left by the producing kernel: no re-read of x
         M = x.M
         accum = _col_accum(x.stats.shape[0], C, dev)
-        call("mss_bn_stats_partials_f32", ptr(x.stats), x.stats.shape[0], C, ptr(accum))
+        st.M = M
+        st.save_mean = torch.empty(C, device=dev, dtype=torch.float32)
+        st.save_invstd = torch.empty(C, device=dev, dtype=torch.float32)
+        mom = 0.1 if bn.momentum is None else float(bn.momentum)
+        track = bn.track_running_stats and bn.running_mean is not None
+        # partial sums -> column sums -> folded affine + running statistics: two launches (the second stage and the fold are one)
+        call("mss_bn_fold_train_from_partials_f32", ptr(x.stats), x.stats.shape[0], C, ptr(accum), M, ptr(bn.weight), ptr(bn.bias),
+             float(bn.eps), mom, ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None, ptr(st.scale),
+             ptr(st.shift), ptr(st.save_mean), ptr(st.save_invstd))
         x.stats = None
+        if track and bn.num_batches_tracked is not None:
+            if _nbt_pending is not None:
+                _nbt_pending.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked += 1
+        return st
     else:
         M = x.M
         accum = _col_accum(M, C, dev)
