@@ -512,9 +512,17 @@ int launch_gemm(const MssConvArgs& p, hipStream_t stream, long long first = 0, l
 int mss_gemm_nt_bf16x6_launch(MssConvArgs p, void* stream);   // gemm_bf16x6.hip (experimental, opt-in)
 
 // Shapes this kernel takes from mss_conv2d_forward_f32 (conv_igemm.hip); p.M is set.
+// 33..64 output channels over many rows (the 48-channel heads and bot_fine, 1 M pixels) on the persistent kernel with a 128 x 64
+// tile instead of conv_igemm's one-tile-per-workgroup 256 x 64 kernel: 0.203 -> 0.184 ms (256 -> 48) and 0.116 -> 0.087 ms
+// (128 -> 48) at 1 x 512 x 1024 (MSS_GEMM_BN64=0 restores the old route)
+static bool gemm_bn64_wanted(const MssConvArgs& p) {
+  const char* e = getenv("MSS_GEMM_BN64");
+  return !(e && atoi(e) == 0) && p.K <= 64 && p.K > 32 && p.batch <= 1 && p.C / BK >= 3 && p.M >= 16384;
+}
+
 bool mss_gemm_nt_eligible(const MssConvArgs& p) {
   if (p.R * p.S != 1 || p.stride != 1 || p.pad != 0 || p.H != p.OH || p.W != p.OW) return false;
-  if (p.K <= 64 || p.C % BK || p.C < 2 * BK) return false;        // narrow outputs stay on the 256x64 tile
+  if ((p.K <= 64 && !gemm_bn64_wanted(p)) || p.C % BK || p.C < 2 * BK) return false;        // narrow outputs stay on the 256x64 tile
   if (p.in_relu && !p.in_scale) return false;                      // ReLU without affine: not a shape this path sees
   if (p.in_scale && p.in_ss_stride && (p.OH * p.OW) % BM) return false;   // per-sample affine: tiles must not straddle images
   return true;
@@ -537,6 +545,13 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
   if (!mss_gemm_nt_eligible(p)) return -1;
   p.H = (p.in_scale && p.in_ss_stride) ? p.OH * p.OW : (p.M > 0 ? p.M : 1);   // rows per affine group
   p.mtiles = mss_cdiv(p.M, BM);
+  if (p.K <= 64) {                                       // (experiment, see gemm_bn64_wanted)
+    p.ntiles = 1;
+    if (p.Kpad < 64) return MSS_ERR_BAD_ARG;
+    const long long span_x = (long long)p.M * p.ldx * 4, span_w = (long long)p.Kpad * p.C * 4;
+    if (span_x >= 0xffffffffll || span_w >= 0xffffffffll) return -1;
+    return p.in_scale ? launch_gemm<true, 3, 64>(p, static_cast<hipStream_t>(stream)) : launch_gemm<false, 3, 64>(p, static_cast<hipStream_t>(stream));
+  }
   p.ntiles = mss_cdiv(p.K, 128);
   if (p.Kpad < p.ntiles * 128) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
