@@ -129,7 +129,7 @@ typedef struct MssConvArgs {
 int mss_conv2d_forward_f32(MssConvArgs* args, void* stream);
 int mss_conv2d_kpad(int K);
 /* 1 if mss_conv2d_forward_f32 runs these arguments on the persistent GEMM kernel (csrc/gemm.hip: 1x1, stride 1,
- * more than 64 output channels), 2 for the few-rows kernel (1x1 over <= 8 pixels, nothing fused), 0 for the implicit-GEMM
+ * more than 64 output channels, or 33..64 of them over >= 16 384 rows), 2 for the few-rows kernel (1x1 over <= 8 pixels, nothing fused), 0 for the implicit-GEMM
  * kernel. Profiling label only. */
 int mss_conv2d_forward_route(const MssConvArgs* args);
 /* w [K][C][R][S] (nn.Conv2d.weight) -> packed [R*S][Kpad][Cp] (zero padded).
