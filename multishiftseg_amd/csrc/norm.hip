@@ -163,18 +163,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   }
 }
 
-// stage 2: one thread per (n, group): chunks and the group's quads added in a fixed order, in double
-__global__ void gn_finalize_kernel(const float* __restrict__ part, int N, int nchunks, int C, int groups, int HW,
-                                   float eps, float* __restrict__ stat) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// stage 2: one WAVE per (n, group): lane l adds chunks l, l + 64, ... (and the group's quads) in order, then a fixed-shape shuffle
+// tree combines the 64 lane sums -- all in double, the order never depends on timing. (One THREAD per (n, group) walked up to a
+// thousand chunks serially: 188 us for the 256 x 512 map of one 1024 x 2048 image.)
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, int N, int nchunks, int C, int groups, int HW,
+                                                         float eps, float* __restrict__ stat) {
+  const int i = blockIdx.x, lane = threadIdx.x;
   if (i >= N * groups) return;
   const int n = i / groups, g = i - n * groups;
   const int C4 = C >> 2, qpg = (C / groups) >> 2;      // quads per group
   double s = 0.0, q = 0.0;
-  for (int ch = 0; ch < nchunks; ++ch) {
+  for (int ch = lane; ch < nchunks; ch += 64) {
     const float* o = part + (((size_t)n * nchunks + ch) * 2) * C4;
     for (int k = 0; k < qpg; ++k) { s += o[g * qpg + k]; q += o[C4 + g * qpg + k]; }
   }
+  s = mss_wave_sum_d(s);
+  q = mss_wave_sum_d(q);
+  if (lane != 0) return;
   const double cnt = (double)HW * (C / groups);
   const double mean = s / cnt;
   double var = q / cnt - mean * mean;
@@ -348,7 +353,7 @@ int mss_groupnorm_nhwc_f32(const float* x, int ldx, long long x_sample_stride, i
   float* part = ws;
   float* stat = ws + (size_t)N * chunks * 2 * (C / 4);
   hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)chunks, N), dim3(256), 0, S_(stream), x, ldx, x_sample_stride, HW, C, part, rpc);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * groups + 63) / 64), dim3(64), 0, S_(stream), part, N, (int)chunks, C, groups, HW, eps, stat);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(64), 0, S_(stream), part, N, (int)chunks, C, groups, HW, eps, stat);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)(((long long)HW * (C / 4) + 255) / 256), N), dim3(256), 0, S_(stream), x, ldx,
                      x_sample_stride, HW, C, groups, stat, gamma, beta, relu, y, ldy, y_sample_stride);
   return mss_launch_status();
@@ -433,17 +438,20 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
 }
 
 // stage 2: per (n, group) the two means of the dx formula, chunks and quads added in a fixed order in double
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int N, int nchunks, int C, int groups, int HW,
-                                       float* __restrict__ m12) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float* __restrict__ part, int N, int nchunks, int C, int groups,
+                                                             int HW, float* __restrict__ m12) {   // one wave per (n, group), as gn_finalize_kernel
+  const int i = blockIdx.x, lane = threadIdx.x;
   if (i >= N * groups) return;
   const int n = i / groups, g = i - n * groups;
   const int C4 = C >> 2, qpg = (C / groups) >> 2;
   double a = 0.0, b = 0.0;
-  for (int ch = 0; ch < nchunks; ++ch) {
+  for (int ch = lane; ch < nchunks; ch += 64) {
     const float* o = part + (((size_t)n * nchunks + ch) * 2) * C4;
     for (int k = 0; k < qpg; ++k) { a += o[g * qpg + k]; b += o[C4 + g * qpg + k]; }
   }
+  a = mss_wave_sum_d(a);
+  b = mss_wave_sum_d(b);
+  if (lane != 0) return;
   const double cnt = (double)HW * (C / groups);
   m12[2 * i] = (float)(a / cnt);
   m12[2 * i + 1] = (float)(b / cnt);
@@ -581,7 +589,7 @@ int mss_groupnorm_nhwc_bwd_f32(const float* gy, int ldg, long long g_sample_stri
   float* m12 = pgb + (size_t)N * chunks * 2 * C;
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3((unsigned)chunks, N), dim3(256), 0, S_(stream), gy, ldg, g_sample_stride, x, ldx,
                      x_sample_stride, HW, C, groups, stat, gamma, beta, relu, part, pgb, rpc);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((N * groups + 63) / 64), dim3(64), 0, S_(stream), part, N, (int)chunks, C, groups, HW, m12);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N * groups), dim3(64), 0, S_(stream), part, N, (int)chunks, C, groups, HW, m12);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(((long long)HW * (C / 4) + 255) / 256), N), dim3(256), 0, S_(stream), gy, ldg,
                      g_sample_stride, x, ldx, x_sample_stride, HW, C, groups, stat, m12, gamma, beta, relu, dx, lddx);
   const int nparts = (int)(N * chunks);

@@ -29,7 +29,7 @@ def _gemm(x, weight, bias=None, relu=False, res=None, res_mask=False, flip=False
     k, c = weight.shape
     cin, cout = (k, c) if flip else (c, k)
     out = torch.empty(x.shape[:-1] + (cout,), device=x.device, dtype=torch.float32)
-    aff = (torch.ones_like(bias), bias.detach()) if bias is not None else None
+    aff = (K.ones(bias.numel(), bias.device), bias.detach()) if bias is not None else None
     K.conv2d(_rows(x, cin), _packed(weight, flip), out_affine=aff, out_relu=relu, out=_rows(out, cout),
              res=_rows(res, cout) if res is not None else None, res_mask=res_mask)
     return out

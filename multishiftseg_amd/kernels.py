@@ -112,6 +112,19 @@ def _cached_pack(param, key, make):
     return val
 
 
+_ONES = {}
+
+
+def ones(n, device):
+    """A shared all-ones fp32 vector (the unit scale of a bias-only epilogue): one tensor per (length, device) for the life of the
+    process instead of a fill kernel per Linear call."""
+    key = (int(n), str(device))
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones(int(n), device=device, dtype=torch.float32)
+    return t
+
+
 def packed(param, flip=False):
     """Cached pack_weight of an nn.Parameter."""
     return _cached_pack(param, ("direct", flip), lambda: pack_weight(param, flip))

@@ -31,7 +31,7 @@ class _LinearFn(Function):
         out = torch.empty(x.shape[:-1] + (k,), device=x.device, dtype=torch.float32)
         aff = None
         if bias is not None:
-            aff = (torch.ones_like(bias), bias.detach())
+            aff = (K.ones(bias.numel(), bias.device), bias.detach())
         K.conv2d(_rows(x2, c), _packed(weight, False), out_affine=aff, out_relu=relu, out=_rows(out, k))
         ctx.save_for_backward(x2, weight, out if relu else None)
         ctx.relu, ctx.has_bias = relu, bias is not None
@@ -67,9 +67,9 @@ class _FfnFn(Function):
         f, c = w1.shape
         x2 = x.contiguous()
         h = torch.empty(x.shape[:-1] + (f,), device=x.device, dtype=torch.float32)
-        K.conv2d(_rows(x2, c), _packed(w1, False), out_affine=(torch.ones_like(b1), b1.detach()), out_relu=True, out=_rows(h, f))
+        K.conv2d(_rows(x2, c), _packed(w1, False), out_affine=(K.ones(b1.numel(), b1.device), b1.detach()), out_relu=True, out=_rows(h, f))
         y = torch.empty(x.shape[:-1] + (w2.shape[0],), device=x.device, dtype=torch.float32)
-        K.conv2d(_rows(h, f), _packed(w2, False), out_affine=(torch.ones_like(b2), b2.detach()), out=_rows(y, w2.shape[0]))
+        K.conv2d(_rows(h, f), _packed(w2, False), out_affine=(K.ones(b2.numel(), b2.device), b2.detach()), out=_rows(y, w2.shape[0]))
         ctx.save_for_backward(x2, w1, w2, h)
         return y
 

@@ -112,7 +112,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
     def _bias_affine(conv):
         if conv.bias is None:
             return None
-        return (torch.ones_like(conv.bias), conv.bias.detach())
+        return (K.ones(conv.bias.numel(), conv.bias.device), conv.bias.detach())
 
     def _conv1x1(self, x_act, conv):
         return K.conv2d(x_act, K.packed(conv.weight), out_affine=self._bias_affine(conv))

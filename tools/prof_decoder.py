@@ -15,9 +15,14 @@ dec = MSDeformAttnPixelDecoder({k: ShapeSpec(*v) for k, v in shape.items()}, tra
                                transformer_dim_feedforward=1024, transformer_enc_layers=6, conv_dim=256, mask_dim=256, norm="GN",
                                transformer_in_features=["res3", "res4", "res5"], common_stride=4).cuda()
 feats = {k: torch.randn(N, c, H // s, W // s, device="cuda") for k, (c, s) in shape.items()}
+fwd_only = os.environ.get("MSS_PROF_FORWARD_ONLY") == "1"        # the inference form (C5: one 1024x2048 image)
 for _ in range(iters):
     for p in dec.parameters():
         p.grad = None
+    if fwd_only:
+        with torch.no_grad():
+            dec.forward_features(feats)
+        continue
     mask, out0, ms = dec.forward_features(feats)
     (mask.sum() + sum(m.sum() for m in ms)).backward()
 torch.cuda.synchronize()
