@@ -40,6 +40,33 @@ __global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, float* __re
   }
 }
 
+// The same for feature maps with many channels (the pixel decoder's res2..res5 inputs arrive NCHW from the backbone:
+// msdeformattn.py:314-330): a 64-pixel x 64-channel tile through LDS -- 256-byte runs along the pixels on the way in, 256-byte
+// runs along the channels on the way out. (The per-pixel loop above writes 16 bytes per lane at a stride of Cp * 4: fine for a
+// 3-channel image, 1.8 TB/s on a 256-channel map.) grid (ceil(HW / 64), ceil(Cp / 64), N).
+__global__ __launch_bounds__(256) void nchw_to_nhwc_tiled_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW,
+                                                                 int Cp) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const float* src = x + (long long)n * C * HW;
+  {
+    const int pl = threadIdx.x & 63, cl = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = c0 + cl + 4 * j, p = p0 + pl;
+      tile[cl + 4 * j][pl] = (c < C && p < HW) ? src[(long long)c * HW + p] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int q = threadIdx.x & 15, pr = threadIdx.x >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pl = pr + 16 * j, p = p0 + pl, c = c0 + 4 * q;
+    if (p < HW && c < Cp)
+      st4(y + ((long long)n * HW + p) * Cp + c, f32x4{tile[4 * q][pl], tile[4 * q + 1][pl], tile[4 * q + 2][pl], tile[4 * q + 3][pl]});
+  }
+}
+
 // ---------------------------------------------------------------- stem: image NCHW -> 3x3 patches, NHWC 32 channels
 // mod1.conv1 (3 -> 64, 3x3, padding 1; wider_resnet.py:303) as a GEMM with K = 27: channel j = c*9 + r*3 + s of output
 // pixel (y, x) holds img[n][c][y+r-1][x+s-1] (0 outside), channels 27..31 are 0 -- the order of weight.reshape(64, 27).
@@ -1101,6 +1128,12 @@ extern "C" {
 
 int mss_nchw_to_nhwc_pad_f32(const float* x, float* y, int N, int C, int H, int W, int Cp, void* stream) {
   if (!x || !y || Cp % 4 || Cp < C) return MSS_ERR_BAD_ARG;
+  const long long HW = (long long)H * W;
+  if (C >= 16 && N <= 65535 && (Cp + 63) / 64 <= 65535 && HW < (1ll << 31) && N > 0 && HW > 0) {
+    hipLaunchKernelGGL(nchw_to_nhwc_tiled_kernel, dim3((unsigned)((HW + 63) / 64), (Cp + 63) / 64, N), dim3(256), 0, S_(stream), x, y, C,
+                       (int)HW, Cp);
+    return mss_launch_status();
+  }
   hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for((long long)N * H * W)), dim3(256), 0, S_(stream), x, y,
                      N, C, H * W, Cp);
   return mss_launch_status();

@@ -574,6 +574,17 @@ def test_conv_on_upsampled_concat_fused_equals_separate_steps(K, monkeypatch, n,
     assert K.conv3x3_on_upsampled_concat(a, small, wt) is None
 
 
+@pytest.mark.parametrize("n,c,h,w,cp", [(2, 256, 37, 53, 256), (1, 70, 9, 130, 80), (3, 16, 1, 1, 16), (1, 3, 20, 30, 16), (1, 2048, 22, 22, 2048)])
+def test_nchw_to_nhwc_conversion(K, n, c, h, w, cp):
+    """mss_nchw_to_nhwc_pad_f32: the tiled LDS transpose (feature maps, >= 16 channels) and the per-pixel kernel (images) against a
+    permute; ragged pixel / channel counts, zero channel padding."""
+    torch.manual_seed(c + h)
+    t = torch.randn(n, c, h, w, device="cuda")
+    a = K.nchw_to_act(t, Cp=cp)
+    assert (a.N, a.H, a.W, a.C) == (n, h, w, cp)
+    assert torch.equal(a.buf[..., :c], t.permute(0, 2, 3, 1)) and bool((a.buf[..., c:] == 0).all())
+
+
 def test_winograd_pair_equals_two_separate_layers(K, monkeypatch):
     """kernels.conv3x3_pair: two dilated 3x3 layers on the same input with their 2 x 64 Winograd-domain products in ONE gemm_nt
     launch (the eval forward's ASPP branches) -- every output element is the same sum in the same order as in the separate
