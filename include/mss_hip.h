@@ -21,9 +21,9 @@
 extern "C" {
 #endif
 
-#define MSS_ABI_VERSION 4      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
+#define MSS_ABI_VERSION 5      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
                                   mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32,
-                                  mss_bn_fold_train_from_partials_f32 */
+                                  mss_bn_fold_train_from_partials_f32; 5 (round 4): mss_adam_step_f32 takes double hyper-parameters */
 int mss_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -353,9 +353,12 @@ int mss_rcl_scatter_add_f32(const float* g, const int32_t* idx, uint32_t n, floa
 int mss_rcl_finalize_f32(const MssRclArgs* a, const double* counters, const uint32_t* sel, float* out,
                          void* stream);
 
-/* Adam with L2-coupled weight decay (torch.optim.Adam semantics, train_deeplab.py:134-149). */
-int mss_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
-                      float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+/* Adam with L2-coupled weight decay (torch.optim.Adam semantics, train_deeplab.py:134-149), one parameter tensor per
+ * call, updated in place together with its two moment buffers. Hyper-parameters are doubles, as Python holds them: the
+ * bias corrections 1 - beta^step, the step size lr / bias1 and sqrt(bias2) are formed in double on the host and only the
+ * derived scalars are rounded to float (torch/optim/adam.py, single-tensor path); step counts from 1. */
+int mss_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, double lr,
+                      double beta1, double beta2, double eps, double weight_decay, int step, void* stream);
 
 /* Mask2Former anomaly score fused with the mask upsample (csrc/m2f.hip): logit = pixel-major
  * low-resolution mask logits [B, hm, wm, ldq] (queries contiguous; produced by mss_conv2d_forward_f32 in batched 1x1

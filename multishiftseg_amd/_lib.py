@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so libmss_hip.
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSS_LIB", os.path.join(_HERE, "libmss_hip.so"))   # MSS_LIB: A/B experiments only
 
-MSS_ABI_VERSION = 4          # include/mss_hip.h
+MSS_ABI_VERSION = 5          # include/mss_hip.h
 MSS_ERR_BAD_ARG = 1001
 MSS_ERR_UNSUPPORTED = 1002
 
@@ -112,7 +112,7 @@ SIGNATURES = {
     "mss_rcl_pairs_global_f32": [P, P, U, U, U, P, P, I, U, U, U, U, F, P, I, F, P, P, P],
     "mss_rcl_gather_f32": [P, P, U, P, P],
     "mss_rcl_scatter_add_f32": [P, P, U, P, P],
-    "mss_adam_step_f32": [P, P, P, P, L, F, F, F, F, F, I, P],
+    "mss_adam_step_f32": [P, P, P, P, L, c_double, c_double, c_double, c_double, c_double, I, P],
     "mss_wino_num_tiles": [I, I, I, I, I],
     "mss_wino_pack_weights_f32": [P, P, I, I, I, I, I, P],
     "mss_wino_input_transform_f32": [P, I, I, I, I, I, I, I, P, P, I, P, P],

@@ -1105,18 +1105,22 @@ __global__ __launch_bounds__(256) void m2f_score_kernel(const float* __restrict_
   }
 }
 
+// torch.optim.Adam's single-tensor arithmetic, operation for operation (torch/optim/adam.py _single_tensor_adam, the path
+// the reference's CPU run takes): grad += wd*p ; m = lerp(m, grad, 1-b1) ; v = v*b2 + (1-b2)*grad*grad ;
+// denom = sqrt(v)/sqrt(bias2) + eps ; p += (-lr/bias1) * (m/denom). step_size and sqrt(bias2) come from the host in double.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
-                            float bc1, float bc2_sqrt) {
+                            float* __restrict__ v, long long n, float one_minus_b1, float b2, float one_minus_b2,
+                            float eps, float wd, float neg_step_size, float bc2_sqrt) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    float grad = g[i] + wd * p[i];
-    float mi = b1 * m[i] + (1.f - b1) * grad;
-    float vi = b2 * v[i] + (1.f - b2) * grad * grad;
+    const float pi = p[i];
+    const float grad = __fmaf_rn(wd, pi, g[i]);                      // grad.add(param, alpha=wd)
+    const float m0 = m[i];
+    const float mi = __fmaf_rn(one_minus_b1, grad - m0, m0);         // exp_avg.lerp_(grad, 1-b1), weight < 0.5 branch
+    const float vi = __fmaf_rn(one_minus_b2 * grad, grad, v[i] * b2); // mul_(b2).addcmul_(grad, grad, value=1-b2)
     m[i] = mi; v[i] = vi;
-    // torch.optim.Adam: denom = sqrt(v)/sqrt(bias2) + eps ; p -= (lr/bias1) * m/denom
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] -= (lr / bc1) * (mi / denom);
+    const float denom = __fsqrt_rn(vi) / bc2_sqrt + eps;
+    p[i] = __fmaf_rn(neg_step_size, mi / denom, pi);                 // addcdiv_(exp_avg, denom, value=-step_size)
   }
 }
 
@@ -1395,14 +1399,18 @@ int mss_m2f_score_f32(const float* cls, const float* mask, int B, int Q, int C, 
   return mss_launch_status();
 }
 
-int mss_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
-                      float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+int mss_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, double lr,
+                      double beta1, double beta2, double eps, double weight_decay, int step, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return MSS_ERR_BAD_ARG;
   if (n <= 0) return MSS_OK;
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2 = 1.f - powf(beta2, (float)step);
+  // bias corrections in double, as Python computes them (1 - beta**step); only the two derived scalars are rounded to float
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float neg_step_size = (float)(-(lr / bc1));
+  const float bc2_sqrt = (float)sqrt(bc2);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, S_(stream), param, grad, exp_avg, exp_avg_sq, n,
-                     lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay,
+                     neg_step_size, bc2_sqrt);
   return mss_launch_status();
 }
 

@@ -1430,6 +1430,13 @@ static int msda_backward_binned(const float* value, const int64_t* shapes, const
   for (int l = 0; l < L; ++l) cells += host_shapes[2 * l] * host_shapes[2 * l + 1];
   if (cells > S) return MSS_ERR_BAD_ARG;
   if (ws_bytes < w.total || (reinterpret_cast<uintptr_t>(ws) & 255)) return MSS_ERR_BAD_ARG;
+  if (cells < S) {
+    // the tiles plain-store exactly the rows of the L levels; a value tensor with more rows than the levels cover
+    // (padding behind the last level, or gaps between levels in level_start_index) must still come back zero there,
+    // as the reference's zero-initialised output does (ms_deform_attn_cuda.cu:126)
+    hipError_t ez = hipMemsetAsync(gvalue, 0, (size_t)N * S * M * D * sizeof(float), stream);
+    if (ez != hipSuccess) return (int)ez;
+  }
   char* base = static_cast<char*>(ws);
   int* ticket = reinterpret_cast<int*>(base);
   unsigned* absmax = reinterpret_cast<unsigned*>(base) + 1;

@@ -26,6 +26,9 @@ class GradAllReduce:
     order (a complete bucket waits for its incomplete predecessors until ``backward_done``), every bucket is launched
     every step, and a gradient that did not arrive travels as zeros and still receives the average (it is assigned to
     ``param.grad`` of a parameter that requires grad) -- ranks can therefore never pair collectives of different sizes.
+
+    Contract: every handled parameter's ``.grad`` must be None when its gradient arrives (``zero_grad(set_to_none=True)``,
+    what TrainStep does): ``param.grad`` aliases the bucket buffer between steps. Violations raise.
     """
 
     def __init__(self, named_params, bucket_bytes=64 << 20, group=None, force=False, close_after_bytes=16 << 20):
@@ -85,6 +88,14 @@ class GradAllReduce:
         if not self.active or name not in self.where:
             return None
         i, off, n = self.where[name]
+        if self.params[name].grad is not None:
+            # autograd steals the returned view as param.grad, so a gradient still defined from an earlier backward IS this
+            # buffer: writing the new one would overwrite it and AccumulateGrad would then add the buffer to itself (silently
+            # doubled gradients), and an accumulated sum would be all-reduced a second time. Accumulation over several
+            # backwards is not what the reference loop does (train_deeplab.py:198-204: zero_grad / backward / step).
+            raise RuntimeError(f"GradAllReduce: {name}.grad is still defined at backward time; call "
+                               "optimizer.zero_grad(set_to_none=True) before every backward (gradient accumulation and "
+                               "zero_grad(set_to_none=False) are not supported with the in-place bucket buffers)")
         view = self._buffer(i)[off:off + n].view(grad.shape)
         torch.mul(grad, 1.0 / self.world, out=view)
         self.arrived[i].add(name)

@@ -289,9 +289,10 @@ class DeepWV3Plus(nn.Module):
                 K.conv2d(x, K.packed(feat[0].weight), out=sl, want_stats=train)
             elif pair_tile and i in (1, 2):
                 if i == 1:
+                    sl2 = raw.slice(256 * 3, 256)          # ONE object: conv3x3_pair leaves the batch statistics on it
                     K.conv3x3_pair(x, feat[0].weight, asp.features[2][0].weight, _ASPP_RATES[0], _ASPP_RATES[1], sl,
-                                   raw.slice(256 * 3, 256), pair_tile, want_stats=train)
-                    pair_slices = {1: sl, 2: raw.slice(256 * 3, 256)}
+                                   sl2, pair_tile, want_stats=train)
+                    pair_slices = {1: sl, 2: sl2}
                 sl = pair_slices[i]              # carries the statistics the producing transform left (train-mode BatchNorm)
                 aspp_xt[i] = None
             else:

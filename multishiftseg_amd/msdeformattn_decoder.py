@@ -331,6 +331,8 @@ class GraphedFeatures:
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.static_out = self.dec.forward_features(self.static_in)
         self._keep = [dict(p.__dict__.get("_mss_packed", {})) for p in self.dec.parameters()]
+        # ... and the level-size / start-index / valid-ratio tensors the sampler kernels read by pointer
+        self._keep.append([dict(m.__dict__.get("_index_cache", {})) for m in self.dec.modules()])
         self._sig = self._signature()
         self.captures += 1
 

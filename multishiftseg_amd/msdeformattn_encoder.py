@@ -162,8 +162,9 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             spatial_shapes._mss_host = [tuple(int(v) for v in hw) for hw in shapes]  # host copy: launch grids, tile geometry
             level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
             valid_ratios = torch.ones((src.shape[0], len(shapes), 2), dtype=torch.float32, device=src.device)
-            if len(cache) >= 8:
-                cache.clear()
+            # Entries are never freed behind a reader's back: a captured hipGraph (msdeformattn_decoder.GraphedFeatures)
+            # reads these three tensors by raw pointer. They are a few hundred bytes per (sizes, batch) combination, so the
+            # cache simply keeps them all; GraphedFeatures additionally holds its own references (`_keep`).
             ent = cache[key] = (spatial_shapes, level_start_index, valid_ratios)
         spatial_shapes, level_start_index, valid_ratios = ent
         memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, None)

@@ -52,6 +52,7 @@ class TrainStep:
         loss across ranks (its gradients come pre-multiplied by the world size, which the averaging
         all-reduce of ddp.GradAllReduce undoes); sync="local" needs no loss communication."""
         self.model, self.criterion = model, criterion
+        self.keep_outputs, self.last_outputs = False, None
         self.set_stage(stage, bucket_bytes)
 
     def set_stage(self, stage, bucket_bytes=64 << 20):
@@ -69,17 +70,21 @@ class TrainStep:
         self.model.grad_sink = self.sync
         self.model.train()
 
-    def __call__(self, img, target):
-        """img [2p,3,H,W] laid out [orig...; aug...], target int64 [2p,H,W] (mutated by the loss)."""
+    def __call__(self, img, target, perms=None):
+        """img [2p,3,H,W] laid out [orig...; aug...], target int64 [2p,H,W] (mutated by the loss). perms: the three pairing
+        permutations of loss.py:129-131 when a parity test replays recorded ones (RelContrastiveLoss.forward(perms=))."""
         score, logit = self.model(img)
+        if self.keep_outputs:                    # parity tests read the step's own forward outputs; off by default (318 MB)
+            self.last_outputs = (score.detach(), logit.detach())
         self.optimizer.zero_grad()
         if hasattr(self.criterion, "value_and_grads") and logit.requires_grad:
             # the fused loss hands out its value AND both gradients; d(loss.mean())/d(loss) = 1 (train_deeplab.py:198-202),
             # so they go to autograd as they are -- no `grad * 1` pass over the 318 MB logit gradient
-            loss, dlogit, dscore = self.criterion.value_and_grads(logit, score, target)
+            loss, dlogit, dscore = self.criterion.value_and_grads(logit, score, target, perms=perms)
             torch.autograd.backward((score, logit), (dscore, dlogit))
         else:
-            loss = self.criterion(logit, score, target).mean()
+            loss = (self.criterion(logit, score, target, perms=perms) if perms is not None
+                    else self.criterion(logit, score, target)).mean()
             loss.backward()
         self.optimizer.step()
         return loss

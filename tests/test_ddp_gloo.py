@@ -62,6 +62,8 @@ def _worker(rank, world, port, out):
         ok = ok and torch.allclose(g2, torch.full_like(g2, 10.0 / world))
     else:
         ok = ok and pd["bot_fine.weight"].grad is not None and torch.allclose(pd["bot_fine.weight"].grad, torch.full((48, 128, 1, 1), 10.0 / world))
+    for p_ in pd.values():
+        p_.grad = None                                             # zero_grad(set_to_none=True), as every step does
     # ranks that produce their gradients in DIFFERENT orders (rank 1 delivers the last bucket first) still issue the
     # collectives in bucket order: no hang, no mis-paired sizes
     sync3 = ddp.GradAllReduce(params, bucket_bytes=30000)
@@ -74,9 +76,38 @@ def _worker(rank, world, port, out):
     sync2("ood_head.weight", g3)
     sync2.abort()
     ok = ok and not any(sync2.arrived) and sync2.next_bucket == 0 and not sync2.inflight and torch.allclose(g3, torch.full_like(g3, 7.0))
+    for p_ in pd.values():
+        p_.grad = None
     got = {n: sync2(n, torch.full(shapes[n], float(rank))) for n in shapes}
     sync2.backward_done()
     ok = ok and all(torch.allclose(got[n], torch.full_like(got[n], (world - 1) / 2)) for n in shapes)
+    # param.grad aliases the bucket buffer between steps, so a second backward without zero_grad(set_to_none=True)
+    # would overwrite the live gradient and then add the buffer to itself -- it must raise instead of doubling silently
+    w = torch.nn.Parameter(torch.ones(4, 4))
+    sync4 = ddp.GradAllReduce([("w", w)])
+
+    class _Node(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.sum() * 2.5
+        @staticmethod
+        def backward(ctx, g):
+            r = sync4("w", torch.full((4, 4), 2.5) * g)
+            return r
+    _Node.apply(w).backward()
+    sync4.backward_done()
+    ok = ok and torch.allclose(w.grad, torch.full((4, 4), 2.5)) and w.grad.data_ptr() == sync4.flat[0].data_ptr()
+    raised = False
+    try:
+        _Node.apply(w).backward()                                  # no zero_grad in between
+    except RuntimeError as e:
+        raised = "zero_grad(set_to_none=True)" in str(e)
+    sync4.abort()
+    ok = ok and raised and torch.allclose(w.grad, torch.full((4, 4), 2.5))      # and the live gradient is untouched
+    w.grad = None
+    _Node.apply(w).backward()
+    sync4.backward_done()
+    ok = ok and torch.allclose(w.grad, torch.full((4, 4), 2.5))
     out[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()

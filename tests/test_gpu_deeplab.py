@@ -48,36 +48,34 @@ def test_state_dict_contract(model, deeplab_params):
                                             ("stage2", ["aspp", "bot_fine", "bot_aspp", "ood_head"], 1e-6)])
 def test_train_step_golden(deeplab_params, stage, names, lr):
     """a-7: one optimizer step with train-mode BN on the frozen trunk, the reference's Dropout2d
-    masks and loss permutations injected."""
+    masks and loss permutations injected -- run through trainer.TrainStep, i.e. the fused loss route and the HIP Adam
+    (multishiftseg_amd/optim.py) that bench.py times, not torch.optim."""
     from multishiftseg_amd import synth
     from multishiftseg_amd.deepv3 import DeepWV3Plus
     from multishiftseg_amd.loss import RelContrastiveLoss
+    from multishiftseg_amd.optim import Adam
+    from multishiftseg_amd.trainer import LOSS_PARAMS, TrainStep
     g = golden("deepwv3plus_train_step")
     pairs, h, w = (int(v) for v in g["shape"])
     m = DeepWV3Plus(19)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in deeplab_params.items()}, strict=True)
     m = m.cuda()
     m.uncertainty_func_init()
-    params = []
-    for n, p in m.named_parameters():
-        p.requires_grad = any(s in n for s in names)
-        if p.requires_grad:
-            params.append(p)
-    opt = torch.optim.Adam(params, lr=lr, weight_decay=1e-4)
-    m.train()
+    crit = RelContrastiveLoss(LOSS_PARAMS)
+    # the product's own step: TrainStep picks the stage's trainable set by substring and drives the HIP Adam
+    # (optim.Adam -> mss_adam_step_f32), exactly what bench.py times
+    step = TrainStep(m, crit, stage=int(stage[-1]))
+    assert isinstance(step.optimizer, Adam) and step.optimizer.lr == lr and step.optimizer.weight_decay == 1e-4
+    assert sorted(step.names) == sorted(n for n, _ in m.named_parameters() if any(s in n for s in names))
+    step.keep_outputs = True
     pre = stage + "_"
     m.dropout_masks = {"mod6": torch.from_numpy(g[pre + "drop_mod6"]), "mod7": torch.from_numpy(g[pre + "drop_mod7"])}
     img = torch.from_numpy(synth.synth_image(int(g["image_seed"]), 2 * pairs, h, w)).cuda()
     target = torch.from_numpy(g["target"].astype(np.int64)).cuda()
-    crit = RelContrastiveLoss({"ce_weights": [50, 10], "conduct_pixel_selection": True, "selection_ratio": 0.8,
-                               "inoutaug_contras_margins_tri": [10, 5, 5]})
     perms = [torch.from_numpy(g[pre + f"perm{i}"].astype(np.int64)) for i in range(3)]
     before = {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
-    score, logit = m(img)
-    loss = crit(logit, score, target, perms=perms).mean()
-    opt.zero_grad()
-    loss.backward()
-    opt.step()
+    loss = step(img, target, perms=perms)
+    score, logit = step.last_outputs
     np.testing.assert_allclose(score.detach().cpu().numpy(), g[pre + "score"], rtol=0, atol=1e-3)
     np.testing.assert_allclose(logit.detach().cpu().numpy()[:, :, ::4, ::4], g[pre + "logit_sub"], rtol=0, atol=1e-3)
     np.testing.assert_allclose(loss.item(), float(g[pre + "loss"]), rtol=1e-4)

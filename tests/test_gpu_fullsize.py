@@ -163,27 +163,20 @@ def _train_step_vs_golden(deeplab_params, fixture, route, tile_check, out_bound)
     pre = "stage2_"
     m = _new_model(deeplab_params)
     m.uncertainty_func_init()
-    params = []
-    for n, p in m.named_parameters():
-        p.requires_grad = any(s in n for s in STAGE2)
-        if p.requires_grad:
-            params.append(p)
-    opt = torch.optim.Adam(params, lr=1e-6, weight_decay=1e-4)
-    m.train()
+    from multishiftseg_amd.trainer import TrainStep
+    crit = RelContrastiveLoss(LOSS_PARAMS)
+    step = TrainStep(m, crit, stage=2)      # the product's step: fused loss route + HIP Adam (optim.py), as bench.py times it
+    step.keep_outputs = True
     m.dropout_masks = {"mod6": torch.from_numpy(g[pre + "drop_mod6"]), "mod7": torch.from_numpy(g[pre + "drop_mod7"])}
     img = torch.from_numpy(synth.synth_image(int(g["image_seed"]), 2 * pairs, h, w)).cuda()
     target = torch.from_numpy(g["target"].astype(np.int64)).cuda()
-    crit = RelContrastiveLoss(LOSS_PARAMS)
     perms = [torch.from_numpy(g[pre + f"perm{i}"].astype(np.int64)) for i in range(3)]
     with _Env(ROUTES_X[route]):
         if route == "winograd":
             h8, w8 = -(-h // 8), -(-w // 8)
             assert [K.wino_tile(h8, w8, r) for r in (1, 2, 4, 12, 24, 36)] == tile_check
-        score, logit = m(img)
-        loss = crit(logit, score, target, perms=perms).mean()
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
+        loss = step(img, target, perms=perms)
+        score, logit = step.last_outputs
     e_s = float(np.abs(score.detach().cpu().numpy()[:, ::ss, ::ss] - g[pre + "score"]).max())
     e_l = float(np.abs(logit.detach().cpu().numpy()[:, :, ::ls, ::ls] - g[pre + "logit_sub"]).max())
     rep = {"score_err": e_s, "logit_err": e_l, "grads": {}}

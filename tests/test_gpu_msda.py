@@ -87,7 +87,8 @@ def test_production_shapes_vs_oracle(F, N, shapes):
 
 
 @pytest.mark.parametrize("tag,N,shapes", [("c4", 1, [(22, 22), (44, 44), (88, 88)]), ("c4_n2", 2, [(22, 22), (44, 44), (88, 88)]),
-                                          ("c5", 1, [(32, 64), (64, 128), (128, 256)])])
+                                          ("c5", 1, [(32, 64), (64, 128), (128, 256)]),
+                                          ("c4_n16", 16, [(22, 22), (44, 44), (88, 88)])])
 def test_full_size_every_query_vs_oracle(F, tag, N, shapes):
     """at the BASELINE token counts (C4: 10 164, C5: 43 008) EVERY output element and EVERY gradient
     element against the oracle -- forward, fused forward and the backward on its default (binned owner-computes) route;
@@ -111,8 +112,12 @@ def test_full_size_every_query_vs_oracle(F, tag, N, shapes):
     ts, tst = torch.from_numpy(shp).cuda(), torch.from_numpy(starts).cuda()
     out = MSDA.ms_deform_attn_forward(t["value"], ts, tst, t["loc"], t["attn"], 128)
     gv, gl, ga = MSDA.ms_deform_attn_backward(t["value"], ts, tst, t["loc"], t["attn"], t["gout"], 128)
-    want = omsda.forward_sampled(value, shp, starts, loc, attn)
-    wv, wl, wa = omsda.backward_sampled(value, shp, starts, loc, attn, gout)
+    # the oracle two images at a time (images are independent; bounds its memory at N = 16, the training batch of C4, whose
+    # binned tile geometry -- 9+9+36 tiles of 5.4 k / 5.4 k / 1.3 k records -- differs from N = 1, 2)
+    parts = [(omsda.forward_sampled(value[i:i + 2], shp, starts, loc[i:i + 2], attn[i:i + 2]),
+              omsda.backward_sampled(value[i:i + 2], shp, starts, loc[i:i + 2], attn[i:i + 2], gout[i:i + 2])) for i in range(0, N, 2)]
+    want = np.concatenate([p_[0] for p_ in parts])
+    wv, wl, wa = (np.concatenate([p_[1][k] for p_ in parts]) for k in range(3))
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(gv.cpu().numpy(), wv, rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(ga.cpu().numpy(), wa, rtol=1e-3, atol=1e-4)
@@ -219,6 +224,38 @@ def test_backward_formulations_vs_oracle(F, force_bwd, mode, N, Lq, shapes):
     np.testing.assert_allclose(v.grad.cpu().numpy(), gv, rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(l.grad.cpu().numpy(), gl, rtol=1e-3, atol=3e-3)
     np.testing.assert_allclose(a.grad.cpu().numpy(), ga, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["0", "2", "b"])
+def test_backward_zero_fills_rows_no_level_covers(F, force_bwd, mode):
+    """a value tensor with more rows than the levels cover -- padding behind the last level and a gap between two
+    levels in level_start_index (the functional API allows both) -- must get ZERO gradient on the uncovered rows on every
+    route, as the reference's zero-initialised grad_value does (ms_deform_attn_cuda.cu:126); the output buffer is handed
+    over dirty to prove it."""
+    from multishiftseg_amd import MultiScaleDeformableAttention as MSDA
+    force_bwd(mode)
+    rng = np.random.default_rng(3)
+    shp = np.array([(12, 20), (7, 9)], dtype=np.int64)
+    starts = np.array([0, 12 * 20 + 37], dtype=np.int64)           # 37 rows nobody owns between the levels
+    S = int(starts[1] + 7 * 9 + 50)                                # and 50 behind the last one
+    N, Lq = 2, 300
+    value = rng.standard_normal((N, S, 8, 32), dtype=np.float32)
+    loc = rng.uniform(-0.2, 1.2, (N, Lq, 8, 2, 4, 2)).astype(np.float32)
+    attn = rng.random((N, Lq, 8, 2, 4), dtype=np.float32)
+    attn /= attn.sum((-1, -2), keepdims=True)
+    gout = rng.standard_normal((N, Lq, 256), dtype=np.float32)
+    junk = torch.full((64 << 20,), float("nan"), device="cuda")   # make the allocator hand out dirty memory
+    del junk
+    gv, gl, ga = MSDA.ms_deform_attn_backward(dev(value), dev(shp), dev(starts), dev(loc), dev(attn), dev(gout), 2)
+    wv, wl, wa = omsda.backward(value, shp, starts, loc, attn, gout)
+    gv = gv.cpu().numpy()
+    covered = np.zeros(S, bool)
+    covered[:240] = True
+    covered[int(starts[1]):int(starts[1]) + 63] = True
+    assert (gv[:, ~covered] == 0).all()
+    np.testing.assert_allclose(gv, wv, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(gl.cpu().numpy(), wl, rtol=1e-3, atol=3e-3)
+    np.testing.assert_allclose(ga.cpu().numpy(), wa, rtol=1e-3, atol=1e-4)
 
 
 def test_owner_backward_is_order_independent_and_matches_atomics_at_full_size(F, force_bwd):

@@ -366,6 +366,83 @@ def gen_train_step(DeepWV3Plus, ref_loss, pairs=2, h=96, w=128, fixture="deepwv3
     save(fixture, **out)
 
 
+def gen_train_steps3(DeepWV3Plus, ref_loss, pairs=2, h=96, w=128, steps=3, fixture="deepwv3plus_train_3steps"):
+    """a-7, optimizer state: `steps` consecutive optimizer steps of each stage of the reference loop (train_deeplab.py:
+    134-149 builds torch.optim.Adam; :198-204 zero_grad / backward / step) on a fresh (pairs+pairs)x3xhxw batch per step,
+    Dropout2d masks and loss permutations recorded per step. Stored: per-step loss, final parameter deltas (small tensors
+    whole, big ones as the usual 64-column slice) and Adam's exp_avg / exp_avg_sq after the last step -- moments are
+    non-zero from step 2 on, which the one-step fixture cannot exercise."""
+    loss_params = {"ce_weights": [50, 10], "conduct_pixel_selection": True, "selection_ratio": 0.8,
+                   "inoutaug_contras_margins_tri": [10, 5, 5]}
+    out = dict(shape=np.array([pairs, h, w]), steps=np.int64(steps), image_seeds=np.arange(20, 20 + steps))
+    for k in range(steps):
+        out[f"target{k}"] = synth.synth_targets(20 + k, pairs, h, w).astype(np.uint8)
+    real_randperm = torch.randperm
+    for stage, (names, lr) in {"stage1": (["ood_head"], 1e-4),
+                               "stage2": (["aspp", "bot_fine", "bot_aspp", "ood_head"], 1e-6)}.items():
+        pre = stage + "_"
+        model = build_ref_model(DeepWV3Plus)
+        model.uncertainty_func_init()
+        params = []
+        for name, p in model.named_parameters():
+            p.requires_grad = any(s_ in name for s_ in names)
+            if p.requires_grad:
+                params.append(p)
+        opt = torch.optim.Adam(params, lr=lr, weight_decay=1e-4)
+        model.train()
+        masks = {}
+        torch.manual_seed(321)
+
+        def make_drop(key, p):
+            def fwd(x):
+                m = (torch.rand(x.shape[0], x.shape[1]) >= p).float() / (1 - p)
+                masks[key] = t2n(m)
+                return x * m[:, :, None, None]
+            return fwd
+        model.mod6.block1.convs.dropout.forward = make_drop("mod6", 0.3)
+        model.mod7.block1.convs.dropout.forward = make_drop("mod7", 0.5)
+        before = {n_: p.detach().clone() for n_, p in model.named_parameters() if p.requires_grad}
+        crit = ref_loss.RelContrastiveLoss(loss_params)
+        for k in range(steps):
+            perms = []
+
+            def logging_randperm(n, *a, **kw):
+                p = real_randperm(n, *a, **kw)
+                perms.append(t2n(p))
+                return p
+            torch.randperm = logging_randperm
+            try:
+                img = torch.from_numpy(synth.synth_image(20 + k, 2 * pairs, h, w))
+                tgt = torch.from_numpy(out[f"target{k}"].astype(np.int64))
+                score, logit = model(img)
+                loss = crit(logit, score, tgt).mean()
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            finally:
+                torch.randperm = real_randperm
+            out[pre + f"loss{k}"] = t2n(loss)
+            out[pre + f"drop_mod6_{k}"], out[pre + f"drop_mod7_{k}"] = masks["mod6"], masks["mod7"]
+            for i, p in enumerate(perms):
+                out[pre + f"perm{i}_{k}"] = p.astype(np.int32)
+            print(f"   {stage} step {k}: loss {float(loss):.6f}")
+
+        def sub(a):
+            if a.size <= 70000:
+                return a
+            flat = a.reshape(a.shape[0], -1)
+            return flat[:, ::max(1, flat.shape[1] // 64)][:, :64].copy()
+        named = dict(model.named_parameters())
+        for n_, b in before.items():
+            out[pre + "delta_" + n_] = sub(t2n(named[n_].detach() - b))
+            st = opt.state[named[n_]]
+            assert int(st["step"]) == steps
+            out[pre + "exp_avg_" + n_] = sub(t2n(st["exp_avg"]))
+            out[pre + "exp_avg_sq_" + n_] = sub(t2n(st["exp_avg_sq"]))
+            out[pre + "lastgrad_" + n_] = sub(t2n(named[n_].grad))
+    save(fixture, **out)
+
+
 # ------------------------------------------------------------------------------------------ loss
 def gen_loss(ref_loss):
     def run(tag, B, H, W, params, seed, tmod=None, full=True):
@@ -637,10 +714,11 @@ def gen_decoder():
           f"levels {[tuple(m.shape) for m in ms]}, {len(grads)} gradient entries")
 
 
-def gen_decoder_fullsize(tag="m2f_decoder_704", n=1, H=704, W=704, layers=6):
+def gen_decoder_fullsize(tag="m2f_decoder_704", n=1, H=704, W=704, layers=6, with_grads=False):
     """a-11 at BASELINE config 4's size: the reference's MSDeformAttnPixelDecoder.forward_features with the SHIPPED depth
     (6 encoder layers, anomaly_ft.yaml:27-31) on the feature maps of a 704x704 crop (levels 22^2 / 44^2 / 88^2, 10 164
-    tokens). Forward only; big outputs as strided slices + float64 checksums. ~1 minute on 8 cores."""
+    tokens). Big outputs as strided slices + float64 checksums; with_grads: the gradients of every parameter and feature map
+    from the reference's autograd as well. ~1 minute forward, a few more with gradients, on 8 cores."""
     Dec, ShapeSpec = import_reference_decoder()
     torch.manual_seed(61)
     shape = {"res2": ShapeSpec(256, 4), "res3": ShapeSpec(512, 8), "res4": ShapeSpec(1024, 16), "res5": ShapeSpec(2048, 32)}
@@ -656,7 +734,32 @@ def gen_decoder_fullsize(tag="m2f_decoder_704", n=1, H=704, W=704, layers=6):
     with torch.no_grad():
         mask, out0, ms = dec.forward_features({k: torch.from_numpy(v) for k, v in feats.items()})
     absum = lambda t: np.float64(np.abs(t2n(t).astype(np.float64)).sum())
-    save(tag, names=np.array(list(sd.keys())), seed=np.int64(64), nhw=np.array([n, H, W]), layers=np.int64(layers),
+    grads = {}
+    if with_grads:
+        # the training path at this size (VERDICT r03 missing #3): the reference class's own autograd of
+        # L = <mask, G> + sum_i <ms[i], G_i> with seeded cotangents, every parameter and the four feature maps
+        for p in dec.parameters():
+            p.requires_grad_(True)
+        tf = {k: torch.from_numpy(v).requires_grad_(True) for k, v in feats.items()}
+        mask_g, _, ms_g = dec.forward_features(tf)
+        crng = np.random.default_rng(65)
+        cot = [torch.from_numpy(crng.standard_normal(tuple(t.shape), dtype=np.float32)) for t in (mask_g, *ms_g)]
+        sum((t * c).sum() for t, c in zip((mask_g, *ms_g), cot)).backward()
+        for k, prm in dec.named_parameters():
+            gk = t2n(prm.grad)
+            grads["gl2_" + k] = np.float64(np.sqrt((gk.astype(np.float64) ** 2).sum()))
+            if gk.size <= 16384:
+                grads["g_" + k] = gk
+            else:
+                flat = gk.reshape(gk.shape[0], -1)
+                grads["gsub_" + k] = flat[::max(1, flat.shape[0] // 32), ::max(1, flat.shape[1] // 64)].copy()
+        for k, t in tf.items():
+            gk = t2n(t.grad)
+            grads["gl2_feat_" + k] = np.float64(np.sqrt((gk.astype(np.float64) ** 2).sum()))
+            grads["gsub_feat_" + k] = gk[:, ::max(1, gk.shape[1] // 32), ::max(1, gk.shape[2] // 16), ::max(1, gk.shape[3] // 16)].copy()
+        grads["cot_seed"] = np.int64(65)
+        print(f"   {tag}: {len(grads)} gradient entries")
+    save(tag, names=np.array(list(sd.keys())), seed=np.int64(64), nhw=np.array([n, H, W]), layers=np.int64(layers), **grads,
          mask_sub=t2n(mask)[:, ::8, ::4, ::4], mask_abs_sum=absum(mask), mask_row=t2n(mask)[:, :, mask.shape[2] // 3],
          out0_sub=t2n(out0)[:, ::4], out0_abs_sum=absum(out0), ms1_sub=t2n(ms[1])[:, ::8, ::2, ::2], ms1_abs_sum=absum(ms[1]),
          ms2_sub=t2n(ms[2])[:, ::8, ::4, ::4], ms2_abs_sum=absum(ms[2]),
@@ -809,7 +912,7 @@ def main():
     if "decoder" in which:
         print("decoder"); gen_decoder()
     if "decoder_704" in which:           # minutes: only on request
-        print("decoder_704"); gen_decoder_fullsize()
+        print("decoder_704"); gen_decoder_fullsize(with_grads=True)
     if "decoder_c5" in which:
         print("decoder_c5"); gen_decoder_fullsize("m2f_decoder_1024x2048", 1, 1024, 2048)
     if "datapath" in which:
@@ -822,6 +925,8 @@ def main():
         print("deeplab"); gen_deeplab(DeepWV3Plus)
     if "train" in which:
         print("train"); gen_train_step(DeepWV3Plus, ref_loss)
+    if "train" in which or "train3" in which:
+        print("train3"); gen_train_steps3(DeepWV3Plus, ref_loss)
     # the two big fixtures take minutes on 8 cores: only on request (python tools/gen_golden.py deeplab_big train_big)
     if "deeplab_big" in which:
         print("deeplab_big"); gen_deeplab_big(DeepWV3Plus)
