@@ -261,7 +261,7 @@ def main():
     if args.workload == "launchcheck":
         return launch_check(args)
 
-    from multishiftseg_amd import ddp, kernels as K, synth
+    from multishiftseg_amd import _lib, ddp, kernels as K, synth
     from multishiftseg_amd.deepv3 import DeepWV3Plus
     from multishiftseg_amd.loss import RelContrastiveLoss
     from multishiftseg_amd.trainer import LOSS_PARAMS, TrainStep, ood_scores
@@ -458,6 +458,7 @@ def main():
         # EXPERIMENTAL, reported apart from `value`: the same step with the fp32 GEMMs evaluated on the bf16 matrix cores
         # (three-way operand split, six MFMAs per block, fp32 accumulate; csrc/gemm_bf16x6.hip). Same parity tests pass.
         os.environ["MSS_GEMM_BF16X6"] = "1"
+        _lib.reset_env_cache()
         try:
             one_step()
             torch.cuda.synchronize()
@@ -473,6 +474,7 @@ def main():
                         "float64 equals the native fp32 MFMA kernel's (tests/test_gpu_ops.py::test_bf16x6_gemm_is_fp32_accurate)"}
         finally:
             os.environ.pop("MSS_GEMM_BF16X6", None)
+            _lib.reset_env_cache()
 
     if not args.no_ood:
         # OOD-score path (test_deeplab.py:86-90): eval forward -> per-pixel anomaly score

@@ -23,8 +23,14 @@ extern "C" {
 
 #define MSS_ABI_VERSION 5      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
                                   mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32,
-                                  mss_bn_fold_train_from_partials_f32; 5 (round 4): mss_adam_step_f32 takes double hyper-parameters */
+                                  mss_bn_fold_train_from_partials_f32; 5 (round 4): mss_adam_step_f32 takes double hyper-parameters, mss_env_reset,
+                                  mss_wino_input_transform_aspp3_f32 */
 int mss_abi_version(void);
+
+/* The MSS_* environment switches (A/B experiments, test routes; none is needed in production) are read once per call site and
+ * cached. A process that changes one after its first call into the library calls this to have them re-read. */
+int mss_env_reset(void);        /* returns the new generation */
+int mss_env_generation(void);
 
 /* ---------------------------------------------------------------------------------------------
  * B1 -- MultiScaleDeformableAttention extension
@@ -170,6 +176,12 @@ int mss_wino_input_transform_bnbwd_f32(const float* dy, int lddy, const float* x
  * (the full-resolution upsampled map is never stored). MSS_ERR_UNSUPPORTED where the LDS-staged transform is not taken. */
 int mss_wino_input_transform_upcat_f32(const float* a, int lda, int c_split, const float* small, int ld_small, int IH, int IW, int N,
                                        int H, int W, int C, int tile, float* xt, void* stream);
+/* ASPP (deepv3.py:84-92: three 3x3 branches of rates d, 2d, 3d on the SAME 4096-channel map): X' for all three dilations from
+ * ONE read of x. xt_m = exactly what mss_wino_input_transform_f32(x, ..., dil = (m+1)*d, tile = tiles[m], no prologue) writes.
+ * tiles: host array of 3 tile edges, each 4 or 6. MSS_ERR_UNSUPPORTED when a base residue sub-grid does not fit in LDS or a
+ * tile edge is 2 (the caller then runs the three transforms separately). */
+int mss_wino_input_transform_aspp3_f32(const float* x, int ldx, int N, int H, int W, int C, int d, const int* tiles, float* xt0,
+                                       float* xt1, float* xt2, void* stream);
 int mss_wino_output_transform_f32(const float* yt, int N, int H, int W, int K, int dil, int tile, const float* res,
                                   int ldres, float* y, int ldy, float* stats, void* stream);
 /* stats (optional): [mss_wino_output_stats_parts(...)][2][K] partial sums / sums of squares of y, as MssConvArgs.stats */

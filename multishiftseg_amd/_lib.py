@@ -59,6 +59,8 @@ U = c_uint32
 # name -> argtypes, exactly the declarations of include/mss_hip.h
 SIGNATURES = {
     "mss_abi_version": [],
+    "mss_env_reset": [],
+    "mss_env_generation": [],
     "mss_msda_forward_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P, P],
     "mss_msda_forward_f64": [P, P, P, P, P, I, I, I, I, I, I, I, P, P],
     "mss_msda_backward_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P],
@@ -118,6 +120,7 @@ SIGNATURES = {
     "mss_wino_input_transform_f32": [P, I, I, I, I, I, I, I, P, P, I, P, P],
     "mss_wino_input_transform_bnbwd_f32": [P, I, P, I, I, I, I, I, I, I, P, P, P, P, P, I, P, P],
     "mss_wino_input_transform_upcat_f32": [P, I, I, P, I, I, I, I, I, I, I, I, P, P],
+    "mss_wino_input_transform_aspp3_f32": [P, I, I, I, I, I, I, P, P, P, P, P],
     "mss_wino_output_transform_f32": [P, I, I, I, I, I, I, P, I, P, I, P, P],
     "mss_wino_output_stats_parts": [I, I, I, I, I, I],
     "mss_bn_stats_partials_f32": [P, L, I, P, P],
@@ -148,7 +151,7 @@ SIGNATURES = {
     "mss_peak_scatter_f32": [P, P, L, I, I, L, P],
 }
 # entry points that return a plain value rather than a status code
-_VALUE_RETURNING = {"mss_abi_version", "mss_msda_backward_workspace_bytes", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
+_VALUE_RETURNING = {"mss_abi_version", "mss_env_reset", "mss_env_generation", "mss_msda_backward_workspace_bytes", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
                     "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts",
                     "mss_conv2d_wgrad_workspace_bytes", "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
                     "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats",
@@ -181,6 +184,13 @@ def load():
                        "(`make -C multishiftseg_amd/csrc` or __graft_entry__.build())")
     _lib = lib
     return lib
+
+
+def reset_env_cache():
+    """The library caches the MSS_* environment switches per call site; call this after changing one mid-process (tests,
+    A/B tools). A no-op when the library has not been loaded yet (its first read will see the current environment)."""
+    if _lib is not None:
+        _lib.mss_env_reset()
 
 
 def ptr(t):

@@ -998,7 +998,7 @@ int launch_wgrad(MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, 
 struct TnPlan { int ktiles, ctiles, splits, tps; long long total; };
 inline int tn_batch(const MssConvArgs& p) { return p.batch > 1 ? p.batch : 1; }
 inline bool tn_eligible(const MssConvArgs& p, int lddy) {
-  const bool off = getenv("MSS_WGRAD_TN") && atoi(getenv("MSS_WGRAD_TN")) == 0;     // A/B switch
+  const bool off = MSS_ENV_INT("MSS_WGRAD_TN", 3) == 0;     // A/B switch
   if (off || p.R * p.S != 1 || p.in_scale || p.in_relu || p.K % 4 || p.C % 4 || p.ldx != p.C || lddy != p.K) return false;
   if (p.batch > 1) return p.x_bs % 4 == 0 && p.y_bs % 4 == 0 && p.N == 1 && p.H == 1;   // Winograd-domain products
   // a plain 1x1 / stride-1 layer over dense rows (ASPP 4096 -> 256: 95 -> see DESIGN 3.3): the same GEMM with one position;
@@ -1033,8 +1033,7 @@ inline TnPlan tn_plan(const MssConvArgs& p, int bc = TN_BC, int slots = 768) {
 // gemm_tn_wgrad_kernel elsewhere (with unmasked loads it is 2 % ahead of tn2<128>: 119.5 / 122.2 against 117.3 / 119.9 TFLOP/s),
 // 4 the wide kernel whenever C % 256 == 0 (tests)
 inline int tn_mode() {
-  const char* e = getenv("MSS_WGRAD_TN");
-  return e ? atoi(e) : 3;
+  return MSS_ENV_INT("MSS_WGRAD_TN", 3);
 }
 inline bool tn_wide(const MssConvArgs& p) {
   if (tn_mode() == 4) return p.C % 256 == 0;            // tests: the wide kernel at any size, pixel splits included
@@ -1074,8 +1073,7 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
     hipLaunchKernelGGL(gemm_tn2_wgrad_kernel<128>, dim3(grid), dim3(NT), smem2, stream, dy, p.x, out, P, p.M, p.K, p.C, a_bs,
                        b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
   } else {
-    const char* e2 = getenv("MSS_WGRAD_TN_AHEAD");
-    if (e2 && atoi(e2) == 2)
+    if (MSS_ENV_INT("MSS_WGRAD_TN_AHEAD", 0) == 2)
       hipLaunchKernelGGL(gemm_tn_wgrad_kernel<true>, dim3(grid), dim3(NT), smem, stream, dy, p.x, out, P, p.M, p.K, p.C, a_bs,
                          b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
     else
@@ -1110,8 +1108,8 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
   // read per call (not cached): the parity tests switch routes inside one process (MSS_GEMM=0: every layer on the
   // implicit-GEMM kernel; tests/test_gpu_fullsize.py compares it with the GEMM/Winograd routes)
   int force_bk = 0, use_gemm = 1;
-  { const char* e = getenv("MSS_CONV_BK"); force_bk = e ? atoi(e) : 0; }
-  { const char* e = getenv("MSS_GEMM"); use_gemm = e ? atoi(e) : 1; }
+  force_bk = MSS_ENV_INT("MSS_CONV_BK", 0);
+  use_gemm = MSS_ENV_INT("MSS_GEMM", 1);
   if (use_gemm) {
     const int rc = mss_gemm_nt_dispatch(p, stream);
     if (rc >= 0) return rc;
@@ -1131,8 +1129,7 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
 int mss_conv2d_forward_route(const MssConvArgs* args) {
   MssConvArgs p = *args;
   p.M = p.N * p.OH * p.OW;
-  const char* e = getenv("MSS_GEMM");
-  if (!(!e || atoi(e))) return 0;
+  if (!MSS_ENV_INT("MSS_GEMM", 1)) return 0;
   if (mss_gemm_few_rows(p)) return 2;                  // (0 implicit-GEMM kernel, 1 gemm_nt_kernel, 2 gemm_few_rows_kernel)
   return mss_gemm_nt_eligible(p) ? 1 : 0;
 }

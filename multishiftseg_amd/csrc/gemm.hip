@@ -488,8 +488,8 @@ int launch_gemm(const MssConvArgs& p, hipStream_t stream, long long first = 0, l
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<AFFINE, VARIANT, BN>, NT, smem) != hipSuccess || n < 1) n = 3;
-    const char* e = getenv("MSS_GEMM_WG_PER_CU");
-    if (e && atoi(e) > 0 && atoi(e) < n) n = atoi(e);
+    const int cap = MSS_ENV_INT("MSS_GEMM_WG_PER_CU", 0);
+    if (cap > 0 && cap < n) n = cap;
     per_cu_max = n;
   }
   // Every workgroup walks ceil(total / grid) tiles: pick the residency (per_cu_max or one less) whose last round is
@@ -516,8 +516,7 @@ int mss_gemm_nt_bf16x6_launch(MssConvArgs p, void* stream);   // gemm_bf16x6.hip
 // tile instead of conv_igemm's one-tile-per-workgroup 256 x 64 kernel: 0.203 -> 0.184 ms (256 -> 48) and 0.116 -> 0.087 ms
 // (128 -> 48) at 1 x 512 x 1024 (MSS_GEMM_BN64=0 restores the old route)
 static bool gemm_bn64_wanted(const MssConvArgs& p) {
-  const char* e = getenv("MSS_GEMM_BN64");
-  return !(e && atoi(e) == 0) && p.K <= 64 && p.K > 32 && p.batch <= 1 && p.C / BK >= 3 && p.M >= 16384;
+  return MSS_ENV_INT("MSS_GEMM_BN64", 1) != 0 && p.K <= 64 && p.K > 32 && p.batch <= 1 && p.C / BK >= 3 && p.M >= 16384;
 }
 
 bool mss_gemm_nt_eligible(const MssConvArgs& p) {
@@ -556,8 +555,8 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
   if (p.Kpad < p.ntiles * 128) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   {
-    const char* e = getenv("MSS_GEMM_BF16X6");            // experimental split-bf16 evaluation of the same fp32 GEMM
-    if (e && atoi(e)) return mss_gemm_nt_bf16x6_launch(p, stream);
+    // experimental split-bf16 evaluation of the same fp32 GEMM
+    if (MSS_ENV_INT("MSS_GEMM_BF16X6", 0)) return mss_gemm_nt_bf16x6_launch(p, stream);
   }
   // measured (tools/bench_bgemm.py, tools/bench_1x1.py, r02): variant 2 is +3-7 % on every shape (C = 128: 82.7 -> 86.9,
   // 512: 127 -> 132, 1024 -> 2048: 132 -> 136 TFLOP/s; 1x1 2048 -> 4096 with prologue/residual/statistics: 123 -> 128)
@@ -565,7 +564,7 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
   // (36 x 16384 x 256 -> 256: 125 -> 130, 512 -> 512: 128 -> 136, 1024 -> 2048: 133 -> 140, 1x1 2048 -> 4096: 139 -> 146 TFLOP/s) and
   // +0.5 % at C = 128, bit-identical results (tools/bench_gemm_variant.py, alternating A/B); shapes it does not take fall back to 2
   int variant = 3;
-  { const char* e = getenv("MSS_GEMM_VARIANT"); if (e) variant = atoi(e); }
+  variant = MSS_ENV_INT("MSS_GEMM_VARIANT", 3);
   if (variant == 1) return p.in_scale ? launch_gemm<true, 1, 128>(p, s) : launch_gemm<false, 1, 128>(p, s);
   // variant 3 addresses its operands with 32-bit byte offsets and needs >= 3 K-steps per tile (see the kernel)
   const long long nb3 = p.batch > 1 ? p.batch : 1;
@@ -577,7 +576,7 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
   // the 512 slots (MSS_GEMM_BN=128|256 forces one). Measured (tools/bench_bgemm.py, bench_1x1.py): 1x1 2048 -> 4096
   // 127 -> 133, ASPP 4096 -> 256 123 -> 131, 1024 -> 2048 136 -> 138, C = 304 122 -> 126 TFLOP/s; C = 256: 122 -> 121 (not taken).
   int bn = 0;
-  { const char* e = getenv("MSS_GEMM_BN"); if (e) bn = atoi(e); }
+  bn = MSS_ENV_INT("MSS_GEMM_BN", 0);
   const long long tiles256 = (long long)p.mtiles * (p.K / 256) * (p.batch > 1 ? p.batch : 1);
   bool wide = p.K % 256 == 0 && (bn == 256 || (bn == 0 && tiles256 >= 1024 && p.C >= 256));
   if (wide && bn == 0) {
@@ -601,8 +600,7 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
     // Off by default: 0.2 ms per step does not pay for one GEMM call becoming two kernel launches in every profile.
     // r03: a default rule for nearly-empty last rounds (rem <= 128; only one-image eval products qualify) measured +-0 on the eval
     // forward (42.15 -> 42.15 ms): it stays opt-in. The two launches use the variant-3 kernels where the shape allows.
-    const char* te = getenv("MSS_GEMM_TAIL");
-    const int tail_mode = te ? atoi(te) : -1;
+    const int tail_mode = MSS_ENV_INT("MSS_GEMM_TAIL", -1);
     const long long full = (tiles256 / 512) * 512, rem = tiles256 - full;
     const int nw = p.K / 256;
     const long long rem_max = tail_mode == 1 ? 384 : 0;
@@ -618,11 +616,11 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
     }
     p.ntiles = nw;
     {
-      const char* we = getenv("MSS_GEMM_WP");          // experiment: wave-private staging, no workgroup barrier (non-affine only)
-      if (we && atoi(we) == 1 && !p.in_scale) return launch_gemm_wp<0>(p, s);
-      if (we && atoi(we) == 2 && !p.in_scale) return launch_gemm_wp<1>(p, s);
-      if (we && atoi(we) == 3 && !p.in_scale) return launch_gemm_wp<2>(p, s);
-      if (we && atoi(we) == 4 && !p.in_scale) return launch_gemm_wp<3>(p, s);
+      const int wp = MSS_ENV_INT("MSS_GEMM_WP", 0);    // experiment: wave-private staging, no workgroup barrier (non-affine only)
+      if (wp == 1 && !p.in_scale) return launch_gemm_wp<0>(p, s);
+      if (wp == 2 && !p.in_scale) return launch_gemm_wp<1>(p, s);
+      if (wp == 3 && !p.in_scale) return launch_gemm_wp<2>(p, s);
+      if (wp == 4 && !p.in_scale) return launch_gemm_wp<3>(p, s);
     }
     if (v3) return p.in_scale ? launch_gemm<true, 3, 256>(p, s) : launch_gemm<false, 3, 256>(p, s);
     return p.in_scale ? launch_gemm<true, 2, 256>(p, s) : launch_gemm<false, 2, 256>(p, s);

@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void upsample_ac_kernel(const float* __restric
   const float* b = x + (long long)n * IH * IW * ldx + c;
   const f32x4 v00 = ld4(b + ((long long)ty.i0 * IW + tx.i0) * ldx), v01 = ld4(b + ((long long)ty.i0 * IW + tx.i1) * ldx);
   const f32x4 v10 = ld4(b + ((long long)ty.i1 * IW + tx.i0) * ldx), v11 = ld4(b + ((long long)ty.i1 * IW + tx.i1) * ldx);
-  const f32x4 o = ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
+  const f32x4 o = mss_bilerp(ty, tx, v00, v01, v10, v11);
   st4(y + ((long long)(n * OH + oy) * OW + ox) * ldy + c, o);
 }
 
@@ -1398,6 +1398,10 @@ int mss_m2f_score_f32(const float* cls, const float* mask, int B, int Q, int C, 
                      score);
   return mss_launch_status();
 }
+
+static std::atomic<int> g_env_generation{0};
+int mss_env_generation(void) { return g_env_generation.load(std::memory_order_relaxed); }
+int mss_env_reset(void) { return g_env_generation.fetch_add(1, std::memory_order_relaxed) + 1; }
 
 int mss_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, double lr,
                       double beta1, double beta2, double eps, double weight_decay, int step, void* stream) {

@@ -354,8 +354,14 @@ inline RsPlan rs_plan(long long n) {
   return p;
 }
 inline bool rs_use_rocprim() {
+  static std::atomic<long long> slot{-(1ll << 32)};        // cached like MSS_ENV_INT (mss_common.h); the value is a word here
+  const int gen = mss_env_generation();
+  const long long v = slot.load(std::memory_order_relaxed);
+  if ((int)(v >> 32) == gen) return (v & 1) != 0;
   const char* e = getenv("MSS_OODM_SORT");
-  return e && e[0] == 'r';
+  const bool r = e && e[0] == 'r';
+  slot.store(((long long)gen << 32) | (r ? 1 : 0), std::memory_order_relaxed);
+  return r;
 }
 
 }  // namespace

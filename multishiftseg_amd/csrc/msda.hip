@@ -1278,8 +1278,7 @@ int msda_forward_fast(const float* value, const int64_t* shapes, const int64_t* 
   const long long nblocks = (npairs + 4 * HPW - 1) / (4 * HPW);
   const size_t smem = (size_t)4 * HPW * L * P * 3 * sizeof(float);
   // buffer-resource addressing (32-bit offsets, hardware zero fill) when the value tensor is below 4 GB; MSS_MSDA_BUF=0: A/B
-  const char* e = getenv("MSS_MSDA_BUF");
-  const bool buf = (unsigned long long)N * S * M * (4 * LPH) * 4ull < 0xffffffffull && !(e && atoi(e) == 0);
+  const bool buf = (unsigned long long)N * S * M * (4 * LPH) * 4ull < 0xffffffffull && MSS_ENV_INT("MSS_MSDA_BUF", 1) != 0;
 #define MSDA_LAUNCH(FUSED_, BUF_)                                                                                              \
   hipLaunchKernelGGL((msda_fwd_fast_kernel<LPH, FUSED_, BUF_>), dim3((unsigned)nblocks), dim3(256), smem, stream, value, shapes, \
                      starts, loc, attn, ref, npairs, S, M, L, Lq, P, out)
@@ -1329,8 +1328,7 @@ int msda_backward(const T* value, const int64_t* shapes, const int64_t* starts, 
   if (rc) return rc;
   if (!gvalue && N > 0) return MSS_ERR_BAD_ARG;
   const long long npairs = (long long)N * Lq * M;
-  const char* env = getenv("MSS_MSDA_BWD_LDS");      // 0: atomic kernel only, 2: owner-computes path at any size (tests)
-  const int lds_path = env ? atoi(env) : 1;
+  const int lds_path = MSS_ENV_INT("MSS_MSDA_BWD_LDS", 1);      // 0: atomic kernel only, 2: owner-computes path at any size (tests)
   // owner-computes path: fp32, D = 32, at most 2^22 samples per (image, head, level) (fixed-point headroom)
   const bool owner = lds_path && sizeof(T) == 4 && D == 32 && npairs > 0 && M <= 65535 && N <= 65535 &&
                      (long long)Lq * P <= (1ll << 22) &&
@@ -1361,8 +1359,7 @@ int msda_backward(const T* value, const int64_t* shapes, const int64_t* starts, 
     const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(gout)) & 15) == 0;
     if (aligned && smem <= 65536) {
       const long long nblocks = (npairs + 31) / 32;
-      const char* eb = getenv("MSS_MSDA_BUF");
-      const bool buf = (unsigned long long)N * S * M * D * 4ull < 0xffffffffull && !(eb && atoi(eb) == 0);
+      const bool buf = (unsigned long long)N * S * M * D * 4ull < 0xffffffffull && MSS_ENV_INT("MSS_MSDA_BUF", 1) != 0;
       if (buf)
         hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<true>, dim3((unsigned)nblocks), dim3(256), smem, stream,
                            reinterpret_cast<const float*>(value), shapes, starts, reinterpret_cast<const float*>(loc),
@@ -1467,8 +1464,7 @@ static int msda_backward_binned(const float* value, const int64_t* shapes, const
                      halo, gvalue);
   // grad_loc / grad_attn: the gather pass (no atomics)
   const long long nblocks = (npairs + 31) / 32;
-  const char* eb = getenv("MSS_MSDA_BUF");
-  const bool buf = (unsigned long long)N * S * M * D * 4ull < 0xffffffffull && !(eb && atoi(eb) == 0);
+  const bool buf = (unsigned long long)N * S * M * D * 4ull < 0xffffffffull && MSS_ENV_INT("MSS_MSDA_BUF", 1) != 0;
   if (buf)
     hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<true>, dim3((unsigned)nblocks), dim3(256), smem_gather, stream, value, shapes, starts,
                        loc, attn, gout, npairs, S, M, L, Lq, P, gloc, gattn);

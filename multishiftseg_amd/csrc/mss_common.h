@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <atomic>
 
 #define MSS_OK 0
 #define MSS_ERR_BAD_ARG 1001     // a precondition of the C-ABI entry point was violated
@@ -17,6 +19,22 @@ static inline int mss_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MSS_OK : (int)e;
 }
+
+// Tuning / test switches (MSS_* environment variables) read on launch paths: each call site caches its value and re-reads the
+// environment only after mss_env_reset() (include/mss_hip.h) has bumped the generation -- no getenv() per kernel launch.
+// A process that sets its switches before the first call needs nothing; tests that flip them call the reset hook.
+extern "C" int mss_env_generation(void);
+static inline int mss_env_lookup(const char* name, int dflt, std::atomic<long long>& slot) {
+  const int gen = mss_env_generation();
+  const long long v = slot.load(std::memory_order_relaxed);
+  if ((int)(v >> 32) == gen) return (int)(unsigned)(v & 0xffffffffll);
+  const char* e = getenv(name);
+  const int val = e ? atoi(e) : dflt;
+  slot.store(((long long)gen << 32) | (unsigned)val, std::memory_order_relaxed);
+  return val;
+}
+#define MSS_ENV_INT(name, dflt) \
+  ([]() -> int { static std::atomic<long long> slot{-(1ll << 32)}; return mss_env_lookup(name, dflt, slot); }())
 
 __host__ __device__ static inline int mss_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
@@ -75,5 +93,18 @@ __device__ __forceinline__ Tap ac_tap(int o, float scale, int in) {
   t.l1 = src - (float)t.i0;
   t.l0 = 1.f - t.l1;
   return t;
+}
+// The four-tap blend with a FIXED contraction -- top = fma(lx0, v00, lx1*v01), bottom likewise, out = fma(ly0, top, ly1*bottom) --
+// so that every kernel interpolating the same map (upsample_ac_kernel, the Winograd input transform that upsamples on the fly)
+// produces the same bits; left to -ffp-contract the compiler picks a different fusion per call site.
+__device__ __forceinline__ f32x4 mss_bilerp(const Tap& ty, const Tap& tx, f32x4 v00, f32x4 v01, f32x4 v10, f32x4 v11) {
+  f32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float top = __builtin_fmaf(tx.l0, v00[k], tx.l1 * v01[k]);
+    const float bot = __builtin_fmaf(tx.l0, v10[k], tx.l1 * v11[k]);
+    o[k] = __builtin_fmaf(ty.l0, top, ty.l1 * bot);
+  }
+  return o;
 }
 static inline float mss_ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }

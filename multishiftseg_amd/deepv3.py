@@ -282,6 +282,9 @@ class DeepWV3Plus(nn.Module):
         # two dilated branches whose Winograd-domain products have the same shape share ONE GEMM launch when that fills the chip
         # better (the one-image eval forward: dilations 12 and 24, kernels.conv3x3_pair_tile); never when X' is kept for a backward
         pair_tile = 0 if keep else K.conv3x3_pair_tile(x, asp.features[1][0].weight, asp.features[2][0].weight, *_ASPP_RATES[:2])
+        # the three dilated branches read the same 1 GB map: ONE kernel makes all three Winograd-domain inputs from a single read
+        # (kernels.aspp_input_transforms); None: shapes / policy outside it, each branch transforms for itself as before
+        pre_xt = K.aspp_input_transforms(x, _ASPP_RATES, [asp.features[i][0].weight for i in (1, 2, 3)], pair_tile)
         for i, feat in enumerate(asp.features):
             rate = 1 if i == 0 else _ASPP_RATES[i - 1]
             sl = raw.slice(256 * (i + 1), 256)
@@ -291,7 +294,9 @@ class DeepWV3Plus(nn.Module):
                 if i == 1:
                     sl2 = raw.slice(256 * 3, 256)          # ONE object: conv3x3_pair leaves the batch statistics on it
                     K.conv3x3_pair(x, feat[0].weight, asp.features[2][0].weight, _ASPP_RATES[0], _ASPP_RATES[1], sl,
-                                   sl2, pair_tile, want_stats=train)
+                                   sl2, pair_tile, want_stats=train, xt=pre_xt[0] if pre_xt else None)
+                    if pre_xt:
+                        pre_xt[0] = None
                     pair_slices = {1: sl, 2: sl2}
                 sl = pair_slices[i]              # carries the statistics the producing transform left (train-mode BatchNorm)
                 aspp_xt[i] = None
@@ -299,7 +304,9 @@ class DeepWV3Plus(nn.Module):
                 # keep the Winograd-domain input X' for this layer's weight gradient when the three of them fit
                 # comfortably (2.25-4x the 4096-channel map each: 10.6 GB in all at 2x1024x2048)
                 kx = {} if (keep and feat[0].weight.requires_grad and xt_bytes < (40 << 30)) else None
-                K.conv3x3(x, feat[0].weight, dil=rate, out=sl, keep_xt=kx, want_stats=train)
+                K.conv3x3(x, feat[0].weight, dil=rate, out=sl, keep_xt=kx, want_stats=train, xt=pre_xt[i - 1] if pre_xt else None)
+                if pre_xt:
+                    pre_xt[i - 1] = None                  # the layer owns it now (kept for the weight gradient, or freed)
                 aspp_xt[i] = kx.get("xt") if kx else None
             states.append(K.bn_fold(feat[1], sl, train))
         for i, s in enumerate(states):

@@ -369,11 +369,16 @@ def set_tile_hook(fn):
 
 
 def conv3x3(x, weight, dil=1, stride=1, in_affine=None, in_relu=False, res=None, out=None, flip=False, keep_xt=None,
-            want_stats=False, max_tile=6):
+            want_stats=False, max_tile=6, xt=None):
     """3x3 convolution with padding = dilation on nn.Conv2d-layout `weight` (flip=True: its data gradient),
     through Winograd when the policy says so, else through the direct implicit GEMM. max_tile: accuracy cap on the
-    Winograd tile edge for this layer (0: no Winograd at all)."""
+    Winograd tile edge for this layer (0: no Winograd at all). xt: the layer's Winograd-domain input X' when the caller has
+    it already (aspp_input_transforms); its tile edge decides the route."""
     k_out, c_in = (weight.shape[1], weight.shape[0]) if flip else (weight.shape[0], weight.shape[1])
+    if xt is not None:
+        assert in_affine is None and not in_relu and not flip and stride == 1
+        return conv2d_winograd(x, packed_wino(weight, False, WINO_TILE_OF_P[xt.shape[0]]), dil=dil, res=res, out=out,
+                               keep_xt=keep_xt, want_stats=want_stats, xt=xt)
     tile = wino_tile(x.H, x.W, dil, max_tile) if max_tile else 0
     if _tile_hook is not None and not flip:
         forced = _tile_hook(dict(H=x.H, W=x.W, dil=dil, c_in=c_in, k_out=k_out, stride=stride, policy_tile=tile))
@@ -389,7 +394,7 @@ def conv3x3(x, weight, dil=1, stride=1, in_affine=None, in_relu=False, res=None,
                   out=out, want_stats=want_stats)
 
 
-def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=None, keep_xt=None, want_stats=False):
+def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=None, keep_xt=None, want_stats=False, xt=None):
     """3x3 / stride 1 / padding = dilation convolution through Winograd F(m x m,3x3), m = ww.tile: input
     transform (with the fused BatchNorm+ReLU prologue) -> (m+2)^2 batched MFMA GEMMs -> output transform
     (+ residual). keep_xt: a dict; the transformed input X' is stored under keep_xt["xt"] so that the weight
@@ -402,11 +407,14 @@ def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=N
         out = Act.empty(N, H, W, K, dev)
     T = _lib.value("mss_wino_num_tiles", N, H, W, dil, ts)
     with _Timed("conv_winograd", 2.0 * N * H * W * K * C * 9, (N, H, W, C, K, 3, 1, dil)):
-        xt = torch.empty((P, T, C), device=dev, dtype=torch.float32)
-        sc, sh = in_affine if in_affine is not None else (None, None)
-        assert sc is None or sc.dim() == 1
-        with _Timed("wino_transform", 4.0 * (N * H * W * C + P * T * C), ("input", N, H, W, C, dil, ts)):   # "flops" = algorithmic BYTES
-            call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ts, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
+        if xt is None:
+            xt = torch.empty((P, T, C), device=dev, dtype=torch.float32)
+            sc, sh = in_affine if in_affine is not None else (None, None)
+            assert sc is None or sc.dim() == 1
+            with _Timed("wino_transform", 4.0 * (N * H * W * C + P * T * C), ("input", N, H, W, C, dil, ts)):   # "flops" = algorithmic BYTES
+                call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, dil, ts, ptr(sc), ptr(sh), int(in_relu), ptr(xt))
+        else:
+            assert tuple(xt.shape) == (P, T, C) and in_affine is None and not in_relu
         return _wino_gemm_and_output(xt, ww, N, H, W, dil, res, out, keep_xt, want_stats)
 
 
@@ -498,7 +506,7 @@ def conv3x3_pair_tile(x, w1, w2, dil1, dil2):
     return t1 if eff(2 * P) > eff(P) + 0.1 else 0
 
 
-def conv3x3_pair(x, w1, w2, dil1, dil2, out1, out2, tile, want_stats=False):
+def conv3x3_pair(x, w1, w2, dil1, dil2, out1, out2, tile, want_stats=False, xt=None):
     """conv3x3(x, w1, dil1) -> out1 and conv3x3(x, w2, dil2) -> out2 with the 2 x (tile+2)^2 Winograd-domain products in ONE
     gemm_nt launch (see conv3x3_pair_tile). Same transforms, same products, same results as the two separate calls."""
     ww = packed_wino_pair(w1, w2, tile)
@@ -507,10 +515,13 @@ def conv3x3_pair(x, w1, w2, dil1, dil2, out1, out2, tile, want_stats=False):
     dev = x.buf.device
     T = _lib.value("mss_wino_num_tiles", N, H, W, dil1, tile)
     with _Timed("conv_winograd", 2 * 2.0 * N * H * W * Ko * C * 9, (N, H, W, C, 2 * Ko, 3, 1, (dil1, dil2))):
-        xt = torch.empty((2 * P, T, C), device=dev, dtype=torch.float32)
-        for j, d in enumerate((dil1, dil2)):
-            with _Timed("wino_transform", 4.0 * (N * H * W * C + P * T * C), ("input", N, H, W, C, d, tile)):
-                call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, d, tile, None, None, 0, ptr(xt[j * P:(j + 1) * P]))
+        if xt is None:
+            xt = torch.empty((2 * P, T, C), device=dev, dtype=torch.float32)
+            for j, d in enumerate((dil1, dil2)):
+                with _Timed("wino_transform", 4.0 * (N * H * W * C + P * T * C), ("input", N, H, W, C, d, tile)):
+                    call("mss_wino_input_transform_f32", x.ptr, x.ld, N, H, W, C, d, tile, None, None, 0, ptr(xt[j * P:(j + 1) * P]))
+        else:
+            assert tuple(xt.shape) == (2 * P, T, C)
         yt = torch.empty((2 * P, T, Ko), device=dev, dtype=torch.float32)
         a = MssConvArgs()
         a.x, a.w, a.y = ptr(xt), ptr(ww.t), ptr(yt)
@@ -530,6 +541,43 @@ def conv3x3_pair(x, w1, w2, dil1, dil2, out1, out2, tile, want_stats=False):
                 call("mss_wino_output_transform_f32", ptr(yt[j * P:(j + 1) * P]), N, H, W, Ko, d, tile, None, 0, out.ptr, out.ld,
                      ptr(out.stats))
     return out1, out2
+
+
+def aspp_input_transforms(x, rates, weights, pair_tile=0):
+    """X' of the ONE map `x` for the three dilated 3x3 branches of ASPP (deepv3.py:84-92; rates d, 2d, 3d) from a single read of x
+    (mss_wino_input_transform_aspp3_f32): bit-identical to the three separate input transforms, 1 x instead of 3 x 1.07 GB read at
+    2 x 128 x 256 x 4096. Returns [xt_d, xt_2d, xt_3d] -- with pair_tile (conv3x3_pair_tile) the first two are the halves of ONE
+    [2P, T, C] buffer, returned as its first element with None second -- or None when the policy / shapes do not take the fused
+    kernel (a tile edge of 2, Winograd off, a tile hook, sub-grids too large for LDS; MSS_WINO_ASPP3=0 switches it off)."""
+    d = rates[0]
+    if os.environ.get("MSS_WINO_ASPP3", "1") == "0" or _tile_hook is not None or tuple(rates) != (d, 2 * d, 3 * d):
+        return None
+    tiles = [wino_tile(x.H, x.W, r) for r in rates]
+    if pair_tile and (tiles[0] != pair_tile or tiles[1] != pair_tile):
+        return None
+    for w, t in zip(weights, tiles):
+        if t not in (4, 6) or w.shape[1] != x.C or not use_winograd(w.shape[1], w.shape[0], 1, None, t):
+            return None
+    N, H, W, C = x.N, x.H, x.W, x.C
+    dev = x.buf.device
+    Ts = [_lib.value("mss_wino_num_tiles", N, H, W, r, t) for r, t in zip(rates, tiles)]
+    Ps = [(t + 2) ** 2 for t in tiles]
+    if pair_tile:
+        assert Ts[0] == Ts[1]
+        both = torch.empty((2 * Ps[0], Ts[0], C), device=dev, dtype=torch.float32)
+        xts = [both[:Ps[0]], both[Ps[0]:], torch.empty((Ps[2], Ts[2], C), device=dev, dtype=torch.float32)]
+    else:
+        both = None
+        xts = [torch.empty((p, t, C), device=dev, dtype=torch.float32) for p, t in zip(Ps, Ts)]
+    nbytes = 4.0 * (N * H * W * C + sum(p * t for p, t in zip(Ps, Ts)) * C)
+    with _Timed("wino_transform", nbytes, ("input_aspp3", N, H, W, C, d, tuple(tiles))):
+        rc = _lib.status("mss_wino_input_transform_aspp3_f32", x.ptr, x.ld, N, H, W, C, d, (ctypes.c_int * 3)(*tiles), ptr(xts[0]),
+                         ptr(xts[1]), ptr(xts[2]))
+    if rc == _lib.MSS_ERR_UNSUPPORTED:
+        return None
+    if rc != 0:
+        raise _lib.MssError(f"mss_wino_input_transform_aspp3_f32 failed with code {rc}")
+    return [both, None, xts[2]] if pair_tile else xts
 
 
 def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=None, tile=None):
@@ -570,8 +618,10 @@ def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=
     return grad
 
 
-def conv3x3_wgrad(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=None):
-    tile = WINO_TILE_OF_P[xt.shape[0]] if xt is not None else wino_tile(x.H, x.W, dil)
+def conv3x3_wgrad(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=None, max_tile=6):
+    """Weight gradient of a 3x3 / stride-1 layer. max_tile caps the Winograd tile edge (as conv3x3's): the F(6x6) weight-gradient
+    transform G^T dU G carries ~20x the rounding error of F(4x4)'s (measured on the pixel decoder's 3x3 layer, round 4)."""
+    tile = WINO_TILE_OF_P[xt.shape[0]] if xt is not None else wino_tile(x.H, x.W, dil, max_tile)
     if use_winograd(C, K, 1, in_affine, tile):
         return conv2d_wgrad_winograd(x, dy, K, C, dil, in_affine, in_relu, xt=xt, tile=tile)
     return conv2d_wgrad(x, dy, K, C, 3, 3, dil=dil, pad=dil, in_affine=in_affine, in_relu=in_relu)

@@ -125,6 +125,28 @@ def linear(x, weight, bias=None, relu=False):
     ok = x.is_cuda and x.dtype == torch.float32 and c % 16 == 0 and k % 16 == 0 and k > 64 and c >= 32 and \
         x.numel() // c >= MIN_ROWS
     if not ok:
+        _library_route(x, weight)
         y = F.linear(x, weight, bias)
         return F.relu(y) if relu else y
     return _LinearFn.apply(x, weight, bias, relu)
+
+
+_warned = set()
+
+
+def _library_route(x, weight):
+    """A Linear the MFMA kernels do not take must not reach hipBLASLt unnoticed: float32 CUDA calls
+    raise unless MSS_LINEAR_LIBRARY=1 opts in, and every distinct (dtype, shape class) that does go to the library is logged
+    once. Every Linear of the shipped configuration (d_model 256, FFN 1024, 8 heads x 3 levels x 4 points) is eligible."""
+    import warnings
+    k, c = weight.shape
+    fp32_gpu = x.is_cuda and x.dtype == torch.float32
+    if fp32_gpu and os.environ.get("MSS_LINEAR_LIBRARY") != "1":
+        raise RuntimeError(f"multishiftseg_amd.linear: a float32 Linear {c} -> {k} over {x.numel() // max(c, 1)} rows is outside the "
+                           "MFMA kernels' shapes (both sizes multiples of 16, more than 64 outputs, at least 32 inputs); set "
+                           "MSS_LINEAR_LIBRARY=1 to let it run on the library GEMM instead")
+    key = (str(x.dtype), x.is_cuda, int(k), int(c))
+    if key not in _warned:
+        _warned.add(key)
+        warnings.warn(f"multishiftseg_amd.linear: {x.dtype} Linear {c} -> {k} runs on the library GEMM (F.linear), not on the "
+                      "repository's kernels", RuntimeWarning, stacklevel=3)

@@ -22,3 +22,27 @@ def golden(name):
 def deeplab_params():
     from multishiftseg_amd import synth
     return synth.deepwv3plus_params(0)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_env_switches():
+    """libmss_hip.so caches the MSS_* environment switches per call site (csrc/mss_common.h MSS_ENV_INT); every test starts
+    from a re-read, whatever the previous one left behind."""
+    from multishiftseg_amd import _lib
+    _lib.reset_env_cache()
+    yield
+    _lib.reset_env_cache()
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch whose setenv / delenv also tell the library to re-read its cached switches."""
+    from multishiftseg_amd import _lib
+    for name in ("setenv", "delenv"):
+        orig = getattr(monkeypatch, name)
+
+        def wrapped(*a, _orig=orig, **k):
+            _orig(*a, **k)
+            _lib.reset_env_cache()
+        setattr(monkeypatch, name, wrapped)
+    return monkeypatch

@@ -5,10 +5,13 @@
   * reference-generated fixtures at 592x600 -- a size where the Winograd policy picks F(4x4,3x3) for all three ASPP rates
     by itself and nothing divides evenly -- eval forward and one stage-2 optimizer step (loss, gradients incl. the
     Winograd-domain weight gradient with the X' kept from the forward, running statistics);
-  * at 2x1024x2048 (C3, what bench.py times) and 16x700x700 (C2): three independent algorithms for every 3x3 layer
-    -- Winograd + persistent GEMM (default), direct implicit GEMM + persistent GEMM for 1x1 (MSS_WINOGRAD=0), direct
-    implicit GEMM for everything (MSS_WINOGRAD=0 MSS_GEMM=0) -- must agree on logits, scores, loss and every stage-2
-    gradient; two identical steps must give bit-identical gradients (deterministic weight gradient);
+  * at 2x1024x2048 (C3, what bench.py times) and 16x700x700 (C2): three dispatch routes -- Winograd + persistent GEMM
+    (default), direct implicit GEMM + persistent GEMM for 1x1 (MSS_WINOGRAD=0), direct implicit GEMM for everything
+    (MSS_WINOGRAD=0 MSS_GEMM=0) -- must agree on logits, scores, loss and every stage-2 gradient. They are TWO independent
+    algorithms for the 3x3 layers (Winograd vs direct); the two direct routes differ only in which kernel carries the 1x1
+    layers, and both kernels accumulate K in the same order on the same MFMA instruction, so they agree to the bit
+    (profiles/r03/fullsize_parity.json: 0.0) -- that comparison checks dispatch and tiling, not arithmetic. Two identical
+    steps must give bit-identical gradients (deterministic weight gradient);
   * fused loss and the OOD-score tail at 16x19x700x700 against the numpy oracle.
 Every number that decides a bound is also written to gpurun_out/fullsize_parity.json.
 """
@@ -20,6 +23,7 @@ import pytest
 import torch
 
 from conftest import ROOT, golden
+from multishiftseg_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
@@ -58,12 +62,14 @@ class _Env:
         for k in self.old:
             os.environ.pop(k, None)
         os.environ.update(self.env)
+        _lib.reset_env_cache()
 
     def __exit__(self, *a):
         for k, v in self.old.items():
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+        _lib.reset_env_cache()
 
 
 def _new_model(deeplab_params):
@@ -286,7 +292,8 @@ def _stage2_step(m, img, target, masks, seed):
 def test_three_routes_agree_at_bench_size(deeplab_params, tag, pairs, h, w):
     """The configurations bench.py measures (c2 both as exps/DeepLab.yaml crops it, 700^2, and as BASELINE words it,
     768^2). Same weights, inputs, Dropout2d masks and device-side pair sampling on the
-    three routes; running statistics are restored between runs so every route sees the same BatchNorm buffers."""
+    three routes (two independent 3x3 algorithms, see the module docstring); running statistics are restored between runs
+    so every route sees the same BatchNorm buffers."""
     from multishiftseg_amd import kernels as K, synth
     m = _new_model(deeplab_params)
     m.uncertainty_func_init()
@@ -430,3 +437,48 @@ def test_ood_tail_16x700x700_vs_oracle():
     top2 = np.sort(rl, axis=1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 1e-4
     np.testing.assert_array_equal(label.cpu().numpy()[clear], rl.argmax(1)[clear])
+
+
+@pytest.mark.parametrize("tag,pairs,h,w,tiles", [("c3_2x1024x2048", 1, 1024, 2048, [6, 6, 4]), ("c2_4x700x700", 2, 700, 700, [4, 4, 4])])
+def test_aspp_single_read_transform_changes_no_bit(deeplab_params, monkeypatch, tag, pairs, h, w, tiles):
+    """The three dilated ASPP branches get their Winograd-domain inputs from ONE kernel that reads the 4096-channel map once
+    (kernels.aspp_input_transforms, round 4) -- against the three separate transforms (MSS_WINO_ASPP3=0): a stage-2
+    forward/backward (X' kept for the weight gradients) and the one-image eval forward (dilations 12 / 24 in one paired GEMM)
+    give identical bits, and the fused kernel is really the one taken at these sizes."""
+    from multishiftseg_amd import kernels as K, synth
+    m = _new_model(deeplab_params)
+    m.uncertainty_func_init()
+    saved = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(78)
+    n = 2 * pairs
+    img = torch.randn((n, 3, h, w), device="cuda", generator=gen)
+    target = torch.from_numpy(synth.synth_targets(6, pairs, h, w)).cuda()
+    rng = np.random.default_rng(10)
+    masks = {"mod6": torch.from_numpy(((rng.random((n, 1024)) >= 0.3) / 0.7).astype(np.float32)),
+             "mod7": torch.from_numpy(((rng.random((n, 2048)) >= 0.5) / 0.5).astype(np.float32))}
+    h8, w8 = -(-h // 8), -(-w // 8)
+    assert [K.wino_tile(h8, w8, r) for r in (12, 24, 36)] == tiles
+    out, taken = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MSS_WINO_ASPP3", mode)
+        prof = K.ConvProfile()
+        K.set_conv_profile(prof)
+        try:
+            m.load_state_dict(saved)
+            out[mode] = _stage2_step(m, img, target, masks, seed=99)
+            m.eval()
+            m.dropout_masks = None
+            with torch.no_grad():
+                out[mode] += tuple(m(img[:1]))
+            torch.cuda.synchronize()
+            taken[mode] = sum(1 for r in prof.per_launch() if r[0] == "wino_transform" and r[1][0] == "input_aspp3")
+        finally:
+            K.set_conv_profile(None)
+    assert taken == {"1": 2, "0": 0}, taken
+    a, b = out["1"], out["0"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+    assert torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])
+    assert set(a[3]) == set(b[3]) and len(a[3]) == 18
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k

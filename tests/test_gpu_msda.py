@@ -121,9 +121,19 @@ def test_full_size_every_query_vs_oracle(F, tag, N, shapes):
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(gv.cpu().numpy(), wv, rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(ga.cpu().numpy(), wa, rtol=1e-3, atol=1e-4)
-    # grad_loc = level size x a difference of corner values: compare relative to its own scale
+    # grad_loc = level size x a difference of corner values: compare relative to its own scale. Bilinear sampling is only
+    # piecewise linear in the location: at a pixel coordinate x = loc * W - 0.5 that is an integer to within fp32 rounding the two
+    # one-sided derivatives differ, and which side an implementation lands on depends on how it rounds that expression (the
+    # kernel -- like the reference's CUDA, ms_deform_im2col_cuda.cuh:258-259 under nvcc's default contraction -- evaluates it
+    # as one fused multiply-add; grid_sample un-normalises differently). Among the 31 M coordinates of N = 16 two samples sit
+    # 1 ulp below an integer (tools/debug_msda_n16.py): such kinks are excluded, everything else must agree.
+    px = loc.astype(np.float64) * shp[None, None, None, :, None, ::-1] - 0.5
+    kink = (np.abs(px - np.round(px)) < 2e-5).any(-1)
+    assert kink.mean() < 1e-4, kink.mean()
     scale = float(np.abs(wl).max())
-    assert float(np.abs(gl.cpu().numpy() - wl).max()) < 2e-5 * scale + 1e-3
+    err = np.abs(gl.cpu().numpy() - wl)
+    err[kink] = 0
+    assert float(err.max()) < 2e-5 * scale + 1e-3
 
 
 def test_full_size_properties(F):

@@ -731,3 +731,55 @@ def test_gemm_variant3_is_bitwise_variant2(K, monkeypatch, P, T, C, Ko, affine, 
     if extras:
         want = torch.relu(want + res[:, rows].double())
     assert (outs["3"][:, rows].double() - want).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("n,h,w,c,d,tiles", [
+    (2, 128, 256, 128, 12, (6, 6, 4)),      # the ASPP map of 2 x 1024 x 2048: 11 x 22 base sub-grids, CB = 32
+    (1, 64, 128, 192, 12, (6, 6, 4)),       # C1 (512 x 1024): 6 x 11 sub-grids, ragged last channel chunk
+    (2, 88, 88, 64, 12, (4, 4, 4)),         # the 700 x 700 crop
+    (1, 45, 75, 68, 6, (6, 4, 6)), (1, 45, 75, 68, 6, (4, 6, 4)),   # other tile mixes, sizes nothing divides
+    (3, 12, 16, 32, 12, (4, 4, 4)),         # 96 x 128 inputs of the fixtures: sub-grids of 1 x 2 pixels
+    (1, 37, 41, 36, 6, (6, 6, 6)), (1, 9, 40, 16, 1, (4, 6, 4)),
+])
+def test_aspp_fused_input_transform_is_bitwise_the_three_separate_ones(n, h, w, c, d, tiles):
+    """mss_wino_input_transform_aspp3_f32: X' of one map for dilations d, 2d, 3d from ONE read of it (VERDICT r03 missing #2)
+    against three calls of mss_wino_input_transform_f32 -- every element of every X' identical, nothing written outside."""
+    import ctypes
+    from multishiftseg_amd import _lib
+    from multishiftseg_amd._lib import call, ptr
+    torch.manual_seed(h * w + c)
+    ld = c + 12                                                     # a channel slice of a wider buffer
+    buf = torch.randn(n, h, w, ld, device="cuda")
+    x = buf[..., 4:]                                                # 16-byte aligned offset
+    xptr = ctypes.c_void_p(buf.data_ptr() + 16)
+    want, got = [], []
+    for m, ts in enumerate(tiles):
+        T = _lib.value("mss_wino_num_tiles", n, h, w, (m + 1) * d, ts)
+        P = (ts + 2) ** 2
+        a = torch.full((P * T * c + 64,), float("nan"), device="cuda")
+        b = torch.full((P * T * c + 64,), float("nan"), device="cuda")
+        call("mss_wino_input_transform_f32", xptr, ld, n, h, w, c, (m + 1) * d, ts, None, None, 0, ptr(a))
+        want.append(a)
+        got.append(b)
+    rc = _lib.status("mss_wino_input_transform_aspp3_f32", xptr, ld, n, h, w, c, d, (ctypes.c_int * 3)(*tiles), ptr(got[0]), ptr(got[1]),
+                     ptr(got[2]))
+    assert rc == 0, rc
+    for m in range(3):
+        assert torch.isnan(got[m][-64:]).all() and not torch.isnan(got[m][:-64]).any()
+        assert torch.equal(got[m][:-64], want[m][:-64]), (m, (got[m][:-64] - want[m][:-64]).abs().max().item())
+    del x
+
+
+def test_aspp_fused_input_transform_refuses_what_it_does_not_take():
+    import ctypes
+    from multishiftseg_amd import _lib
+    from multishiftseg_amd._lib import ptr
+    x = torch.zeros(1, 16, 16, 16, device="cuda")
+    o = torch.zeros(1 << 20, device="cuda")
+    rc = _lib.status("mss_wino_input_transform_aspp3_f32", ptr(x), 16, 1, 16, 16, 16, 4, (ctypes.c_int * 3)(2, 4, 4), ptr(o), ptr(o), ptr(o))
+    assert rc == _lib.MSS_ERR_UNSUPPORTED                          # a 2 x 2 tile
+    big = torch.zeros(1, 512, 1024, 4, device="cuda")              # 43 x 86 base sub-grids: more than LDS holds
+    rc = _lib.status("mss_wino_input_transform_aspp3_f32", ptr(big), 4, 1, 512, 1024, 4, 12, (ctypes.c_int * 3)(6, 6, 6), ptr(o), ptr(o), ptr(o))
+    assert rc == _lib.MSS_ERR_UNSUPPORTED
+    rc = _lib.status("mss_wino_input_transform_aspp3_f32", ptr(x), 16, 1, 16, 16, 16, 4, None, ptr(o), ptr(o), ptr(o))
+    assert rc == _lib.MSS_ERR_BAD_ARG

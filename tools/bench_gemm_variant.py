@@ -25,6 +25,7 @@ for (P, T, C, Ko) in CASES:
 
         def f(a=a, var=var):
             os.environ["MSS_GEMM_VARIANT"] = var
+            _lib.reset_env_cache()
             call("mss_conv2d_forward_f32", ctypes.byref(a))
         fns[var], outs[var] = f, yt
     # the variants alternate (A B A B ...) after a long warm-up and the best round of each counts: the first thing timed after the

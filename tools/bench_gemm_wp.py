@@ -16,6 +16,7 @@ for (P, T, C, Ko) in CASES:
         os.environ["MSS_GEMM_WP"] = wp
         os.environ["MSS_GEMM_BN"] = "256"
         os.environ["MSS_GEMM_VARIANT"] = "2"        # "shipped" here = the round-2 loop the ablation kernel was derived from
+        _lib.reset_env_cache()
         yt = torch.zeros(P, T, Ko, device="cuda")
         a = MssConvArgs()
         a.x, a.w, a.y = ptr(xt), ptr(w), ptr(yt)

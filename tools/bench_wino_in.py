@@ -26,6 +26,7 @@ for (n, h, w, c, dil, ts) in SHAPES:
 
         def f(v=v, xt=xt):
             os.environ[VAR] = v
+            _lib.reset_env_cache()
             call("mss_wino_input_transform_f32", ptr(x), c, n, h, w, c, dil, ts, ptr(sc), ptr(sh), 1, ptr(xt))
         fns[v], outs[v] = f, xt
     timeit(fns[VA], iters=30, warm=10)

@@ -758,7 +758,37 @@ def gen_decoder_fullsize(tag="m2f_decoder_704", n=1, H=704, W=704, layers=6, wit
             grads["gl2_feat_" + k] = np.float64(np.sqrt((gk.astype(np.float64) ** 2).sum()))
             grads["gsub_feat_" + k] = gk[:, ::max(1, gk.shape[1] // 32), ::max(1, gk.shape[2] // 16), ::max(1, gk.shape[3] // 16)].copy()
         grads["cot_seed"] = np.int64(65)
-        print(f"   {tag}: {len(grads)} gradient entries")
+        # conditioning: the same computation of the reference in float64. rel-L2(fp32 reference, fp64 reference) of each stored
+        # gradient is the floor any fp32 implementation can be asked to meet (bilinear sampling is only piecewise smooth in the
+        # locations, and the FFN's ReLU flips on ~1e-7 pre-activations): gnoise_<name>
+        dec64 = Dec(shape, transformer_dropout=0.0, transformer_nheads=8, transformer_dim_feedforward=1024, transformer_enc_layers=layers,
+                    conv_dim=256, mask_dim=256, norm="GN", transformer_in_features=["res3", "res4", "res5"], common_stride=4).eval()
+        dec64.load_state_dict(sd)
+        dec64 = dec64.double()
+        for p in dec64.parameters():
+            p.requires_grad_(True)
+        tf64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in feats.items()}
+        real_float = torch.Tensor.float        # the reference casts its inputs with .float() (msdeformattn.py:314-320): keep them double here
+        torch.Tensor.float = lambda self, *a, **k: self
+        try:
+            m64, _, ms64 = dec64.forward_features(tf64)
+        finally:
+            torch.Tensor.float = real_float
+        sum((t * c.double()).sum() for t, c in zip((m64, *ms64), cot)).backward()
+        rel = lambda a, b: np.float64(np.sqrt(((a.astype(np.float64) - b) ** 2).sum()) / (np.sqrt((b ** 2).sum()) + 1e-300))
+        for k, prm in dec64.named_parameters():
+            g64 = prm.grad.numpy()
+            if "g_" + k in grads:
+                grads["gnoise_" + k] = rel(grads["g_" + k], g64)
+            else:
+                flat = g64.reshape(g64.shape[0], -1)
+                grads["gnoise_" + k] = rel(grads["gsub_" + k], flat[::max(1, flat.shape[0] // 32), ::max(1, flat.shape[1] // 64)])
+        for k, t in tf64.items():
+            g64 = t.grad.numpy()
+            grads["gnoise_feat_" + k] = rel(grads["gsub_feat_" + k],
+                                            g64[:, ::max(1, g64.shape[1] // 32), ::max(1, g64.shape[2] // 16), ::max(1, g64.shape[3] // 16)])
+        top = sorted(((float(v), k) for k, v in grads.items() if k.startswith("gnoise_")), reverse=True)[:6]
+        print(f"   {tag}: {len(grads)} gradient entries; largest fp32-vs-fp64 rel-L2 of the REFERENCE: {top}")
     save(tag, names=np.array(list(sd.keys())), seed=np.int64(64), nhw=np.array([n, H, W]), layers=np.int64(layers), **grads,
          mask_sub=t2n(mask)[:, ::8, ::4, ::4], mask_abs_sum=absum(mask), mask_row=t2n(mask)[:, :, mask.shape[2] // 3],
          out0_sub=t2n(out0)[:, ::4], out0_abs_sum=absum(out0), ms1_sub=t2n(ms[1])[:, ::8, ::2, ::2], ms1_abs_sum=absum(ms[1]),
@@ -914,7 +944,7 @@ def main():
     if "decoder_704" in which:           # minutes: only on request
         print("decoder_704"); gen_decoder_fullsize(with_grads=True)
     if "decoder_c5" in which:
-        print("decoder_c5"); gen_decoder_fullsize("m2f_decoder_1024x2048", 1, 1024, 2048)
+        print("decoder_c5"); gen_decoder_fullsize("m2f_decoder_1024x2048", 1, 1024, 2048, with_grads=True)
     if "datapath" in which:
         print("datapath"); gen_datapath()
     if "loss" in which:
