@@ -24,7 +24,7 @@ extern "C" {
 #define MSS_ABI_VERSION 5      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
                                   mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32,
                                   mss_bn_fold_train_from_partials_f32; 5 (round 4): mss_adam_step_f32 takes double hyper-parameters, mss_env_reset,
-                                  mss_wino_input_transform_aspp3_f32 */
+                                  mss_wino_input_transform_aspp3_f32, mss_msda_prepare_backward_ld_f32, mss_rcl_pairs_device2_f32, mss_rcl_loss_device_f32, mss_m2f_fused_score_ws_f32, mss_oodm_compact_packed_f32 */
 int mss_abi_version(void);
 
 /* The MSS_* environment switches (A/B experiments, test routes; none is needed in production) are read once per call site and
@@ -100,6 +100,13 @@ int mss_msda_prepare_f32(const float* offsets, const float* logits, const float*
 int mss_msda_prepare_backward_f32(const float* attn_weight, const float* grad_attn, const float* grad_loc,
                                   const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P, float* grad_offsets,
                                   float* grad_logits, void* stream);
+/* The same with row strides: grad_offsets row (n, q) at + (n*Lq + q) * ld_offsets (>= M*2*L*P floats), grad_logits likewise with
+ * ld_logits (>= M*L*P). Both gradients in ONE [N*Lq, M*3*L*P] buffer (offsets | logits) make the weight gradient and the data
+ * gradient of `sampling_offsets` and `attention_weights` -- two Linears on the same query (ops/modules/ms_deform_attn.py:98-100)
+ * -- one GEMM each. */
+int mss_msda_prepare_backward_ld_f32(const float* attn_weight, const float* grad_attn, const float* grad_loc,
+                                     const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P, float* grad_offsets,
+                                     long long ld_offsets, float* grad_logits, long long ld_logits, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * B2 -- DeepWV3Plus operator set (replaces the cuDNN/ATen ops under
@@ -351,6 +358,12 @@ int mss_rcl_pairs_f32(const float* score, const int32_t* idx_a, const int64_t* p
 int mss_rcl_pairs_device_f32(const float* score, const int32_t* idx_a, const int32_t* idx_o, const uint32_t* n_out,
                              int set_a, long long max_samples, uint32_t seed_a, uint32_t seed_o, float margin,
                              double* counters, int slot, float grad_w, float* dscore, void* stream);
+/* Both hinge terms of the device-pairing mode in one launch: pair i of set `orig` (slot 0, margin_orig) and of set `aug` (slot 1,
+ * margin_aug) against OOD element feistel(i, n_ood, seed_ood); same sums, same gradients as two mss_rcl_pairs_device_f32 calls
+ * with (set 0, seed_orig) and (set 1, seed_aug). */
+int mss_rcl_pairs_device2_f32(const float* score, const int32_t* idx_orig, const int32_t* idx_aug, const int32_t* idx_ood,
+                              const uint32_t* n_out, long long max_samples, uint32_t seed_orig, uint32_t seed_aug, uint32_t seed_ood,
+                              float margin_orig, float margin_aug, double* counters, float grad_w, float* dscore, void* stream);
 /* data-parallel pairing over the rank-major concatenation of all ranks' sets: this rank owns the
  * slice [a_off, a_off+a_cnt_local) of global set A (a_cnt_global elements); ood_all is the
  * all-gathered [W][cap] OOD score vector with exclusive global offsets ood_off[W+1]; gradients w.r.t.
@@ -361,6 +374,14 @@ int mss_rcl_pairs_global_f32(const float* score, const int32_t* idx_a, uint32_t 
                              double* counters, int slot, float coef, float* dscore, float* g_ood, void* stream);
 int mss_rcl_gather_f32(const float* src, const int32_t* idx, uint32_t n, float* dst, void* stream);
 int mss_rcl_scatter_add_f32(const float* g, const int32_t* idx, uint32_t n, float* dst, void* stream);
+/* The whole loss of the device-pairing mode in ONE call (pass 1, radix select, pass 2, compaction, the in-distribution hinge, both
+ * paired hinges, finalize -- the launches of the entry points above, issued back to back): workspace of
+ * mss_rcl_workspace_bytes(B, H, W) bytes (256-byte aligned, contents irrelevant), max_samples = int(B*H*W * sample_ratio),
+ * seed = the caller's step counter (pair i of step s couples Feistel(i; s) elements), dlogit / dscore nullable, out float[8] as
+ * mss_rcl_finalize_f32. No host synchronisation. */
+long long mss_rcl_workspace_bytes(int B, int H, int W);
+int mss_rcl_loss_device_f32(const MssRclArgs* a, void* workspace, long long workspace_bytes, long long max_samples, uint32_t seed,
+                            float* dlogit, float* dscore, float* out, void* stream);
 /* out: float[8] = {loss, ce_orig, ce_aug, c_orig, c_aug, c_in, -, -} (loss.py:73-88,147). */
 int mss_rcl_finalize_f32(const MssRclArgs* a, const double* counters, const uint32_t* sel, float* out,
                          void* stream);
@@ -379,6 +400,11 @@ int mss_adam_step_f32(float* param, const float* grad, float* exp_avg, float* ex
  * sigmoid, the class mix and 1 - max (train_m2f.py:387-407) and writes the crop [B,H,W]. Q % 4 == 0, C <= 20. */
 int mss_m2f_fused_score_f32(const float* cls, const float* logit, int B, int Q, int C, int hm, int wm, int ldq, int Hi,
                             int Wi, int H, int W, float* score, void* stream);
+/* The same with a scratch of B * Q * 32 floats: the class mix then runs on the matrix cores (v_mfma_f32_32x32x2_f32: [classes x Q] x
+ * [Q x pixels] per 32-pixel strip, one interpolation + sigmoid per lane and MFMA) instead of 20 multiply-adds per (pixel, query)
+ * on the vector ALUs; results agree with the form above to fp32 summation order. prob_ws NULL = the form above. */
+int mss_m2f_fused_score_ws_f32(const float* cls, const float* logit, int B, int Q, int C, int hm, int wm, int ldq, int Hi,
+                               int Wi, int H, int W, float* score, float* prob_ws, void* stream);
 
 /* Pixel-level OOD metrics on the device (csrc/metric.hip): exact AUROC / average precision / FPR at `recall_level`
  * over all pixels with label id_out (positives) and id_in (negatives). Replaces eval_ood_measure, get_measures and
@@ -394,6 +420,10 @@ int mss_m2f_fused_score_f32(const float* cls, const float* logit, int B, int Q, 
  *             metric.py:176-180 does). */
 int mss_oodm_compact_f32(const float* score, const long long* label, long long n, long long id_in, long long id_out,
                          unsigned int* keys, unsigned long long* counts, void* stream);
+/* The same with both totals in ONE counter: *packed_count (zero on entry) ends as #id_in | (#id_out << 32); n < 2^32. Half the
+ * same-address atomics of the form above (they were most of the kernel's time on a 1024 x 2048 map). */
+int mss_oodm_compact_packed_f32(const float* score, const long long* label, long long n, long long id_in, long long id_out,
+                                unsigned int* keys, unsigned long long* packed_count, void* stream);
 long long mss_oodm_sort_temp_bytes(long long n);
 int mss_oodm_sort_u32(const unsigned int* keys_in, unsigned int* keys_out, long long n, void* temp, long long temp_bytes,
                       void* stream);

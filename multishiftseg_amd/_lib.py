@@ -71,6 +71,7 @@ SIGNATURES = {
     "mss_msda_forward_window_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
     "mss_msda_prepare_f32": [P, P, P, P, I, I, I, I, I, P, P, P],
     "mss_msda_prepare_backward_f32": [P, P, P, P, I, I, I, I, I, P, P, P],
+    "mss_msda_prepare_backward_ld_f32": [P, P, P, P, I, I, I, I, I, P, L, P, L, P],
     "mss_conv2d_forward_f32": [POINTER(MssConvArgs), P],
     "mss_conv2d_kpad": [I],
     "mss_conv2d_forward_route": [POINTER(MssConvArgs)],
@@ -107,6 +108,9 @@ SIGNATURES = {
     "mss_rcl_cin_bwd_f32": [POINTER(MssRclArgs), P, P, F, P, P],
     "mss_rcl_pairs_f32": [P, P, P, P, P, L, F, P, I, F, P, P],
     "mss_rcl_pairs_device_f32": [P, P, P, P, I, L, U, U, F, P, I, F, P, P],
+    "mss_rcl_pairs_device2_f32": [P, P, P, P, P, L, U, U, U, F, F, P, F, P, P],
+    "mss_rcl_workspace_bytes": [I, I, I],
+    "mss_rcl_loss_device_f32": [POINTER(MssRclArgs), P, L, L, U, P, P, P, P],
     "mss_rcl_finalize_f32": [POINTER(MssRclArgs), P, P, P, P],
     "mss_rcl_select_init_f32": [P, F, P, P, P],
     "mss_rcl_select_hist_f32": [P, L, P, I, P, P],
@@ -127,7 +131,9 @@ SIGNATURES = {
     "mss_wino_grad_output_transform_f32": [P, I, I, I, I, I, I, I, P, P],
     "mss_wino_weight_grad_transform_f32": [P, P, I, I, I, I, I, P],
     "mss_m2f_fused_score_f32": [P, P, I, I, I, I, I, I, I, I, I, I, P, P],
+    "mss_m2f_fused_score_ws_f32": [P, P, I, I, I, I, I, I, I, I, I, I, P, P, P],
     "mss_oodm_compact_f32": [P, P, L, L, L, P, P, P],
+    "mss_oodm_compact_packed_f32": [P, P, L, L, L, P, P, P],
     "mss_oodm_sort_temp_bytes": [L],
     "mss_oodm_sort_u32": [P, P, L, P, L, P],
     "mss_oodm_rank_blocks": [L],
@@ -151,12 +157,12 @@ SIGNATURES = {
     "mss_peak_scatter_f32": [P, P, L, I, I, L, P],
 }
 # entry points that return a plain value rather than a status code
-_VALUE_RETURNING = {"mss_abi_version", "mss_env_reset", "mss_env_generation", "mss_msda_backward_workspace_bytes", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
+_VALUE_RETURNING = {"mss_abi_version", "mss_env_reset", "mss_env_generation", "mss_rcl_workspace_bytes", "mss_msda_backward_workspace_bytes", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
                     "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts",
                     "mss_conv2d_wgrad_workspace_bytes", "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
                     "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats",
                     "mss_groupnorm_stat_offset", "mss_groupnorm_bwd_workspace_floats"}
-_RETURNS_LONGLONG = {"mss_msda_backward_workspace_bytes", "mss_wino_num_tiles", "mss_oodm_sort_temp_bytes", "mss_conv2d_wgrad_workspace_bytes",
+_RETURNS_LONGLONG = {"mss_rcl_workspace_bytes", "mss_msda_backward_workspace_bytes", "mss_wino_num_tiles", "mss_oodm_sort_temp_bytes", "mss_conv2d_wgrad_workspace_bytes",
                      "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
                      "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats",
                      "mss_groupnorm_stat_offset", "mss_groupnorm_bwd_workspace_floats"}
@@ -200,14 +206,27 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """The current torch stream of the current device as a raw hipStream_t. Through torch._C this costs ~0.3 us; building a
+    torch.cuda.Stream object per launch (`torch.cuda.current_stream().cuda_stream`) cost ~3 us of the ~10 us a launch takes
+    from Python -- and the one-image eval forward and the metric updates are bound by exactly that."""
+    if _raw_stream is not None:
+        return c_void_p(_raw_stream(torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_fns = {}
 
 
 def call(name, *args):
     """Call a status-returning entry point on the current torch stream; raise on non-zero."""
-    lib = load()
-    rc = getattr(lib, name)(*args, stream_ptr())
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    rc = fn(*args, stream_ptr())
     if rc != 0:
         kind = {MSS_ERR_BAD_ARG: "bad argument", MSS_ERR_UNSUPPORTED: "unsupported shape"}.get(rc, "hipError_t")
         raise MssError(f"{name} failed with code {rc} ({kind})")

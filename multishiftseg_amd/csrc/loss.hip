@@ -626,6 +626,50 @@ __global__ __launch_bounds__(256) void rcl_pairs_kernel(const float* __restrict_
   if (blockIdx.x == 0 && threadIdx.x == 0) counters[CNT_N_PAIRS] = (double)n;
 }
 
+// r04: both hinge terms of the device-pairing mode in ONE launch and WITHOUT atomics. The two launches of rcl_pairs_kernel<true>
+// were 2 x 34 us of the 0.42 ms loss at 2 x 19 x 1024 x 2048, bound by ~4e5 scattered float atomics into dscore. Pair i of BOTH
+// terms meets the same OOD element (the OOD permutation has one seed), the three permutations are bijections, and the three sets
+// are disjoint -- so thread i is the ONLY writer of dscore[orig_i], dscore[aug_i] and dscore[ood_i]: plain read-modify-writes, in
+// the order the two launches applied them (orig term, then aug term), hence the same bits, and no order dependence at all.
+__global__ __launch_bounds__(256) void rcl_pairs2_kernel(const float* __restrict__ score, const int32_t* __restrict__ idx_orig,
+                                                         const int32_t* __restrict__ idx_aug, const int32_t* __restrict__ idx_ood,
+                                                         const uint32_t* __restrict__ n_out, long long max_samples, uint32_t seed0,
+                                                         uint32_t seed1, uint32_t seed_o, float margin0, float margin1,
+                                                         double* __restrict__ counters, float grad_w, float* __restrict__ dscore) {
+  long long n = max_samples;
+  if (n > (long long)n_out[0]) n = n_out[0];
+  if (n > (long long)n_out[1]) n = n_out[1];
+  if (n > (long long)n_out[2]) n = n_out[2];
+  if ((long long)blockIdx.x * blockDim.x >= n && blockIdx.x != 0) return;          // workgroup-uniform
+  const uint32_t n0 = n_out[0], n1 = n_out[1], no = n_out[2];
+  const float coef = n > 0 ? grad_w / (float)n : 0.f;
+  float acc[2] = {0.f, 0.f};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const uint32_t j0 = feistel_perm((uint32_t)i, n0, seed0), j1 = feistel_perm((uint32_t)i, n1, seed1);
+    const uint32_t jo = feistel_perm((uint32_t)i, no, seed_o);
+    const int32_t p0 = idx_orig[j0], p1 = idx_aug[j1], po = idx_ood[jo];
+    const float so = score[po];
+    const float v0 = score[p0] + margin0 - so, v1 = score[p1] + margin1 - so;
+    if (v0 > 0.f) acc[0] += v0;
+    if (v1 > 0.f) acc[1] += v1;
+    if (dscore) {
+      if (v0 > 0.f) dscore[p0] += coef;
+      if (v1 > 0.f) dscore[p1] += coef;
+      if (v0 > 0.f || v1 > 0.f) {
+        float t = dscore[po];
+        if (v0 > 0.f) t += -coef;
+        if (v1 > 0.f) t += -coef;
+        dscore[po] = t;
+      }
+    }
+  }
+  __shared__ int slots[2];
+  if (threadIdx.x == 0) { slots[0] = CNT_SUM_CORIG; slots[1] = CNT_SUM_CAUG; }
+  __syncthreads();
+  block_add<2>(acc, counters, slots);
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[CNT_N_PAIRS] = (double)n;
+}
+
 // ---- data-parallel ("global") pairing ------------------------------------------------------------
 // The three score sets are the rank-major concatenation of every rank's compaction. Pair i couples
 // element perm_a(i) of the global set A with element perm_o(i) of the global OOD set (keyed Feistel
@@ -878,6 +922,86 @@ int mss_rcl_pairs_device_f32(const float* score, const int32_t* idx_a, const int
                      nullptr, 0ll, n_out, set_a, max_samples, seed_a, seed_o, margin, counters,
                      slot == 0 ? CNT_SUM_CORIG : CNT_SUM_CAUG, grad_w, dscore);
   return mss_launch_status();
+}
+
+int mss_rcl_pairs_device2_f32(const float* score, const int32_t* idx_orig, const int32_t* idx_aug, const int32_t* idx_ood,
+                              const uint32_t* n_out, long long max_samples, uint32_t seed_orig, uint32_t seed_aug, uint32_t seed_ood,
+                              float margin_orig, float margin_aug, double* counters, float grad_w, float* dscore, void* stream) {
+  if (!score || !idx_orig || !idx_aug || !idx_ood || !n_out || !counters || max_samples < 0) return MSS_ERR_BAD_ARG;
+  // one thread per pair up to the host-side bound of the pair count (every set is a subset of the batch's pixels); the
+  // workgroups beyond the device-side count return immediately
+  long long blocks = (max_samples + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 512) blocks = 512;       // each live workgroup ends with one same-address atomic on its sum
+  hipLaunchKernelGGL(rcl_pairs2_kernel, dim3((unsigned)blocks), dim3(256), 0, S_(stream), score, idx_orig, idx_aug, idx_ood, n_out,
+                     max_samples, seed_orig, seed_aug, seed_ood, margin_orig, margin_aug, counters, grad_w, dscore);
+  return mss_launch_status();
+}
+
+// ---- the whole loss in ONE call (device pairing, one process) ------------------------------------------------------------------
+// The sequence above is ~17 dependent launches of 4-120 us; issued one by one through the Python binding (~10 us of host time
+// each) the standalone loss was bound by the HOST (0.42 ms at 2 x 19 x 1024 x 2048 against ~0.33 ms of kernel time). One entry
+// point carves every intermediate out of one workspace and issues the launches back to back.
+struct RclWs { size_t lse, ce_aug, kind, counters, sel, hist, idx, block_counts, n_out, total; };
+static RclWs rcl_ws_layout(int B, int H, int W) {
+  const size_t total = (size_t)B * H * W, half = (size_t)(B / 2) * H * W;
+  const size_t nb = (size_t)mss_rcl_num_compact_blocks(B, H, W);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  RclWs w;
+  w.lse = 0;
+  w.ce_aug = up(w.lse + total * 4);
+  w.kind = up(w.ce_aug + half * 4);
+  w.counters = up(w.kind + total);
+  w.sel = up(w.counters + 16 * 8);
+  w.hist = up(w.sel + 8 * 4);
+  w.idx = up(w.hist + 256 * 4);
+  w.block_counts = up(w.idx + 3 * total * 4);
+  w.n_out = up(w.block_counts + 3 * nb * 4);
+  w.total = up(w.n_out + 4 * 4);
+  return w;
+}
+
+long long mss_rcl_workspace_bytes(int B, int H, int W) {
+  if (B < 2 || B % 2 || H <= 0 || W <= 0) return -1;
+  return (long long)rcl_ws_layout(B, H, W).total;
+}
+
+int mss_rcl_loss_device_f32(const MssRclArgs* a, void* workspace, long long workspace_bytes, long long max_samples, uint32_t seed,
+                            float* dlogit, float* dscore, float* out, void* stream) {
+  int rc = rcl_check(a);
+  if (rc) return rc;
+  if (!workspace || !out || (reinterpret_cast<uintptr_t>(workspace) & 255)) return MSS_ERR_BAD_ARG;
+  const RclWs w = rcl_ws_layout(a->B, a->H, a->W);
+  if (workspace_bytes < (long long)w.total) return MSS_ERR_BAD_ARG;
+  char* base = static_cast<char*>(workspace);
+  float* lse = reinterpret_cast<float*>(base + w.lse);
+  float* ce_aug = reinterpret_cast<float*>(base + w.ce_aug);
+  uint8_t* kind = reinterpret_cast<uint8_t*>(base + w.kind);
+  double* counters = reinterpret_cast<double*>(base + w.counters);
+  uint32_t* sel = reinterpret_cast<uint32_t*>(base + w.sel);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(base + w.hist);
+  const size_t total = (size_t)a->B * a->H * a->W;
+  int32_t* idx0 = reinterpret_cast<int32_t*>(base + w.idx);
+  int32_t* idx1 = idx0 + total;
+  int32_t* idx2 = idx1 + total;
+  uint32_t* block_counts = reinterpret_cast<uint32_t*>(base + w.block_counts);
+  uint32_t* n_out = reinterpret_cast<uint32_t*>(base + w.n_out);
+  if ((rc = mss_rcl_pass1_f32(a, lse, ce_aug, kind, counters, dlogit, stream))) return rc;
+  const bool select = a->select != 0;
+  if (select) {
+    if ((rc = mss_rcl_select_f32(ce_aug, (long long)(a->B / 2) * a->H * a->W, counters, a->selection_ratio, hist, sel, stream))) return rc;
+    if ((rc = mss_rcl_pass2_f32(a, lse, ce_aug, kind, sel, counters, 1.0f, dlogit, stream))) return rc;
+  } else {
+    hipError_t e = hipMemsetAsync(sel, 0, 8 * sizeof(uint32_t), S_(stream));
+    if (e != hipSuccess) return (int)e;
+  }
+  if ((rc = mss_rcl_compact_f32(kind, a->B, a->H, a->W, idx0, idx1, idx2, block_counts, n_out, stream))) return rc;
+  if (dscore && (rc = mss_rcl_cin_bwd_f32(a, kind, counters, a->w_contras, dscore, stream))) return rc;
+  const uint32_t s0 = seed * 0x9E3779B1u;
+  if ((rc = mss_rcl_pairs_device2_f32(a->score, idx0, idx1, idx2, n_out, max_samples, s0 + 1, s0 + 2, s0 + 7, a->m0, a->m1, counters,
+                                      a->w_contras, dscore, stream)))
+    return rc;
+  return mss_rcl_finalize_f32(a, counters, sel, out, stream);
 }
 
 int mss_rcl_cin_bwd_f32(const MssRclArgs* a, const uint8_t* kind, const double* counters, float grad_w,

@@ -1217,10 +1217,12 @@ __global__ __launch_bounds__(256) void msda_prepare_kernel(const float* __restri
   for (int i = threadIdx.x; i < np * LP * 2; i += 256) loc[pair0 * LP * 2 + i] = so[i];
 }
 
+// ldo / ldl: row strides (floats) of goffsets / glogits per (n, q) -- M*2LP / M*LP when dense; larger when both live in ONE
+// [N*Lq, M*3LP] buffer (offsets | logits), so that the two projections' weight and data gradients are one GEMM each (r04)
 __global__ __launch_bounds__(256) void msda_prepare_bwd_kernel(const float* __restrict__ attn, const float* __restrict__ gattn,
                                                                const float* __restrict__ gloc, const int64_t* __restrict__ shapes,
-                                                               long long npairs, int L, int P, float* __restrict__ goffsets,
-                                                               float* __restrict__ glogits) {
+                                                               long long npairs, int M, int L, int P, float* __restrict__ goffsets,
+                                                               long long ldo, float* __restrict__ glogits, long long ldl) {
   extern __shared__ float sm[];
   const int LP = L * P;
   float* sa = sm;                 // [256][LP]   attn
@@ -1231,7 +1233,8 @@ __global__ __launch_bounds__(256) void msda_prepare_bwd_kernel(const float* __re
   // d_offsets is elementwise: coalesced straight through
   for (int i = threadIdx.x; i < np * LP * 2; i += 256) {
     const int l = (i / 2 % LP) / P;
-    goffsets[pair0 * LP * 2 + i] = gloc[pair0 * LP * 2 + i] / (float)shapes[2 * l + ((i & 1) ? 0 : 1)];
+    const long long pair = pair0 + i / (2 * LP);
+    goffsets[pair / M * ldo + (pair % M) * (2 * LP) + i % (2 * LP)] = gloc[pair0 * LP * 2 + i] / (float)shapes[2 * l + ((i & 1) ? 0 : 1)];
   }
   __syncthreads();
   if ((int)threadIdx.x < np) {
@@ -1242,7 +1245,10 @@ __global__ __launch_bounds__(256) void msda_prepare_bwd_kernel(const float* __re
     for (int i = 0; i < LP; ++i) ga[i] = a[i] * (ga[i] - dot);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < np * LP; i += 256) glogits[pair0 * LP + i] = sg[i];
+  for (int i = threadIdx.x; i < np * LP; i += 256) {
+    const long long pair = pair0 + i / LP;
+    glogits[pair / M * ldl + (pair % M) * LP + i % LP] = sg[i];
+  }
 }
 
 template <typename T>
@@ -1595,17 +1601,25 @@ int mss_msda_prepare_f32(const float* offsets, const float* logits, const float*
   return mss_launch_status();
 }
 
-int mss_msda_prepare_backward_f32(const float* attn_weight, const float* grad_attn, const float* grad_loc,
-                                  const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P, float* grad_offsets,
-                                  float* grad_logits, void* stream) {
+int mss_msda_prepare_backward_ld_f32(const float* attn_weight, const float* grad_attn, const float* grad_loc,
+                                     const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P, float* grad_offsets,
+                                     long long ld_offsets, float* grad_logits, long long ld_logits, void* stream) {
   if (N < 0 || Lq < 0 || M <= 0 || L <= 0 || P <= 0 || L * P > MSDA_MAX_LP) return MSS_ERR_UNSUPPORTED;
   const long long npairs = (long long)N * Lq * M;
   if (npairs == 0) return MSS_OK;
   if (!attn_weight || !grad_attn || !grad_loc || !spatial_shapes || !grad_offsets || !grad_logits) return MSS_ERR_BAD_ARG;
+  if (ld_offsets < (long long)M * 2 * L * P || ld_logits < (long long)M * L * P) return MSS_ERR_BAD_ARG;
   hipLaunchKernelGGL(msda_prepare_bwd_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256),
-                     (size_t)256 * 2 * L * P * sizeof(float), static_cast<hipStream_t>(stream), attn_weight, grad_attn, grad_loc, spatial_shapes, npairs, L, P,
-                     grad_offsets, grad_logits);
+                     (size_t)256 * 2 * L * P * sizeof(float), static_cast<hipStream_t>(stream), attn_weight, grad_attn, grad_loc, spatial_shapes, npairs, M, L, P,
+                     grad_offsets, ld_offsets, grad_logits, ld_logits);
   return mss_launch_status();
+}
+
+int mss_msda_prepare_backward_f32(const float* attn_weight, const float* grad_attn, const float* grad_loc,
+                                  const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P, float* grad_offsets,
+                                  float* grad_logits, void* stream) {
+  return mss_msda_prepare_backward_ld_f32(attn_weight, grad_attn, grad_loc, spatial_shapes, N, Lq, M, L, P, grad_offsets,
+                                          (long long)M * 2 * L * P, grad_logits, (long long)M * L * P, stream);
 }
 
 int mss_msda_backward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,

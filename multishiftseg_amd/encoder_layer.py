@@ -12,6 +12,8 @@ projection, residual; q: two projections; s1: FFN, residual) with one elementwis
 166 MB passes per layer at 16 x 10 164 tokens. Here those sums ride in the residual input of the data-gradient GEMMs'
 epilogues (`MssConvArgs.res`), and one explicit add per layer is left (a GEMM epilogue takes one residual).
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -33,6 +35,18 @@ def _gemm(x, weight, bias=None, relu=False, res=None, res_mask=False, flip=False
     K.conv2d(_rows(x, cin), _packed(weight, flip), out_affine=aff, out_relu=relu, out=_rows(out, cout),
              res=_rows(res, cout) if res is not None else None, res_mask=res_mask)
     return out
+
+
+def _packed_pair_flip(w1, w2):
+    """The data-gradient pack of the row-concatenation [w1; w2] (two Linears on the same input): cached on w1 until either
+    parameter changes (optimizer step: tensor._version; moved: data_ptr)."""
+    key = (w1._version, w1.data_ptr(), w2._version, w2.data_ptr())
+    cache = w1.__dict__.setdefault("_mss_packed", {})
+    ent = cache.get("pair_flip")
+    if ent is None or ent[0] != key:
+        w = torch.cat((w1.detach(), w2.detach()), 0)
+        ent = cache["pair_flip"] = (key, K.pack_weight(w.view(w.shape[0], w.shape[1], 1, 1), flip=True))
+    return ent[1]
 
 
 def _wgrad(x, gy, weight):
@@ -108,6 +122,7 @@ class _EncoderLayerFn(Function):
         f = _gemm(h, p["l2_w"], p["l2_b"])
         out, stat2 = _layernorm(s1, f, p["n2_w"], p["n2_b"], eps2)
         ctx.geom = geom
+        ctx.pos_batch = pos.shape[0]
         ctx.shapes_host = getattr(shapes, "_mss_host", None)
         ctx.save_for_backward(src, q, ref, shapes, starts, value, offs, logits, samp, attn, stat1, s1, h, f, stat2, *params)
         return out
@@ -151,31 +166,38 @@ class _EncoderLayerFn(Function):
         call("mss_msda_prepare_f32", ptr(offs6), ptr(logits), ptr(ref), ptr(shapes), N, S, M, L, P, ptr(loc), ptr(aw))
         gvalue, gloc, gaw = MSDA.ms_deform_attn_backward(value.view(N, S, M, D), shapes, starts, loc, aw, dsamp, 128)
         del dsamp, loc
-        goff = torch.empty_like(offs6)
-        glog = torch.empty((N, S, M, L * P), device=src.device, dtype=torch.float32)
-        call("mss_msda_prepare_backward_f32", ptr(aw), ptr(gaw), ptr(gloc), ptr(shapes), N, S, M, L, P, ptr(goff), ptr(glog))
+        # `sampling_offsets` and `attention_weights` are two Linears on the SAME q: their output gradients go side by side into one
+        # [N, S, 192 + 96] buffer, so the weight gradient, the bias gradient and the data gradient are one product each (r04:
+        # the narrow 192- / 96-wide products ran at 71 / 59 TFLOP/s for the weight and 119 / 73 for the data gradient)
+        ko, ka = M * L * P * 2, M * L * P
+        gol = torch.empty((N, S, ko + ka), device=src.device, dtype=torch.float32)
+        call("mss_msda_prepare_backward_ld_f32", ptr(aw), ptr(gaw), ptr(gloc), ptr(shapes), N, S, M, L, P, ptr(gol), ko + ka,
+             ctypes.c_void_p(gol.data_ptr() + 4 * ko), ko + ka)
         del gloc, gaw, aw
-        goff, glog, gvalue = goff.view(N, S, -1), glog.view(N, S, -1), gvalue.view(N, S, C)
-        # ---- the three input projections: d(q) = goff Woff + glog Watt (chained through the residual input), d(src) = g1 + gvalue Wv + d(q)
-        if need["off_w"]:
-            g["off_w"] = _wgrad(q, goff, p["off_w"])
-        if need["off_b"]:
-            g["off_b"] = _bgrad(goff, goff.shape[-1])
-        if need["att_w"]:
-            g["att_w"] = _wgrad(q, glog, p["att_w"])
-        if need["att_b"]:
-            g["att_b"] = _bgrad(glog, glog.shape[-1])
+        gvalue = gvalue.view(N, S, C)
+        # ---- the three input projections: d(q) = [goff | glog] [Woff ; Watt], d(src) = g1 + gvalue Wv + d(q)
+        if need["off_w"] or need["att_w"]:
+            gw = K.conv2d_wgrad(_rows(q, C), _rows(gol, ko + ka), ko + ka, C, 1, 1).view(ko + ka, C)
+            g["off_w"], g["att_w"] = gw[:ko], gw[ko:]
+        if need["off_b"] or need["att_b"]:
+            gb = _bgrad(gol, ko + ka)
+            g["off_b"], g["att_b"] = gb[:ko], gb[ko:]
         if need["val_w"]:
             g["val_w"] = _wgrad(src, gvalue, p["val_w"])
         if need["val_b"]:
             g["val_b"] = _bgrad(gvalue, C)
         dq = dsrc = None
         if need["src"] or need["pos"]:
-            dq = _gemm(glog, p["att_w"], res=_gemm(goff, p["off_w"], flip=True), flip=True)
+            dq = torch.empty((N, S, C), device=src.device, dtype=torch.float32)
+            K.conv2d(_rows(gol, ko + ka), _packed_pair_flip(p["off_w"], p["att_w"]), out=_rows(dq, C))
         if need["src"]:
             dsrc = _gemm(gvalue, p["val_w"], res=g1, flip=True)
             dsrc += dq
-        return (dsrc, dq if need["pos"] else None, None, None, None, None) + tuple(g.get(n) if need[n] else None for n in _PARAMS)
+        dpos = None
+        if need["pos"]:
+            # a position input shared by the whole batch ([1, S, C], msdeformattn_encoder.forward_tokens): its gradient is the batch sum
+            dpos = dq.sum(0, keepdim=True) if ctx.pos_batch == 1 and N > 1 else dq
+        return (dsrc, dpos, None, None, None, None) + tuple(g.get(n) if need[n] else None for n in _PARAMS)
 
 
 def eligible(layer, src, pos, reference_points, spatial_shapes, padding_mask):
@@ -184,7 +206,8 @@ def eligible(layer, src, pos, reference_points, spatial_shapes, padding_mask):
     import torch.nn.functional as F
     a = layer.self_attn
     C = src.shape[-1]
-    return (src.is_cuda and src.dtype == torch.float32 and pos is not None and pos.shape == src.shape and padding_mask is None
+    return (src.is_cuda and src.dtype == torch.float32 and pos is not None and pos.dim() == 3 and pos.shape[1:] == src.shape[1:]
+            and pos.shape[0] in (1, src.shape[0]) and pos.dtype == torch.float32 and padding_mask is None
             and reference_points.shape[-1] == 2 and not reference_points.requires_grad and spatial_shapes.dtype == torch.int64
             and C == a.d_model and C % 256 == 0 and C <= 1024 and C // a.n_heads == 32 and a.n_levels * a.n_points <= 20
             and a.n_heads * a.n_levels * a.n_points > 64 and (a.n_heads * a.n_levels * a.n_points) % 16 == 0

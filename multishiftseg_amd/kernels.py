@@ -403,8 +403,6 @@ def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=N
     N, H, W, C, K, ts = x.N, x.H, x.W, ww.C, ww.K, ww.tile
     P = (ts + 2) ** 2
     dev = x.buf.device
-    if out is None:
-        out = Act.empty(N, H, W, K, dev)
     T = _lib.value("mss_wino_num_tiles", N, H, W, dil, ts)
     with _Timed("conv_winograd", 2.0 * N * H * W * K * C * 9, (N, H, W, C, K, 3, 1, dil)):
         if xt is None:
@@ -425,7 +423,9 @@ def _wino_gemm_and_output(xt, ww, N, H, W, dil, res, out, keep_xt, want_stats):
     P, T = xt.shape[0], xt.shape[1]
     dev = xt.device
     if out is None:
-        out = Act.empty(N, H, W, K, dev)
+        # pixel rows on 128-byte lines: a 304-channel map (the decoder's first data gradient) with ld = 304 shares every other
+        # cache line between two pixels that different waves write (0.99 -> 0.94 ms at 2 x 512 x 1024, tools/bench_wino_r04.py)
+        out = Act.empty(N, H, W, K, dev, ld=_round_up(K, 32) if K % 32 else None)
     yt = torch.empty((P, T, K), device=dev, dtype=torch.float32)
     a = MssConvArgs()
     a.x, a.w, a.y = ptr(xt), ptr(ww.t), ptr(yt)
@@ -957,7 +957,8 @@ def m2f_score_fused(class_logits, mask_logits_nhwc, image_size, size=None):
     cls = class_logits.contiguous().float()
     lg = mask_logits_nhwc.contiguous()
     out = torch.empty((B, H, W), device=cls.device, dtype=torch.float32)
-    call("mss_m2f_fused_score_f32", ptr(cls), ptr(lg), B, Q, C1 - 1, hm, wm, ldq, Hi, Wi, H, W, ptr(out))
+    prob = torch.empty((B, Q, 32), device=cls.device, dtype=torch.float32)      # class-probability table of the MFMA kernel
+    call("mss_m2f_fused_score_ws_f32", ptr(cls), ptr(lg), B, Q, C1 - 1, hm, wm, ldq, Hi, Wi, H, W, ptr(out), ptr(prob))
     return out
 
 

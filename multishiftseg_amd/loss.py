@@ -221,13 +221,26 @@ class RelContrastiveLoss(nn.Module):
         a.select, a.selection_ratio = int(select), float(self.selection_ratio)
         ra = ctypes.byref(a)
 
+        dlogit = torch.empty_like(logits) if need_dl else None
+        if perms is None and self.pairing == "device":
+            # no host round trip anywhere in this mode: ONE call issues the whole launch sequence (pass 1, radix select, pass 2,
+            # compaction, the three hinge terms, finalize) out of one workspace -- issued one by one through this binding the
+            # ~17 launches were bound by the host (csrc/loss.hip, mss_rcl_loss_device_f32)
+            nbytes = _lib.value("mss_rcl_workspace_bytes", B, H, W)
+            ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            dscore = torch.empty_like(score) if need_ds else None
+            out = torch.empty(8, device=dev, dtype=torch.float32)
+            self._step += 1
+            call("mss_rcl_loss_device_f32", ra, ptr(ws), nbytes, int(total * self.sample_ratio), self._step & 0xFFFFFFFF, ptr(dlogit),
+                 ptr(dscore), ptr(out))
+            self.last_terms = out
+            return out, dlogit, dscore
         lse = torch.empty(total, device=dev, dtype=torch.float32)
         ce_aug = torch.empty(half, device=dev, dtype=torch.float32)
         kind = torch.empty(total, device=dev, dtype=torch.uint8)
         counters = torch.empty(16, device=dev, dtype=torch.float64)
         sel = torch.zeros(8, device=dev, dtype=torch.int32)
         hist = torch.empty(256, device=dev, dtype=torch.int32)
-        dlogit = torch.empty_like(logits) if need_dl else None
         call("mss_rcl_pass1_f32", ra, ptr(lse), ptr(ce_aug), ptr(kind), ptr(counters), ptr(dlogit))
         if select:
             call("mss_rcl_select_f32", ptr(ce_aug), half, ptr(counters), float(self.selection_ratio), ptr(hist), ptr(sel))
@@ -243,24 +256,18 @@ class RelContrastiveLoss(nn.Module):
         if need_ds:
             call("mss_rcl_cin_bwd_f32", ra, ptr(kind), ptr(counters), wc, ptr(dscore))
         max_samples = int(total * self.sample_ratio)
-        if perms is None and self.pairing == "device":
-            self._step += 1
-            s0 = (self._step * 0x9E3779B1) & 0xFFFFFFFF
-            for slot, (set_a, margin) in enumerate(((0, a.m0), (1, a.m1))):
-                call("mss_rcl_pairs_device_f32", ptr(score), ptr(idx[set_a]), ptr(idx[2]), ptr(n_out), set_a, max_samples,
-                     (s0 + 1 + slot) & 0xFFFFFFFF, (s0 + 7) & 0xFFFFFFFF, float(margin), ptr(counters), slot, wc, ptr(dscore))
-        else:
-            n_orig, n_aug, n_ood = (int(v) for v in n_out[:3].tolist())      # host sync, as the reference's .sum()/int()
-            n_bad = int(counters[12].item())
-            if n_bad:       # F.nll_loss raises here (loss.py:59); the device-pairing mode reports NaN + last_terms[6]
-                raise IndexError(f"{n_bad} target value(s) outside [0, {C}) and below in_id=99")
-            n = min(max_samples, n_ood, n_orig, n_aug)                         # loss.py:149-156
-            if perms is None:
-                perms = [torch.randperm(k) for k in (n_orig, n_aug, n_ood)]    # CPU default generator, loss.py:129-131
-            p_orig, p_aug, p_ood = (p[:n].to(dev, torch.int64).contiguous() for p in perms)
-            for slot, (set_a, pa, margin) in enumerate(((0, p_orig, a.m0), (1, p_aug, a.m1))):
-                call("mss_rcl_pairs_f32", ptr(score), ptr(idx[set_a]), ptr(pa), ptr(idx[2]), ptr(p_ood), n, float(margin),
-                     ptr(counters), slot, wc, ptr(dscore))
+        # reference pairing / injected permutations (the device-pairing mode returned above)
+        n_orig, n_aug, n_ood = (int(v) for v in n_out[:3].tolist())      # host sync, as the reference's .sum()/int()
+        n_bad = int(counters[12].item())
+        if n_bad:       # F.nll_loss raises here (loss.py:59); the device-pairing mode reports NaN + last_terms[6]
+            raise IndexError(f"{n_bad} target value(s) outside [0, {C}) and below in_id=99")
+        n = min(max_samples, n_ood, n_orig, n_aug)                         # loss.py:149-156
+        if perms is None:
+            perms = [torch.randperm(k) for k in (n_orig, n_aug, n_ood)]    # CPU default generator, loss.py:129-131
+        p_orig, p_aug, p_ood = (p[:n].to(dev, torch.int64).contiguous() for p in perms)
+        for slot, (set_a, pa, margin) in enumerate(((0, p_orig, a.m0), (1, p_aug, a.m1))):
+            call("mss_rcl_pairs_f32", ptr(score), ptr(idx[set_a]), ptr(pa), ptr(idx[2]), ptr(p_ood), n, float(margin),
+                 ptr(counters), slot, wc, ptr(dscore))
         out = torch.empty(8, device=dev, dtype=torch.float32)
         call("mss_rcl_finalize_f32", ra, ptr(counters), ptr(sel), ptr(out))
         self.last_terms = out

@@ -144,10 +144,9 @@ class MSDeformAttnPixelDecoder(nn.Module):
             raise NotImplementedError("MSDeformAttnPixelDecoder (multishiftseg_amd): the backward is built for three transformer "
                                       "levels + one GroupNorm FPN level (the Mask2Former configs); call under torch.no_grad()")
         shapes = [(x.shape[2], x.shape[3]) for x in xs]
-        pos = [self.pe_layer(x) for x in xs]
         ip = [m for proj in self.input_proj for m in (proj[0].weight, proj[0].bias, proj[1].weight, proj[1].bias)]
         tokens = _InputProjFn.apply(self, *xs, *ip)
-        memory, _, _ = self.transformer.forward_tokens(tokens, pos, shapes)
+        memory, _, _ = self.transformer.forward_tokens(tokens, None, shapes, pe_layer=self.pe_layer)
         lat, outc = self.lateral_convs[0], self.output_convs[0]
         x2 = features[self.in_features[0]].float()
         mask, m0, m1, m2 = _FpnFn.apply(self, shapes, memory, x2, lat.weight, lat.norm.weight, lat.norm.bias, outc.weight,
@@ -161,14 +160,12 @@ class MSDeformAttnPixelDecoder(nn.Module):
         S, C = starts[-1], self.input_proj[0][1].num_channels
         dev = xs[0].device
         tokens = torch.empty((N, S, C), device=dev, dtype=torch.float32)
-        pos = []
         for idx, x in enumerate(xs):
             conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
             y = self._conv1x1(K.nchw_to_act(x), conv)
             # GroupNorm output goes straight to rows [start, start + H*W) of every sample of the token buffer
             K.groupnorm(y, gn, out=tokens[0, starts[idx]:], out_sample_stride=S * C, out_ld=C)
-            pos.append(self.pe_layer(x))
-        memory, spatial_shapes, level_start_index = self.transformer.forward_tokens(tokens, pos, shapes)
+        memory, spatial_shapes, level_start_index = self.transformer.forward_tokens(tokens, None, shapes, pe_layer=self.pe_layer)
         levels = [K.TokenLevel(memory, starts[i], *shapes[i]) for i in range(len(shapes))]
         out = list(levels)
         for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):

@@ -105,3 +105,32 @@ def test_odd_batch_is_refused():
     lt = torch.zeros(3, 19, 8, 8, device="cuda")
     with pytest.raises(RuntimeError, match="odd"):
         crit(lt, torch.zeros(3, 8, 8, device="cuda"), torch.zeros(3, 8, 8, dtype=torch.int64, device="cuda"))
+
+
+@pytest.mark.parametrize("n_sets,cap", [((5000, 4000, 900), 1 << 20), ((70000, 90000, 150000), 60000), ((300, 0, 50), 1 << 20), ((1, 1, 1), 1),
+                                        ((180000, 190000, 170000), 1 << 20)])
+def test_merged_pair_launch_equals_the_two_separate_ones(n_sets, cap):
+    """mss_rcl_pairs_device2_f32 (round 4: both hinge terms in one launch, no atomics: thread i is the only writer of the three
+    score-gradient elements pair i touches) against two mss_rcl_pairs_device_f32 calls (float atomics): the same pairs, so the
+    same hinge sums (to the rounding of a differently grouped block sum) and bit-identical score gradients."""
+    from multishiftseg_amd._lib import call, ptr
+    g = torch.Generator(device="cuda").manual_seed(sum(n_sets))
+    npx = 600000
+    score = torch.randn(npx, device="cuda", generator=g) * 4
+    perm = torch.randperm(npx, device="cuda", generator=g).int()
+    n0, n1, n2 = n_sets
+    idx = [perm[:n0].contiguous(), perm[n0:n0 + n1].contiguous(), perm[n0 + n1:n0 + n1 + n2].contiguous()]
+    idx = [t if t.numel() else torch.zeros(1, dtype=torch.int32, device="cuda") for t in idx]
+    n_out = torch.tensor([n0, n1, n2, 0], dtype=torch.int32, device="cuda")
+    s0, m0, m1, wc = 0x1234567, 10.0, 5.0, 1.0
+    c_a, c_b = torch.zeros(16, dtype=torch.float64, device="cuda"), torch.zeros(16, dtype=torch.float64, device="cuda")
+    d_a, d_b = torch.zeros(npx, device="cuda"), torch.zeros(npx, device="cuda")
+    for slot, margin in enumerate((m0, m1)):
+        call("mss_rcl_pairs_device_f32", ptr(score), ptr(idx[slot]), ptr(idx[2]), ptr(n_out), slot, cap, s0 + 1 + slot, s0 + 7, margin,
+             ptr(c_a), slot, wc, ptr(d_a))
+    call("mss_rcl_pairs_device2_f32", ptr(score), ptr(idx[0]), ptr(idx[1]), ptr(idx[2]), ptr(n_out), cap, s0 + 1, s0 + 2, s0 + 7, m0, m1,
+         ptr(c_b), wc, ptr(d_b))
+    assert torch.equal(d_a, d_b)
+    np.testing.assert_allclose(c_b.cpu().numpy(), c_a.cpu().numpy(), rtol=2e-6, atol=0)   # float partial sums grouped by another grid
+    n = min(cap, n0, n1, n2)
+    assert (d_a != 0).sum().item() <= 4 * n and (n == 0 or c_a.abs().sum().item() > 0)

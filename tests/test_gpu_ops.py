@@ -534,7 +534,8 @@ def test_dgrad_after_bn_fused_equals_separate_steps(K, monkeypatch, n, h, w, cin
     sep = K.conv3x3_dgrad_after_bn(dy, x, st, wt)
     monkeypatch.setenv("MSS_BNBWD_FUSED", "1")
     fus = K.conv3x3_dgrad_after_bn(dy, x, st, wt)
-    assert torch.equal(sep.buf, fus.buf)
+    assert sep.ld == fus.ld and sep.ld % 32 == 0              # fresh Winograd outputs sit on 128-byte pixel rows (304 -> ld 320)
+    assert torch.equal(sep.buf[..., :sep.C], fus.buf[..., :fus.C])
     # float64 reference ON THE SAME BatchNorm input (the fp32 values of x: a ReLU mask decided by a differently rounded x would
     # flip at the elements within 1e-5 of zero and dominate the comparison): BN(train) -> ReLU backward, then the convolution's
     bnd = torch.nn.BatchNorm2d(cin).cuda().double().train()
@@ -783,3 +784,23 @@ def test_aspp_fused_input_transform_refuses_what_it_does_not_take():
     assert rc == _lib.MSS_ERR_UNSUPPORTED
     rc = _lib.status("mss_wino_input_transform_aspp3_f32", ptr(x), 16, 1, 16, 16, 16, 4, None, ptr(o), ptr(o), ptr(o))
     assert rc == _lib.MSS_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("b,q,c,hm,wm,image,crop", [(2, 100, 19, 24, 32, (96, 128), (90, 120)), (1, 100, 19, 13, 17, (50, 70), (50, 70)),
+                                                   (1, 20, 7, 9, 9, (33, 65), (31, 64)), (3, 8, 19, 6, 40, (7, 161), (7, 161)),
+                                                   (1, 100, 19, 64, 128, (256, 512), (256, 512))])
+def test_m2f_fused_score_mfma_equals_valu_kernel(K, monkeypatch, b, q, c, hm, wm, image, crop):
+    """The class mix of the fused Mask2Former score on the matrix cores (round 4: A = prob^T [32 classes x 2 queries], B = the sigmoids
+    of 32 pixels, v_mfma_f32_32x32x2_f32) against the all-VALU kernel it replaces (MSS_M2F_MFMA=0), over ragged tiles, 4 / 8 / 16-row
+    tiles, query counts that leave a 2-step tail, fewer classes, and against the numpy oracle."""
+    g = torch.Generator(device="cuda").manual_seed(b * q + hm)
+    cls = torch.randn(b, q, c + 1, device="cuda", generator=g) * 2
+    lg = torch.randn(b, hm, wm, q, device="cuda", generator=g) * 3
+    got = K.m2f_score_fused(cls, lg, image, crop)
+    monkeypatch.setenv("MSS_M2F_MFMA", "0")
+    want = K.m2f_score_fused(cls, lg, image, crop)
+    assert got.shape == want.shape == (b,) + tuple(crop)
+    assert (got - want).abs().max().item() < 2e-6, (got - want).abs().max().item()
+    up = torch.nn.functional.interpolate(lg.permute(0, 3, 1, 2).double(), size=image, mode="bilinear", align_corners=False)
+    ref = 1 - torch.einsum("bqc,bqhw->bchw", torch.softmax(cls.double(), -1)[..., :-1], up.sigmoid())[:, :, :crop[0], :crop[1]].max(1)[0]
+    assert (got.double() - ref).abs().max().item() < 1e-5

@@ -34,8 +34,11 @@ def main():
         score = (torch.randn(B, H, W, device=dev) * 4).requires_grad_(True)
         tgt = torch.from_numpy(synth.synth_targets(3, B // 2, H, W)).to(dev)
         crit = RelContrastiveLoss(LOSS_PARAMS, pairing="device")
+        # the loss mutates its targets in place (loss.py:110-115): a fresh copy per call, made OUTSIDE the timed region (the 33 MB
+        # clone used to be ~27 us of the figure)
+        pool = [tgt.clone() for _ in range(16)]
         def f():
-            crit(logits, score, tgt.clone())
+            crit.value_and_grads(logits.detach(), score.detach(), pool.pop())
         ms = timeit(f, iters=5)
         row(f"rel_contrastive_loss value+grads {B}x19x{H}x{W}", ms, B * H * W * 168.0, "168 B/px minimum")
     # BN statistics + maxpool + upsample at train sizes
