@@ -42,9 +42,26 @@ static_assert(NKC == 2, "the step body below is written for two 8-k chunks");
 // BN: output-channel extent of a tile. 128 (2x2 waves of 64x64, 4 workgroups per CU) or 256 (2x2 waves of 64x128: 64 MFMAs
 // per wave and barrier instead of 32, a quarter less operand traffic per FLOP and half the per-tile prologue/epilogue
 // share, at 2 workgroups per CU).
+#ifndef GEMM_GROUP_M_DEFAULT
+#define GEMM_GROUP_M_DEFAULT 8
+#endif
+// Tile index -> (row tile, column tile). group_m == 0: column tile fastest (the 16 column tiles of one row block of a 2048 -> 4096
+// product are consecutive). group_m > 0 (r04): groups of `group_m` row tiles, row tile fastest inside a group, so that the ~64
+// workgroups an XCD runs together form a SQUARE-ish block of tiles (8 x 8 instead of 4 x 16): every K-slice of A is then shared by
+// 8 and every K-slice of B by 8 of them in that XCD's L2, instead of 16 / 4. A bijection of the same tile set: results unchanged.
+__device__ __forceinline__ void tile_mn(int v, int mtiles, int ntiles, int group_m, int& mt, int& nt) {
+  if (group_m <= 0 || ntiles == 1) { mt = v / ntiles; nt = v - mt * ntiles; return; }
+  const int gsz = group_m * ntiles;
+  const int g = v / gsz, r = v - g * gsz;
+  const int first = g * group_m;
+  const int rows = mtiles - first < group_m ? mtiles - first : group_m;
+  nt = r / rows;
+  mt = first + (r - nt * rows);
+}
+
 template <bool AFFINE, int VARIANT, int BN>
 __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvArgs p, long long first_tile, long long total_tiles,
-                                                                        int tiles_per_batch) {
+                                                                        int tiles_per_batch, int group_m) {
   constexpr int WTN = BN / 2, TN = WTN / 32, B_LD = BN / RPP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                       // [2][BM][LDK]
@@ -73,7 +90,7 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
   auto setup_off = [&](long long t, unsigned* ao, unsigned* bo, unsigned& so) {
     const int b = (int)(t / tiles_per_batch);
     const int v = (int)(t - (long long)b * tiles_per_batch);
-    const int mt = v / p.ntiles, nt = v - mt * p.ntiles;
+    int mt, nt; tile_mn(v, p.mtiles, p.ntiles, group_m, mt, nt);
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       int row = mt * BM + row0 + j * RPP;
@@ -89,7 +106,7 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
     if (VARIANT == 3) { setup_off(t, a_off, b_off, s_off); return; }
     const int b = (int)(t / tiles_per_batch);
     const int v = (int)(t - (long long)b * tiles_per_batch);
-    const int mt = v / p.ntiles, nt = v - mt * p.ntiles;
+    int mt, nt; tile_mn(v, p.mtiles, p.ntiles, group_m, mt, nt);
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       int row = mt * BM + row0 + j * RPP;
@@ -208,7 +225,7 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
   auto epilogue = [&](long long t) {
     const int b = (int)(t / tiles_per_batch);
     const int v = (int)(t - (long long)b * tiles_per_batch);
-    const int mt = v / p.ntiles, nt = v - mt * p.ntiles;
+    int mt, nt; tile_mn(v, p.mtiles, p.ntiles, group_m, mt, nt);
     mss_epilogue_store<TM, TN>(acc, p, p.y + (size_t)b * p.y_bs, mt * BM + wm * WTM, nt * BN + wn * WTN, lane);
   };
 
@@ -503,7 +520,9 @@ int launch_gemm(const MssConvArgs& p, hipStream_t stream, long long first = 0, l
     const double eff = (double)total / (double)(rounds * g);
     if (eff > best + 0.02) { best = eff; grid = (int)g; }
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<AFFINE, VARIANT, BN>), dim3(grid), dim3(NT), smem, stream, p, first, end, tiles_per_batch);
+  // the square-ish tile order only for whole launches: the hybrid wide + narrow split (MSS_GEMM_TAIL) relies on tile ranges
+  const int group_m = (first == 0 && end == (long long)tiles_per_batch * batch) ? MSS_ENV_INT("MSS_GEMM_GROUP_M", GEMM_GROUP_M_DEFAULT) : 0;
+  hipLaunchKernelGGL((gemm_nt_kernel<AFFINE, VARIANT, BN>), dim3(grid), dim3(NT), smem, stream, p, first, end, tiles_per_batch, group_m);
   return mss_launch_status();
 }
 

@@ -804,3 +804,53 @@ def test_m2f_fused_score_mfma_equals_valu_kernel(K, monkeypatch, b, q, c, hm, wm
     up = torch.nn.functional.interpolate(lg.permute(0, 3, 1, 2).double(), size=image, mode="bilinear", align_corners=False)
     ref = 1 - torch.einsum("bqc,bqhw->bchw", torch.softmax(cls.double(), -1)[..., :-1], up.sigmoid())[:, :, :crop[0], :crop[1]].max(1)[0]
     assert (got.double() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("P,T,C,Ko,extras", [
+    (1, 3000, 256, 1024, False),       # 24 row tiles x 4 wide column tiles: three full groups of 8
+    (1, 1300, 128, 4096, True),        # 11 row tiles (last group has 3) x 16 column tiles, affine prologue + residual + statistics
+    (3, 1000, 64, 640, False),         # batched, narrow 128-wide tiles: 8 x 5 per batch entry
+    (1, 130, 512, 512, False),         # 2 row tiles: fewer than one group
+])
+def test_gemm_grouped_tile_order_is_a_permutation_of_the_same_tiles(K, monkeypatch, P, T, C, Ko, extras):
+    """gemm.hip tile_mn (round 4): walking the tile grid in groups of 8 row tiles (row tile fastest inside a group) instead of column
+    tile fastest changes WHICH workgroup computes a tile and when -- the L2 sharing between the workgroups of an XCD -- never the
+    tile itself: outputs and BatchNorm partial sums are equal bit for bit with MSS_GEMM_GROUP_M=0, and nothing is left unwritten."""
+    import ctypes
+    from multishiftseg_amd import _lib
+    from multishiftseg_amd._lib import MssConvArgs, call, ptr
+    torch.manual_seed(T + Ko)
+    x = torch.randn(P, T, C, device="cuda")
+    kpad = _lib.value("mss_conv2d_kpad", Ko)
+    w = torch.zeros(P, kpad, C, device="cuda")
+    w[:, :Ko] = torch.randn(P, Ko, C, device="cuda") / C ** 0.5
+    sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    res = torch.randn(P, T, Ko, device="cuda")
+    outs, stats = {}, {}
+    for g in ("0", "8", "3"):
+        monkeypatch.setenv("MSS_GEMM_GROUP_M", g)
+        y = torch.full((P, T, Ko), float("nan"), device="cuda")
+        st = torch.full((-(-T // 64), 2, Ko), float("nan"), device="cuda")
+        a = MssConvArgs()
+        a.x, a.w, a.y = ptr(x), ptr(w), ptr(y)
+        a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
+        a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, Ko, kpad, Ko
+        a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+        if P > 1:
+            a.batch, a.x_bs, a.w_bs, a.y_bs = P, T * C, kpad * C, T * Ko
+        if extras:
+            a.in_scale, a.in_shift, a.in_relu = ptr(sc), ptr(sh), 1
+            a.res, a.ldres, a.out_relu, a.stats = ptr(res), Ko, 1, ptr(st)
+        call("mss_conv2d_forward_f32", ctypes.byref(a))
+        outs[g], stats[g] = y, st
+    assert not torch.isnan(outs["8"]).any()
+    assert torch.equal(outs["0"], outs["8"]) and torch.equal(outs["0"], outs["3"])
+    if extras:
+        assert torch.equal(stats["0"], stats["8"]) and torch.equal(stats["0"], stats["3"])
+    xin = x.double()
+    if extras:
+        xin = torch.relu(xin * sc.double() + sh.double())
+    want = torch.einsum("ptc,pkc->ptk", xin[:, ::7], w[:, :Ko].double())
+    if extras:
+        want = torch.relu(want + res[:, ::7].double())
+    assert (outs["8"][:, ::7].double() - want).abs().max().item() < 1e-4

@@ -6,9 +6,10 @@ import torch
 from multishiftseg_amd import _lib
 from multishiftseg_amd._lib import MssConvArgs, call, ptr
 from tools.microbench import timeit
-CASES = [(36, 65536, 128, 128), (36, 16384, 256, 256), (36, 4096, 512, 512), (64, 1936, 512, 1024), (64, 1936, 1024, 512), (64, 2112, 1024, 2048),
+CASES = [(1, 65536, 2048, 1024), (36, 65536, 128, 128), (36, 16384, 256, 256), (36, 4096, 512, 512), (64, 1936, 512, 1024), (64, 1936, 1024, 512), (64, 2112, 1024, 2048),
          (64, 2304, 4096, 256), (36, 5184, 4096, 256), (64, 29412, 304, 256), (64, 29412, 256, 256), (1, 65536, 2048, 4096), (1, 65536, 1024, 2048)]
 VA, VB = (sys.argv[1].split(",") if len(sys.argv) > 1 else ["2", "3"])
+VAR = sys.argv[2] if len(sys.argv) > 2 else "MSS_GEMM_VARIANT"        # e.g. `bench_gemm_variant.py 0,8 MSS_GEMM_GROUP_M`
 for (P, T, C, Ko) in CASES:
     Kpad = _lib.value("mss_conv2d_kpad", Ko)
     w = torch.randn(P, Kpad, C, device="cuda")
@@ -24,7 +25,7 @@ for (P, T, C, Ko) in CASES:
         a.batch, a.x_bs, a.w_bs, a.y_bs = P, T * C, Kpad * C, T * Ko
 
         def f(a=a, var=var):
-            os.environ["MSS_GEMM_VARIANT"] = var
+            os.environ[VAR] = var
             _lib.reset_env_cache()
             call("mss_conv2d_forward_f32", ctypes.byref(a))
         fns[var], outs[var] = f, yt

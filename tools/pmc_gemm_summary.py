@@ -31,6 +31,21 @@ for key, ctr in sorted(rows.items(), key=lambda kv: kv[0][1]):
     if wc:
         print(f"\nwave cycles: parked (s_waitcnt / barrier) {100 * wa / wc:.1f} %, issue-stalled {100 * wi / wc:.1f} %, issuing {100 * ai / wc:.1f} %")
     mf, busy = m("SQ_INSTS_MFMA"), m("SQ_BUSY_CYCLES")
+    if mf and m("GRBM_GUI_ACTIVE") and m("SQ_VALU_MFMA_BUSY_CYCLES"):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; one v_mfma_f32_32x32x2_f32 holds its SIMD's matrix pipe for 64 cycles and
+        # SQ_VALU_MFMA_BUSY_CYCLES counts exactly that (= 64 x SQ_INSTS_MFMA); 256 CUs x 4 SIMDs
+        cyc = m("GRBM_GUI_ACTIVE") / 8.0
+        share = m("SQ_VALU_MFMA_BUSY_CYCLES") / (cyc * 1024.0)
+        flops = mf * 4096.0
+        match = [b for b in bench if abs(2.0 * b["P"] * b["T"] * b["C"] * b["K"] / flops - 1) < 0.07]     # executed MFMAs include the rows that pad the last 128-row tile
+        line = f"\n**matrix pipe busy {100 * share:.1f} % of the launch's {cyc / 1e6:.3f} M shader cycles** (MFMA count x 64 / (cycles x 1024 SIMDs))"
+        if match:
+            b = match[0]
+            clk = cyc / (b["ms"] * 1e-3) / 1e9
+            line += (f"; product {b['P']} x {b['T']} x {b['C']} -> {b['K']}: {b['ms']} ms un-profiled = {b['tflops']} TFLOP/s = "
+                     f"{b['tflops'] / 157.3:.3f} of the nominal 157.3 (2.4 GHz); cycles / time = {clk:.2f} GHz effective clock, i.e. "
+                     f"{b['tflops'] / (157.3 * clk / 2.4):.3f} of the peak AT THAT CLOCK")
+        print(line)
     if mf and m("SQ_INSTS_VALU"):
         print(f"instructions per MFMA: VALU {m('SQ_INSTS_VALU') / mf:.2f}, LDS {m('SQ_INSTS_LDS') / mf:.2f}, SALU {m('SQ_INSTS_SALU') / mf:.2f}, "
               f"VMEM rd {m('SQ_INSTS_VMEM_RD') / mf:.3f}, wr {m('SQ_INSTS_VMEM_WR') / mf:.3f}")
