@@ -994,11 +994,105 @@ int launch_wgrad(MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, 
   return mss_launch_status();
 }
 
+// ---- TN weight gradient WITHOUT LDS (r04 experiment -> see launch_wgrad_tn, MSS_WGRAD_TN=5 / default rule) --------------------------
+// dW[k][c] = sum_r dy[r][k] * x[r][c]. In the 32x32x2 fp32 MFMA, operand A is [m][kk] with lane = m + 32 * kk: for THIS product the
+// contraction index kk is the ROW of both operands, so the 32 lanes of one kk read 32 consecutive floats of one row -- the layout the
+// tensors already have in memory. A lane therefore loads 16 bytes (4 consecutive columns) of row r0 + (lane >> 5) of dy and of x
+// straight into registers and its four components feed four MFMAs each way: block (a, b) accumulates the output elements
+// (k = k0 + 4 m + a, c = c0 + 4 n + b), i.e. the 128 x 128 tile of a WAVE is computed as 16 interleaved 32 x 32 blocks with
+// 2 global loads per 16 MFMAs, no LDS staging, no transposing reads (gemm_tn_wgrad_kernel: one ds_read_b32 per MFMA and operand)
+// and no workgroup barrier. The price: 256 accumulator registers per wave, so one wave per SIMD, and each operand row piece is
+// fetched by every wave that needs it (from L2: 4 waves of a workgroup are the 4 column tiles of one k tile over the same rows).
+// A ring of TND row pairs is in flight per wave. Output: whole 128 x 128 tiles of the (split, position) slab, 16-byte stores.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// KB: 32-column blocks of dy per wave. 4: a 128 x 128 tile, 256 accumulator registers, ONE wave per SIMD. 2: a 64 x 128 tile, 128
+// accumulators, TWO waves per SIMD (the second wave fills the matrix pipe while the first issues its loads and address arithmetic)
+// at 1.5x the operand traffic per MFMA.
+template <int KB>
+__global__ __launch_bounds__(256, KB == 4 ? 1 : 2) void gemm_tn_direct_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                float* __restrict__ out, int P, int M, int K, int C, long long a_bs,
+                                                                long long b_bs, int Kpad, int Cp, int ktiles, int ctiles, int splits,
+                                                                int tps, long long total) {
+  typedef typename std::conditional<KB == 4, f32x4, f32x2>::type avec;
+  constexpr int TND = KB == 4 ? 8 : 5;                         // row pairs per register block (two blocks: one consumed, one in flight)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long job = (long long)blockIdx.x * 4 + wave;
+  if (job >= total) return;                                   // no barrier anywhere in this kernel
+  long long t = job;
+  const int ct = (int)(t % ctiles); t /= ctiles;
+  const int kt = (int)(t % ktiles); t /= ktiles;
+  const int sp = (int)(t % splits);
+  const int pb = (int)(t / splits);
+  const int half = lane >> 5, j = lane & 31;
+  const int r0 = sp * tps, r1 = r0 + tps < M ? r0 + tps : M;
+  const float* a = A + (size_t)pb * a_bs + (size_t)(kt * (32 * KB) + KB * j);
+  const float* b = B + (size_t)pb * b_bs + (size_t)(ct * 128 + 4 * j);
+  f32x16 acc[KB][4];
+#pragma unroll
+  for (int i = 0; i < KB; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
+  // Two register blocks of TND row pairs each: while the 4 * KB * TND MFMAs of one block run, the 2 * TND loads of the other are in
+  // flight. Rows past the end of the split are fetched from the last valid row (a legal address) and zeroed by a factor applied when
+  // the pair is CONSUMED (a use at fetch time would wait on the load). The loop body handles both blocks in straight-line code, so no
+  // register of the ring is ever copied while its load is pending; the scheduling fences keep hipcc from sinking the loads down to
+  // their uses (it does: shorter live ranges).
+  avec a0[TND], a1[TND];
+  f32x4 b0[TND], b1[TND];
+  float k0[TND], k1[TND];
+  const int last = r1 - 1;
+  auto fetch = [&](int row, avec& va, f32x4& vb, float& kp) {
+    const bool ok = row <= last;
+    const size_t rr = (size_t)(ok ? row : last);
+    va = *reinterpret_cast<const avec*>(a + rr * K);
+    vb = *reinterpret_cast<const f32x4*>(b + rr * C);
+    kp = ok ? 1.f : 0.f;
+  };
+  auto compute = [&](const avec (&va)[TND], const f32x4 (&vb)[TND], const float (&kp)[TND]) {
+#pragma unroll
+    for (int d = 0; d < TND; ++d) {
+      const avec ca = va[d] * kp[d];                           // A zeroed is enough: the product is zero
+      const f32x4 cb = vb[d];
+#pragma unroll
+      for (int i = 0; i < KB; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i], cb[q], acc[i][q], 0, 0, 0);
+    }
+  };
+  // (a mask-free main loop with a separate remainder loop was tried: a second loop that touches the accumulators makes hipcc keep
+  // part of them in architectural registers and spill)
+#pragma unroll
+  for (int d = 0; d < TND; ++d) fetch(r0 + 2 * d + half, a0[d], b0[d], k0[d]);
+  for (int r = r0; r < r1; r += 4 * TND) {
+#pragma unroll
+    for (int d = 0; d < TND; ++d) fetch(r + 2 * TND + 2 * d + half, a1[d], b1[d], k1[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(a0, b0, k0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < TND; ++d) fetch(r + 4 * TND + 2 * d + half, a0[d], b0[d], k0[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(a1, b1, k1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float* o = out + ((size_t)sp * P + pb) * Kpad * Cp + (size_t)(ct * 128 + 4 * j);
+#pragma unroll
+  for (int i = 0; i < KB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+      *reinterpret_cast<f32x4*>(o + (size_t)(kt * (32 * KB) + KB * m + i) * Cp) = v;
+    }
+}
+
 // ---- the TN route of the batched (Winograd-domain) weight gradient ----
 struct TnPlan { int ktiles, ctiles, splits, tps; long long total; };
 inline int tn_batch(const MssConvArgs& p) { return p.batch > 1 ? p.batch : 1; }
 inline bool tn_eligible(const MssConvArgs& p, int lddy) {
-  const bool off = MSS_ENV_INT("MSS_WGRAD_TN", 3) == 0;     // A/B switch
+  const bool off = MSS_ENV_INT("MSS_WGRAD_TN", 5) == 0;     // A/B switch
   if (off || p.R * p.S != 1 || p.in_scale || p.in_relu || p.K % 4 || p.C % 4 || p.ldx != p.C || lddy != p.K) return false;
   if (p.batch > 1) return p.x_bs % 4 == 0 && p.y_bs % 4 == 0 && p.N == 1 && p.H == 1;   // Winograd-domain products
   // a plain 1x1 / stride-1 layer over dense rows (ASPP 4096 -> 256: 95 -> see DESIGN 3.3): the same GEMM with one position;
@@ -1028,23 +1122,88 @@ inline TnPlan tn_plan(const MssConvArgs& p, int bc = TN_BC, int slots = 768) {
   pl.total = base * pl.splits;
   return pl;
 }
-// MSS_WGRAD_TN: 0 the convolution-loader kernel, 1 gemm_tn_wgrad_kernel, 2 gemm_tn2_wgrad_kernel<128>, 3 (default) tn2 with
+// MSS_WGRAD_TN: 5 (default, r04) the LDS-free gemm_tn_direct_kernel<4> wherever K and C are multiples of 128 -- measured against
+// the kernels below (tools/bench_wgrad_tn.py): ASPP F(6x6) 64 x 2304 x 4096 -> 256 116.9 -> 121.9 TFLOP/s, F(4x4) 36 x 5184 118.1 ->
+// 123.9, decoder F(6x6) 64 x 29412 x 256 -> 256 119.9 -> 131.4, the pixel decoder's Linears 162624 x 256 -> 256 / 1024 -> 256 /
+// 256 -> 1024 107.9 / 121.5 / 121.8 -> 111.9 / 129.7 / 129.5, 1x1 65536 x 4096 -> 256 123.5 -> 132.6 -- when its one-wave jobs fill at
+// least 3/4 of the SIMDs, and rule 3 elsewhere; 7: that kernel at any size (tests); 6: its 64 x 128-tile, two-waves-per-SIMD form
+// (102-120: slower everywhere, kept for the tests). Forcing the older kernels:
+// 0 the convolution-loader kernel, 1 gemm_tn_wgrad_kernel, 2 gemm_tn2_wgrad_kernel<128>, 3 (the round-3 default) tn2 with
 // 256-wide c tiles where they need no pixel split and fill their rounds (C % 256 == 0 and at least 2 rounds of 512 slots) and
 // gemm_tn_wgrad_kernel elsewhere (with unmasked loads it is 2 % ahead of tn2<128>: 119.5 / 122.2 against 117.3 / 119.9 TFLOP/s),
 // 4 the wide kernel whenever C % 256 == 0 (tests)
 inline int tn_mode() {
-  return MSS_ENV_INT("MSS_WGRAD_TN", 3);
+  return MSS_ENV_INT("MSS_WGRAD_TN", 5);
 }
 inline bool tn_wide(const MssConvArgs& p) {
   if (tn_mode() == 4) return p.C % 256 == 0;            // tests: the wide kernel at any size, pixel splits included
-  if (tn_mode() != 3 || p.C % 256) return false;
+  if ((tn_mode() != 3 && tn_mode() < 5) || p.C % 256) return false;
   const TnPlan w = tn_plan(p, 256, 512);
   const double eff = (double)w.total / (double)(((w.total + 511) / 512) * 512);
   return w.splits == 1 && w.total >= 1024 && eff >= 0.9;
 }
-inline TnPlan tn_plan_for(const MssConvArgs& p) { return tn_wide(p) ? tn_plan(p, 256, 512) : tn_plan(p); }
+inline bool tn_direct(const MssConvArgs& p);
+inline TnPlan tn_plan_direct(const MssConvArgs& p);
+inline TnPlan tn_plan_for(const MssConvArgs& p) { return tn_direct(p) ? tn_plan_direct(p) : tn_wide(p) ? tn_plan(p, 256, 512) : tn_plan(p); }
+inline TnPlan tn_plan_direct(const MssConvArgs& p);
+inline bool tn_direct(const MssConvArgs& p) {
+  const int mode = tn_mode();
+  if ((mode != 5 && mode != 6 && mode != 7) || p.K % 128 || p.C % 128) return false;
+  if (mode != 5) return true;                                  // 6 / 7 (tests, A/B): the direct kernels at any size
+  // one wave per job and at least 256 rows per split: a product with few rows (the pixel decoder at ONE image: 10 164 tokens x
+  // 256 -> 256 is 4 tiles x 39 splits = 156 waves for 1024 SIMDs; forward + backward 8.4 -> 9.2 ms) keeps the workgroup-tile kernels
+  const TnPlan pl = tn_plan_direct(p);
+  const long long slots = tn_mode() == 6 ? 2048 : 1024;
+  return pl.total * 4 >= slots * 3;
+}
+// plan of the LDS-free kernel: one WAVE per (position, split, tile); mode 5: 128 x 128 tiles, 1024 wave slots (one per SIMD);
+// mode 6: 64 x 128 tiles, 2048 slots
+inline TnPlan tn_plan_direct(const MssConvArgs& p) {
+  TnPlan pl;
+  const int kb = tn_mode() == 6 ? 64 : 128;
+  pl.ktiles = p.K / kb; pl.ctiles = p.C / 128;
+  const long long base = (long long)tn_batch(p) * pl.ktiles * pl.ctiles;
+  const int slots = tn_mode() == 6 ? 2048 : 1024;
+  int max_splits = mss_cdiv(p.M, 256);
+  const int cap = p.batch > 1 ? 64 : 256;
+  if (max_splits > cap) max_splits = cap;
+  if (max_splits < 1) max_splits = 1;
+  int splits = 1;
+  double best = 0.0;
+  for (int sp = 1; sp <= max_splits; ++sp) {
+    const long long total = base * sp;
+    const double eff = (double)total / (double)(((total + slots - 1) / slots) * slots);
+    if (eff > best + 1e-9) { best = eff; splits = sp; }
+    if (eff >= 0.95 && total >= slots) break;
+  }
+  pl.tps = mss_cdiv(mss_cdiv(p.M, splits), 2) * 2;
+  pl.splits = mss_cdiv(p.M, pl.tps);
+  pl.total = base * pl.splits;
+  return pl;
+}
 int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, float* ws, long long ws_bytes,
                     hipStream_t stream) {
+  if (tn_direct(p)) {
+    const TnPlan pl = tn_plan_direct(p);
+    const int P = tn_batch(p);
+    const long long a_bs = p.batch > 1 ? p.y_bs : 0, b_bs = p.batch > 1 ? p.x_bs : 0;
+    const long long slab = (long long)P * p.Kpad * Cp;
+    if (pl.splits > 1 && (!ws || ws_bytes < (long long)pl.splits * slab * 4)) return MSS_ERR_BAD_ARG;
+    float* out = pl.splits > 1 ? ws : dwp;
+    if (tn_mode() == 6)
+      hipLaunchKernelGGL(gemm_tn_direct_kernel<2>, dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, out, P, p.M, p.K,
+                         p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+    else
+      hipLaunchKernelGGL(gemm_tn_direct_kernel<4>, dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, out, P, p.M, p.K,
+                         p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+    if (pl.splits > 1) {
+      const long long slab4 = slab / 4;
+      long long blocks = (slab4 + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, ws, dwp, slab4, pl.splits);
+    }
+    return mss_launch_status();
+  }
   const bool wide = tn_wide(p);
   const TnPlan pl = tn_plan_for(p);
   const int P = tn_batch(p);

@@ -450,12 +450,14 @@ def test_bf16x6_gemm_is_fp32_accurate(K, monkeypatch, rows, c, k, batch):
     assert not torch.equal(y32, y6)          # it really is a different evaluation
 
 
-@pytest.mark.parametrize("mode", ["0", "1", "2", "4"])
+@pytest.mark.parametrize("mode", ["0", "1", "2", "4", "5", "6", "7"])
 @pytest.mark.parametrize("P,T,C,Ko", [(3, 700, 512, 128), (2, 1000, 256, 72), (4, 37, 768, 256)])
 def test_batched_wgrad_routes_vs_float64(K, monkeypatch, mode, P, T, C, Ko):
-    """dU[p] = dY'[p]^T X'[p] (the Winograd-domain weight gradient) on its four kernels -- the convolution-loader kernel (0),
-    the TN kernel (1), the transposing-loader kernel with 128-wide (2) and 256-wide (4) c tiles, ragged T and K, with and
-    without a pixel split -- against a float64 product; and twice with identical bits."""
+    """dU[p] = dY'[p]^T X'[p] (the Winograd-domain weight gradient) on its kernels -- the convolution-loader kernel (0),
+    the TN kernel (1), the transposing-loader kernel with 128-wide (2) and 256-wide (4) c tiles, the round-4 LDS-free kernel
+    with 128 x 128 (7; 5 = the default rule, which keeps these small products on the older kernels) and 64 x 128 tiles per wave
+    (6), ragged and odd T, K not a multiple of 128 (falls back), with and without a pixel split -- against a float64 product;
+    and twice with identical bits."""
     import ctypes
     from multishiftseg_amd._lib import MssConvArgs, call, ptr
     monkeypatch.setenv("MSS_WGRAD_TN", mode)
