@@ -1005,6 +1005,7 @@ int launch_wgrad(MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, 
 // fetched by every wave that needs it (from L2: 4 waves of a workgroup are the 4 column tiles of one k tile over the same rows).
 // A ring of TND row pairs is in flight per wave. Output: whole 128 x 128 tiles of the (split, position) slab, 16-byte stores.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ const float tn_zero_row[4096] = {0.f};              // the A operand of rows past the end of a split
 // KB: 32-column blocks of dy per wave. 4: a 128 x 128 tile, 256 accumulator registers, ONE wave per SIMD. 2: a 64 x 128 tile, 128
 // accumulators, TWO waves per SIMD (the second wave fills the matrix pipe while the first issues its loads and address arithmetic)
 // at 1.5x the operand traffic per MFMA.
@@ -1035,25 +1036,25 @@ __global__ __launch_bounds__(256, KB == 4 ? 1 : 2) void gemm_tn_direct_kernel(co
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
   // Two register blocks of TND row pairs each: while the 4 * KB * TND MFMAs of one block run, the 2 * TND loads of the other are in
-  // flight. Rows past the end of the split are fetched from the last valid row (a legal address) and zeroed by a factor applied when
-  // the pair is CONSUMED (a use at fetch time would wait on the load). The loop body handles both blocks in straight-line code, so no
+  // flight. Rows past the end of the split take their A operand from a row of zeros (tn_zero_row) and their B operand from the last
+  // valid row: no mask arithmetic on loaded values (a use at fetch time would wait on the load; a multiply at consume time costs 4
+  // VALU + hazard nops per 16 MFMAs). The loop body handles both blocks in straight-line code, so no
   // register of the ring is ever copied while its load is pending; the scheduling fences keep hipcc from sinking the loads down to
   // their uses (it does: shorter live ranges).
   avec a0[TND], a1[TND];
   f32x4 b0[TND], b1[TND];
-  float k0[TND], k1[TND];
   const int last = r1 - 1;
-  auto fetch = [&](int row, avec& va, f32x4& vb, float& kp) {
+  const float* az = tn_zero_row + (kt * (32 * KB) + KB * j);    // K <= 4096 (host check)
+  auto fetch = [&](int row, avec& va, f32x4& vb) {
     const bool ok = row <= last;
     const size_t rr = (size_t)(ok ? row : last);
-    va = *reinterpret_cast<const avec*>(a + rr * K);
+    va = *reinterpret_cast<const avec*>(ok ? a + rr * K : az);  // a row past the end contributes A = 0: the product is zero
     vb = *reinterpret_cast<const f32x4*>(b + rr * C);
-    kp = ok ? 1.f : 0.f;
   };
-  auto compute = [&](const avec (&va)[TND], const f32x4 (&vb)[TND], const float (&kp)[TND]) {
+  auto compute = [&](const avec (&va)[TND], const f32x4 (&vb)[TND]) {
 #pragma unroll
     for (int d = 0; d < TND; ++d) {
-      const avec ca = va[d] * kp[d];                           // A zeroed is enough: the product is zero
+      const avec ca = va[d];
       const f32x4 cb = vb[d];
 #pragma unroll
       for (int i = 0; i < KB; ++i)
@@ -1064,17 +1065,17 @@ __global__ __launch_bounds__(256, KB == 4 ? 1 : 2) void gemm_tn_direct_kernel(co
   // (a mask-free main loop with a separate remainder loop was tried: a second loop that touches the accumulators makes hipcc keep
   // part of them in architectural registers and spill)
 #pragma unroll
-  for (int d = 0; d < TND; ++d) fetch(r0 + 2 * d + half, a0[d], b0[d], k0[d]);
+  for (int d = 0; d < TND; ++d) fetch(r0 + 2 * d + half, a0[d], b0[d]);
   for (int r = r0; r < r1; r += 4 * TND) {
 #pragma unroll
-    for (int d = 0; d < TND; ++d) fetch(r + 2 * TND + 2 * d + half, a1[d], b1[d], k1[d]);
+    for (int d = 0; d < TND; ++d) fetch(r + 2 * TND + 2 * d + half, a1[d], b1[d]);
     __builtin_amdgcn_sched_barrier(0);
-    compute(a0, b0, k0);
+    compute(a0, b0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int d = 0; d < TND; ++d) fetch(r + 4 * TND + 2 * d + half, a0[d], b0[d], k0[d]);
+    for (int d = 0; d < TND; ++d) fetch(r + 4 * TND + 2 * d + half, a0[d], b0[d]);
     __builtin_amdgcn_sched_barrier(0);
-    compute(a1, b1, k1);
+    compute(a1, b1);
     __builtin_amdgcn_sched_barrier(0);
   }
   float* o = out + ((size_t)sp * P + pb) * Kpad * Cp + (size_t)(ct * 128 + 4 * j);
@@ -1148,7 +1149,7 @@ inline TnPlan tn_plan_for(const MssConvArgs& p) { return tn_direct(p) ? tn_plan_
 inline TnPlan tn_plan_direct(const MssConvArgs& p);
 inline bool tn_direct(const MssConvArgs& p) {
   const int mode = tn_mode();
-  if ((mode != 5 && mode != 6 && mode != 7) || p.K % 128 || p.C % 128) return false;
+  if ((mode != 5 && mode != 6 && mode != 7) || p.K % 128 || p.C % 128 || p.K > 4096) return false;
   if (mode != 5) return true;                                  // 6 / 7 (tests, A/B): the direct kernels at any size
   // one wave per job and at least 256 rows per split: a product with few rows (the pixel decoder at ONE image: 10 164 tokens x
   // 256 -> 256 is 4 tiles x 39 splits = 156 waves for 1024 SIMDs; forward + backward 8.4 -> 9.2 ms) keeps the workgroup-tile kernels
