@@ -24,7 +24,8 @@ extern "C" {
 #define MSS_ABI_VERSION 5      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
                                   mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32,
                                   mss_bn_fold_train_from_partials_f32; 5 (round 4): mss_adam_step_f32 takes double hyper-parameters, mss_env_reset,
-                                  mss_wino_input_transform_aspp3_f32, mss_msda_prepare_backward_ld_f32, mss_rcl_pairs_device2_f32, mss_rcl_loss_device_f32, mss_m2f_fused_score_ws_f32, mss_oodm_compact_packed_f32 */
+                                  mss_wino_input_transform_aspp3_f32, mss_msda_prepare_backward_ld_f32, mss_rcl_pairs_device2_f32, mss_rcl_loss_device_f32, mss_m2f_fused_score_ws_f32, mss_oodm_compact_packed_f32,
+                                  mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32 */
 int mss_abi_version(void);
 
 /* The MSS_* environment switches (A/B experiments, test routes; none is needed in production) are read once per call site and
@@ -107,6 +108,16 @@ int mss_msda_prepare_backward_f32(const float* attn_weight, const float* grad_at
 int mss_msda_prepare_backward_ld_f32(const float* attn_weight, const float* grad_attn, const float* grad_loc,
                                      const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P, float* grad_offsets,
                                      long long ld_offsets, float* grad_logits, long long ld_logits, void* stream);
+/* Forward side of the same idea (ops/modules/ms_deform_attn.py:98-101: `sampling_offsets(query)` and `attention_weights(query)`):
+ * offsets row (n, q) at + (n*Lq + q) * ld_offsets, logits likewise with ld_logits (0 = dense), so that both may be column ranges of
+ * the [N*Lq, M*3*L*P] output of ONE product query [Woff ; Watt]^T. Outputs of the prepare form stay dense. */
+int mss_msda_forward_fused_ld_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                  const float* offsets, long long ld_offsets, const float* logits, long long ld_logits,
+                                  const float* reference_points, int N, int S, int M, int D, int L, int Lq, int P, float* out,
+                                  void* stream);
+int mss_msda_prepare_ld_f32(const float* offsets, long long ld_offsets, const float* logits, long long ld_logits,
+                            const float* reference_points, const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P,
+                            float* sampling_loc, float* attn_weight, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * B2 -- DeepWV3Plus operator set (replaces the cuDNN/ATen ops under

@@ -42,7 +42,7 @@ template <int LPH, bool FUSED, bool BUF>
 __global__ __launch_bounds__(256) void msda_fwd_fast_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
     const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ ref, long long npairs, int S,
-    int M, int L, int Lq, int P, float* __restrict__ out) {
+    int M, int L, int Lq, int P, float* __restrict__ out, long long ldo, long long ldl) {
   constexpr int D = 4 * LPH;
   constexpr int HPW = 64 / LPH;  // pairs per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -55,12 +55,23 @@ __global__ __launch_bounds__(256) void msda_fwd_fast_kernel(
   if (pair0 >= npairs) return;  // whole wave leaves together (no block barrier below)
   const int npw = (int)min((long long)HPW, npairs - pair0);
 
-  // stage loc/attn of the wave's pairs (contiguous in memory)
-  {
-    const float* gl = loc + pair0 * LP * 2;
-    const float* ga = attn + pair0 * LP;
+  // stage loc/attn of the wave's pairs. ldo / ldl: floats between the rows of consecutive (n, q) -- M*2LP / M*LP when the two
+  // tensors are dense; r04: both projections' outputs side by side in ONE [N*Lq, M*3LP] buffer (a single 288-wide product).
+  // The wave's pairs are contiguous in memory when dense, and also when the wave holds exactly the M heads of one query.
+  if (M == HPW || (ldo == (long long)M * LP * 2 && ldl == (long long)M * LP)) {
+    const float* gl = M == HPW ? loc + pair0 / M * ldo : loc + pair0 * LP * 2;
+    const float* ga = M == HPW ? attn + pair0 / M * ldl : attn + pair0 * LP;
     for (int i = lane; i < npw * LP * 2; i += 64) sloc[i] = gl[i];
     for (int i = lane; i < npw * LP; i += 64) sattn[i] = ga[i];
+  } else {
+    for (int i = lane; i < npw * LP * 2; i += 64) {
+      const long long pr = pair0 + i / (LP * 2);
+      sloc[i] = loc[pr / M * ldo + (pr % M) * (LP * 2) + i % (LP * 2)];
+    }
+    for (int i = lane; i < npw * LP; i += 64) {
+      const long long pr = pair0 + i / LP;
+      sattn[i] = attn[pr / M * ldl + (pr % M) * LP + i % LP];
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -1182,15 +1193,26 @@ __global__ __launch_bounds__(256) void msda_bin_merge_kernel(MsdaBinGeom g, cons
 __global__ __launch_bounds__(256) void msda_prepare_kernel(const float* __restrict__ offsets, const float* __restrict__ logits,
                                                            const float* __restrict__ ref, const int64_t* __restrict__ shapes,
                                                            long long npairs, int M, int L, int P, float* __restrict__ loc,
-                                                           float* __restrict__ attn) {
+                                                           float* __restrict__ attn, long long ldo, long long ldl) {
   extern __shared__ float sm[];
   const int LP = L * P;
   float* sl = sm;                 // [256][LP]      logits -> attention weights
   float* so = sm + 256 * LP;      // [256][2 LP]    offsets -> locations
   const long long pair0 = (long long)blockIdx.x * 256;
   const int np = (int)min((long long)256, npairs - pair0);
-  for (int i = threadIdx.x; i < np * LP; i += 256) sl[i] = logits[pair0 * LP + i];
-  for (int i = threadIdx.x; i < np * LP * 2; i += 256) so[i] = offsets[pair0 * LP * 2 + i];
+  if (ldo == (long long)M * LP * 2 && ldl == (long long)M * LP) {
+    for (int i = threadIdx.x; i < np * LP; i += 256) sl[i] = logits[pair0 * LP + i];
+    for (int i = threadIdx.x; i < np * LP * 2; i += 256) so[i] = offsets[pair0 * LP * 2 + i];
+  } else {          // inputs are column ranges of a wider buffer (ldo / ldl floats per (n, q) row); outputs stay dense
+    for (int i = threadIdx.x; i < np * LP; i += 256) {
+      const long long pr = pair0 + i / LP;
+      sl[i] = logits[pr / M * ldl + (pr % M) * LP + i % LP];
+    }
+    for (int i = threadIdx.x; i < np * LP * 2; i += 256) {
+      const long long pr = pair0 + i / (LP * 2);
+      so[i] = offsets[pr / M * ldo + (pr % M) * (LP * 2) + i % (LP * 2)];
+    }
+  }
   __syncthreads();
   if ((int)threadIdx.x < np) {
     const long long nq = (pair0 + threadIdx.x) / M;
@@ -1278,16 +1300,18 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* starts, c
 template <int LPH>
 int msda_forward_fast(const float* value, const int64_t* shapes, const int64_t* starts, const float* loc,
                       const float* attn, const float* ref, int N, int S, int M, int L, int Lq, int P, float* out,
-                      hipStream_t stream) {
+                      hipStream_t stream, long long ldo = 0, long long ldl = 0) {
   constexpr int HPW = 64 / LPH;
   const long long npairs = (long long)N * Lq * M;
   const long long nblocks = (npairs + 4 * HPW - 1) / (4 * HPW);
+  if (ldo <= 0) ldo = (long long)M * L * P * 2;
+  if (ldl <= 0) ldl = (long long)M * L * P;
   const size_t smem = (size_t)4 * HPW * L * P * 3 * sizeof(float);
   // buffer-resource addressing (32-bit offsets, hardware zero fill) when the value tensor is below 4 GB; MSS_MSDA_BUF=0: A/B
   const bool buf = (unsigned long long)N * S * M * (4 * LPH) * 4ull < 0xffffffffull && MSS_ENV_INT("MSS_MSDA_BUF", 1) != 0;
 #define MSDA_LAUNCH(FUSED_, BUF_)                                                                                              \
   hipLaunchKernelGGL((msda_fwd_fast_kernel<LPH, FUSED_, BUF_>), dim3((unsigned)nblocks), dim3(256), smem, stream, value, shapes, \
-                     starts, loc, attn, ref, npairs, S, M, L, Lq, P, out)
+                     starts, loc, attn, ref, npairs, S, M, L, Lq, P, out, ldo, ldl)
   if (ref) { if (buf) MSDA_LAUNCH(true, true); else MSDA_LAUNCH(true, false); }
   else { if (buf) MSDA_LAUNCH(false, true); else MSDA_LAUNCH(false, false); }
 #undef MSDA_LAUNCH
@@ -1510,26 +1534,41 @@ int mss_msda_forward_f32(const float* value, const int64_t* spatial_shapes, cons
 }
 
 // forward straight from the module's raw projections (softmax + location arithmetic inside the sampling kernel); fp32,
-// head dimension 16 / 32 / 64 only -- MSS_ERR_UNSUPPORTED otherwise (the caller then runs prepare + forward)
-int mss_msda_forward_fused_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
-                               const float* offsets, const float* logits, const float* reference_points, int N, int S,
-                               int M, int D, int L, int Lq, int P, float* out, void* stream) {
+// head dimension 16 / 32 / 64 only -- MSS_ERR_UNSUPPORTED otherwise (the caller then runs prepare + forward).
+// ld_offsets / ld_logits: floats between the rows of consecutive (n, q) of `offsets` [N,Lq,M,L,P,2] / `logits` [N,Lq,M,L,P];
+// 0 = dense. With both > dense the two tensors may be column ranges of ONE [N*Lq, M*3*L*P] buffer, i.e. the output of a single
+// product q [Woff ; Watt]^T (ops/modules/ms_deform_attn.py:98-101 are two Linears on the same query).
+int mss_msda_forward_fused_ld_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                  const float* offsets, long long ld_offsets, const float* logits, long long ld_logits,
+                                  const float* reference_points, int N, int S, int M, int D, int L, int Lq, int P, float* out,
+                                  void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = msda_check(value, spatial_shapes, level_start_index, offsets, logits, N, S, M, D, L, Lq, P);
   if (rc) return rc;
   if ((long long)N * Lq * M == 0) return MSS_OK;
   if (!out || !reference_points) return MSS_ERR_BAD_ARG;
+  if ((ld_offsets && ld_offsets < (long long)M * 2 * L * P) || (ld_logits && ld_logits < (long long)M * L * P)) return MSS_ERR_BAD_ARG;
   if (L * P > 20) return MSS_ERR_UNSUPPORTED;           // per-lane sample slots of the in-LDS softmax (as mss_msda_prepare_f32)
   const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   const size_t smem_per_lp = (size_t)4 * 3 * sizeof(float) * L * P;
   if (!aligned) return MSS_ERR_UNSUPPORTED;
   if (D == 32 && smem_per_lp * 8 <= 65536)
-    return msda_forward_fast<8>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s);
+    return msda_forward_fast<8>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s,
+                                ld_offsets, ld_logits);
   if (D == 16 && smem_per_lp * 16 <= 65536)
-    return msda_forward_fast<4>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s);
+    return msda_forward_fast<4>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s,
+                                ld_offsets, ld_logits);
   if (D == 64 && smem_per_lp * 4 <= 65536)
-    return msda_forward_fast<16>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s);
+    return msda_forward_fast<16>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s,
+                                 ld_offsets, ld_logits);
   return MSS_ERR_UNSUPPORTED;
+}
+
+int mss_msda_forward_fused_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                               const float* offsets, const float* logits, const float* reference_points, int N, int S,
+                               int M, int D, int L, int Lq, int P, float* out, void* stream) {
+  return mss_msda_forward_fused_ld_f32(value, spatial_shapes, level_start_index, offsets, 0, logits, 0, reference_points, N, S, M, D,
+                                       L, Lq, P, out, stream);
 }
 
 // forward through LDS windows (msda_fwd_window_kernel): `host_shapes` is a HOST copy of spatial_shapes [L][2]; reference_points
@@ -1588,17 +1627,28 @@ int mss_msda_backward_binned_f32(const float* value, const int64_t* spatial_shap
                               static_cast<hipStream_t>(stream));
 }
 
-int mss_msda_prepare_f32(const float* offsets, const float* logits, const float* reference_points,
-                         const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P, float* sampling_loc,
-                         float* attn_weight, void* stream) {
+int mss_msda_prepare_ld_f32(const float* offsets, long long ld_offsets, const float* logits, long long ld_logits,
+                            const float* reference_points, const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P,
+                            float* sampling_loc, float* attn_weight, void* stream) {
   if (N < 0 || Lq < 0 || M <= 0 || L <= 0 || P <= 0 || L * P > MSDA_MAX_LP) return MSS_ERR_UNSUPPORTED;
   const long long npairs = (long long)N * Lq * M;
   if (npairs == 0) return MSS_OK;
   if (!offsets || !logits || !reference_points || !spatial_shapes || !sampling_loc || !attn_weight) return MSS_ERR_BAD_ARG;
+  if (ld_offsets <= 0) ld_offsets = (long long)M * 2 * L * P;
+  if (ld_logits <= 0) ld_logits = (long long)M * L * P;
+  if (ld_offsets < (long long)M * 2 * L * P || ld_logits < (long long)M * L * P) return MSS_ERR_BAD_ARG;
   hipLaunchKernelGGL(msda_prepare_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), (size_t)256 * 3 * L * P * sizeof(float),
                      static_cast<hipStream_t>(stream),
-                     offsets, logits, reference_points, spatial_shapes, npairs, M, L, P, sampling_loc, attn_weight);
+                     offsets, logits, reference_points, spatial_shapes, npairs, M, L, P, sampling_loc, attn_weight, ld_offsets,
+                     ld_logits);
   return mss_launch_status();
+}
+
+int mss_msda_prepare_f32(const float* offsets, const float* logits, const float* reference_points,
+                         const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P, float* sampling_loc,
+                         float* attn_weight, void* stream) {
+  return mss_msda_prepare_ld_f32(offsets, 0, logits, 0, reference_points, spatial_shapes, N, Lq, M, L, P, sampling_loc, attn_weight,
+                                 stream);
 }
 
 int mss_msda_prepare_backward_ld_f32(const float* attn_weight, const float* grad_attn, const float* grad_loc,

@@ -37,15 +37,30 @@ def _gemm(x, weight, bias=None, relu=False, res=None, res_mask=False, flip=False
     return out
 
 
-def _packed_pair_flip(w1, w2):
-    """The data-gradient pack of the row-concatenation [w1; w2] (two Linears on the same input): cached on w1 until either
-    parameter changes (optimizer step: tensor._version; moved: data_ptr)."""
+def _packed_pair(w1, w2, flip):
+    """The forward (flip=False) or data-gradient (flip=True) pack of the row-concatenation [w1; w2] (two Linears on the same
+    input): cached on w1 until either parameter changes (optimizer step: tensor._version; moved: data_ptr)."""
     key = (w1._version, w1.data_ptr(), w2._version, w2.data_ptr())
     cache = w1.__dict__.setdefault("_mss_packed", {})
-    ent = cache.get("pair_flip")
+    name = "pair_flip" if flip else "pair"
+    ent = cache.get(name)
     if ent is None or ent[0] != key:
         w = torch.cat((w1.detach(), w2.detach()), 0)
-        ent = cache["pair_flip"] = (key, K.pack_weight(w.view(w.shape[0], w.shape[1], 1, 1), flip=True))
+        ent = cache[name] = (key, K.pack_weight(w.view(w.shape[0], w.shape[1], 1, 1), flip=flip))
+    return ent[1]
+
+
+def _packed_pair_flip(w1, w2):
+    return _packed_pair(w1, w2, True)
+
+
+def _bias_pair(b1, b2):
+    """[b1; b2] as one epilogue bias vector, cached like the packed weights."""
+    key = (b1._version, b1.data_ptr(), b2._version, b2.data_ptr())
+    cache = b1.__dict__.setdefault("_mss_packed", {})
+    ent = cache.get("bias_pair")
+    if ent is None or ent[0] != key:
+        ent = cache["bias_pair"] = (key, torch.cat((b1.detach(), b2.detach()), 0))
     return ent[1]
 
 
@@ -110,12 +125,17 @@ class _EncoderLayerFn(Function):
         src = src.contiguous()
         q = src + pos
         value = _gemm(src, p["val_w"], p["val_b"])
-        offs = _gemm(q, p["off_w"], p["off_b"])
-        logits = _gemm(q, p["att_w"], p["att_b"])
+        # `sampling_offsets(q)` and `attention_weights(q)` (ops/modules/ms_deform_attn.py:98-101) as ONE product into a
+        # [N, S, 192 + 96] buffer whose two column ranges the sampler reads with a row stride (r04; the backward already did)
+        ko, ka = M * L * P * 2, M * L * P
+        ol = torch.empty((N, S, ko + ka), device=src.device, dtype=torch.float32)
+        bias = _bias_pair(p["off_b"], p["att_b"])
+        K.conv2d(_rows(q, C), _packed_pair(p["off_w"], p["att_w"], False), out_affine=(K.ones(ko + ka, bias.device), bias),
+                 out=_rows(ol, ko + ka))
         ref = ref.contiguous().float()
         samp = torch.empty((N, S, C), device=src.device, dtype=torch.float32)
-        call("mss_msda_forward_fused_f32", ptr(value), ptr(shapes), ptr(starts), ptr(offs), ptr(logits), ptr(ref),
-             N, S, M, D, L, S, P, ptr(samp))
+        call("mss_msda_forward_fused_ld_f32", ptr(value), ptr(shapes), ptr(starts), ptr(ol), ko + ka,
+             ctypes.c_void_p(ol.data_ptr() + 4 * ko), ko + ka, ptr(ref), N, S, M, D, L, S, P, ptr(samp))
         attn = _gemm(samp, p["out_w"], p["out_b"])
         s1, stat1 = _layernorm(src, attn, p["n1_w"], p["n1_b"], eps1)
         h = _gemm(s1, p["l1_w"], p["l1_b"], relu=True)
@@ -124,14 +144,14 @@ class _EncoderLayerFn(Function):
         ctx.geom = geom
         ctx.pos_batch = pos.shape[0]
         ctx.shapes_host = getattr(shapes, "_mss_host", None)
-        ctx.save_for_backward(src, q, ref, shapes, starts, value, offs, logits, samp, attn, stat1, s1, h, f, stat2, *params)
+        ctx.save_for_backward(src, q, ref, shapes, starts, value, ol, samp, attn, stat1, s1, h, f, stat2, *params)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
-        src, q, ref, shapes, starts, value, offs, logits, samp, attn, stat1, s1, h, f, stat2 = ctx.saved_tensors[:15]
-        p = dict(zip(_PARAMS, ctx.saved_tensors[15:]))
+        src, q, ref, shapes, starts, value, ol, samp, attn, stat1, s1, h, f, stat2 = ctx.saved_tensors[:14]
+        p = dict(zip(_PARAMS, ctx.saved_tensors[14:]))
         need = dict(zip(("src", "pos") + (None,) * 4 + _PARAMS, ctx.needs_input_grad))
         M, L, P, _, _ = ctx.geom
         N, S, C = src.shape
@@ -160,16 +180,16 @@ class _EncoderLayerFn(Function):
             g["out_w"] = _wgrad(samp, g1, p["out_w"])
         dsamp = _gemm(g1, p["out_w"], flip=True)
         # ---- the sampling op: locations / weights rebuilt by the one-pass prepare kernel (bit-identical to the forward's)
-        offs6 = offs.view(N, S, M, L, P, 2)
-        loc = torch.empty_like(offs6)
+        ko, ka = M * L * P * 2, M * L * P
+        loc = torch.empty((N, S, M, L, P, 2), device=src.device, dtype=torch.float32)
         aw = torch.empty((N, S, M, L, P), device=src.device, dtype=torch.float32)
-        call("mss_msda_prepare_f32", ptr(offs6), ptr(logits), ptr(ref), ptr(shapes), N, S, M, L, P, ptr(loc), ptr(aw))
+        call("mss_msda_prepare_ld_f32", ptr(ol), ko + ka, ctypes.c_void_p(ol.data_ptr() + 4 * ko), ko + ka, ptr(ref), ptr(shapes),
+             N, S, M, L, P, ptr(loc), ptr(aw))
         gvalue, gloc, gaw = MSDA.ms_deform_attn_backward(value.view(N, S, M, D), shapes, starts, loc, aw, dsamp, 128)
         del dsamp, loc
         # `sampling_offsets` and `attention_weights` are two Linears on the SAME q: their output gradients go side by side into one
         # [N, S, 192 + 96] buffer, so the weight gradient, the bias gradient and the data gradient are one product each (r04:
         # the narrow 192- / 96-wide products ran at 71 / 59 TFLOP/s for the weight and 119 / 73 for the data gradient)
-        ko, ka = M * L * P * 2, M * L * P
         gol = torch.empty((N, S, ko + ka), device=src.device, dtype=torch.float32)
         call("mss_msda_prepare_backward_ld_f32", ptr(aw), ptr(gaw), ptr(gloc), ptr(shapes), N, S, M, L, P, ptr(gol), ko + ka,
              ctypes.c_void_p(gol.data_ptr() + 4 * ko), ko + ka)

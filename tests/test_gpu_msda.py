@@ -368,6 +368,47 @@ def test_fused_sampling_equals_prepare_then_sample(N, Lq, M, D, shapes, P):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6, msg=name)
 
 
+@pytest.mark.parametrize("N,Lq,M,D,shapes,P,pad", [(2, 300, 8, 32, [(22, 22), (44, 44), (88, 88)], 4, 0), (1, 77, 4, 16, [(9, 13), (5, 6)], 2, 8),
+                                                  (3, 50, 2, 64, [(12, 10)], 4, 4), (1, 1, 8, 32, [(3, 3)], 1, 0)])
+def test_strided_projection_buffer_is_bitwise_the_dense_tensors(N, Lq, M, D, shapes, P, pad):
+    """r04: offsets and logits as column ranges of ONE [N*Lq, M*3*L*P (+ pad)] buffer (the output of a single product
+    q [Woff ; Watt]^T, ops/modules/ms_deform_attn.py:98-101) through mss_msda_forward_fused_ld_f32 / mss_msda_prepare_ld_f32:
+    the same bits as the dense tensors through the entry points without strides; strides below the dense ones are refused."""
+    from multishiftseg_amd._lib import call, ptr
+    from multishiftseg_amd import _lib
+    import ctypes
+    torch.manual_seed(Lq + D + pad)
+    L = len(shapes)
+    shp = torch.as_tensor(shapes, dtype=torch.long, device="cuda")
+    starts = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    S = int(shp.prod(1).sum())
+    value = torch.randn(N, S, M, D, device="cuda")
+    off = torch.randn(N, Lq, M, L, P, 2, device="cuda") * 4
+    lg = torch.randn(N, Lq, M, L * P, device="cuda") * 2
+    ref = torch.rand(N, Lq, L, 2, device="cuda") * 1.2 - 0.1
+    ko, ka = M * L * P * 2, M * L * P
+    ld = ko + ka + pad
+    both = torch.full((N, Lq, ld), float("nan"), device="cuda")
+    both[..., :ko] = off.view(N, Lq, ko)
+    both[..., ko:ko + ka] = lg.view(N, Lq, ka)
+    plog = ctypes.c_void_p(both.data_ptr() + 4 * ko)
+    out_d, out_s = torch.empty(N, Lq, M * D, device="cuda"), torch.empty(N, Lq, M * D, device="cuda")
+    call("mss_msda_forward_fused_f32", ptr(value), ptr(shp), ptr(starts), ptr(off), ptr(lg), ptr(ref), N, S, M, D, L, Lq, P, ptr(out_d))
+    call("mss_msda_forward_fused_ld_f32", ptr(value), ptr(shp), ptr(starts), ptr(both), ld, plog, ld, ptr(ref), N, S, M, D, L, Lq, P,
+         ptr(out_s))
+    assert torch.equal(out_d, out_s)
+    loc_d, aw_d = torch.empty_like(off), torch.empty(N, Lq, M, L, P, device="cuda")
+    loc_s, aw_s = torch.empty_like(off), torch.empty(N, Lq, M, L, P, device="cuda")
+    call("mss_msda_prepare_f32", ptr(off), ptr(lg), ptr(ref), ptr(shp), N, Lq, M, L, P, ptr(loc_d), ptr(aw_d))
+    call("mss_msda_prepare_ld_f32", ptr(both), ld, plog, ld, ptr(ref), ptr(shp), N, Lq, M, L, P, ptr(loc_s), ptr(aw_s))
+    assert torch.equal(loc_d, loc_s) and torch.equal(aw_d, aw_s)
+    with pytest.raises(RuntimeError):
+        call("mss_msda_prepare_ld_f32", ptr(both), ko - 1, plog, ld, ptr(ref), ptr(shp), N, Lq, M, L, P, ptr(loc_s), ptr(aw_s))
+    with pytest.raises(RuntimeError):
+        call("mss_msda_forward_fused_ld_f32", ptr(value), ptr(shp), ptr(starts), ptr(both), ld, plog, ka - 1, ptr(ref), N, S, M, D, L, Lq,
+             P, ptr(out_s))
+
+
 def test_module_golden_unfused_route(monkeypatch):
     """The reference module's output through prepare -> sample (MSS_MSDA_FUSED=0); test_module_golden covers the fused default."""
     monkeypatch.setenv("MSS_MSDA_FUSED", "0")
