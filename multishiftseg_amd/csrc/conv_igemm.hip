@@ -1013,19 +1013,37 @@ template <int KB>
 __global__ __launch_bounds__(256, KB == 4 ? 1 : 2) void gemm_tn_direct_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                 float* __restrict__ out, int P, int M, int K, int C, long long a_bs,
                                                                 long long b_bs, int Kpad, int Cp, int ktiles, int ctiles, int splits,
-                                                                int tps, long long total) {
+                                                                int tps, long long total, long long full, float* __restrict__ tail_ws) {
   typedef typename std::conditional<KB == 4, f32x4, f32x2>::type avec;
   constexpr int TND = KB == 4 ? 8 : 5;                         // row pairs per register block (two blocks: one consumed, one in flight)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long job = (long long)blockIdx.x * 4 + wave;
   if (job >= total) return;                                   // no barrier anywhere in this kernel
+  // Two job layouts. full < 0: every (position, tile) is cut into `splits` row ranges (slab per split in `out`, reduced afterwards).
+  // full >= 0 (TAIL plan, r04: more tiles than wave slots and not a multiple of them -- 36 x 2 x 32 = 2304 tiles on 1024 SIMDs are
+  // 2.25 rounds): the first `full` jobs are whole tiles written straight to the result; the remaining tiles are cut into `splits`
+  // row ranges each, so that the last round is 1/splits as long; their partial tiles go to tail_ws [split][tail tile][128][128].
   long long t = job;
+  int sp = 0, nsp = 1;
+  long long tail_tile = -1;
+  if (full >= 0) {
+    if (job >= full) {
+      const long long ntail = (total - full) / splits;
+      sp = (int)((job - full) / ntail);
+      tail_tile = (job - full) - (long long)sp * ntail;
+      t = full + tail_tile;
+      nsp = splits;
+    }
+  } else {
+    nsp = splits;
+  }
   const int ct = (int)(t % ctiles); t /= ctiles;
   const int kt = (int)(t % ktiles); t /= ktiles;
-  const int sp = (int)(t % splits);
-  const int pb = (int)(t / splits);
+  int pb;
+  if (full >= 0) pb = (int)t;
+  else { sp = (int)(t % splits); pb = (int)(t / splits); }
   const int half = lane >> 5, j = lane & 31;
-  const int r0 = sp * tps, r1 = r0 + tps < M ? r0 + tps : M;
+  const int r0 = nsp > 1 ? sp * tps : 0, r1 = nsp > 1 ? (r0 + tps < M ? r0 + tps : M) : M;
   const float* a = A + (size_t)pb * a_bs + (size_t)(kt * (32 * KB) + KB * j);
   const float* b = B + (size_t)pb * b_bs + (size_t)(ct * 128 + 4 * j);
   f32x16 acc[KB][4];
@@ -1078,20 +1096,47 @@ __global__ __launch_bounds__(256, KB == 4 ? 1 : 2) void gemm_tn_direct_kernel(co
     compute(a1, b1);
     __builtin_amdgcn_sched_barrier(0);
   }
-  float* o = out + ((size_t)sp * P + pb) * Kpad * Cp + (size_t)(ct * 128 + 4 * j);
+  float* o;
+  size_t ostride;
+  if (tail_tile >= 0) {          // partial tile of the tail plan: compact [128][128]
+    const long long ntail = (total - full) / splits;
+    o = tail_ws + ((size_t)sp * ntail + tail_tile) * (128 * 128) + (size_t)(4 * j);
+    ostride = 128;
+  } else {
+    o = out + ((size_t)(full >= 0 ? 0 : sp) * P + pb) * Kpad * Cp + (size_t)(kt * (32 * KB)) * Cp + (size_t)(ct * 128 + 4 * j);
+    ostride = Cp;
+  }
 #pragma unroll
   for (int i = 0; i < KB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
       const f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-      *reinterpret_cast<f32x4*>(o + (size_t)(kt * (32 * KB) + KB * m + i) * Cp) = v;
+      *reinterpret_cast<f32x4*>(o + (size_t)(KB * m + i) * ostride) = v;
     }
 }
 
+// tail plan: result tile = sum over splits (ascending) of its partial tiles; one workgroup per (tail tile, 16 rows)
+__global__ __launch_bounds__(256) void tn_tail_reduce_kernel(const float* __restrict__ tail_ws, float* __restrict__ dwp, long long full,
+                                                             long long ntail, int splits, int ktiles, int ctiles, int Kpad, int Cp) {
+  const long long ti = blockIdx.x / 16;
+  const int part = blockIdx.x % 16;
+  long long t = full + ti;
+  const int ct = (int)(t % ctiles); t /= ctiles;
+  const int kt = (int)(t % ktiles); t /= ktiles;
+  const int pb = (int)t;
+  const int e = part * 1024 + threadIdx.x * 4;                       // element of the 128 x 128 tile (4 consecutive columns)
+  const int row = e >> 7, col = e & 127;
+  const float* src = tail_ws + (size_t)ti * (128 * 128) + e;
+  f32x4 a = *reinterpret_cast<const f32x4*>(src);
+  for (int sp = 1; sp < splits; ++sp) a += *reinterpret_cast<const f32x4*>(src + (size_t)sp * ntail * (128 * 128));
+  *reinterpret_cast<f32x4*>(dwp + (size_t)pb * Kpad * Cp + (size_t)(kt * 128 + row) * Cp + ct * 128 + col) = a;
+}
+
 // ---- the TN route of the batched (Winograd-domain) weight gradient ----
-struct TnPlan { int ktiles, ctiles, splits, tps; long long total; };
+struct TnPlan { int ktiles, ctiles, splits, tps; long long total; long long full = -1; };   // full >= 0: the tail plan of gemm_tn_direct_kernel
 inline int tn_batch(const MssConvArgs& p) { return p.batch > 1 ? p.batch : 1; }
+inline long long tn_tail_bytes(const TnPlan& pl) { return pl.full >= 0 ? (pl.total - pl.full) * (128ll * 128 * 4) : 0; }
 inline bool tn_eligible(const MssConvArgs& p, int lddy) {
   const bool off = MSS_ENV_INT("MSS_WGRAD_TN", 5) == 0;     // A/B switch
   if (off || p.R * p.S != 1 || p.in_scale || p.in_relu || p.K % 4 || p.C % 4 || p.ldx != p.C || lddy != p.K) return false;
@@ -1166,6 +1211,22 @@ inline TnPlan tn_plan_direct(const MssConvArgs& p) {
   const long long base = (long long)tn_batch(p) * pl.ktiles * pl.ctiles;
   const int slots = tn_mode() == 6 ? 2048 : 1024;
   int max_splits = mss_cdiv(p.M, 256);
+  // more tiles than slots, and the last round mostly empty: whole tiles for the full rounds, the rest cut so that they fill one
+  // short round (the ASPP F(4x4) product: 2304 tiles = 2048 whole + 256 x 4 quarter jobs; only the 256 tail tiles are reduced)
+  if (tn_mode() != 6 && MSS_ENV_INT("MSS_WGRAD_TN_TAIL", 1) != 0 && base > slots && base % slots != 0 &&
+      (double)base / (double)(((base + slots - 1) / slots) * slots) < 0.95) {
+    const long long tail = base % slots;
+    int ts = (int)(slots / tail);
+    if (ts > max_splits) ts = max_splits;
+    if (ts > 16) ts = 16;
+    if (ts >= 2) {
+      pl.full = base - tail;
+      pl.tps = mss_cdiv(mss_cdiv(p.M, ts), 2) * 2;
+      pl.splits = mss_cdiv(p.M, pl.tps);
+      pl.total = pl.full + tail * pl.splits;
+      return pl;
+    }
+  }
   const int cap = p.batch > 1 ? 64 : 256;
   if (max_splits > cap) max_splits = cap;
   if (max_splits < 1) max_splits = 1;
@@ -1189,14 +1250,23 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
     const int P = tn_batch(p);
     const long long a_bs = p.batch > 1 ? p.y_bs : 0, b_bs = p.batch > 1 ? p.x_bs : 0;
     const long long slab = (long long)P * p.Kpad * Cp;
+    if (pl.full >= 0) {
+      const long long ntail = (pl.total - pl.full) / pl.splits;
+      if (!ws || ws_bytes < tn_tail_bytes(pl)) return MSS_ERR_BAD_ARG;
+      hipLaunchKernelGGL(gemm_tn_direct_kernel<4>, dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, dwp, P, p.M, p.K,
+                         p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, pl.full, ws);
+      hipLaunchKernelGGL(tn_tail_reduce_kernel, dim3((unsigned)(ntail * 16)), dim3(256), 0, stream, ws, dwp, pl.full, ntail, pl.splits,
+                         pl.ktiles, pl.ctiles, p.Kpad, Cp);
+      return mss_launch_status();
+    }
     if (pl.splits > 1 && (!ws || ws_bytes < (long long)pl.splits * slab * 4)) return MSS_ERR_BAD_ARG;
     float* out = pl.splits > 1 ? ws : dwp;
     if (tn_mode() == 6)
       hipLaunchKernelGGL(gemm_tn_direct_kernel<2>, dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, out, P, p.M, p.K,
-                         p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+                         p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, -1ll, (float*)nullptr);
     else
       hipLaunchKernelGGL(gemm_tn_direct_kernel<4>, dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, out, P, p.M, p.K,
-                         p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+                         p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, -1ll, (float*)nullptr);
     if (pl.splits > 1) {
       const long long slab4 = slab / 4;
       long long blocks = (slab4 + 255) / 256;
@@ -1325,7 +1395,7 @@ long long mss_conv2d_wgrad_workspace_bytes(const MssConvArgs* args, int Cp) {
   long long tn_bytes = 0;
   if (tn_eligible(p, p.K)) {                 // lddy == K is assumed here and checked again at launch
     const TnPlan pl = tn_plan_for(p);
-    tn_bytes = pl.splits > 1 ? (long long)pl.splits * tn_batch(p) * p.Kpad * Cp * 4 : 0;
+    tn_bytes = pl.full >= 0 ? tn_tail_bytes(pl) : pl.splits > 1 ? (long long)pl.splits * tn_batch(p) * p.Kpad * Cp * 4 : 0;
     if (p.batch > 1) return tn_bytes;        // Winograd-domain products always have lddy == K
   }
   // a plain 1x1 layer whose dy is a channel slice of a wider buffer falls back to conv_wgrad_kernel at launch: enough for both

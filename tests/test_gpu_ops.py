@@ -484,6 +484,42 @@ def test_batched_wgrad_routes_vs_float64(K, monkeypatch, mode, P, T, C, Ko):
     assert not torch.isnan(outs[0]).any()
 
 
+@pytest.mark.parametrize("P,T,C,Ko,tail", [(36, 1100, 4096, 256, "1"), (36, 1100, 4096, 256, "0"), (9, 777, 2048, 1024, "1"), (5, 300, 4096, 512, "1")])
+def test_direct_wgrad_tail_plan_vs_float64(K, monkeypatch, P, T, C, Ko, tail):
+    """r04: more output tiles than wave slots and a mostly empty last round (36 x 2 x 32 = 2304 tiles on 1024 SIMDs, the ASPP F(4x4)
+    product): gemm_tn_direct_kernel runs the whole rounds as unsplit tiles written straight to the result and cuts only the remaining
+    tiles into row ranges (MSS_WGRAD_TN_TAIL=0: every tile split, all slabs reduced). Both against a float64 product, twice with
+    identical bits, every element written."""
+    import ctypes
+    from multishiftseg_amd._lib import MssConvArgs, call, ptr
+    monkeypatch.setenv("MSS_WGRAD_TN", "7")
+    monkeypatch.setenv("MSS_WGRAD_TN_TAIL", tail)
+    torch.manual_seed(P * T + C)
+    xt = torch.randn(P, T, C, device="cuda")
+    dyt = torch.randn(P, T, Ko, device="cuda")
+    a = MssConvArgs()
+    a.x = ptr(xt)
+    a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
+    a.OH, a.OW, a.K, a.Kpad = 1, T, Ko, Ko
+    a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+    a.batch, a.x_bs, a.y_bs = P, T * C, T * Ko
+    outs = []
+    for _ in range(2):
+        du = torch.full((P, Ko, C), float("nan"), device="cuda")
+        ws, wsb = K._wgrad_workspace(a, C, "cuda")
+        if ws is not None:
+            ws.fill_(float("nan"))
+        call("mss_conv2d_wgrad_f32", ctypes.byref(a), ptr(dyt), Ko, ptr(du), C, ptr(ws), wsb)
+        outs.append(du)
+    assert torch.equal(outs[0], outs[1])
+    assert not torch.isnan(outs[0]).any()
+    err = 0.0
+    for p0 in range(0, P, 4):                      # float64 reference in slices (the whole einsum would take 2 x 36 x 1100 x 4096 x 8 B)
+        want = torch.einsum("ptk,ptc->pkc", dyt[p0:p0 + 4].double(), xt[p0:p0 + 4].double())
+        err = max(err, (outs[0][p0:p0 + 4].double() - want).abs().max().item())
+    assert err <= 2e-6 * T ** 0.5 * 16, err
+
+
 @pytest.mark.parametrize("n,h,w", [(1, 64, 128), (2, 37, 53), (1, 1, 1), (1, 2, 33), (3, 90, 150), (1, 70, 1000), (1, 33, 2048)])
 def test_fused_stem_conv_pool(K, n, h, w):
     """csrc/stem.hip: conv3x3(3 -> 64, padding 1) + MaxPool2d(3, 2, 1) in one kernel (wave per pooled row, MFMA from registers,

@@ -73,11 +73,30 @@ def msda_leg(N, shapes):
     fwd_b = 4 * (N * S * 256 + 3 * N * S * 8 * 12 + N * S * 256)
     bwd_b = 4 * (N * S * 256 + 3 * N * S * 8 * 12 + N * S * 256 + 2 * N * S * 256 + 3 * N * S * 8 * 12)
     gather = N * S * 8 * 48 * 128
+    # rows the kernel really fetches per (query, head): corners outside the image cost no memory access (out-of-range buffer offset)
+    # and samples of one level may share rows -- counted exactly on image 0 ("report unique rows")
+    with torch.no_grad():
+        ids = []
+        for l, (h, w) in enumerate(shapes):
+            x, y = t["loc"][0, :, :, l, :, 0] * w - 0.5, t["loc"][0, :, :, l, :, 1] * h - 0.5
+            x0, y0 = torch.floor(x).long(), torch.floor(y).long()
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    xx, yy = x0 + dx, y0 + dy
+                    ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+                    ids.append(torch.where(ok, int(t["starts"][l]) + yy * w + xx, torch.full_like(xx, -1)))
+        ids = torch.cat(ids, -1).sort(-1).values                               # [S, 8, 48]
+        distinct = (ids[..., 1:] != ids[..., :-1]).sum(-1) + 1 - (ids[..., 0] < 0).long()   # the -1 group (if any) is not a row
+        rows = float(distinct.float().mean())
+    gather_u = N * S * 8 * rows * 128
     return {"N": N, "tokens": S, "forward_ms": round(f, 4), "fused_forward_ms": round(ff, 4), "backward_ms": round(b, 4),
             "forward_compulsory_MB": round(fwd_b / 1e6, 1), "forward_GBs": round(fwd_b / f / 1e6, 1),
             "forward_frac_of_hbm_peak": round(fwd_b / f / 1e6 / HBM_PEAK_GBS, 4),
             "forward_L2_row_gather_GBs": round(gather / f / 1e6, 1),
             "forward_frac_of_L2_gather_ceiling": round(gather / f / 1e6 / L2_GATHER_GBS, 3),
+            "forward_unique_rows_per_query_head": round(rows, 2),
+            "forward_L2_unique_row_gather_GBs": round(gather_u / f / 1e6, 1),
+            "forward_frac_of_L2_gather_ceiling_unique_rows": round(gather_u / f / 1e6 / L2_GATHER_GBS, 3),
             "backward_algorithmic_MB": round(bwd_b / 1e6, 1), "backward_GBs": round(bwd_b / b / 1e6, 1),
             "backward_frac_of_hbm_peak": round(bwd_b / b / 1e6 / HBM_PEAK_GBS, 4)}
 
@@ -176,7 +195,7 @@ def metric_leg(images=64, h=1024, w=2048):
 def measure():
     out = {"msda": {"c4_n1": msda_leg(1, C4), "c4_n16": msda_leg(16, C4), "c5_n1": msda_leg(1, C5),
                     "roofline_note": "HBM bound on the compulsory bytes of SURVEY 8(d) (8 TB/s); the forward is a row gather served "
-                                     "by L2 (48 x 128 B per (query, head)), its rate is forward_L2_row_gather_GBs; the chip's measured ceiling "
+                                     "by L2 (48 x 128 B per (query, head)), its rate is forward_L2_row_gather_GBs (forward_L2_unique_row_gather_GBs counts only the distinct in-image rows of a (query, head), measured on image 0); the chip's measured ceiling "
                                      "for L2-resident row gathers is 16.8-18.8 TB/s (MI355X_MICROARCH.md, Indexed rows): forward_frac_of_L2_gather_ceiling"},
            "pixel_decoder_forward_features": decoder_leg(), "fused_score": fused_score_leg(), "metric_sweep": metric_leg()}
     torch.cuda.empty_cache()
