@@ -939,6 +939,61 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// The same sum when there are MANY splits of a SMALL slab (the narrow head gradients: 1536 splits of 20 KB; a Linear of the pixel
+// decoder: 256 splits of 256 KB): one thread per output float4 walks the splits one dependent load chain after the other
+// (1536 / 8 round trips = 90 us for 30 MB). Here G threads share an output element: thread g adds the splits g, g + G, g + 2G, ...
+// in ascending order, and the G partial sums are added in the order g = 0 .. G-1 through LDS -- a fixed tree, so the result is as
+// reproducible as the sequential sum (it is a different rounding of the same sum).
+template <int G>
+__global__ __launch_bounds__(256) void wgrad_reduce_par_kernel(const float* __restrict__ ws, float* __restrict__ dwp, long long slab4,
+                                                               int splits) {
+  constexpr int EPB = 256 / G;                       // output float4s per workgroup
+  __shared__ f32x4 part[G][EPB];
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(ws);
+  const int el = threadIdx.x % EPB, g = threadIdx.x / EPB;
+  const long long i = (long long)blockIdx.x * EPB + el;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (i < slab4) {
+    int sp = g;
+    for (; sp + 3 * G < splits; sp += 4 * G) {       // four loads in flight, added in ascending split order
+      const f32x4 v0 = w4[(long long)sp * slab4 + i], v1 = w4[(long long)(sp + G) * slab4 + i];
+      const f32x4 v2 = w4[(long long)(sp + 2 * G) * slab4 + i], v3 = w4[(long long)(sp + 3 * G) * slab4 + i];
+      a += v0; a += v1; a += v2; a += v3;
+    }
+    for (; sp < splits; sp += G) a += w4[(long long)sp * slab4 + i];
+  }
+  part[g][el] = a;
+  __syncthreads();
+  if (g == 0 && i < slab4) {
+    f32x4 t = part[0][el];
+#pragma unroll
+    for (int k = 1; k < G; ++k) t += part[k][el];
+    reinterpret_cast<f32x4*>(dwp)[i] = t;
+  }
+}
+
+inline void launch_wgrad_reduce(const float* ws, float* dwp, long long slab4, int splits, hipStream_t stream) {
+  // threads wanted: ~64 k; G split-lanes per element while each lane still has >= 4 splits
+  int G = 1;
+  while (G < 32 && slab4 * G < 65536 && splits >= 8 * G) G *= 2;
+  if (MSS_ENV_INT("MSS_WGRAD_REDUCE_PAR", 1) == 0) G = 1;
+  if (G == 1) {
+    long long blocks = (slab4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, ws, dwp, slab4, splits);
+    return;
+  }
+#define RED(G_) hipLaunchKernelGGL(wgrad_reduce_par_kernel<G_>, dim3((unsigned)((slab4 + 256 / G_ - 1) / (256 / G_))), dim3(256), 0, stream, ws, dwp, slab4, splits)
+  switch (G) {
+    case 2: RED(2); break;
+    case 4: RED(4); break;
+    case 8: RED(8); break;
+    case 16: RED(16); break;
+    default: RED(32); break;
+  }
+#undef RED
+}
+
 struct WgradPlan { int ktiles, ctiles, taps, splits, pps; };
 
 template <int BKO, int BCI, int BP>
@@ -986,10 +1041,7 @@ int launch_wgrad(MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, 
                      pl.splits > 1 ? ws : dwp, Cp, pl.pps);
   if (pl.splits > 1) {
     // every element of every partial slab was written (see the kernel's epilogue), so whole slabs are swept
-    const long long slab4 = slab / 4;
-    long long blocks = (slab4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, ws, dwp, slab4, pl.splits);
+    launch_wgrad_reduce(ws, dwp, slab / 4, pl.splits, stream);
   }
   return mss_launch_status();
 }
@@ -1133,6 +1185,148 @@ __global__ __launch_bounds__(256) void tn_tail_reduce_kernel(const float* __rest
   *reinterpret_cast<f32x4*>(dwp + (size_t)pb * Kpad * Cp + (size_t)(kt * 128 + row) * Cp + ct * 128 + col) = a;
 }
 
+// ---- narrow weight gradients (K <= 64 output channels: the 19-channel heads, bot_fine's 48) without LDS (r04) -----------------------
+// dW[k][c] = sum_r dy[r][k] * act(x[r][c]) with a handful of output channels is a STREAM over x (1.07 GB for the 256-channel head
+// input at 2 x 512 x 1024) with 2 K FLOP per element: conv_wgrad_kernel<32 / 64, 128, 16> stages 16 pixels at a time through LDS
+// and runs at 2.4-3.0 TB/s. Here, as in gemm_tn_direct_kernel, the operands go from global memory straight into the MFMA layout:
+// lane (j, half) loads KB2 floats of dy row r + half (columns KB2 * j ..; lanes past K read a row of zeros) and 16 bytes of x
+// (channels ct * 128 + 4 j ..), 4 * KB2 MFMAs per row pair, a wave owns a [32 * KB2] x 128 tile (64 / 128 accumulators), two or three
+// waves per SIMD keep >= 16 KB per wave in flight. The BatchNorm + ReLU prologue of the forward (deepv3.py:235-252) is applied to the
+// x registers at consume time. Partial tiles per row split in slabs, added in split order by wgrad_reduce_kernel: deterministic.
+__device__ float tn_zeros_rt[64];          // zero-initialised and never written; NOT const, so that the compiler keeps `cond ? row : zeros`
+                                           // a select of two addresses in front of ONE load (a const array of zeros folds to a branch around the load)
+template <int KB2, bool AFFINE>
+__global__ __launch_bounds__(256, 2) void gemm_tn_narrow_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                int relu, float* __restrict__ out, int M, int K, int Kpad, int Cp,
+                                                                int ctiles, int tps, long long total) {
+  typedef typename std::conditional<KB2 == 2, f32x2, float>::type avec;
+  constexpr int TND = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long job = (long long)blockIdx.x * 4 + wave;
+  if (job >= total) return;
+  const int ct = (int)(job % ctiles), sp = (int)(job / ctiles);
+  const int half = lane >> 5, j = lane & 31;
+  const int r0 = sp * tps, r1 = r0 + tps < M ? r0 + tps : M;
+  const bool a_ok = KB2 * j + KB2 - 1 < K;
+  const float* a = A + KB2 * j;
+  const float* b = B + (size_t)(ct * 128 + 4 * j);
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (AFFINE) {
+    if (scale) sc = *reinterpret_cast<const f32x4*>(scale + ct * 128 + 4 * j);
+    if (shift) sh = *reinterpret_cast<const f32x4*>(shift + ct * 128 + 4 * j);
+  }
+  const float fl = relu ? 0.f : -__builtin_huge_valf();
+  f32x16 acc[KB2][4];
+#pragma unroll
+  for (int i = 0; i < KB2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
+  avec a0[TND], a1[TND];
+  f32x4 b0[TND], b1[TND];
+  const int last = r1 - 1;
+  auto fetch = [&](int row, avec& va, f32x4& vb) {
+    const bool ok = row <= last;
+    const size_t rr = (size_t)(ok ? row : last);
+    va = *reinterpret_cast<const avec*>((ok && a_ok) ? a + rr * lda : tn_zeros_rt);
+    vb = *reinterpret_cast<const f32x4*>(b + rr * ldb);
+  };
+  auto compute = [&](const avec (&va)[TND], const f32x4 (&vb)[TND]) {
+#pragma unroll
+    for (int d = 0; d < TND; ++d) {
+      f32x4 cb = vb[d];
+      if (AFFINE) {
+        cb = cb * sc + sh;
+        cb.x = fmaxf(cb.x, fl); cb.y = fmaxf(cb.y, fl); cb.z = fmaxf(cb.z, fl); cb.w = fmaxf(cb.w, fl);
+      }
+#pragma unroll
+      for (int i = 0; i < KB2; ++i) {
+        float ai;
+        if constexpr (KB2 == 2) ai = va[d][i]; else ai = va[d];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, cb[q], acc[i][q], 0, 0, 0);
+      }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < TND; ++d) fetch(r0 + 2 * d + half, a0[d], b0[d]);
+  for (int r = r0; r < r1; r += 4 * TND) {
+#pragma unroll
+    for (int d = 0; d < TND; ++d) fetch(r + 2 * TND + 2 * d + half, a1[d], b1[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < TND; ++d) fetch(r + 4 * TND + 2 * d + half, a0[d], b0[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float* o = out + (size_t)sp * Kpad * Cp + (size_t)(ct * 128 + 4 * j);
+#pragma unroll
+  for (int i = 0; i < KB2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = KB2 * ((r & 3) + 8 * (r >> 2) + 4 * half) + i;
+      const f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+      if (k < Kpad) *reinterpret_cast<f32x4*>(o + (size_t)k * Cp) = v;       // rows K .. Kpad-1: zeros (their A lanes read the zero row)
+    }
+}
+
+struct NarrowPlan { int ctiles, splits, tps; long long total; };
+inline bool narrow_shape_ok(const MssConvArgs& p, int Cp) {      // the part of the rule that needs no pointers (workspace query)
+  if (MSS_ENV_INT("MSS_WGRAD_NARROW", 1) == 0) return false;
+  if (p.R * p.S != 1 || p.stride != 1 || p.pad != 0 || p.batch > 1 || p.OH != p.H || p.OW != p.W) return false;
+  if (p.K > 64 || (p.K > 32 && p.K % 2) || p.C % 128 || Cp != p.C || p.ldx % 4) return false;
+  if ((p.in_scale || p.in_shift) && p.in_ss_stride != 0) return false;      // per-sample affines (Dropout2d folds): the LDS kernel
+  return p.M >= 16384;                                                     // below that the launch is all ramp
+}
+inline bool narrow_eligible(const MssConvArgs& p, const float* dy, int lddy, int Cp) {
+  if (!narrow_shape_ok(p, Cp)) return false;
+  if (p.K > 32 && (lddy % 2 || (reinterpret_cast<uintptr_t>(dy) & 7))) return false;
+  if (reinterpret_cast<uintptr_t>(p.x) & 15) return false;
+  if ((p.in_scale && (reinterpret_cast<uintptr_t>(p.in_scale) & 15)) || (p.in_shift && (reinterpret_cast<uintptr_t>(p.in_shift) & 15))) return false;
+  return true;
+}
+inline NarrowPlan narrow_plan(const MssConvArgs& p) {
+  NarrowPlan pl;
+  pl.ctiles = p.C / 128;
+  int splits = (p.K <= 32 ? 3072 : 2048) / pl.ctiles;   // one round of the resident waves: 3 per SIMD (166 registers), 2 for the 64-row tile (248)
+  const int max_splits = mss_cdiv(p.M, 512);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  pl.tps = mss_cdiv(mss_cdiv(p.M, splits), 2) * 2;
+  pl.splits = mss_cdiv(p.M, pl.tps);
+  pl.total = (long long)pl.ctiles * pl.splits;
+  return pl;
+}
+inline long long narrow_ws_bytes(const MssConvArgs& p, int Cp) {
+  if (!narrow_shape_ok(p, Cp)) return 0;
+  const NarrowPlan pl = narrow_plan(p);
+  return pl.splits > 1 ? (long long)pl.splits * p.Kpad * Cp * 4 : 0;
+}
+int launch_wgrad_narrow(const MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, float* ws, long long ws_bytes,
+                        hipStream_t stream) {
+  const NarrowPlan pl = narrow_plan(p);
+  const long long slab = (long long)p.Kpad * Cp;
+  if (pl.splits > 1 && (!ws || ws_bytes < (long long)pl.splits * slab * 4)) return MSS_ERR_BAD_ARG;
+  float* out = pl.splits > 1 ? ws : dwp;
+  const bool aff = p.in_scale || p.in_shift || p.in_relu;
+  const dim3 grid((unsigned)((pl.total + 3) / 4));
+#define NARROW(KB2_, AFF_)                                                                                                          \
+  hipLaunchKernelGGL((gemm_tn_narrow_kernel<KB2_, AFF_>), grid, dim3(256), 0, stream, dy, lddy, p.x, p.ldx, p.in_scale, p.in_shift,  \
+                     p.in_relu, out, p.M, p.K, p.Kpad, Cp, pl.ctiles, pl.tps, pl.total)
+  if (p.K <= 32) { if (aff) NARROW(1, true); else NARROW(1, false); }
+  else { if (aff) NARROW(2, true); else NARROW(2, false); }
+#undef NARROW
+  if (pl.splits > 1) {
+    launch_wgrad_reduce(ws, dwp, slab / 4, pl.splits, stream);
+  }
+  return mss_launch_status();
+}
+
 // ---- the TN route of the batched (Winograd-domain) weight gradient ----
 struct TnPlan { int ktiles, ctiles, splits, tps; long long total; long long full = -1; };   // full >= 0: the tail plan of gemm_tn_direct_kernel
 inline int tn_batch(const MssConvArgs& p) { return p.batch > 1 ? p.batch : 1; }
@@ -1268,10 +1462,7 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
       hipLaunchKernelGGL(gemm_tn_direct_kernel<4>, dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, out, P, p.M, p.K,
                          p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, -1ll, (float*)nullptr);
     if (pl.splits > 1) {
-      const long long slab4 = slab / 4;
-      long long blocks = (slab4 + 255) / 256;
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, ws, dwp, slab4, pl.splits);
+      launch_wgrad_reduce(ws, dwp, slab / 4, pl.splits, stream);
     }
     return mss_launch_status();
   }
@@ -1311,10 +1502,7 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
                          b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
   }
   if (pl.splits > 1) {
-    const long long slab4 = slab / 4;
-    long long blocks = (slab4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, ws, dwp, slab4, pl.splits);
+    launch_wgrad_reduce(ws, dwp, slab / 4, pl.splits, stream);
   }
   return mss_launch_status();
 }
@@ -1400,6 +1588,8 @@ long long mss_conv2d_wgrad_workspace_bytes(const MssConvArgs* args, int Cp) {
   }
   // a plain 1x1 layer whose dy is a channel slice of a wider buffer falls back to conv_wgrad_kernel at launch: enough for both
   long long cw;
+  const long long nb = narrow_ws_bytes(p, Cp);     // eligibility depends on pointers known only at launch: enough for either route
+  if (nb > tn_bytes) tn_bytes = nb;
   if (p.K <= 32) cw = wgrad_ws_bytes<32, 128, 16>(p, Cp);
   else if (p.K <= 64) cw = wgrad_ws_bytes<64, 128, 16>(p, Cp);
   else cw = wgrad_ws_bytes<128, 128, 16>(p, Cp);
@@ -1420,6 +1610,7 @@ int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dw
   if (p.batch > 1 && (p.R * p.S != 1 || p.batch > 65535)) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (tn_eligible(p, lddy)) return launch_wgrad_tn(p, dy, dwp, Cp, ws, ws_bytes, s);
+  if (narrow_eligible(p, dy, lddy, Cp)) return launch_wgrad_narrow(p, dy, lddy, dwp, Cp, ws, ws_bytes, s);
   // output-channel tile: 32 rows (1x4 waves) for the 19-channel heads, 64 for bot_fine's 48, else 128
   if (p.K <= 32) return launch_wgrad<32, 128, 16, 1>(p, dy, lddy, dwp, Cp, ws, ws_bytes, s);
   if (p.K <= 64) return launch_wgrad<64, 128, 16, 2>(p, dy, lddy, dwp, Cp, ws, ws_bytes, s);

@@ -484,6 +484,34 @@ def test_batched_wgrad_routes_vs_float64(K, monkeypatch, mode, P, T, C, Ko):
     assert not torch.isnan(outs[0]).any()
 
 
+@pytest.mark.parametrize("n,h,w,cin,k,ld,c0,affine", [(1, 128, 160, 256, 19, 48, 20, True), (2, 96, 100, 128, 48, 48, 0, False),
+                                                     (1, 130, 131, 256, 20, 20, 0, True), (1, 128, 129, 384, 34, 36, 0, True),
+                                                     (1, 128, 128, 128, 64, 64, 0, False), (1, 150, 120, 256, 19, 48, 0, False)])
+def test_narrow_wgrad_direct_kernel_vs_float64(K, monkeypatch, n, h, w, cin, k, ld, c0, affine):
+    """r04: weight gradients with <= 64 output channels (the 19-channel heads over a slice of the 48-wide gradient buffer, bot_fine's
+    48) on the LDS-free streaming kernel gemm_tn_narrow_kernel, with and without the BatchNorm + ReLU prologue on x, against the
+    LDS kernel (MSS_WGRAD_NARROW=0) and a float64 product; odd pixel counts; twice with identical bits."""
+    torch.manual_seed(h * w + k)
+    x = K.Act(torch.randn(n, h, w, cin, device="cuda"))
+    dybuf = torch.randn(n, h, w, ld, device="cuda")
+    dy = K.Act(dybuf, k, c0)
+    aff = (torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.3) if affine else None
+    outs = {}
+    for mode in ("1", "1", "0"):
+        monkeypatch.setenv("MSS_WGRAD_NARROW", mode)
+        outs.setdefault(mode, []).append(K.conv2d_wgrad(x, dy, k, cin, 1, 1, in_affine=aff, in_relu=affine))
+    assert torch.equal(outs["1"][0], outs["1"][1])
+    xa = x.buf.double().view(-1, cin)
+    if affine:
+        xa = torch.relu(xa * aff[0].double() + aff[1].double())
+    want = dybuf.double().view(-1, ld)[:, c0:c0 + k].t() @ xa
+    scale = want.abs().max().item()
+    e_new = (outs["1"][0].view(k, cin).double() - want).abs().max().item() / scale
+    e_old = (outs["0"][0].view(k, cin).double() - want).abs().max().item() / scale
+    assert e_new < 2e-6 and e_new < 4 * e_old + 1e-7, (e_new, e_old)
+    assert not torch.equal(outs["1"][0], outs["0"][0]) or True      # (different summation orders; equality is not required)
+
+
 @pytest.mark.parametrize("P,T,C,Ko,tail", [(36, 1100, 4096, 256, "1"), (36, 1100, 4096, 256, "0"), (9, 777, 2048, 1024, "1"), (5, 300, 4096, 512, "1")])
 def test_direct_wgrad_tail_plan_vs_float64(K, monkeypatch, P, T, C, Ko, tail):
     """r04: more output tiles than wave slots and a mostly empty last round (36 x 2 x 32 = 2304 tiles on 1024 SIMDs, the ASPP F(4x4)
