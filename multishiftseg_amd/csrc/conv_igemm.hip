@@ -1061,11 +1061,15 @@ __device__ const float tn_zero_row[4096] = {0.f};              // the A operand 
 // KB: 32-column blocks of dy per wave. 4: a 128 x 128 tile, 256 accumulator registers, ONE wave per SIMD. 2: a 64 x 128 tile, 128
 // accumulators, TWO waves per SIMD (the second wave fills the matrix pipe while the first issues its loads and address arithmetic)
 // at 1.5x the operand traffic per MFMA.
-template <int KB>
+// AFFINE: x enters as relu(x * scale[c] + shift[c]) (the forward's BatchNorm + ReLU prologue, one affine for all rows), applied to the
+// registers at consume time -- bot_aspp's 1280 -> 256 weight gradient (deepv3.py:235-240 reads the BN+ReLU of the five ASPP branches)
+template <int KB, bool AFFINE = false>
 __global__ __launch_bounds__(256, KB == 4 ? 1 : 2) void gemm_tn_direct_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                 float* __restrict__ out, int P, int M, int K, int C, long long a_bs,
                                                                 long long b_bs, int Kpad, int Cp, int ktiles, int ctiles, int splits,
-                                                                int tps, long long total, long long full, float* __restrict__ tail_ws) {
+                                                                int tps, long long total, long long full, float* __restrict__ tail_ws,
+                                                                const float* __restrict__ scale = nullptr,
+                                                                const float* __restrict__ shift = nullptr, int relu = 0) {
   typedef typename std::conditional<KB == 4, f32x4, f32x2>::type avec;
   constexpr int TND = KB == 4 ? 8 : 5;                         // row pairs per register block (two blocks: one consumed, one in flight)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1121,11 +1125,21 @@ __global__ __launch_bounds__(256, KB == 4 ? 1 : 2) void gemm_tn_direct_kernel(co
     va = *reinterpret_cast<const avec*>(ok ? a + rr * K : az);  // a row past the end contributes A = 0: the product is zero
     vb = *reinterpret_cast<const f32x4*>(b + rr * C);
   };
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (AFFINE) {
+    if (scale) sc = *reinterpret_cast<const f32x4*>(scale + ct * 128 + 4 * j);
+    if (shift) sh = *reinterpret_cast<const f32x4*>(shift + ct * 128 + 4 * j);
+  }
+  const float fl = relu ? 0.f : -__builtin_huge_valf();
   auto compute = [&](const avec (&va)[TND], const f32x4 (&vb)[TND]) {
 #pragma unroll
     for (int d = 0; d < TND; ++d) {
       const avec ca = va[d];
-      const f32x4 cb = vb[d];
+      f32x4 cb = vb[d];
+      if (AFFINE) {
+        cb = cb * sc + sh;
+        cb.x = fmaxf(cb.x, fl); cb.y = fmaxf(cb.y, fl); cb.z = fmaxf(cb.z, fl); cb.w = fmaxf(cb.w, fl);
+      }
 #pragma unroll
       for (int i = 0; i < KB; ++i)
 #pragma unroll
@@ -1331,9 +1345,15 @@ int launch_wgrad_narrow(const MssConvArgs& p, const float* dy, int lddy, float* 
 struct TnPlan { int ktiles, ctiles, splits, tps; long long total; long long full = -1; };   // full >= 0: the tail plan of gemm_tn_direct_kernel
 inline int tn_batch(const MssConvArgs& p) { return p.batch > 1 ? p.batch : 1; }
 inline long long tn_tail_bytes(const TnPlan& pl) { return pl.full >= 0 ? (pl.total - pl.full) * (128ll * 128 * 4) : 0; }
+inline bool tn_direct(const MssConvArgs& p);
 inline bool tn_eligible(const MssConvArgs& p, int lddy) {
   const bool off = MSS_ENV_INT("MSS_WGRAD_TN", 5) == 0;     // A/B switch
-  if (off || p.R * p.S != 1 || p.in_scale || p.in_relu || p.K % 4 || p.C % 4 || p.ldx != p.C || lddy != p.K) return false;
+  if (off || p.R * p.S != 1 || p.K % 4 || p.C % 4 || p.ldx != p.C || lddy != p.K) return false;
+  if (p.in_scale || p.in_shift || p.in_relu) {
+    // a prologue on x: only the LDS-free kernel applies one (a single affine for all rows, 16-byte aligned vectors), one position
+    if (p.batch > 1 || p.in_ss_stride != 0 || !tn_direct(p) || MSS_ENV_INT("MSS_WGRAD_TN_AFFINE", 1) == 0) return false;
+    if ((p.in_scale && (reinterpret_cast<uintptr_t>(p.in_scale) & 15)) || (p.in_shift && (reinterpret_cast<uintptr_t>(p.in_shift) & 15))) return false;
+  }
   if (p.batch > 1) return p.x_bs % 4 == 0 && p.y_bs % 4 == 0 && p.N == 1 && p.H == 1;   // Winograd-domain products
   // a plain 1x1 / stride-1 layer over dense rows (ASPP 4096 -> 256: 95 -> see DESIGN 3.3): the same GEMM with one position;
   // narrow outputs (<= 64 channels: bot_fine, the heads) keep conv_wgrad_kernel's 64- / 32-row tiles
@@ -1447,8 +1467,13 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
     if (pl.full >= 0) {
       const long long ntail = (pl.total - pl.full) / pl.splits;
       if (!ws || ws_bytes < tn_tail_bytes(pl)) return MSS_ERR_BAD_ARG;
-      hipLaunchKernelGGL(gemm_tn_direct_kernel<4>, dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, dwp, P, p.M, p.K,
-                         p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, pl.full, ws);
+      if (p.in_scale || p.in_shift || p.in_relu)
+        hipLaunchKernelGGL((gemm_tn_direct_kernel<4, true>), dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, dwp, P, p.M,
+                           p.K, p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, pl.full, ws, p.in_scale,
+                           p.in_shift, p.in_relu);
+      else
+        hipLaunchKernelGGL(gemm_tn_direct_kernel<4>, dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, dwp, P, p.M, p.K,
+                           p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, pl.full, ws);
       hipLaunchKernelGGL(tn_tail_reduce_kernel, dim3((unsigned)(ntail * 16)), dim3(256), 0, stream, ws, dwp, pl.full, ntail, pl.splits,
                          pl.ktiles, pl.ctiles, p.Kpad, Cp);
       return mss_launch_status();
@@ -1458,6 +1483,10 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
     if (tn_mode() == 6)
       hipLaunchKernelGGL(gemm_tn_direct_kernel<2>, dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, out, P, p.M, p.K,
                          p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, -1ll, (float*)nullptr);
+    else if (p.in_scale || p.in_shift || p.in_relu)
+      hipLaunchKernelGGL((gemm_tn_direct_kernel<4, true>), dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, out, P, p.M,
+                         p.K, p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, -1ll, (float*)nullptr,
+                         p.in_scale, p.in_shift, p.in_relu);
     else
       hipLaunchKernelGGL(gemm_tn_direct_kernel<4>, dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, out, P, p.M, p.K,
                          p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, -1ll, (float*)nullptr);

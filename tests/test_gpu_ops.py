@@ -512,6 +512,30 @@ def test_narrow_wgrad_direct_kernel_vs_float64(K, monkeypatch, n, h, w, cin, k, 
     assert not torch.equal(outs["1"][0], outs["0"][0]) or True      # (different summation orders; equality is not required)
 
 
+@pytest.mark.parametrize("n,h,w,cin,k,relu", [(2, 128, 256, 1280, 256, True), (1, 200, 333, 256, 128, True), (1, 128, 256, 512, 256, False)])
+def test_direct_wgrad_with_bn_relu_prologue_vs_float64(K, monkeypatch, n, h, w, cin, k, relu):
+    """r04: a 1x1 layer's weight gradient whose forward reads relu(x * scale + shift) (bot_aspp over the five ASPP branches'
+    BatchNorm + ReLU, deepv3.py:235-240) on the LDS-free kernel, the affine applied to the x registers at consume time, against
+    the LDS kernel (MSS_WGRAD_TN_AFFINE=0) and a float64 product; twice with identical bits."""
+    torch.manual_seed(h + w + cin)
+    x = K.Act(torch.randn(n, h, w, cin, device="cuda"))
+    dy = K.Act(torch.randn(n, h, w, k, device="cuda"))
+    aff = (torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.3)
+    outs = {}
+    for mode in ("1", "1", "0"):
+        monkeypatch.setenv("MSS_WGRAD_TN_AFFINE", mode)
+        outs.setdefault(mode, []).append(K.conv2d_wgrad(x, dy, k, cin, 1, 1, in_affine=aff, in_relu=relu))
+    assert torch.equal(outs["1"][0], outs["1"][1])
+    xa = x.buf.double().view(-1, cin) * aff[0].double() + aff[1].double()
+    if relu:
+        xa = torch.relu(xa)
+    want = dy.buf.double().view(-1, k).t() @ xa
+    scale = want.abs().max().item()
+    e_new = (outs["1"][0].view(k, cin).double() - want).abs().max().item() / scale
+    e_old = (outs["0"][0].view(k, cin).double() - want).abs().max().item() / scale
+    assert e_new < 2e-6 and e_new < 4 * e_old + 1e-7, (e_new, e_old)
+
+
 @pytest.mark.parametrize("P,T,C,Ko,tail", [(36, 1100, 4096, 256, "1"), (36, 1100, 4096, 256, "0"), (9, 777, 2048, 1024, "1"), (5, 300, 4096, 512, "1")])
 def test_direct_wgrad_tail_plan_vs_float64(K, monkeypatch, P, T, C, Ko, tail):
     """r04: more output tiles than wave slots and a mostly empty last round (36 x 2 x 32 = 2304 tiles on 1024 SIMDs, the ASPP F(4x4)
