@@ -198,6 +198,129 @@ __global__ __launch_bounds__(256) void msda_fwd_fast_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// forward, r04: per-sample RECORDS. In msda_fwd_fast_kernel every one of the LPH lanes that share a (query, head) repeats the
+// sample's location arithmetic (pixel coordinates, floor, four weights, four corner offsets with their in-image tests: ~20 of the
+// ~40 VALU instructions per sample; the kernel is VALU-issue-bound next to the L2 gather ceiling). Here the
+// lanes of a group split the L*P samples between them ONCE: lane j prepares samples j, j + LPH, ... -- it loads their raw values
+// itself (no LDS staging of loc / attn), for the fused form takes part in the group's softmax through shuffles, and leaves a
+// record in LDS: four byte offsets into the value tensor (out-of-image corners: an out-of-range offset, answered with zeros by
+// the buffer hardware), the four bilinear weights, the attention weight. The sampling loop then costs, per sample and lane, three
+// LDS reads (group-uniform addresses: broadcasts), four address adds and the 20 multiply-adds of the accumulation.
+// Arithmetic per output identical to msda_fwd_fast_kernel's (same expressions in the same order): bit-identical results.
+template <int LPH, bool FUSED>
+__global__ __launch_bounds__(256) void msda_fwd_rec_kernel(
+    const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
+    const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ ref, long long npairs, int S,
+    int M, int L, int Lq, int P, float* __restrict__ out, long long ldo, long long ldl, int LPpad) {
+  constexpr int D = 4 * LPH;
+  constexpr int HPW = 64 / LPH;  // pairs per wave
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LP = L * P;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // per wave: offsets [HPW][LPpad] x 4 words, weights [HPW][LPpad] x 4 words, attention [HPW][LPpad]; LPpad = L*P + 1 makes the
+  // pair stride 4 * LPpad words, which spreads the eight groups' 16-byte reads over distinct banks for L*P = 12
+  const int pstride = 4 * LPpad;
+  unsigned* soff = reinterpret_cast<unsigned*>(smem) + wave * (HPW * LPpad * 9);
+  float* swgt = reinterpret_cast<float*>(soff) + HPW * pstride;
+  float* satt = swgt + HPW * pstride;
+
+  const long long pair0 = ((long long)blockIdx.x * 4 + wave) * HPW;
+  if (pair0 >= npairs) return;  // whole wave leaves together (no block barrier below)
+  const int npw = (int)min((long long)HPW, npairs - pair0);
+  const int g = lane / LPH, j = lane % LPH;
+  const bool mine = g < npw;
+  const long long pair = pair0 + (mine ? g : 0);
+  const int m = (int)(pair % M);
+  const long long nq = pair / M;
+  const int n = (int)(nq / Lq);
+  const size_t row_stride = (size_t)M * D;
+  const unsigned rs4 = (unsigned)(row_stride * sizeof(float));
+  const unsigned pair_off = (unsigned)(((size_t)n * S * row_stride + (size_t)m * D) * sizeof(float));
+  const float* gl = loc + nq * ldo + (size_t)m * (LP * 2);
+  const float* ga = attn + nq * ldl + (size_t)m * LP;
+
+  // ---- softmax of the group's logits (fused form): lane j holds logits j, j + LPH, ...
+  constexpr int MAXI = (20 + LPH - 1) / LPH;          // L*P <= 20 in the fused form (checked by the launcher)
+  float inv = 1.f, mx = 0.f;
+  if (FUSED) {
+    mx = -__builtin_huge_valf();
+    float lg[MAXI];
+#pragma unroll
+    for (int t = 0; t < MAXI; ++t) {
+      const int i = j + t * LPH;
+      lg[t] = (mine && i < LP) ? ga[i] : -__builtin_huge_valf();
+      mx = fmaxf(mx, lg[t]);
+    }
+#pragma unroll
+    for (int o = LPH / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXI; ++t) {
+      const int i = j + t * LPH;
+      part += (mine && i < LP) ? expf(lg[t] - mx) : 0.f;
+    }
+    inv = 1.f / pair_reduce<float, LPH>(part);
+  }
+  // ---- records of this lane's samples
+  if (mine) {
+    for (int i = j; i < LP; i += LPH) {
+      const int l = i / P;
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      float lx = gl[2 * i], ly = gl[2 * i + 1], aw = ga[i];
+      if (FUSED) {
+        aw = expf(aw - mx) * inv;
+        lx = ref[(nq * L + l) * 2] + lx / (float)W;
+        ly = ref[(nq * L + l) * 2 + 1] + ly / (float)H;
+      }
+      const float w_im = lx * W - 0.5f, h_im = ly * H - 0.5f;
+      const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const int h0 = (int)hf, w0 = (int)wf;
+      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+      const bool okh0 = inside && h0 >= 0, okh1 = inside && h0 + 1 <= H - 1;
+      const bool okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
+      const unsigned o00 = pair_off + (unsigned)starts[l] * rs4 + (unsigned)(h0 * W + w0) * rs4;
+      const unsigned oob = 0xffffff00u;                    // + 16 * j stays out of range (host: the tensor is below that)
+      uint4 o;
+      o.x = (okh0 && okw0) ? o00 : oob;
+      o.y = (okh0 && okw1) ? o00 + rs4 : oob;
+      o.z = (okh1 && okw0) ? o00 + W * rs4 : oob;
+      o.w = (okh1 && okw1) ? o00 + W * rs4 + rs4 : oob;
+      *reinterpret_cast<uint4*>(soff + g * pstride + 4 * i) = o;
+      const f32x4 w = {hh * hw, hh * lw, lh * hw, lh * lw};
+      *reinterpret_cast<f32x4*>(swgt + g * pstride + 4 * i) = w;
+      satt[g * LPpad + i] = aw;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (!mine) return;
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(value), 0, (int)(unsigned)min((unsigned long long)npairs / M / Lq * S * row_stride * 4ull, 0xffffffffull),
+      0x00020000);
+  const unsigned j16 = 16u * (unsigned)j;
+  const unsigned* mo = soff + g * pstride;
+  const float* mw = swgt + g * pstride;
+  const float* ma = satt + g * LPpad;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int i = 0; i < LP; ++i) {
+    const uint4 o = *reinterpret_cast<const uint4*>(mo + 4 * i);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(mw + 4 * i);
+    const float aw = ma[i];
+    const f32x4 v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + j16, 0, 0));
+    const f32x4 v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + j16, 0, 0));
+    const f32x4 v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + j16, 0, 0));
+    const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + j16, 0, 0));
+    const f32x4 val = w.x * v1 + w.y * v2 + w.z * v3 + w.w * v4;
+    acc += aw * val;
+  }
+  *reinterpret_cast<f32x4*>(out + pair * D + 4 * j) = acc;
+}
+
+// ------------------------------------------------------------------------------------------
 // forward through LDS windows (fp32, D = 32). The fast kernel above sits on the L2 row-gather rate (48 x 128-B rows per
 // (query, head), 16-17 TB/s measured); in the encoder the queries are the pixels of the levels themselves and their
 // samples lie a few pixels around their own position, so neighbouring queries gather the same rows again and again.
@@ -1312,6 +1435,19 @@ int msda_forward_fast(const float* value, const int64_t* shapes, const int64_t* 
 #define MSDA_LAUNCH(FUSED_, BUF_)                                                                                              \
   hipLaunchKernelGGL((msda_fwd_fast_kernel<LPH, FUSED_, BUF_>), dim3((unsigned)nblocks), dim3(256), smem, stream, value, shapes, \
                      starts, loc, attn, ref, npairs, S, M, L, Lq, P, out, ldo, ldl)
+  // r04: per-sample records prepared once per (query, head) group (msda_fwd_rec_kernel); needs the buffer addressing and, for
+  // the 0xffffff00 out-of-range marker, a tensor below that size. MSS_MSDA_REC=0: the round-2/3 kernel (A/B, tests)
+  const size_t smem_rec = (size_t)4 * HPW * (L * P + 1) * 9 * sizeof(float);
+  if (buf && (unsigned long long)N * S * M * (4 * LPH) * 4ull < 0xffffff00ull && smem_rec <= 65536 &&
+      MSS_ENV_INT("MSS_MSDA_REC", 1) != 0) {
+    if (ref)
+      hipLaunchKernelGGL((msda_fwd_rec_kernel<LPH, true>), dim3((unsigned)nblocks), dim3(256), smem_rec, stream, value, shapes, starts, loc,
+                         attn, ref, npairs, S, M, L, Lq, P, out, ldo, ldl, L * P + 1);
+    else
+      hipLaunchKernelGGL((msda_fwd_rec_kernel<LPH, false>), dim3((unsigned)nblocks), dim3(256), smem_rec, stream, value, shapes, starts, loc,
+                         attn, ref, npairs, S, M, L, Lq, P, out, ldo, ldl, L * P + 1);
+    return mss_launch_status();
+  }
   if (ref) { if (buf) MSDA_LAUNCH(true, true); else MSDA_LAUNCH(true, false); }
   else { if (buf) MSDA_LAUNCH(false, true); else MSDA_LAUNCH(false, false); }
 #undef MSDA_LAUNCH
