@@ -31,7 +31,10 @@ LOSS_PARAMS = {"ce_weights": [50, 10], "conduct_pixel_selection": True, "selecti
                "inoutaug_contras_margins_tri": [10, 5, 5]}
 STAGE2 = ["aspp", "bot_fine", "bot_aspp", "ood_head"]
 ROUTES = {"winograd": {}, "direct3x3": {"MSS_WINOGRAD": "0"},
-          "igemm_only": {"MSS_WINOGRAD": "0", "MSS_GEMM": "0", "MSS_STEM_IM2COL": "0"}}
+          "igemm_only": {"MSS_WINOGRAD": "0", "MSS_GEMM": "0", "MSS_STEM_IM2COL": "0"},
+          # r04 (direct3x3 and igemm_only share K-order and MFMA instruction, i.e. the same bits): a THIRD 3x3
+          # algorithm -- every Winograd layer forced to F(2x2) (its own transform matrices, 16 products per tile, other GEMM shapes)
+          "winograd_f2": {"MSS_WINO_TILE": "2"}}
 # "winograd" is the policy's own mix (F(6x6) wherever it saves >= 5 % over F(4x4), else F(4x4) / F(2x2)); winograd_f4 keeps
 # the policy off the 6x6 tiles so that the F(4x4) kernels stay pinned by the same fixtures. The experimental
 # fp32-on-bf16-matrix-cores GEMM has to pass the same reference fixtures to be reported at all
@@ -292,7 +295,8 @@ def _stage2_step(m, img, target, masks, seed):
 def test_three_routes_agree_at_bench_size(deeplab_params, tag, pairs, h, w):
     """The configurations bench.py measures (c2 both as exps/DeepLab.yaml crops it, 700^2, and as BASELINE words it,
     768^2). Same weights, inputs, Dropout2d masks and device-side pair sampling on the
-    three routes (two independent 3x3 algorithms, see the module docstring); running statistics are restored between runs
+    routes (THREE independent 3x3 algorithms since r04: the policy's Winograd mix, F(2x2) forced everywhere, and the direct
+    implicit GEMM, the last one on two launch paths that produce the same bits); running statistics are restored between runs
     so every route sees the same BatchNorm buffers."""
     from multishiftseg_amd import kernels as K, synth
     m = _new_model(deeplab_params)
@@ -327,7 +331,7 @@ def test_three_routes_agree_at_bench_size(deeplab_params, tag, pairs, h, w):
     ref = out["igemm_only"]
     rep = {"wino_tiles": tiles, "nondeterministic_grads": nondet}
     bad = []
-    for route in ("winograd", "direct3x3"):
+    for route in ("winograd", "direct3x3", "winograd_f2"):
         s, l, loss, grads, tgt = out[route]
         e_s = float((s - ref[0]).abs().max())
         e_l = float((l - ref[1]).abs().max())
