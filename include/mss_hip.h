@@ -25,7 +25,7 @@ extern "C" {
                                   mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32,
                                   mss_bn_fold_train_from_partials_f32; 5 (round 4): mss_adam_step_f32 takes double hyper-parameters, mss_env_reset,
                                   mss_wino_input_transform_aspp3_f32, mss_msda_prepare_backward_ld_f32, mss_rcl_pairs_device2_f32, mss_rcl_loss_device_f32, mss_m2f_fused_score_ws_f32, mss_oodm_compact_packed_f32,
-                                  mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32 */
+                                  mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32, mss_add_layernorm_q_f32, mss_add_layernorm_bwd_sum2_f32 */
 int mss_abi_version(void);
 
 /* The MSS_* environment switches (A/B experiments, test routes; none is needed in production) are read once per call site and
@@ -457,6 +457,15 @@ int mss_add_layernorm_bwd_f32(const float* gy, const float* x, const float* res,
 int mss_add_layernorm_bwd_sum_f32(const float* gy, const float* x, const float* res, const float* stat, long long rows, int C,
                                   const float* gamma, float* dz, float* dgamma, float* dbeta, float* dzsum, float* ws,
                                   void* stream);
+/* r04: the output of an encoder layer's second LayerNorm has two consumers in the next layer, the layer input `src` and the
+ * query q = src + pos (msdeformattn.py:116-118 with_pos_embed). mss_add_layernorm_q_f32 also writes q = y + pos[row % pos_rows]
+ * (pos: [pos_rows][C], one image's tokens when the batch shares them); mss_add_layernorm_bwd_sum2_f32 takes the two gradients
+ * (gy2 may be NULL) and adds them while loading. Same bits as the separate elementwise passes they replace. */
+int mss_add_layernorm_q_f32(const float* x, const float* res, long long rows, int C, const float* gamma, const float* beta,
+                            float eps, float* y, float* stat, const float* pos, long long pos_rows, float* q, void* stream);
+int mss_add_layernorm_bwd_sum2_f32(const float* gy, const float* gy2, const float* x, const float* res, const float* stat, long long rows,
+                                   int C, const float* gamma, float* dz, float* dgamma, float* dbeta, float* dzsum, float* ws,
+                                   void* stream);
 /* nn.GroupNorm(groups, C) on NHWC x [N][HW][C] (pixel stride ldx, sample stride x_sample_stride floats), optional ReLU,
  * output with its own pixel / sample strides (e.g. straight into the encoder's token buffer [N][sum HW][C]).
  * C/groups a multiple of 4, C <= 1024. ws: scratch of mss_groupnorm_workspace_floats floats. Deterministic. */

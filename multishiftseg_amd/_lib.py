@@ -144,6 +144,8 @@ SIGNATURES = {
     "mss_add_layernorm_bwd_workspace_floats": [L, I],
     "mss_add_layernorm_bwd_f32": [P, P, P, P, L, I, P, P, P, P, P, P],
     "mss_add_layernorm_bwd_sum_f32": [P, P, P, P, L, I, P, P, P, P, P, P, P],
+    "mss_add_layernorm_q_f32": [P, P, L, I, P, P, F, P, P, P, L, P, P],
+    "mss_add_layernorm_bwd_sum2_f32": [P, P, P, P, P, L, I, P, P, P, P, P, P, P],
     "mss_groupnorm_workspace_floats": [I, I, I, I],
     "mss_groupnorm_nhwc_f32": [P, I, L, I, I, I, I, P, P, F, I, P, I, L, P, P],
     "mss_groupnorm_stat_offset": [I, I, I],

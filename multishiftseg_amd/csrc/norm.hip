@@ -20,7 +20,9 @@ template <int Q>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             long long rows, int C, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
-                                                            float* __restrict__ y, float* __restrict__ stat) {
+                                                            float* __restrict__ y, float* __restrict__ stat,
+                                                            const float* __restrict__ pos = nullptr, long long pos_rows = 0,
+                                                            float* __restrict__ qout = nullptr) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -44,7 +46,11 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
 #pragma unroll
   for (int k = 0; k < Q; ++k) {
     const int c = (lane + 64 * k) * 4;
-    st4(y + row * C + c, (v[k] - mean) * rstd * ld4(gamma + c) + ld4(beta + c));
+    const f32x4 yv = (v[k] - mean) * rstd * ld4(gamma + c) + ld4(beta + c);
+    st4(y + row * C + c, yv);
+    // r04: the NEXT encoder layer's query q = y + pos (msdeformattn.py:116: with_pos_embed) leaves with the same pass; pos has
+    // pos_rows rows (one image's tokens when it is shared by the batch)
+    if (qout) st4(qout + row * C + c, yv + ld4(pos + (row % pos_rows) * C + c));
   }
   if (stat && lane == 0) { stat[2 * row] = mean; stat[2 * row + 1] = rstd; }
 }
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
                                                                 const float* __restrict__ res, const float* __restrict__ stat,
                                                                 long long rows, int C, const float* __restrict__ gamma,
                                                                 float* __restrict__ dz, float* __restrict__ part,
-                                                                int rows_per_block) {
+                                                                int rows_per_block, const float* __restrict__ gy2 = nullptr) {
   constexpr int NP = SUM ? 3 : 2;
   __shared__ f32x4 red[NP][4][64 * Q];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -80,6 +86,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
       f32x4 z = ld4(x + row * C + c);
       if (res) z += ld4(res + row * C + c);
       g[k] = ld4(gy + row * C + c);
+      if (gy2) g[k] += ld4(gy2 + row * C + c);          // a second consumer of y (the next layer's query): gradients summed on load
       xh[k] = (z - mean) * rstd;
       const f32x4 gg = g[k] * gm[k];
       s1 += (gg.x + gg.y) + (gg.z + gg.w);
@@ -279,6 +286,22 @@ int mss_add_layernorm_f32(const float* x, const float* res, long long rows, int 
   return mss_launch_status();
 }
 
+// The same, also writing q = y + pos[row % pos_rows] (the query of the next MSDeformAttn encoder layer, msdeformattn.py:116-118)
+int mss_add_layernorm_q_f32(const float* x, const float* res, long long rows, int C, const float* gamma, const float* beta,
+                            float eps, float* y, float* stat, const float* pos, long long pos_rows, float* q, void* stream) {
+  if (!x || !gamma || !beta || !y || rows < 0 || !pos || !q || pos_rows <= 0) return MSS_ERR_BAD_ARG;
+  if (rows == 0) return MSS_OK;
+  if (C % 256 || C > 1024) return MSS_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  switch (C / 256) {
+    case 1: hipLaunchKernelGGL(add_layernorm_kernel<1>, grid, dim3(256), 0, S_(stream), x, res, rows, C, gamma, beta, eps, y, stat, pos, pos_rows, q); break;
+    case 2: hipLaunchKernelGGL(add_layernorm_kernel<2>, grid, dim3(256), 0, S_(stream), x, res, rows, C, gamma, beta, eps, y, stat, pos, pos_rows, q); break;
+    case 3: hipLaunchKernelGGL(add_layernorm_kernel<3>, grid, dim3(256), 0, S_(stream), x, res, rows, C, gamma, beta, eps, y, stat, pos, pos_rows, q); break;
+    default: hipLaunchKernelGGL(add_layernorm_kernel<4>, grid, dim3(256), 0, S_(stream), x, res, rows, C, gamma, beta, eps, y, stat, pos, pos_rows, q); break;
+  }
+  return mss_launch_status();
+}
+
 // workspace floats for the backward's per-workgroup partial sums of (dgamma | dbeta)
 long long mss_add_layernorm_bwd_workspace_floats(long long rows, int C) {
   if (rows <= 0 || C <= 0) return 0;
@@ -292,7 +315,8 @@ long long mss_add_layernorm_bwd_workspace_floats(long long rows, int C) {
 namespace {
 template <bool SUM>
 int launch_add_layernorm_bwd(const float* gy, const float* x, const float* res, const float* stat, long long rows, int C,
-                             const float* gamma, float* dz, float* dgamma, float* dbeta, float* dzsum, float* ws, void* stream) {
+                             const float* gamma, float* dz, float* dgamma, float* dbeta, float* dzsum, float* ws, void* stream,
+                             const float* gy2 = nullptr) {
   if (!gy || !x || !stat || !gamma || !dz || !ws || rows < 0) return MSS_ERR_BAD_ARG;
   if (rows == 0) return MSS_OK;
   if (C % 256 || C > 1024) return MSS_ERR_UNSUPPORTED;
@@ -302,10 +326,10 @@ int launch_add_layernorm_bwd(const float* gy, const float* x, const float* res, 
   blocks = (rows + rpb - 1) / rpb;
   const dim3 grid((unsigned)blocks);
   switch (C / 256) {
-    case 1: hipLaunchKernelGGL((add_layernorm_bwd_kernel<1, SUM>), grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
-    case 2: hipLaunchKernelGGL((add_layernorm_bwd_kernel<2, SUM>), grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
-    case 3: hipLaunchKernelGGL((add_layernorm_bwd_kernel<3, SUM>), grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
-    default: hipLaunchKernelGGL((add_layernorm_bwd_kernel<4, SUM>), grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb); break;
+    case 1: hipLaunchKernelGGL((add_layernorm_bwd_kernel<1, SUM>), grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb, gy2); break;
+    case 2: hipLaunchKernelGGL((add_layernorm_bwd_kernel<2, SUM>), grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb, gy2); break;
+    case 3: hipLaunchKernelGGL((add_layernorm_bwd_kernel<3, SUM>), grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb, gy2); break;
+    default: hipLaunchKernelGGL((add_layernorm_bwd_kernel<4, SUM>), grid, dim3(256), 0, S_(stream), gy, x, res, stat, rows, C, gamma, dz, ws, rpb, gy2); break;
   }
   // part is [block][NP][C]: rows of dgamma at stride NP*C from offset 0, rows of dbeta from offset C, of sum(dz) from 2C
   const long long st = (SUM ? 3ll : 2ll) * C;
@@ -328,6 +352,14 @@ int mss_add_layernorm_bwd_sum_f32(const float* gy, const float* x, const float* 
                                   const float* gamma, float* dz, float* dgamma, float* dbeta, float* dzsum, float* ws, void* stream) {
   if (!dzsum) return MSS_ERR_BAD_ARG;
   return launch_add_layernorm_bwd<true>(gy, x, res, stat, rows, C, gamma, dz, dgamma, dbeta, dzsum, ws, stream);
+}
+
+// the same for an output with TWO consumers: the gradient is gy + gy2 (gy2 may be NULL), added while it is loaded
+int mss_add_layernorm_bwd_sum2_f32(const float* gy, const float* gy2, const float* x, const float* res, const float* stat, long long rows,
+                                   int C, const float* gamma, float* dz, float* dgamma, float* dbeta, float* dzsum, float* ws,
+                                   void* stream) {
+  if (!dzsum) return MSS_ERR_BAD_ARG;
+  return launch_add_layernorm_bwd<true>(gy, x, res, stat, rows, C, gamma, dz, dgamma, dbeta, dzsum, ws, stream, gy2);
 }
 
 // GroupNorm over NHWC x [N][HW][C] (pixel stride ldx, sample stride x_sample_stride floats): y = (x - mean[n,g]) *

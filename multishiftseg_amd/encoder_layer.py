@@ -82,15 +82,27 @@ def _layernorm(x, res, weight, bias, eps):
     return y, stat
 
 
-def _layernorm_bwd(gy, x, res, stat, weight):
-    """-> dz, dgamma, dbeta, column sums of dz (= the bias gradient of the Linear that produced `res`: no colsum pass over dz)."""
+def _layernorm_q(x, res, weight, bias, eps, pos):
+    """_layernorm that also leaves q = y + pos (the next layer's query) with the same pass; pos [1 | N, S, C]."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y, q = torch.empty_like(x), torch.empty_like(x)
+    stat = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    call("mss_add_layernorm_q_f32", ptr(x), ptr(res), rows, C, ptr(weight), ptr(bias), float(eps), ptr(y), ptr(stat), ptr(pos),
+         pos.shape[0] * pos.shape[1], ptr(q))
+    return y, stat, q
+
+
+def _layernorm_bwd(gy, x, res, stat, weight, gy2=None):
+    """-> dz, dgamma, dbeta, column sums of dz (= the bias gradient of the Linear that produced `res`: no colsum pass over dz).
+    gy2: the gradient from a second consumer of the LayerNorm's output (the next layer's query), added while loading."""
     C = x.shape[-1]
     rows = x.numel() // C
     dz = torch.empty_like(x)
     dg, db, dzsum = torch.empty_like(weight), torch.empty_like(weight), torch.empty_like(weight)
     ws = torch.empty(_lib.value("mss_add_layernorm_bwd_workspace_floats", rows, C) // 2 * 3, device=x.device, dtype=torch.float32)
-    call("mss_add_layernorm_bwd_sum_f32", ptr(gy), ptr(x), ptr(res), ptr(stat), rows, C, ptr(weight), ptr(dz), ptr(dg), ptr(db),
-         ptr(dzsum), ptr(ws))
+    call("mss_add_layernorm_bwd_sum2_f32", ptr(gy), ptr(gy2), ptr(x), ptr(res), ptr(stat), rows, C, ptr(weight), ptr(dz), ptr(dg),
+         ptr(db), ptr(dzsum), ptr(ws))
     return dz, dg, db, dzsum
 
 
@@ -110,20 +122,22 @@ def _gemm_with_colsum(x, weight, res, res_mask, flip):
     return out, accum[:cout].float()
 
 
-# positions of the parameters in _EncoderLayerFn.apply's argument list (after src, pos, ref, shapes, starts, geometry)
+# positions of the parameters in _EncoderLayerFn.apply's argument list (after src, q, pos, ref, shapes, starts, geometry)
 _PARAMS = ("off_w", "off_b", "att_w", "att_b", "val_w", "val_b", "out_w", "out_b", "n1_w", "n1_b",
            "l1_w", "l1_b", "l2_w", "l2_b", "n2_w", "n2_b")
 
 
 class _EncoderLayerFn(Function):
     @staticmethod
-    def forward(ctx, src, pos, ref, shapes, starts, geom, *params):
+    def forward(ctx, src, q_in, pos, ref, shapes, starts, geom, *params):
+        """-> (out, q_next). q_in: src + pos when the previous layer's LayerNorm already produced it (None: formed here);
+        q_next = out + pos, written by this layer's second LayerNorm when geom asks for it (else None)."""
         p = dict(zip(_PARAMS, params))
-        M, L, P, eps1, eps2 = geom
+        M, L, P, eps1, eps2, want_q = geom
         N, S, C = src.shape
         D = C // M
         src = src.contiguous()
-        q = src + pos
+        q = src + pos if q_in is None else q_in.contiguous()
         value = _gemm(src, p["val_w"], p["val_b"])
         # `sampling_offsets(q)` and `attention_weights(q)` (ops/modules/ms_deform_attn.py:98-101) as ONE product into a
         # [N, S, 192 + 96] buffer whose two column ranges the sampler reads with a row stride (r04; the backward already did)
@@ -140,20 +154,27 @@ class _EncoderLayerFn(Function):
         s1, stat1 = _layernorm(src, attn, p["n1_w"], p["n1_b"], eps1)
         h = _gemm(s1, p["l1_w"], p["l1_b"], relu=True)
         f = _gemm(h, p["l2_w"], p["l2_b"])
-        out, stat2 = _layernorm(s1, f, p["n2_w"], p["n2_b"], eps2)
+        qn = None
+        if want_q:
+            out, stat2, qn = _layernorm_q(s1, f, p["n2_w"], p["n2_b"], eps2, pos.contiguous())
+        else:
+            out, stat2 = _layernorm(s1, f, p["n2_w"], p["n2_b"], eps2)
         ctx.geom = geom
         ctx.pos_batch = pos.shape[0]
+        ctx.q_is_input = q_in is not None
         ctx.shapes_host = getattr(shapes, "_mss_host", None)
         ctx.save_for_backward(src, q, ref, shapes, starts, value, ol, samp, attn, stat1, s1, h, f, stat2, *params)
-        return out
+        if qn is None:
+            return out, None
+        return out, qn
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gout):
+    def backward(ctx, gout, gqn):
         src, q, ref, shapes, starts, value, ol, samp, attn, stat1, s1, h, f, stat2 = ctx.saved_tensors[:14]
         p = dict(zip(_PARAMS, ctx.saved_tensors[14:]))
-        need = dict(zip(("src", "pos") + (None,) * 4 + _PARAMS, ctx.needs_input_grad))
-        M, L, P, _, _ = ctx.geom
+        need = dict(zip(("src", "q", "pos") + (None,) * 4 + _PARAMS, ctx.needs_input_grad))
+        M, L, P = ctx.geom[:3]
         N, S, C = src.shape
         D = C // M
         if ctx.shapes_host is not None:
@@ -162,7 +183,10 @@ class _EncoderLayerFn(Function):
         # ---- LayerNorm2 and the FFN: d(s1) = g2 + dh W1 rides in the last data-gradient GEMM's residual input
         # (three of the six bias gradients come out of kernels that run anyway: linear2's and output_proj's are the column sums of
         # the LayerNorm backward's dz, linear1's the column sums of the ReLU-gated data-gradient GEMM's output)
-        g2, g["n2_w"], g["n2_b"], g["l2_b"] = _layernorm_bwd(gout.contiguous(), s1, f, stat2, p["n2_w"])
+        if gout is None:                      # only the query of the next layer was used
+            gout, gqn = gqn, None
+        g2, g["n2_w"], g["n2_b"], g["l2_b"] = _layernorm_bwd(gout.contiguous(), s1, f, stat2, p["n2_w"],
+                                                             gy2=gqn.contiguous() if gqn is not None else None)
         if need["l2_w"]:
             g["l2_w"] = _wgrad(h, g2, p["l2_w"])
         if need["l1_b"]:
@@ -207,17 +231,24 @@ class _EncoderLayerFn(Function):
         if need["val_b"]:
             g["val_b"] = _bgrad(gvalue, C)
         dq = dsrc = None
-        if need["src"] or need["pos"]:
+        q_own = not ctx.q_is_input                        # q = src + pos was formed inside this node
+        if need["q"] or (q_own and (need["src"] or need["pos"])):
             dq = torch.empty((N, S, C), device=src.device, dtype=torch.float32)
             K.conv2d(_rows(gol, ko + ka), _packed_pair_flip(p["off_w"], p["att_w"]), out=_rows(dq, C))
         if need["src"]:
             dsrc = _gemm(gvalue, p["val_w"], res=g1, flip=True)
-            dsrc += dq
+            if q_own:
+                dsrc += dq
         dpos = None
         if need["pos"]:
-            # a position input shared by the whole batch ([1, S, C], msdeformattn_encoder.forward_tokens): its gradient is the batch sum
-            dpos = dq.sum(0, keepdim=True) if ctx.pos_batch == 1 and N > 1 else dq
-        return (dsrc, dpos, None, None, None, None) + tuple(g.get(n) if need[n] else None for n in _PARAMS)
+            # a position input shared by the whole batch ([1, S, C], msdeformattn_encoder.forward_tokens): its gradient is the batch
+            # sum -- of d(q) when q was formed here, and of the gradient of q_next = out + pos when this node produced it
+            batch = (lambda t: t.sum(0, keepdim=True)) if ctx.pos_batch == 1 and N > 1 else (lambda t: t)
+            if q_own:
+                dpos = batch(dq)
+            if gqn is not None:
+                dpos = batch(gqn) if dpos is None else dpos + batch(gqn)
+        return (dsrc, dq if need["q"] else None, dpos, None, None, None, None) + tuple(g.get(n) if need[n] else None for n in _PARAMS)
 
 
 def eligible(layer, src, pos, reference_points, spatial_shapes, padding_mask):
@@ -237,11 +268,14 @@ def eligible(layer, src, pos, reference_points, spatial_shapes, padding_mask):
             and not MSDA.use_window(src.new_empty((1, 1, a.n_heads, 32)), a.n_levels, a.n_points))
 
 
-def encoder_layer(layer, src, pos, reference_points, spatial_shapes, level_start_index):
+def encoder_layer(layer, src, pos, reference_points, spatial_shapes, level_start_index, q=None, want_q=False):
+    """-> (out, q_next). q: src + pos if the caller already has it (the previous layer's q_next); want_q: also return out + pos,
+    written by the layer's last LayerNorm kernel (r04: neither `src + pos` nor the sum of the two gradients of `out` is an
+    elementwise pass of its own any more)."""
     a = layer.self_attn
-    geom = (a.n_heads, a.n_levels, a.n_points, layer.norm1.eps, layer.norm2.eps)
+    geom = (a.n_heads, a.n_levels, a.n_points, layer.norm1.eps, layer.norm2.eps, bool(want_q))
     return _EncoderLayerFn.apply(
-        src, pos, reference_points, spatial_shapes.contiguous(), level_start_index.contiguous(), geom,
+        src, q, pos, reference_points, spatial_shapes.contiguous(), level_start_index.contiguous(), geom,
         a.sampling_offsets.weight, a.sampling_offsets.bias, a.attention_weights.weight, a.attention_weights.bias,
         a.value_proj.weight, a.value_proj.bias, a.output_proj.weight, a.output_proj.bias,
         layer.norm1.weight, layer.norm1.bias, layer.linear1.weight, layer.linear1.bias,

@@ -75,7 +75,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         if os.environ.get("MSS_ENCODER_FUSED", "1") != "0" and \
                 encoder_layer.eligible(self, src, pos, reference_points, spatial_shapes, padding_mask):
             # the whole layer as ONE autograd node: same kernels, the backward's gradient sums in GEMM epilogues (encoder_layer.py)
-            return encoder_layer.encoder_layer(self, src, pos, reference_points, spatial_shapes, level_start_index)
+            return encoder_layer.encoder_layer(self, src, pos, reference_points, spatial_shapes, level_start_index)[0]
         q = src if pos is None else src + pos
         # residual add + LayerNorm in one HIP pass (csrc/norm.hip); Dropout is the identity at the reference's p = 0.0
         src = K.add_layernorm(src, self.dropout1(
@@ -116,9 +116,18 @@ class MSDeformAttnTransformerEncoder(nn.Module):
 
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None):
         ref = self.get_reference_points(spatial_shapes, valid_ratios, src.device)
-        out = src
-        for layer in self.layers:
-            out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask)
+        out, q = src, None
+        fused = os.environ.get("MSS_ENCODER_FUSED", "1") != "0"
+        carry = os.environ.get("MSS_ENCODER_CARRY_Q", "1") != "0"
+        ok = [fused and encoder_layer.eligible(layer, src, pos, ref, spatial_shapes, padding_mask) for layer in self.layers]
+        for i, layer in enumerate(self.layers):
+            if ok[i]:
+                # the layer's last LayerNorm also writes the NEXT layer's query out + pos, and its backward adds the two gradients of
+                # `out` while loading them (r04): no elementwise pass for either
+                want_q = carry and i + 1 < len(self.layers) and ok[i + 1]
+                out, q = encoder_layer.encoder_layer(layer, out, pos, ref, spatial_shapes, level_start_index, q=q, want_q=want_q)
+            else:
+                out, q = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask), None
         return out
 
 
