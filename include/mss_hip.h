@@ -25,7 +25,7 @@ extern "C" {
                                   mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32,
                                   mss_bn_fold_train_from_partials_f32; 5 (round 4): mss_adam_step_f32 takes double hyper-parameters, mss_env_reset,
                                   mss_wino_input_transform_aspp3_f32, mss_msda_prepare_backward_ld_f32, mss_rcl_pairs_device2_f32, mss_rcl_loss_device_f32, mss_m2f_fused_score_ws_f32, mss_oodm_compact_packed_f32,
-                                  mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32, mss_add_layernorm_q_f32, mss_add_layernorm_bwd_sum2_f32 */
+                                  mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32, mss_add_layernorm_q_f32, mss_add_layernorm_bwd_sum2_f32, mss_msda_forward_fused_save_f32 */
 int mss_abi_version(void);
 
 /* The MSS_* environment switches (A/B experiments, test routes; none is needed in production) are read once per call site and
@@ -115,6 +115,12 @@ int mss_msda_forward_fused_ld_f32(const float* value, const int64_t* spatial_sha
                                   const float* offsets, long long ld_offsets, const float* logits, long long ld_logits,
                                   const float* reference_points, int N, int S, int M, int D, int L, int Lq, int P, float* out,
                                   void* stream);
+/* ... and with the sampling locations / attention weights the kernel formed written out (both or neither), for a backward that
+ * reads what the forward used (mss_msda_backward_*_f32 take exactly these two tensors) instead of re-deriving them. */
+int mss_msda_forward_fused_save_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                    const float* offsets, long long ld_offsets, const float* logits, long long ld_logits,
+                                    const float* reference_points, int N, int S, int M, int D, int L, int Lq, int P, float* out,
+                                    float* sampling_loc_out, float* attn_weight_out, void* stream);
 int mss_msda_prepare_ld_f32(const float* offsets, long long ld_offsets, const float* logits, long long ld_logits,
                             const float* reference_points, const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P,
                             float* sampling_loc, float* attn_weight, void* stream);

@@ -73,6 +73,7 @@ SIGNATURES = {
     "mss_msda_prepare_backward_f32": [P, P, P, P, I, I, I, I, I, P, P, P],
     "mss_msda_prepare_backward_ld_f32": [P, P, P, P, I, I, I, I, I, P, L, P, L, P],
     "mss_msda_forward_fused_ld_f32": [P, P, P, P, L, P, L, P, I, I, I, I, I, I, I, P, P],
+    "mss_msda_forward_fused_save_f32": [P, P, P, P, L, P, L, P, I, I, I, I, I, I, I, P, P, P, P],
     "mss_msda_prepare_ld_f32": [P, L, P, L, P, P, I, I, I, I, I, P, P, P],
     "mss_conv2d_forward_f32": [POINTER(MssConvArgs), P],
     "mss_conv2d_kpad": [I],

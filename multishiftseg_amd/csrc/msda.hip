@@ -211,7 +211,8 @@ template <int LPH, bool FUSED>
 __global__ __launch_bounds__(256) void msda_fwd_rec_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
     const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ ref, long long npairs, int S,
-    int M, int L, int Lq, int P, float* __restrict__ out, long long ldo, long long ldl, int LPpad) {
+    int M, int L, int Lq, int P, float* __restrict__ out, long long ldo, long long ldl, int LPpad,
+    float* __restrict__ loc_out = nullptr, float* __restrict__ attn_out = nullptr) {
   constexpr int D = 4 * LPH;
   constexpr int HPW = 64 / LPH;  // pairs per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -271,6 +272,11 @@ __global__ __launch_bounds__(256) void msda_fwd_rec_kernel(
         aw = expf(aw - mx) * inv;
         lx = ref[(nq * L + l) * 2] + lx / (float)W;
         ly = ref[(nq * L + l) * 2 + 1] + ly / (float)H;
+        if (loc_out) {        // training: the backward wants exactly these locations / weights (dense [N,Lq,M,L,P,2] / [N,Lq,M,L,P])
+          loc_out[(pair * LP + i) * 2] = lx;
+          loc_out[(pair * LP + i) * 2 + 1] = ly;
+          attn_out[pair * LP + i] = aw;
+        }
       }
       const float w_im = lx * W - 0.5f, h_im = ly * H - 0.5f;
       const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
@@ -1423,7 +1429,7 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* starts, c
 template <int LPH>
 int msda_forward_fast(const float* value, const int64_t* shapes, const int64_t* starts, const float* loc,
                       const float* attn, const float* ref, int N, int S, int M, int L, int Lq, int P, float* out,
-                      hipStream_t stream, long long ldo = 0, long long ldl = 0) {
+                      hipStream_t stream, long long ldo = 0, long long ldl = 0, float* loc_out = nullptr, float* attn_out = nullptr) {
   constexpr int HPW = 64 / LPH;
   const long long npairs = (long long)N * Lq * M;
   const long long nblocks = (npairs + 4 * HPW - 1) / (4 * HPW);
@@ -1442,12 +1448,13 @@ int msda_forward_fast(const float* value, const int64_t* shapes, const int64_t* 
       MSS_ENV_INT("MSS_MSDA_REC", 1) != 0) {
     if (ref)
       hipLaunchKernelGGL((msda_fwd_rec_kernel<LPH, true>), dim3((unsigned)nblocks), dim3(256), smem_rec, stream, value, shapes, starts, loc,
-                         attn, ref, npairs, S, M, L, Lq, P, out, ldo, ldl, L * P + 1);
+                         attn, ref, npairs, S, M, L, Lq, P, out, ldo, ldl, L * P + 1, loc_out, attn_out);
     else
       hipLaunchKernelGGL((msda_fwd_rec_kernel<LPH, false>), dim3((unsigned)nblocks), dim3(256), smem_rec, stream, value, shapes, starts, loc,
                          attn, ref, npairs, S, M, L, Lq, P, out, ldo, ldl, L * P + 1);
     return mss_launch_status();
   }
+  if (loc_out) return MSS_ERR_UNSUPPORTED;              // only the record kernel hands its locations / weights back
   if (ref) { if (buf) MSDA_LAUNCH(true, true); else MSDA_LAUNCH(true, false); }
   else { if (buf) MSDA_LAUNCH(false, true); else MSDA_LAUNCH(false, false); }
 #undef MSDA_LAUNCH
@@ -1674,11 +1681,15 @@ int mss_msda_forward_f32(const float* value, const int64_t* spatial_shapes, cons
 // ld_offsets / ld_logits: floats between the rows of consecutive (n, q) of `offsets` [N,Lq,M,L,P,2] / `logits` [N,Lq,M,L,P];
 // 0 = dense. With both > dense the two tensors may be column ranges of ONE [N*Lq, M*3*L*P] buffer, i.e. the output of a single
 // product q [Woff ; Watt]^T (ops/modules/ms_deform_attn.py:98-101 are two Linears on the same query).
-int mss_msda_forward_fused_ld_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
-                                  const float* offsets, long long ld_offsets, const float* logits, long long ld_logits,
-                                  const float* reference_points, int N, int S, int M, int D, int L, int Lq, int P, float* out,
-                                  void* stream) {
+// mss_msda_forward_fused_save_f32: the same, and the sampling locations [N,Lq,M,L,P,2] / attention weights [N,Lq,M,L,P] the kernel
+// formed on the way are written out (training: the backward reads exactly what the forward used instead of re-deriving them with
+// mss_msda_prepare_f32). MSS_ERR_UNSUPPORTED where the record kernel does not run (the caller then saves nothing and prepares).
+int mss_msda_forward_fused_save_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                    const float* offsets, long long ld_offsets, const float* logits, long long ld_logits,
+                                    const float* reference_points, int N, int S, int M, int D, int L, int Lq, int P, float* out,
+                                    float* sampling_loc_out, float* attn_weight_out, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if ((sampling_loc_out == nullptr) != (attn_weight_out == nullptr)) return MSS_ERR_BAD_ARG;
   int rc = msda_check(value, spatial_shapes, level_start_index, offsets, logits, N, S, M, D, L, Lq, P);
   if (rc) return rc;
   if ((long long)N * Lq * M == 0) return MSS_OK;
@@ -1690,14 +1701,22 @@ int mss_msda_forward_fused_ld_f32(const float* value, const int64_t* spatial_sha
   if (!aligned) return MSS_ERR_UNSUPPORTED;
   if (D == 32 && smem_per_lp * 8 <= 65536)
     return msda_forward_fast<8>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s,
-                                ld_offsets, ld_logits);
+                                ld_offsets, ld_logits, sampling_loc_out, attn_weight_out);
   if (D == 16 && smem_per_lp * 16 <= 65536)
     return msda_forward_fast<4>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s,
-                                ld_offsets, ld_logits);
+                                ld_offsets, ld_logits, sampling_loc_out, attn_weight_out);
   if (D == 64 && smem_per_lp * 4 <= 65536)
     return msda_forward_fast<16>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s,
-                                 ld_offsets, ld_logits);
+                                 ld_offsets, ld_logits, sampling_loc_out, attn_weight_out);
   return MSS_ERR_UNSUPPORTED;
+}
+
+int mss_msda_forward_fused_ld_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                  const float* offsets, long long ld_offsets, const float* logits, long long ld_logits,
+                                  const float* reference_points, int N, int S, int M, int D, int L, int Lq, int P, float* out,
+                                  void* stream) {
+  return mss_msda_forward_fused_save_f32(value, spatial_shapes, level_start_index, offsets, ld_offsets, logits, ld_logits,
+                                         reference_points, N, S, M, D, L, Lq, P, out, nullptr, nullptr, stream);
 }
 
 int mss_msda_forward_fused_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,

@@ -13,6 +13,7 @@ projection, residual; q: two projections; s1: FFN, residual) with one elementwis
 epilogues (`MssConvArgs.res`), and one explicit add per layer is left (a GEMM epilogue takes one residual).
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -133,7 +134,7 @@ class _EncoderLayerFn(Function):
         """-> (out, q_next). q_in: src + pos when the previous layer's LayerNorm already produced it (None: formed here);
         q_next = out + pos, written by this layer's second LayerNorm when geom asks for it (else None)."""
         p = dict(zip(_PARAMS, params))
-        M, L, P, eps1, eps2, want_q = geom
+        M, L, P, eps1, eps2, want_q, save_loc = geom
         N, S, C = src.shape
         D = C // M
         src = src.contiguous()
@@ -148,8 +149,22 @@ class _EncoderLayerFn(Function):
                  out=_rows(ol, ko + ka))
         ref = ref.contiguous().float()
         samp = torch.empty((N, S, C), device=src.device, dtype=torch.float32)
-        call("mss_msda_forward_fused_ld_f32", ptr(value), ptr(shapes), ptr(starts), ptr(ol), ko + ka,
-             ctypes.c_void_p(ol.data_ptr() + 4 * ko), ko + ka, ptr(ref), N, S, M, D, L, S, P, ptr(samp))
+        # training: the sampler also writes the locations / weights it formed, so that the backward reads what the forward used
+        # instead of re-deriving them from `ol` (r04: one prepare kernel less per layer; `ol` is then not kept)
+        loc = aw = None
+        plog = ctypes.c_void_p(ol.data_ptr() + 4 * ko)
+        if save_loc and any(ctx.needs_input_grad):
+            loc = torch.empty((N, S, M, L, P, 2), device=src.device, dtype=torch.float32)
+            aw = torch.empty((N, S, M, L, P), device=src.device, dtype=torch.float32)
+            rc = _lib.status("mss_msda_forward_fused_save_f32", ptr(value), ptr(shapes), ptr(starts), ptr(ol), ko + ka, plog, ko + ka,
+                             ptr(ref), N, S, M, D, L, S, P, ptr(samp), ptr(loc), ptr(aw))
+            if rc == _lib.MSS_ERR_UNSUPPORTED:
+                loc = aw = None
+            elif rc != 0:
+                raise _lib.MssError(f"mss_msda_forward_fused_save_f32 failed with code {rc}")
+        if loc is None:
+            call("mss_msda_forward_fused_ld_f32", ptr(value), ptr(shapes), ptr(starts), ptr(ol), ko + ka, plog, ko + ka, ptr(ref),
+                 N, S, M, D, L, S, P, ptr(samp))
         attn = _gemm(samp, p["out_w"], p["out_b"])
         s1, stat1 = _layernorm(src, attn, p["n1_w"], p["n1_b"], eps1)
         h = _gemm(s1, p["l1_w"], p["l1_b"], relu=True)
@@ -163,7 +178,9 @@ class _EncoderLayerFn(Function):
         ctx.pos_batch = pos.shape[0]
         ctx.q_is_input = q_in is not None
         ctx.shapes_host = getattr(shapes, "_mss_host", None)
-        ctx.save_for_backward(src, q, ref, shapes, starts, value, ol, samp, attn, stat1, s1, h, f, stat2, *params)
+        ctx.saved_loc = loc is not None
+        keep = (loc, aw) if loc is not None else (ol, ol)
+        ctx.save_for_backward(src, q, ref, shapes, starts, value, keep[0], keep[1], samp, attn, stat1, s1, h, f, stat2, *params)
         if qn is None:
             return out, None
         return out, qn
@@ -171,8 +188,8 @@ class _EncoderLayerFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gout, gqn):
-        src, q, ref, shapes, starts, value, ol, samp, attn, stat1, s1, h, f, stat2 = ctx.saved_tensors[:14]
-        p = dict(zip(_PARAMS, ctx.saved_tensors[14:]))
+        src, q, ref, shapes, starts, value, k0, k1, samp, attn, stat1, s1, h, f, stat2 = ctx.saved_tensors[:15]
+        p = dict(zip(_PARAMS, ctx.saved_tensors[15:]))
         need = dict(zip(("src", "q", "pos") + (None,) * 4 + _PARAMS, ctx.needs_input_grad))
         M, L, P = ctx.geom[:3]
         N, S, C = src.shape
@@ -205,10 +222,14 @@ class _EncoderLayerFn(Function):
         dsamp = _gemm(g1, p["out_w"], flip=True)
         # ---- the sampling op: locations / weights rebuilt by the one-pass prepare kernel (bit-identical to the forward's)
         ko, ka = M * L * P * 2, M * L * P
-        loc = torch.empty((N, S, M, L, P, 2), device=src.device, dtype=torch.float32)
-        aw = torch.empty((N, S, M, L, P), device=src.device, dtype=torch.float32)
-        call("mss_msda_prepare_ld_f32", ptr(ol), ko + ka, ctypes.c_void_p(ol.data_ptr() + 4 * ko), ko + ka, ptr(ref), ptr(shapes),
-             N, S, M, L, P, ptr(loc), ptr(aw))
+        if ctx.saved_loc:
+            loc, aw = k0, k1                   # what the forward's sampler used
+        else:
+            ol = k0
+            loc = torch.empty((N, S, M, L, P, 2), device=src.device, dtype=torch.float32)
+            aw = torch.empty((N, S, M, L, P), device=src.device, dtype=torch.float32)
+            call("mss_msda_prepare_ld_f32", ptr(ol), ko + ka, ctypes.c_void_p(ol.data_ptr() + 4 * ko), ko + ka, ptr(ref), ptr(shapes),
+                 N, S, M, L, P, ptr(loc), ptr(aw))
         gvalue, gloc, gaw = MSDA.ms_deform_attn_backward(value.view(N, S, M, D), shapes, starts, loc, aw, dsamp, 128)
         del dsamp, loc
         # `sampling_offsets` and `attention_weights` are two Linears on the SAME q: their output gradients go side by side into one
@@ -273,7 +294,9 @@ def encoder_layer(layer, src, pos, reference_points, spatial_shapes, level_start
     written by the layer's last LayerNorm kernel (r04: neither `src + pos` nor the sum of the two gradients of `out` is an
     elementwise pass of its own any more)."""
     a = layer.self_attn
-    geom = (a.n_heads, a.n_levels, a.n_points, layer.norm1.eps, layer.norm2.eps, bool(want_q))
+    # grad mode is always off INSIDE Function.forward: what the caller runs under is read here
+    save_loc = torch.is_grad_enabled() and os.environ.get("MSS_ENCODER_SAVE_LOC", "1") != "0"
+    geom = (a.n_heads, a.n_levels, a.n_points, layer.norm1.eps, layer.norm2.eps, bool(want_q), save_loc)
     return _EncoderLayerFn.apply(
         src, q, pos, reference_points, spatial_shapes.contiguous(), level_start_index.contiguous(), geom,
         a.sampling_offsets.weight, a.sampling_offsets.bias, a.attention_weights.weight, a.attention_weights.bias,

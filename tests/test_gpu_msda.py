@@ -402,6 +402,15 @@ def test_strided_projection_buffer_is_bitwise_the_dense_tensors(N, Lq, M, D, sha
     call("mss_msda_prepare_f32", ptr(off), ptr(lg), ptr(ref), ptr(shp), N, Lq, M, L, P, ptr(loc_d), ptr(aw_d))
     call("mss_msda_prepare_ld_f32", ptr(both), ld, plog, ld, ptr(ref), ptr(shp), N, Lq, M, L, P, ptr(loc_s), ptr(aw_s))
     assert torch.equal(loc_d, loc_s) and torch.equal(aw_d, aw_s)
+    # the training form: the sampler hands back the locations / weights it formed (what the backward then reads) -- the same
+    # output bits, and the prepare kernel's values up to the order in which the L*P exponentials are added
+    out_k = torch.empty_like(out_s)
+    loc_k, aw_k = torch.full_like(loc_d, float("nan")), torch.full_like(aw_d, float("nan"))
+    call("mss_msda_forward_fused_save_f32", ptr(value), ptr(shp), ptr(starts), ptr(both), ld, plog, ld, ptr(ref), N, S, M, D, L, Lq, P,
+         ptr(out_k), ptr(loc_k), ptr(aw_k))
+    assert torch.equal(out_k, out_s)
+    torch.testing.assert_close(loc_k, loc_d, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(aw_k, aw_d, rtol=2e-6, atol=1e-7)
     with pytest.raises(RuntimeError):
         call("mss_msda_prepare_ld_f32", ptr(both), ko - 1, plog, ld, ptr(ref), ptr(shp), N, Lq, M, L, P, ptr(loc_s), ptr(aw_s))
     with pytest.raises(RuntimeError):
