@@ -25,7 +25,7 @@ extern "C" {
                                   mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32,
                                   mss_bn_fold_train_from_partials_f32; 5 (round 4): mss_adam_step_f32 takes double hyper-parameters, mss_env_reset,
                                   mss_wino_input_transform_aspp3_f32, mss_msda_prepare_backward_ld_f32, mss_rcl_pairs_device2_f32, mss_rcl_loss_device_f32, mss_m2f_fused_score_ws_f32, mss_oodm_compact_packed_f32,
-                                  mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32, mss_add_layernorm_q_f32, mss_add_layernorm_bwd_sum2_f32, mss_msda_forward_fused_save_f32 */
+                                  mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32, mss_add_layernorm_q_f32, mss_add_layernorm_bwd_sum2_f32, mss_msda_forward_fused_save_f32, mss_msda_backward_binned_proj_f32 */
 int mss_abi_version(void);
 
 /* The MSS_* environment switches (A/B experiments, test routes; none is needed in production) are read once per call site and
@@ -108,6 +108,13 @@ int mss_msda_prepare_backward_f32(const float* attn_weight, const float* grad_at
 int mss_msda_prepare_backward_ld_f32(const float* attn_weight, const float* grad_attn, const float* grad_loc,
                                      const int64_t* spatial_shapes, int N, int Lq, int M, int L, int P, float* grad_offsets,
                                      long long ld_offsets, float* grad_logits, long long ld_logits, void* stream);
+/* mss_msda_backward_binned_f32 with that module backward folded into its gather pass: d(offsets) / d(logits) leave instead of
+ * grad_sampling_loc / grad_attn_weight (never materialised; no prepare-backward launch). Bit-identical to the two-call sequence. */
+int mss_msda_backward_binned_proj_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                      const int64_t* host_shapes, const float* sampling_loc, const float* attn_weight,
+                                      const float* grad_out, int N, int S, int M, int D, int L, int Lq, int P, float* grad_value,
+                                      float* grad_offsets, long long ld_offsets, float* grad_logits, long long ld_logits,
+                                      void* workspace, long long workspace_bytes, void* stream);
 /* Forward side of the same idea (ops/modules/ms_deform_attn.py:98-101: `sampling_offsets(query)` and `attention_weights(query)`):
  * offsets row (n, q) at + (n*Lq + q) * ld_offsets, logits likewise with ld_logits (0 = dense), so that both may be column ranges of
  * the [N*Lq, M*3*L*P] output of ONE product query [Woff ; Watt]^T. Outputs of the prepare form stay dense. */

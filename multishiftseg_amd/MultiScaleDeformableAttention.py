@@ -112,6 +112,30 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return [grad_value, grad_loc, grad_attn]
 
 
+def ms_deform_attn_backward_proj(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, grad_proj, ko):
+    """The op's backward with the MODULE's backward (softmax, location arithmetic: ops/modules/ms_deform_attn.py:100-109) folded into
+    its gather pass: writes d(sampling offsets) into grad_proj[..., :ko] and d(attention logits) into grad_proj[..., ko:] (one
+    [N, Lq, M*3*L*P] buffer: the output gradient of the merged projection) and returns grad_value -- or None where the binned path
+    does not run (the caller then uses ms_deform_attn_backward + the prepare-backward kernel)."""
+    N, S, M, D, L, Lq, P = _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, 128,
+                                  extra=(("grad_output", grad_output),))
+    if not (value.dtype == torch.float32 and D == 32 and N * Lq > 0 and L * P <= 20 and os.environ.get("MSS_MSDA_BWD_BINNED", "1") != "0"
+            and os.environ.get("MSS_MSDA_BWD_PROJ", "1") != "0" and value.data_ptr() % 16 == 0 and grad_output.data_ptr() % 16 == 0):
+        return None
+    hs = host_shapes(spatial_shapes)
+    nbytes = _lib.value("mss_msda_backward_workspace_bytes", hs, N, M, D, L, Lq, P) if hs is not None else 0
+    if nbytes <= 0:
+        return None
+    ld = grad_proj.shape[-1]
+    assert grad_proj.is_contiguous() and ld >= ko + M * L * P and ko == M * L * P * 2
+    grad_value = torch.empty_like(value)
+    ws = torch.empty(nbytes, device=value.device, dtype=torch.uint8)
+    call("mss_msda_backward_binned_proj_f32", ptr(value), ptr(spatial_shapes), ptr(level_start_index), hs, ptr(sampling_loc),
+         ptr(attn_weight), ptr(grad_output), N, S, M, D, L, Lq, P, ptr(grad_value), ptr(grad_proj), ld,
+         ctypes.c_void_p(grad_proj.data_ptr() + 4 * ko), ld, ptr(ws), nbytes)
+    return grad_value
+
+
 def install():
     """Register this module under the extension's name for `import MultiScaleDeformableAttention`."""
     sys.modules["MultiScaleDeformableAttention"] = sys.modules[__name__]

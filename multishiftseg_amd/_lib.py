@@ -67,6 +67,7 @@ SIGNATURES = {
     "mss_msda_backward_f64": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P],
     "mss_msda_backward_workspace_bytes": [P, I, I, I, I, I, I],
     "mss_msda_backward_binned_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, L, P],
+    "mss_msda_backward_binned_proj_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, L, P, L, P, L, P],
     "mss_msda_forward_fused_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
     "mss_msda_forward_window_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
     "mss_msda_prepare_f32": [P, P, P, P, I, I, I, I, I, P, P, P],

@@ -686,13 +686,21 @@ template <bool BUF>
 __global__ __launch_bounds__(256) void msda_bwd_gather_fast_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
     const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ gout, long long npairs, int S,
-    int M, int L, int Lq, int P, float* __restrict__ gloc, float* __restrict__ gattn) {
+    int M, int L, int Lq, int P, float* __restrict__ gloc, float* __restrict__ gattn, float* __restrict__ goff = nullptr,
+    long long ldo = 0, float* __restrict__ glog = nullptr, long long ldl = 0) {
   constexpr int LPH = 8, D = 32, HPW = 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int LP = L * P;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* sloc = smem + wave * (HPW * LP * 3);  // [HPW][LP][2]
+  // PROJ (goff != NULL, r04): the module's backward through the softmax and the location arithmetic
+  // (ops/modules/ms_deform_attn.py:100-109) happens here, on the gradients this wave holds in LDS anyway -- what leaves is
+  // d(offsets) = g_loc / (W_l, H_l) and d(logits) = attn * (g_attn - sum(attn * g_attn)), written straight into the (strided)
+  // buffer of the two projections' output gradients; grad_loc / grad_attn are never materialised and msda_prepare_bwd_kernel
+  // does not run. Same expressions in the same order as that kernel: the same bits.
+  const bool proj = goff != nullptr;
+  float* sloc = smem + wave * (HPW * LP * 4);  // [HPW][LP][2]
   float* sattn = sloc + HPW * LP * 2;          // [HPW][LP]
+  float* skeep = sattn + HPW * LP;             // [HPW][LP]: the attention weights (sattn is overwritten with their gradients)
   const long long pair0 = ((long long)blockIdx.x * 4 + wave) * HPW;
   if (pair0 >= npairs) return;  // whole wave leaves together (no block barrier below)
   const int npw = (int)min((long long)HPW, npairs - pair0);
@@ -700,7 +708,7 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_fast_kernel(
     const float* gl = loc + pair0 * LP * 2;
     const float* ga = attn + pair0 * LP;
     for (int i = lane; i < npw * LP * 2; i += 64) sloc[i] = gl[i];
-    for (int i = lane; i < npw * LP; i += 64) sattn[i] = ga[i];
+    for (int i = lane; i < npw * LP; i += 64) { const float a = ga[i]; sattn[i] = a; skeep[i] = a; }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -765,6 +773,38 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_fast_kernel(
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (proj) {
+    if (live) {
+      const float* a = skeep + g * LP;
+      float* ga = sattn + g * LP;
+      float dot = 0.f;
+      for (int i = 0; i < LP; ++i) dot = __builtin_fmaf(a[i], ga[i], dot);     // every lane of the group: the same ascending sum
+      float d[3];                                                              // L*P <= 20 (host check): <= 3 samples per lane
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int i = j + t * LPH;
+        d[t] = i < LP ? a[i] * (ga[i] - dot) : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int i = j + t * LPH;
+        if (i < LP) ga[i] = d[t];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = lane; i < npw * LP * 2; i += 64) {
+      const int l = (i / 2 % LP) / P;
+      const long long pr = pair0 + i / (2 * LP);
+      goff[pr / M * ldo + (pr % M) * (2 * LP) + i % (2 * LP)] = sloc[i] / (float)shapes[2 * l + ((i & 1) ? 0 : 1)];
+    }
+    for (int i = lane; i < npw * LP; i += 64) {
+      const long long pr = pair0 + i / LP;
+      glog[pr / M * ldl + (pr % M) * LP + i % LP] = sattn[i];
+    }
+    return;
+  }
   {
     float* gl = gloc + pair0 * LP * 2;
     float* ga = gattn + pair0 * LP;
@@ -1392,7 +1432,7 @@ __global__ __launch_bounds__(256) void msda_prepare_bwd_kernel(const float* __re
     const float* a = sa + threadIdx.x * LP;
     float* ga = sg + threadIdx.x * LP;
     float dot = 0.f;
-    for (int i = 0; i < LP; ++i) dot += a[i] * ga[i];
+    for (int i = 0; i < LP; ++i) dot = __builtin_fmaf(a[i], ga[i], dot);     // (explicit: the gather kernel's PROJ epilogue must round alike)
     for (int i = 0; i < LP; ++i) ga[i] = a[i] * (ga[i] - dot);
   }
   __syncthreads();
@@ -1528,7 +1568,7 @@ int msda_backward(const T* value, const int64_t* shapes, const int64_t* starts, 
                        starts, reinterpret_cast<const float*>(loc), reinterpret_cast<const float*>(attn),
                        reinterpret_cast<const float*>(gout), absmax, S, M, L, Lq, P, reinterpret_cast<float*>(gvalue));
     // grad_loc / grad_attn: the gather pass (no atomics)
-    const size_t smem = (size_t)4 * 8 * L * P * 3 * sizeof(float);
+    const size_t smem = (size_t)4 * 8 * L * P * 4 * sizeof(float);
     const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(gout)) & 15) == 0;
     if (aligned && smem <= 65536) {
       const long long nblocks = (npairs + 31) / 32;
@@ -1582,16 +1622,20 @@ static bool msda_bin_layout(const MsdaBinGeom& g, int N, int M, int L, int Lq, i
 static int msda_backward_binned(const float* value, const int64_t* shapes, const int64_t* starts, const int64_t* host_shapes,
                                 const float* loc, const float* attn, const float* gout, int N, int S, int M, int D, int L,
                                 int Lq, int P, float* gvalue, float* gloc, float* gattn, void* ws, size_t ws_bytes,
-                                hipStream_t stream) {
+                                hipStream_t stream, float* goff = nullptr, long long ldo = 0, float* glog = nullptr, long long ldl = 0) {
   if (!host_shapes) return MSS_ERR_BAD_ARG;
+  if (goff || glog) {          // the module's backward folded into the gather pass: both outputs, strides at least dense, L*P <= 20
+    if (!goff || !glog || ldo < (long long)M * 2 * L * P || ldl < (long long)M * L * P) return MSS_ERR_BAD_ARG;
+    if (L * P > 20) return MSS_ERR_UNSUPPORTED;
+  }
   int rc = msda_check(value, host_shapes, starts, loc, attn, N, S, M, D, L, Lq, P);
   if (rc) return rc;
   const long long npairs = (long long)N * Lq * M;
   if (npairs == 0 || (long long)N * S == 0) return MSS_ERR_UNSUPPORTED;
   if (D != 32 || M > 65535 || (long long)Lq * P > (1ll << 22)) return MSS_ERR_UNSUPPORTED;
   if ((unsigned long long)N * Lq * M * D * 4ull >= 0xffffffffull) return MSS_ERR_UNSUPPORTED;      // grad_out as one buffer resource
-  if (!gvalue || !gout || !gloc || !gattn || !ws) return MSS_ERR_BAD_ARG;
-  const size_t smem_gather = (size_t)4 * 8 * L * P * 3 * sizeof(float);
+  if (!gvalue || !gout || !ws || (!goff && (!gloc || !gattn))) return MSS_ERR_BAD_ARG;
+  const size_t smem_gather = (size_t)4 * 8 * L * P * 4 * sizeof(float);
   if (((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(gout)) & 15) != 0 || smem_gather > 65536) return MSS_ERR_UNSUPPORTED;
   MsdaBinGeom g;
   MsdaBinWs w;
@@ -1640,10 +1684,10 @@ static int msda_backward_binned(const float* value, const int64_t* shapes, const
   const bool buf = (unsigned long long)N * S * M * D * 4ull < 0xffffffffull && MSS_ENV_INT("MSS_MSDA_BUF", 1) != 0;
   if (buf)
     hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<true>, dim3((unsigned)nblocks), dim3(256), smem_gather, stream, value, shapes, starts,
-                       loc, attn, gout, npairs, S, M, L, Lq, P, gloc, gattn);
+                       loc, attn, gout, npairs, S, M, L, Lq, P, gloc, gattn, goff, ldo, glog, ldl);
   else
     hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<false>, dim3((unsigned)nblocks), dim3(256), smem_gather, stream, value, shapes, starts,
-                       loc, attn, gout, npairs, S, M, L, Lq, P, gloc, gattn);
+                       loc, attn, gout, npairs, S, M, L, Lq, P, gloc, gattn, goff, ldo, glog, ldl);
   return mss_launch_status();
 }
 
@@ -1767,7 +1811,7 @@ long long mss_msda_backward_workspace_bytes(const int64_t* host_shapes, int N, i
   MsdaBinWs w;
   if (!host_shapes || D != 32 || N <= 0 || Lq <= 0 || M <= 0 || P <= 0 || M > 65535 || (long long)Lq * P > (1ll << 22)) return 0;
   if ((unsigned long long)N * Lq * M * D * 4ull >= 0xffffffffull) return 0;
-  if ((size_t)4 * 8 * L * P * 3 * sizeof(float) > 65536) return 0;
+  if ((size_t)4 * 8 * L * P * 4 * sizeof(float) > 65536) return 0;
   if (!msda_bin_geom(host_shapes, L, Lq, P, (long long)N * Lq * M * L * P, g) || !msda_bin_layout(g, N, M, L, Lq, P, w)) return 0;
   return (long long)w.total;
 }
@@ -1780,6 +1824,21 @@ int mss_msda_backward_binned_f32(const float* value, const int64_t* spatial_shap
   return msda_backward_binned(value, spatial_shapes, level_start_index, host_shapes, sampling_loc, attn_weight, grad_out, N, S, M, D,
                               L, Lq, P, grad_value, grad_loc, grad_attn, workspace, (size_t)(workspace_bytes < 0 ? 0 : workspace_bytes),
                               static_cast<hipStream_t>(stream));
+}
+
+// The same with the MODULE's backward folded in (ops/modules/ms_deform_attn.py:100-109: softmax over the L*P logits, loc = ref +
+// offset / (W_l, H_l)): instead of grad_sampling_loc / grad_attn_weight it writes d(offsets) and d(logits), row (n, q) at
+// + (n*Lq + q) * ld (both may be column ranges of one [N*Lq, M*3*L*P] buffer, the output gradient of the merged projection).
+// Equal, bit for bit, to mss_msda_backward_binned_f32 followed by mss_msda_prepare_backward_ld_f32; L*P <= 20.
+int mss_msda_backward_binned_proj_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                      const int64_t* host_shapes, const float* sampling_loc, const float* attn_weight,
+                                      const float* grad_out, int N, int S, int M, int D, int L, int Lq, int P, float* grad_value,
+                                      float* grad_offsets, long long ld_offsets, float* grad_logits, long long ld_logits,
+                                      void* workspace, long long workspace_bytes, void* stream) {
+  if (!spatial_shapes || !grad_offsets || !grad_logits) return MSS_ERR_BAD_ARG;
+  return msda_backward_binned(value, spatial_shapes, level_start_index, host_shapes, sampling_loc, attn_weight, grad_out, N, S, M, D,
+                              L, Lq, P, grad_value, nullptr, nullptr, workspace, (size_t)(workspace_bytes < 0 ? 0 : workspace_bytes),
+                              static_cast<hipStream_t>(stream), grad_offsets, ld_offsets, grad_logits, ld_logits);
 }
 
 int mss_msda_prepare_ld_f32(const float* offsets, long long ld_offsets, const float* logits, long long ld_logits,

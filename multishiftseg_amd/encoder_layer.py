@@ -230,15 +230,18 @@ class _EncoderLayerFn(Function):
             aw = torch.empty((N, S, M, L, P), device=src.device, dtype=torch.float32)
             call("mss_msda_prepare_ld_f32", ptr(ol), ko + ka, ctypes.c_void_p(ol.data_ptr() + 4 * ko), ko + ka, ptr(ref), ptr(shapes),
                  N, S, M, L, P, ptr(loc), ptr(aw))
-        gvalue, gloc, gaw = MSDA.ms_deform_attn_backward(value.view(N, S, M, D), shapes, starts, loc, aw, dsamp, 128)
-        del dsamp, loc
         # `sampling_offsets` and `attention_weights` are two Linears on the SAME q: their output gradients go side by side into one
         # [N, S, 192 + 96] buffer, so the weight gradient, the bias gradient and the data gradient are one product each (r04:
-        # the narrow 192- / 96-wide products ran at 71 / 59 TFLOP/s for the weight and 119 / 73 for the data gradient)
+        # the narrow 192- / 96-wide products ran at 71 / 59 TFLOP/s for the weight and 119 / 73 for the data gradient); the
+        # op's gather pass writes them there itself (softmax / location backward folded in: no grad_loc / grad_attn tensors)
         gol = torch.empty((N, S, ko + ka), device=src.device, dtype=torch.float32)
-        call("mss_msda_prepare_backward_ld_f32", ptr(aw), ptr(gaw), ptr(gloc), ptr(shapes), N, S, M, L, P, ptr(gol), ko + ka,
-             ctypes.c_void_p(gol.data_ptr() + 4 * ko), ko + ka)
-        del gloc, gaw, aw
+        gvalue = MSDA.ms_deform_attn_backward_proj(value.view(N, S, M, D), shapes, starts, loc, aw, dsamp, gol, ko)
+        if gvalue is None:
+            gvalue, gloc, gaw = MSDA.ms_deform_attn_backward(value.view(N, S, M, D), shapes, starts, loc, aw, dsamp, 128)
+            call("mss_msda_prepare_backward_ld_f32", ptr(aw), ptr(gaw), ptr(gloc), ptr(shapes), N, S, M, L, P, ptr(gol), ko + ka,
+                 ctypes.c_void_p(gol.data_ptr() + 4 * ko), ko + ka)
+            del gloc, gaw
+        del dsamp, loc, aw
         gvalue = gvalue.view(N, S, C)
         # ---- the three input projections: d(q) = [goff | glog] [Woff ; Watt], d(src) = g1 + gvalue Wv + d(q)
         if need["off_w"] or need["att_w"]:

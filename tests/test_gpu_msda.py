@@ -418,6 +418,39 @@ def test_strided_projection_buffer_is_bitwise_the_dense_tensors(N, Lq, M, D, sha
              P, ptr(out_s))
 
 
+@pytest.mark.parametrize("N,shapes,P,pad", [(2, [(22, 22), (44, 44), (88, 88)], 4, 0), (1, [(9, 13), (5, 6)], 2, 4), (3, [(31, 17)], 4, 0)])
+def test_backward_with_module_backward_folded_in_is_bitwise_the_two_calls(F, N, shapes, P, pad):
+    """r04: mss_msda_backward_binned_proj_f32 (the op's gather pass writes d(offsets) / d(logits) of the module itself, through the
+    softmax and the location arithmetic of ops/modules/ms_deform_attn.py:100-109, into one strided buffer) against
+    mss_msda_backward_binned_f32 followed by mss_msda_prepare_backward_ld_f32: the same bits, grad_value included."""
+    import ctypes
+    from multishiftseg_amd._lib import call, ptr
+    from multishiftseg_amd import MultiScaleDeformableAttention as MSDA
+    torch.manual_seed(N + P + pad)
+    M, D, L = 8, 32, len(shapes)
+    shp = torch.as_tensor(shapes, dtype=torch.long, device="cuda")
+    shp._mss_host = [tuple(s) for s in shapes]
+    starts = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    S = int(shp.prod(1).sum())
+    Lq = S
+    value = torch.randn(N, S, M, D, device="cuda")
+    loc = torch.rand(N, Lq, M, L, P, 2, device="cuda") * 1.2 - 0.1
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P, device="cuda"), -1).view(N, Lq, M, L, P).contiguous()
+    gout = torch.randn(N, Lq, M * D, device="cuda")
+    ko, ka = M * L * P * 2, M * L * P
+    ld = ko + ka + pad
+    gv, gloc, gattn = MSDA.ms_deform_attn_backward(value, shp, starts, loc, attn, gout, 128)
+    two = torch.full((N, Lq, ld), float("nan"), device="cuda")
+    call("mss_msda_prepare_backward_ld_f32", ptr(attn), ptr(gattn), ptr(gloc), ptr(shp), N, Lq, M, L, P, ptr(two), ld,
+         ctypes.c_void_p(two.data_ptr() + 4 * ko), ld)
+    one = torch.full((N, Lq, ld), float("nan"), device="cuda")
+    gv1 = MSDA.ms_deform_attn_backward_proj(value, shp, starts, loc, attn, gout, one, ko)
+    assert gv1 is not None
+    assert torch.equal(gv1, gv)
+    assert torch.equal(one[..., :ko + ka], two[..., :ko + ka])
+    assert torch.isnan(one[..., ko + ka:]).all()
+
+
 def test_module_golden_unfused_route(monkeypatch):
     """The reference module's output through prepare -> sample (MSS_MSDA_FUSED=0); test_module_golden covers the fused default."""
     monkeypatch.setenv("MSS_MSDA_FUSED", "0")
