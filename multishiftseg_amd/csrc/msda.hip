@@ -767,7 +767,12 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_fast_kernel(
       const float s_attn = hh * hw * p1 + hh * lw * p2 + lh * hw * p3 + lh * lw * p4;
       const float s_w = aw * (float)W * (-hh * p1 + hh * p2 - lh * p3 + lh * p4);
       const float s_h = aw * (float)H * (-hw * p1 - lw * p2 + hw * p3 + lw * p4);
-      if (live && j == 0) { myloc[sidx * 2] = s_w; myloc[sidx * 2 + 1] = s_h; myattn[sidx] = s_attn; }
+      if (live && j == 0) {
+        // PROJ: d(offset) = g_loc / (W_l, H_l) right here, where the level is known (the same division the prepare-backward kernel does)
+        myloc[sidx * 2] = proj ? s_w / (float)W : s_w;
+        myloc[sidx * 2 + 1] = proj ? s_h / (float)H : s_h;
+        myattn[sidx] = s_attn;
+      }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -794,10 +799,16 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_fast_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (M == HPW) {            // the wave's pairs are the M heads of ONE query: its row of the buffer is contiguous
+      float* ro = goff + pair0 / M * ldo;
+      float* rl = glog + pair0 / M * ldl;
+      for (int i = lane; i < npw * LP * 2; i += 64) ro[i] = sloc[i];
+      for (int i = lane; i < npw * LP; i += 64) rl[i] = sattn[i];
+      return;
+    }
     for (int i = lane; i < npw * LP * 2; i += 64) {
-      const int l = (i / 2 % LP) / P;
       const long long pr = pair0 + i / (2 * LP);
-      goff[pr / M * ldo + (pr % M) * (2 * LP) + i % (2 * LP)] = sloc[i] / (float)shapes[2 * l + ((i & 1) ? 0 : 1)];
+      goff[pr / M * ldo + (pr % M) * (2 * LP) + i % (2 * LP)] = sloc[i];
     }
     for (int i = lane; i < npw * LP; i += 64) {
       const long long pr = pair0 + i / LP;

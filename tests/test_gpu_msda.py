@@ -418,8 +418,9 @@ def test_strided_projection_buffer_is_bitwise_the_dense_tensors(N, Lq, M, D, sha
              P, ptr(out_s))
 
 
-@pytest.mark.parametrize("N,shapes,P,pad", [(2, [(22, 22), (44, 44), (88, 88)], 4, 0), (1, [(9, 13), (5, 6)], 2, 4), (3, [(31, 17)], 4, 0)])
-def test_backward_with_module_backward_folded_in_is_bitwise_the_two_calls(F, N, shapes, P, pad):
+@pytest.mark.parametrize("N,shapes,P,pad,M", [(2, [(22, 22), (44, 44), (88, 88)], 4, 0, 8), (1, [(9, 13), (5, 6)], 2, 4, 8), (3, [(31, 17)], 4, 0, 8),
+                                              (2, [(12, 9), (20, 31)], 4, 8, 4), (1, [(17, 5)], 3, 0, 3)])
+def test_backward_with_module_backward_folded_in_is_bitwise_the_two_calls(F, N, shapes, P, pad, M):
     """r04: mss_msda_backward_binned_proj_f32 (the op's gather pass writes d(offsets) / d(logits) of the module itself, through the
     softmax and the location arithmetic of ops/modules/ms_deform_attn.py:100-109, into one strided buffer) against
     mss_msda_backward_binned_f32 followed by mss_msda_prepare_backward_ld_f32: the same bits, grad_value included."""
@@ -427,7 +428,7 @@ def test_backward_with_module_backward_folded_in_is_bitwise_the_two_calls(F, N, 
     from multishiftseg_amd._lib import call, ptr
     from multishiftseg_amd import MultiScaleDeformableAttention as MSDA
     torch.manual_seed(N + P + pad)
-    M, D, L = 8, 32, len(shapes)
+    D, L = 32, len(shapes)
     shp = torch.as_tensor(shapes, dtype=torch.long, device="cuda")
     shp._mss_host = [tuple(s) for s in shapes]
     starts = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
