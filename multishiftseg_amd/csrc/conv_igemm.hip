@@ -1069,8 +1069,9 @@ __global__ __launch_bounds__(256, KB == 4 ? 1 : 2) void gemm_tn_direct_kernel(co
                                                                 long long b_bs, int Kpad, int Cp, int ktiles, int ctiles, int splits,
                                                                 int tps, long long total, long long full, float* __restrict__ tail_ws,
                                                                 const float* __restrict__ scale = nullptr,
-                                                                const float* __restrict__ shift = nullptr, int relu = 0) {
+                                                                const float* __restrict__ shift = nullptr, int relu = 0, int lda = 0) {
   typedef typename std::conditional<KB == 4, f32x4, f32x2>::type avec;
+  if (lda <= 0) lda = K;               // row stride of A (dy): larger when dy is a channel slice of a wider buffer
   constexpr int TND = KB == 4 ? 8 : 5;                         // row pairs per register block (two blocks: one consumed, one in flight)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long job = (long long)blockIdx.x * 4 + wave;
@@ -1122,7 +1123,7 @@ __global__ __launch_bounds__(256, KB == 4 ? 1 : 2) void gemm_tn_direct_kernel(co
   auto fetch = [&](int row, avec& va, f32x4& vb) {
     const bool ok = row <= last;
     const size_t rr = (size_t)(ok ? row : last);
-    va = *reinterpret_cast<const avec*>(ok ? a + rr * K : az);  // a row past the end contributes A = 0: the product is zero
+    va = *reinterpret_cast<const avec*>(ok ? a + rr * lda : az);  // a row past the end contributes A = 0: the product is zero
     vb = *reinterpret_cast<const f32x4*>(b + rr * C);
   };
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -1346,9 +1347,11 @@ struct TnPlan { int ktiles, ctiles, splits, tps; long long total; long long full
 inline int tn_batch(const MssConvArgs& p) { return p.batch > 1 ? p.batch : 1; }
 inline long long tn_tail_bytes(const TnPlan& pl) { return pl.full >= 0 ? (pl.total - pl.full) * (128ll * 128 * 4) : 0; }
 inline bool tn_direct(const MssConvArgs& p);
+inline int tn_mode();
 inline bool tn_eligible(const MssConvArgs& p, int lddy) {
   const bool off = MSS_ENV_INT("MSS_WGRAD_TN", 5) == 0;     // A/B switch
-  if (off || p.R * p.S != 1 || p.K % 4 || p.C % 4 || p.ldx != p.C || lddy != p.K) return false;
+  if (off || p.R * p.S != 1 || p.K % 4 || p.C % 4 || p.ldx != p.C || lddy < p.K || lddy % 4) return false;
+  if (lddy != p.K && (p.batch > 1 || !tn_direct(p) || tn_mode() == 6)) return false;      // a slice of a wider dy: the LDS-free kernel takes a row stride
   if (p.in_scale || p.in_shift || p.in_relu) {
     // a prologue on x: only the LDS-free kernel applies one (a single affine for all rows, 16-byte aligned vectors), one position
     if (p.batch > 1 || p.in_ss_stride != 0 || !tn_direct(p) || MSS_ENV_INT("MSS_WGRAD_TN_AFFINE", 1) == 0) return false;
@@ -1458,7 +1461,7 @@ inline TnPlan tn_plan_direct(const MssConvArgs& p) {
   return pl;
 }
 int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, float* ws, long long ws_bytes,
-                    hipStream_t stream) {
+                    hipStream_t stream, int lddy = 0) {
   if (tn_direct(p)) {
     const TnPlan pl = tn_plan_direct(p);
     const int P = tn_batch(p);
@@ -1470,10 +1473,11 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
       if (p.in_scale || p.in_shift || p.in_relu)
         hipLaunchKernelGGL((gemm_tn_direct_kernel<4, true>), dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, dwp, P, p.M,
                            p.K, p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, pl.full, ws, p.in_scale,
-                           p.in_shift, p.in_relu);
+                           p.in_shift, p.in_relu, lddy);
       else
         hipLaunchKernelGGL(gemm_tn_direct_kernel<4>, dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, dwp, P, p.M, p.K,
-                           p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, pl.full, ws);
+                           p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, pl.full, ws, (const float*)nullptr,
+                           (const float*)nullptr, 0, lddy);
       hipLaunchKernelGGL(tn_tail_reduce_kernel, dim3((unsigned)(ntail * 16)), dim3(256), 0, stream, ws, dwp, pl.full, ntail, pl.splits,
                          pl.ktiles, pl.ctiles, p.Kpad, Cp);
       return mss_launch_status();
@@ -1486,10 +1490,11 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
     else if (p.in_scale || p.in_shift || p.in_relu)
       hipLaunchKernelGGL((gemm_tn_direct_kernel<4, true>), dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, out, P, p.M,
                          p.K, p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, -1ll, (float*)nullptr,
-                         p.in_scale, p.in_shift, p.in_relu);
+                         p.in_scale, p.in_shift, p.in_relu, lddy);
     else
       hipLaunchKernelGGL(gemm_tn_direct_kernel<4>, dim3((unsigned)((pl.total + 3) / 4)), dim3(256), 0, stream, dy, p.x, out, P, p.M, p.K,
-                         p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, -1ll, (float*)nullptr);
+                         p.C, a_bs, b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, -1ll, (float*)nullptr,
+                         (const float*)nullptr, (const float*)nullptr, 0, lddy);
     if (pl.splits > 1) {
       launch_wgrad_reduce(ws, dwp, slab / 4, pl.splits, stream);
     }
@@ -1638,7 +1643,7 @@ int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dw
   if (p.M <= 0) return MSS_OK;
   if (p.batch > 1 && (p.R * p.S != 1 || p.batch > 65535)) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (tn_eligible(p, lddy)) return launch_wgrad_tn(p, dy, dwp, Cp, ws, ws_bytes, s);
+  if (tn_eligible(p, lddy)) return launch_wgrad_tn(p, dy, dwp, Cp, ws, ws_bytes, s, lddy);
   if (narrow_eligible(p, dy, lddy, Cp)) return launch_wgrad_narrow(p, dy, lddy, dwp, Cp, ws, ws_bytes, s);
   // output-channel tile: 32 rows (1x4 waves) for the 19-channel heads, 64 for bot_fine's 48, else 128
   if (p.K <= 32) return launch_wgrad<32, 128, 16, 1>(p, dy, lddy, dwp, Cp, ws, ws_bytes, s);
