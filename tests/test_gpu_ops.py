@@ -536,6 +536,22 @@ def test_direct_wgrad_with_bn_relu_prologue_vs_float64(K, monkeypatch, n, h, w, 
     assert e_new < 2e-6 and e_new < 4 * e_old + 1e-7, (e_new, e_old)
 
 
+@pytest.mark.parametrize("c0,ld", [(0, 288), (32, 288), (4, 260)])
+def test_direct_wgrad_takes_a_channel_slice_of_a_wider_gradient_buffer(K, monkeypatch, c0, ld):
+    """r04: dy as 256 columns of a wider buffer (row stride ld) on the LDS-free kernel (forced: MSS_WGRAD_TN=7) against the same
+    columns copied out densely -- the same bits -- and a float64 product."""
+    monkeypatch.setenv("MSS_WGRAD_TN", "7")
+    torch.manual_seed(c0 + ld)
+    n, h, w, cin, k = 1, 200, 333, 256, 256
+    x = K.Act(torch.randn(n, h, w, cin, device="cuda"))
+    buf = torch.randn(n, h, w, ld, device="cuda")
+    got = K.conv2d_wgrad(x, K.Act(buf, k, c0), k, cin, 1, 1)
+    dense = K.conv2d_wgrad(x, K.Act(buf[..., c0:c0 + k].contiguous()), k, cin, 1, 1)
+    assert torch.equal(got, dense)
+    want = buf[..., c0:c0 + k].double().reshape(-1, k).t() @ x.buf.double().view(-1, cin)
+    assert (got.view(k, cin).double() - want).abs().max().item() / want.abs().max().item() < 2e-6
+
+
 @pytest.mark.parametrize("P,T,C,Ko,tail", [(36, 1100, 4096, 256, "1"), (36, 1100, 4096, 256, "0"), (9, 777, 2048, 1024, "1"), (5, 300, 4096, 512, "1")])
 def test_direct_wgrad_tail_plan_vs_float64(K, monkeypatch, P, T, C, Ko, tail):
     """r04: more output tiles than wave slots and a mostly empty last round (36 x 2 x 32 = 2304 tiles on 1024 SIMDs, the ASPP F(4x4)
