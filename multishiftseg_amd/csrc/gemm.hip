@@ -619,10 +619,14 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
     // Off by default: 0.2 ms per step does not pay for one GEMM call becoming two kernel launches in every profile.
     // r03: a default rule for nearly-empty last rounds (rem <= 128; only one-image eval products qualify) measured +-0 on the eval
     // forward (42.15 -> 42.15 ms): it stays opt-in. The two launches use the variant-3 kernels where the shape allows.
+    // r04 default rule (-1): single-position products with at most four whole rounds, where the idle part of the last round is a
+    // visible share of the launch -- the pixel decoder's Linears over 16 x 10 164 tokens are 1271 wide tiles = 2.48 rounds: decoder
+    // forward + backward 66.15 -> 65.78 ms with the hybrid, bit-identical; no product of the DeepLab step or of its eval forward
+    // qualifies (their tile counts are whole rounds), so the per-launch accounting of bench.py is unchanged. 0: never, 1: always.
     const int tail_mode = MSS_ENV_INT("MSS_GEMM_TAIL", -1);
     const long long full = (tiles256 / 512) * 512, rem = tiles256 - full;
     const int nw = p.K / 256;
-    const long long rem_max = tail_mode == 1 ? 384 : 0;
+    const long long rem_max = tail_mode == 1 ? 384 : (tail_mode == -1 && p.batch <= 1 && full <= 4 * 512) ? 384 : 0;
     if (bn == 0 && full > 0 && rem > 0 && rem <= rem_max) {
       MssConvArgs q = p;
       q.ntiles = nw;
