@@ -9,7 +9,8 @@ bench.py prints as roofline.traffic."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
-FAMILIES = ["gemm_nt_kernel", "conv_igemm_kernel", "conv_wgrad_kernel", "wino_input_transform_lds", "wino_input_transform_kernel",
+FAMILIES = ["gemm_nt_kernel", "conv_igemm_kernel", "conv_wgrad_kernel", "gemm_tn_direct_kernel", "gemm_tn_narrow_kernel", "gemm_tn_wgrad_kernel",
+            "wino_input_transform_aspp", "wino_input_transform_lds", "wino_input_transform_kernel",
             "wino_output_transform", "wino_grad_output_transform", "bn_stats_kernel", "bn_relu_bwd_reduce", "bn_relu_bwd_apply",
             "ood_score_v4", "ood_score_bwd_tiled", "rcl_pass1_v4", "rcl_pass2_v4", "upsample_ac_kernel", "upsample_ac_bwd_fast",
             "maxpool3s2", "colsum_kernel", "im2col3x3_c3", "m2f_score_kernel", "adam_kernel"]
