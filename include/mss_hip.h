@@ -25,7 +25,7 @@ extern "C" {
                                   mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32,
                                   mss_bn_fold_train_from_partials_f32; 5 (round 4): mss_adam_step_f32 takes double hyper-parameters, mss_env_reset,
                                   mss_wino_input_transform_aspp3_f32, mss_msda_prepare_backward_ld_f32, mss_rcl_pairs_device2_f32, mss_rcl_loss_device_f32, mss_m2f_fused_score_ws_f32, mss_oodm_compact_packed_f32,
-                                  mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32, mss_add_layernorm_q_f32, mss_add_layernorm_bwd_sum2_f32, mss_msda_forward_fused_save_f32, mss_msda_backward_binned_proj_f32 */
+                                  mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32, mss_add_layernorm_q_f32, mss_add_layernorm_bwd_sum2_f32, mss_msda_forward_fused_save_f32, mss_msda_backward_binned_proj_f32, mss_gap_from_partials_f32 */
 int mss_abi_version(void);
 
 /* The MSS_* environment switches (A/B experiments, test routes; none is needed in production) are read once per call site and
@@ -286,6 +286,9 @@ int mss_maxpool3s2_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N, i
  * floats (pixel-range partials, added in a fixed order: no atomics). */
 long long mss_colsum_workspace_floats(int N, int HW, int C);
 int mss_gap_nhwc_f32(const float* x, int ldx, float* y, int N, int HW, int C, float* ws, void* stream);
+/* the same from the per-64-row column sums a producing conv / GEMM left in MssConvArgs.stats ([ceil(N*HW/64)][2][C]; HW % 64 == 0,
+ * MSS_ERR_UNSUPPORTED otherwise): the map itself is not read again (r04). float64 accumulation in a fixed order. */
+int mss_gap_from_partials_f32(const float* partials, int N, int HW, int C, float* y, void* stream);
 /* broadcast y[n][p][c] = relu?(v[n][c]*scale[c]+shift[c]) over HW pixels: the "Upsample" of the
  * 1x1 image-pooling map (deepv3.py:86). */
 int mss_broadcast_rows_nhwc_f32(const float* v, float* y, int ldy, int N, int HW, int C, const float* scale,

@@ -97,6 +97,7 @@ SIGNATURES = {
     "mss_col_reduce_accum_doubles": [L, I],
     "mss_colsum_workspace_floats": [I, I, I],
     "mss_gap_nhwc_f32": [P, I, P, I, I, I, P, P],
+    "mss_gap_from_partials_f32": [P, I, I, I, P, P],
     "mss_broadcast_rows_nhwc_f32": [P, P, I, I, I, I, P, P, I, P],
     "mss_colsum_nhwc_f32": [P, I, P, I, I, I, P, P],
     "mss_upsample_ac_nhwc_f32": [P, I, P, I, I, I, I, I, I, I, P],

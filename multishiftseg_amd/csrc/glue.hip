@@ -1286,6 +1286,41 @@ int mss_maxpool3s2_nhwc_f32(const float* x, int ldx, float* y, int ldy, int N, i
   return mss_launch_status();
 }
 
+// AdaptiveAvgPool2d(1) from the per-64-row column sums the PRODUCING kernel's epilogue left (MssConvArgs.stats: [blocks][2][C], the
+// BatchNorm-statistics epilogue of DESIGN 3.4; first half of a block's row = sums): y[n][c] = sum over the image's blocks / HW.
+// The 1.07 GB map is not read again for the image-pooling branch (deepv3.py:84-88). 64 channels x 4 block lanes per workgroup,
+// float64 accumulation, fixed order.
+__global__ __launch_bounds__(256) void gap_from_partials_kernel(const float* __restrict__ part, int blocks_per_image, int C, double inv_hw,
+                                                                float* __restrict__ y) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, n = blockIdx.y;
+  double s = 0.0;
+  if (c < C) {
+    const float* p = part + (size_t)n * blocks_per_image * 2 * C + c;
+    for (int r0 = rl; r0 < blocks_per_image; r0 += 4 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + 4 * u;
+        v[u] = r < blocks_per_image ? p[(size_t)r * 2 * C] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+  }
+  __shared__ double red[4][64];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) y[(size_t)n * C + c] = (float)((((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl]) * inv_hw);
+}
+
+int mss_gap_from_partials_f32(const float* partials, int N, int HW, int C, float* y, void* stream) {
+  if (!partials || !y || N <= 0 || HW <= 0 || C <= 0) return MSS_ERR_BAD_ARG;
+  if (HW % 64) return MSS_ERR_UNSUPPORTED;          // the 64-row blocks of the partial sums would straddle images
+  hipLaunchKernelGGL(gap_from_partials_kernel, dim3((C + 63) / 64, N), dim3(256), 0, S_(stream), partials, HW / 64, C, 1.0 / (double)HW, y);
+  return mss_launch_status();
+}
+
 int mss_gap_nhwc_f32(const float* x, int ldx, float* y, int N, int HW, int C, float* ws, void* stream) {
   if (!x || !y || !ws || C % 4 || ldx % 4 || HW <= 0) return MSS_ERR_BAD_ARG;
   return launch_colsum(x, ldx, y, N, HW, C, 1.f / (float)HW, ws, S_(stream));

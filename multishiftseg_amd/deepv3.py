@@ -195,7 +195,9 @@ class DeepWV3Plus(nn.Module):
             mask = torch.bernoulli(torch.full((n, st.scale.numel()), keep, device=st.scale.device)) / keep
         return ((st.scale[None, :] * mask).contiguous(), (st.shift[None, :] * mask).contiguous())
 
-    def _run_block(self, blk, a, name):
+    def _run_block(self, blk, a, name, out_stats=False):
+        """out_stats: the block's output kernel leaves its per-64-row column sums even in eval mode (the trunk's last block: the ASPP
+        image-pooling branch takes its global average from them, kernels.gap)."""
         train = self.training
         st1 = K.bn_fold(blk.bn1[0], a, train)
         aff1 = (st1.scale, st1.shift)
@@ -212,14 +214,14 @@ class DeepWV3Plus(nn.Module):
                           max_tile=cap)
             st2 = K.bn_fold(c.bn2[0], o, train)
             return K.conv3x3(o, c.conv2.weight, dil=d, in_affine=self._dropout_affine(st2, blk, name, a.N), in_relu=True,
-                             res=shortcut, want_stats=train, max_tile=cap)
+                             res=shortcut, want_stats=train or out_stats, max_tile=cap)
         o = K.conv2d(a, K.packed(c.conv1.weight), stride=blk.stride, in_affine=aff1, in_relu=True, want_stats=train)
         st2 = K.bn_fold(c.bn2[0], o, train)
         o2 = K.conv3x3(o, c.conv2.weight, dil=d, in_affine=(st2.scale, st2.shift), in_relu=True, want_stats=train,
                        max_tile=cap)
         st3 = K.bn_fold(c.bn3[0], o2, train)
         return K.conv2d(o2, K.packed(c.conv3.weight), in_affine=self._dropout_affine(st3, blk, name, a.N), in_relu=True,
-                        res=shortcut, want_stats=train)
+                        res=shortcut, want_stats=train or out_stats)
 
     def _run_trunk(self, inp):
         fused_stem = os.environ.get("MSS_STEM_FUSED", "1") != "0"
@@ -238,8 +240,9 @@ class DeepWV3Plus(nn.Module):
             name = f"mod{mod_id + 2}"
             if mod_id < 2 and not (fused_stem and mod_id == 0):
                 a = K.maxpool3s2(a)
-            for blk in getattr(self, name):
-                a = self._run_block(blk, a, name)
+            blocks = list(getattr(self, name))
+            for i, blk in enumerate(blocks):
+                a = self._run_block(blk, a, name, out_stats=(mod_id == 5 and i == len(blocks) - 1))
             if mod_id == 0:
                 m2 = a
         return a, m2

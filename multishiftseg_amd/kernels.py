@@ -861,6 +861,12 @@ def maxpool3s2(x):
 
 def gap(x):
     y = torch.empty((x.N, x.C), device=x.buf.device, dtype=torch.float32)
+    # the producing kernel's epilogue left per-64-row column sums (x.stats, wanted for BatchNorm statistics or asked for by the
+    # caller): the mean comes from those few MB instead of another pass over the map (r04; MSS_GAP_FROM_STATS=0: always the pass)
+    if x.stats is not None and (x.H * x.W) % 64 == 0 and x.stats.shape[0] * 64 == x.M and x.stats.shape[2] == x.C \
+            and os.environ.get("MSS_GAP_FROM_STATS", "1") != "0":
+        call("mss_gap_from_partials_f32", ptr(x.stats), x.N, x.H * x.W, x.C, ptr(y))
+        return y
     ws = torch.empty(_lib.value("mss_colsum_workspace_floats", x.N, x.H * x.W, x.C), device=x.buf.device, dtype=torch.float32)
     call("mss_gap_nhwc_f32", x.ptr, x.ld, ptr(y), x.N, x.H * x.W, x.C, ptr(ws))
     return y

@@ -960,3 +960,24 @@ def test_gemm_grouped_tile_order_is_a_permutation_of_the_same_tiles(K, monkeypat
     if extras:
         want = torch.relu(want + res[:, ::7].double())
     assert (outs["8"][:, ::7].double() - want).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("n,h,w,c", [(2, 128, 256, 4096), (3, 24, 40, 512), (1, 8, 8, 256), (2, 6, 10, 256)])
+def test_gap_from_the_producers_partial_sums(K, monkeypatch, n, h, w, c):
+    """r04: AdaptiveAvgPool2d(1) from the per-64-row column sums a producing GEMM's epilogue left (kernels.gap with x.stats) against
+    the pass over the map (MSS_GAP_FROM_STATS=0) and float64; image sizes that are not multiples of 64 pixels keep the pass."""
+    torch.manual_seed(n * h + c)
+    cin = 64
+    xin = K.Act(torch.randn(n, h, w, cin, device="cuda"))
+    wt = torch.randn(c, cin, 1, 1, device="cuda") / 8
+    y = K.conv2d(xin, K.pack_weight(wt), want_stats=True)
+    assert y.stats is not None
+    got = K.gap(y)
+    monkeypatch.setenv("MSS_GAP_FROM_STATS", "0")
+    old = K.gap(y)
+    want = y.buf[..., :c].double().mean((1, 2))
+    scale = want.abs().max().item()
+    assert (got.double() - want).abs().max().item() <= 2e-6 * scale + 1e-7
+    assert (old.double() - want).abs().max().item() <= 2e-6 * scale + 1e-7
+    if (h * w) % 64:
+        assert torch.equal(got, old)                # the fallback ran
