@@ -179,7 +179,7 @@ class _EncoderLayerFn(Function):
         ctx.q_is_input = q_in is not None
         ctx.shapes_host = getattr(shapes, "_mss_host", None)
         ctx.saved_loc = loc is not None
-        keep = (loc, aw) if loc is not None else (ol, ol)
+        keep = (loc, aw) if loc is not None else (ol, None)      # what the backward derives the sampling operands from
         ctx.save_for_backward(src, q, ref, shapes, starts, value, keep[0], keep[1], samp, attn, stat1, s1, h, f, stat2, *params)
         if qn is None:
             return out, None
