@@ -21,11 +21,11 @@
 extern "C" {
 #endif
 
-#define MSS_ABI_VERSION 5      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
+#define MSS_ABI_VERSION 6      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
                                   mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32,
                                   mss_bn_fold_train_from_partials_f32; 5 (round 4): mss_adam_step_f32 takes double hyper-parameters, mss_env_reset,
                                   mss_wino_input_transform_aspp3_f32, mss_msda_prepare_backward_ld_f32, mss_rcl_pairs_device2_f32, mss_rcl_loss_device_f32, mss_m2f_fused_score_ws_f32, mss_oodm_compact_packed_f32,
-                                  mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32, mss_add_layernorm_q_f32, mss_add_layernorm_bwd_sum2_f32, mss_msda_forward_fused_save_f32, mss_msda_backward_binned_proj_f32, mss_gap_from_partials_f32 */
+                                  6 (late round 4, additive): mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32, mss_add_layernorm_q_f32, mss_add_layernorm_bwd_sum2_f32, mss_msda_forward_fused_save_f32, mss_msda_backward_binned_proj_f32, mss_gap_from_partials_f32 */
 int mss_abi_version(void);
 
 /* The MSS_* environment switches (A/B experiments, test routes; none is needed in production) are read once per call site and

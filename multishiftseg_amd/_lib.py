@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so libmss_hip.
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSS_LIB", os.path.join(_HERE, "libmss_hip.so"))   # MSS_LIB: A/B experiments only
 
-MSS_ABI_VERSION = 5          # include/mss_hip.h
+MSS_ABI_VERSION = 6          # include/mss_hip.h
 MSS_ERR_BAD_ARG = 1001
 MSS_ERR_UNSUPPORTED = 1002
 
