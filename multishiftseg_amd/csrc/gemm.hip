@@ -547,17 +547,21 @@ bool mss_gemm_nt_eligible(const MssConvArgs& p) {
 }
 
 // Returns -1 when the shape is not handled here (the implicit-GEMM kernel takes it).
-// 1x1 layers over <= 8 pixels with nothing fused: gemm_few_rows_kernel (p.M is set)
+// 1x1 layers over <= 32 pixels with nothing fused (the ASPP image-pooling product: one row per image -- 16 at 16 x 768 x 768, where
+// the MFMA tile path took 0.255 ms): gemm_few_rows_kernel (p.M is set)
 bool mss_gemm_few_rows(const MssConvArgs& p) {
-  return p.R * p.S == 1 && p.stride == 1 && p.pad == 0 && p.H == p.OH && p.W == p.OW && p.M > 0 && p.M <= 8 && p.batch <= 1 &&
+  return p.R * p.S == 1 && p.stride == 1 && p.pad == 0 && p.H == p.OH && p.W == p.OW && p.M > 0 && p.M <= 32 && p.batch <= 1 &&
          p.C % 4 == 0 && p.ldx % 4 == 0 && !p.in_scale && !p.in_relu && !p.out_scale && !p.out_relu && !p.res && !p.stats &&
          ((reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.w)) & 15) == 0;
 }
 
 int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
   if (mss_gemm_few_rows(p)) {
-    hipLaunchKernelGGL(gemm_few_rows_kernel<8>, dim3((p.K + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), p.x, p.ldx, p.w,
-                       p.y, p.ldy, p.M, p.C, p.K);
+    const dim3 grid((p.K + 3) / 4);
+    hipStream_t fs = static_cast<hipStream_t>(stream);
+    if (p.M <= 8) hipLaunchKernelGGL(gemm_few_rows_kernel<8>, grid, dim3(256), 0, fs, p.x, p.ldx, p.w, p.y, p.ldy, p.M, p.C, p.K);
+    else if (p.M <= 16) hipLaunchKernelGGL(gemm_few_rows_kernel<16>, grid, dim3(256), 0, fs, p.x, p.ldx, p.w, p.y, p.ldy, p.M, p.C, p.K);
+    else hipLaunchKernelGGL(gemm_few_rows_kernel<32>, grid, dim3(256), 0, fs, p.x, p.ldx, p.w, p.y, p.ldy, p.M, p.C, p.K);
     return mss_launch_status();
   }
   if (!mss_gemm_nt_eligible(p)) return -1;

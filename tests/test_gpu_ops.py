@@ -609,10 +609,12 @@ def test_fused_stem_conv_pool(K, n, h, w):
     assert n * h * w <= 8 or torch.equal(got.nchw(), two.nchw()), (got.nchw() - two.nchw()).abs().max().item()
 
 
-@pytest.mark.parametrize("m,c,k", [(1, 4096, 256), (2, 4096, 256), (8, 64, 19), (3, 528, 100), (9, 4096, 256)])
+@pytest.mark.parametrize("m,c,k", [(1, 4096, 256), (2, 4096, 256), (8, 64, 19), (3, 528, 100), (9, 4096, 256), (16, 4096, 256), (32, 512, 48),
+                                   (33, 4096, 256)])
 def test_few_rows_1x1_route(K, m, c, k):
-    """1x1 convolutions over <= 8 pixels in all (ASPP's image-pooling branch: [N, 4096] -> 256) take the wave-per-output-channel
-    kernel of gemm.hip instead of one MFMA tile walking the whole reduction; 9 rows take the MFMA kernels. Against float64."""
+    """1x1 convolutions over <= 32 pixels in all (ASPP's image-pooling branch: [N, 4096] -> 256, N = 16 at 16 x 768 x 768) take the
+    wave-per-output-channel kernel of gemm.hip instead of one MFMA tile walking the whole reduction; 33 rows take the MFMA kernels.
+    Against float64."""
     torch.manual_seed(m + c + k)
     x = torch.randn(m, 1, 1, c, device="cuda")
     w = torch.randn(k, c, 1, 1, device="cuda") / c ** 0.5

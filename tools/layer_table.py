@@ -9,12 +9,13 @@ from multishiftseg_amd.loss import RelContrastiveLoss
 from multishiftseg_amd.trainer import LOSS_PARAMS, TrainStep
 
 H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 2048)
+PAIRS = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # (orig, aug) pairs: `layer_table.py 768 768 8` = the c2 workload
 model = DeepWV3Plus(19)
 model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.deepwv3plus_params(0).items()})
 model = model.cuda(); model.uncertainty_func_init()
 step = TrainStep(model, RelContrastiveLoss(LOSS_PARAMS, pairing="device"), stage=2)
-img = torch.randn(2, 3, H, W, device="cuda")
-tgt = torch.from_numpy(synth.synth_targets(1, 1, H, W)).cuda()
+img = torch.randn(2 * PAIRS, 3, H, W, device="cuda")
+tgt = torch.from_numpy(synth.synth_targets(1, PAIRS, H, W)).cuda()
 step(img, tgt.clone())
 prof = K.ConvProfile(); K.set_conv_profile(prof)
 torch.cuda.synchronize()
