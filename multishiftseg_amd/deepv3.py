@@ -278,7 +278,8 @@ class DeepWV3Plus(nn.Module):
         pooled_act = Act(pooled.view(N, 1, 1, 4096))
         u0 = K.conv2d(pooled_act, K.packed(asp.img_conv[0].weight))
         u0_rows = u0.buf.view(N, 256)
-        st = K.bn_fold(asp.img_conv[1], train=train, x_rows=u0_rows)
+        # every branch's folded BatchNorm goes straight into its 256-channel slice of the concat's (scale, shift) vectors
+        st = K.bn_fold(asp.img_conv[1], train=train, x_rows=u0_rows, out=(scale[0:256], shift[0:256]))
         K.broadcast_rows(u0_rows, raw.slice(0, 256))
         states.append(st)
         xt_bytes = sum(K.wino_xt_bytes(N, h8, w8, 4096, r) for r in _ASPP_RATES)
@@ -311,10 +312,7 @@ class DeepWV3Plus(nn.Module):
                 if pre_xt:
                     pre_xt[i - 1] = None                  # the layer owns it now (kept for the weight gradient, or freed)
                 aspp_xt[i] = kx.get("xt") if kx else None
-            states.append(K.bn_fold(feat[1], sl, train))
-        for i, s in enumerate(states):
-            scale[256 * i:256 * (i + 1)].copy_(s.scale)
-            shift[256 * i:256 * (i + 1)].copy_(s.shift)
+            states.append(K.bn_fold(feat[1], sl, train, out=(scale[256 * (i + 1):256 * (i + 2)], shift[256 * (i + 1):256 * (i + 2)])))
         up_small = K.conv2d(raw, K.packed(self.bot_aspp.weight), in_affine=(scale, shift), in_relu=True)
         # dec0 = concat [bot_fine(m2), up(bot_aspp)]: when nothing needs it as a tensor (final.0 is not trained in either stage of
         # exps/DeepLab.yaml, so no weight gradient reads it), the x4 bilinear upsample is interpolated inside final.0's Winograd

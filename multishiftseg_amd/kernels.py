@@ -679,16 +679,21 @@ def _col_accum(M, C, device):
     return torch.empty(_lib.value("mss_col_reduce_accum_doubles", M, C), device=device, dtype=torch.float64)
 
 
-def bn_fold(bn, x=None, train=False, M=None, x_rows=None):
+def bn_fold(bn, x=None, train=False, M=None, x_rows=None, out=None):
     """Fold nn.BatchNorm2d `bn` into (scale, shift). train=True computes batch statistics of the
     NHWC activation x (Act) and updates the running buffers exactly like F.batch_norm
-    (momentum 0.1, unbiased running variance; mynn.py:8-12)."""
+    (momentum 0.1, unbiased running variance; mynn.py:8-12). out: (scale, shift) to write into -- e.g. a 256-channel
+    slice of the 1280-channel vectors of the ASPP concat, instead of a copy afterwards."""
     C = bn.num_features
     dev = bn.weight.device
     st = BNState()
     st.train = train
-    st.scale = torch.empty(C, device=dev, dtype=torch.float32)
-    st.shift = torch.empty(C, device=dev, dtype=torch.float32)
+    if out is not None:
+        st.scale, st.shift = out
+        assert st.scale.numel() == C and st.shift.numel() == C and st.scale.is_contiguous() and st.shift.is_contiguous()
+    else:
+        st.scale = torch.empty(C, device=dev, dtype=torch.float32)
+        st.shift = torch.empty(C, device=dev, dtype=torch.float32)
     st.save_mean = st.save_invstd = None
     if not train:
         call("mss_bn_fold_eval_f32", ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
