@@ -21,11 +21,12 @@
 extern "C" {
 #endif
 
-#define MSS_ABI_VERSION 6      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
+#define MSS_ABI_VERSION 7      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
                                   mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32,
                                   mss_bn_fold_train_from_partials_f32; 5 (round 4): mss_adam_step_f32 takes double hyper-parameters, mss_env_reset,
                                   mss_wino_input_transform_aspp3_f32, mss_msda_prepare_backward_ld_f32, mss_rcl_pairs_device2_f32, mss_rcl_loss_device_f32, mss_m2f_fused_score_ws_f32, mss_oodm_compact_packed_f32,
-                                  6 (late round 4, additive): mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32, mss_add_layernorm_q_f32, mss_add_layernorm_bwd_sum2_f32, mss_msda_forward_fused_save_f32, mss_msda_backward_binned_proj_f32, mss_gap_from_partials_f32 */
+                                  6 (late round 4, additive): mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32, mss_add_layernorm_q_f32, mss_add_layernorm_bwd_sum2_f32, mss_msda_forward_fused_save_f32, mss_msda_backward_binned_proj_f32, mss_gap_from_partials_f32;
+                                  7 (round 5): MssConvArgs.w_split + mss_gemm_split_weights_bf16x3 (the split-bf16 GEMM route) */
 int mss_abi_version(void);
 
 /* The MSS_* environment switches (A/B experiments, test routes; none is needed in production) are read once per call site and
@@ -161,14 +162,27 @@ typedef struct MssConvArgs {
                            /*   64g..64g+63); reduce with mss_bn_stats_partials_f32. Not with batch > 1.            */
   int res_mask;            /* 1: `res` gates instead of adds -- y = res[m*ldres + k] > 0 ? y : 0 -- the ReLU backward of a  */
                            /*   producer whose stored OUTPUT is `res` (FFN of msdeformattn.py:122-131) fused in the dgrad   */
+  const void* w_split;     /* optional: the SAME weights as `w`, split into three bf16 planes by mss_gemm_split_weights_bf16x3.     */
+                           /*   Non-NULL selects the split-bf16 route (6 bf16 MFMAs with fp32 accumulation per product block,       */
+                           /*   fp32 accuracy) for every shape the persistent GEMM kernel takes (1x1, > 64 output channels,         */
+                           /*   >= 48 input channels); other shapes run the native fp32 kernels on `w` (which must always be set).   */
 } MssConvArgs;
 
 int mss_conv2d_forward_f32(MssConvArgs* args, void* stream);
 int mss_conv2d_kpad(int K);
 /* 1 if mss_conv2d_forward_f32 runs these arguments on the persistent GEMM kernel (csrc/gemm.hip: 1x1, stride 1,
- * more than 64 output channels, or 33..64 of them over >= 16 384 rows), 2 for the few-rows kernel (1x1 over <= 8 pixels, nothing fused), 0 for the implicit-GEMM
- * kernel. Profiling label only. */
+ * more than 64 output channels, or 33..64 of them over >= 16 384 rows), 2 for the few-rows kernel (1x1 over <= 8 pixels, nothing fused), 3 for the
+ * split-bf16 form of the persistent GEMM kernel (args->w_split set and the shape eligible), 0 for the implicit-GEMM kernel. Profiling label only. */
 int mss_conv2d_forward_route(const MssConvArgs* args);
+/* The split-bf16 form of packed weights for MssConvArgs.w_split: w [batch][Kpad][C] fp32 (batch stride w_bs floats; what
+ * mss_conv2d_pack_weights_f32 with R = S = 1 or mss_wino_pack_weights_f32 produce, Kpad % 128 == 0, C % 16 == 0) -> `planes`,
+ * mss_gemm_split_weights_bytes(batch, Kpad, C) = batch * Kpad * C * 6 bytes: every value as three round-to-nearest bf16 terms
+ * hi + mid + lo (exact), stored per 128-row block and 16-deep K-step in the order the kernel stages them. A fp32 product is then
+ * a_hi b_hi + a_hi b_mid + a_mid b_hi + a_hi b_lo + a_lo b_hi + a_mid b_mid on the bf16 matrix cores with fp32 accumulation
+ * (the three dropped terms are below 2^-26 |a b|): same contraction as nn.Conv2d / F.linear in fp32
+ * (deepv3.py:47-92,258-285, wider_resnet.py:169-182), at fp32 accuracy. mss_conv2d_forward_route answers 3 when a call runs it. */
+long long mss_gemm_split_weights_bytes(int batch, int Kpad, int C);
+int mss_gemm_split_weights_bf16x3(const float* w, void* planes, int batch, int Kpad, int C, long long w_bs, void* stream);
 /* w [K][C][R][S] (nn.Conv2d.weight) -> packed [R*S][Kpad][Cp] (zero padded).
  * flip=1 packs the data-gradient filter instead (K<->C swapped, taps rotated 180 degrees);
  * then Kpad/Cp refer to the swapped roles. */

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so libmss_hip.
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSS_LIB", os.path.join(_HERE, "libmss_hip.so"))   # MSS_LIB: A/B experiments only
 
-MSS_ABI_VERSION = 6          # include/mss_hip.h
+MSS_ABI_VERSION = 7          # include/mss_hip.h
 MSS_ERR_BAD_ARG = 1001
 MSS_ERR_UNSUPPORTED = 1002
 
@@ -37,6 +37,7 @@ class MssConvArgs(Structure):
         ("batch", c_int), ("x_bs", c_longlong), ("w_bs", c_longlong), ("y_bs", c_longlong),
         ("stats", c_void_p),
         ("res_mask", c_int),
+        ("w_split", c_void_p),
     ]
 
 
@@ -79,6 +80,8 @@ SIGNATURES = {
     "mss_conv2d_forward_f32": [POINTER(MssConvArgs), P],
     "mss_conv2d_kpad": [I],
     "mss_conv2d_forward_route": [POINTER(MssConvArgs)],
+    "mss_gemm_split_weights_bytes": [I, I, I],
+    "mss_gemm_split_weights_bf16x3": [P, P, I, I, I, L, P],
     "mss_conv2d_pack_weights_f32": [P, P, I, I, I, I, I, I, I, P],
     "mss_conv2d_wgrad_workspace_bytes": [POINTER(MssConvArgs), I],
     "mss_conv2d_wgrad_f32": [POINTER(MssConvArgs), P, I, P, I, P, L, P],
@@ -164,12 +167,12 @@ SIGNATURES = {
     "mss_peak_scatter_f32": [P, P, L, I, I, L, P],
 }
 # entry points that return a plain value rather than a status code
-_VALUE_RETURNING = {"mss_abi_version", "mss_env_reset", "mss_env_generation", "mss_rcl_workspace_bytes", "mss_msda_backward_workspace_bytes", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
+_VALUE_RETURNING = {"mss_gemm_split_weights_bytes", "mss_abi_version", "mss_env_reset", "mss_env_generation", "mss_rcl_workspace_bytes", "mss_msda_backward_workspace_bytes", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
                     "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts",
                     "mss_conv2d_wgrad_workspace_bytes", "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
                     "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats",
                     "mss_groupnorm_stat_offset", "mss_groupnorm_bwd_workspace_floats"}
-_RETURNS_LONGLONG = {"mss_rcl_workspace_bytes", "mss_msda_backward_workspace_bytes", "mss_wino_num_tiles", "mss_oodm_sort_temp_bytes", "mss_conv2d_wgrad_workspace_bytes",
+_RETURNS_LONGLONG = {"mss_gemm_split_weights_bytes", "mss_rcl_workspace_bytes", "mss_msda_backward_workspace_bytes", "mss_wino_num_tiles", "mss_oodm_sort_temp_bytes", "mss_conv2d_wgrad_workspace_bytes",
                      "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
                      "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats",
                      "mss_groupnorm_stat_offset", "mss_groupnorm_bwd_workspace_floats"}

@@ -24,6 +24,7 @@
 int mss_gemm_nt_dispatch(MssConvArgs p, void* stream);   // gemm.hip: persistent GEMM for the 1x1 / stride-1 shapes
 bool mss_gemm_nt_eligible(const MssConvArgs& p);
 bool mss_gemm_few_rows(const MssConvArgs& p);
+bool mss_gemm_nt_bf16x3_eligible(const MssConvArgs& p);   // gemm_bf16x3.hip
 
 namespace {
 
@@ -1583,7 +1584,9 @@ int mss_conv2d_forward_route(const MssConvArgs* args) {
   p.M = p.N * p.OH * p.OW;
   if (!MSS_ENV_INT("MSS_GEMM", 1)) return 0;
   if (mss_gemm_few_rows(p)) return 2;                  // (0 implicit-GEMM kernel, 1 gemm_nt_kernel, 2 gemm_few_rows_kernel)
-  return mss_gemm_nt_eligible(p) ? 1 : 0;
+  if (!mss_gemm_nt_eligible(p)) return 0;
+  p.mtiles = (p.M + 127) / 128;
+  return mss_gemm_nt_bf16x3_eligible(p) ? 3 : 1;
 }
 
 // Kpad the packed layout must use for a conv with K output channels (multiple of the N tile).

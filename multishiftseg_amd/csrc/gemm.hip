@@ -16,6 +16,7 @@
 // Tile order is n-fastest and an XCD owns a contiguous run of tiles, so the n-tiles that share an X tile hit in the
 // same L2.
 #include "mss_epilogue.h"
+#include "mss_gemm_tiles.h"
 #include <stdlib.h>
 
 namespace {
@@ -42,23 +43,6 @@ static_assert(NKC == 2, "the step body below is written for two 8-k chunks");
 // BN: output-channel extent of a tile. 128 (2x2 waves of 64x64, 4 workgroups per CU) or 256 (2x2 waves of 64x128: 64 MFMAs
 // per wave and barrier instead of 32, a quarter less operand traffic per FLOP and half the per-tile prologue/epilogue
 // share, at 2 workgroups per CU).
-#ifndef GEMM_GROUP_M_DEFAULT
-#define GEMM_GROUP_M_DEFAULT 8
-#endif
-// Tile index -> (row tile, column tile). group_m == 0: column tile fastest (the 16 column tiles of one row block of a 2048 -> 4096
-// product are consecutive). group_m > 0 (r04): groups of `group_m` row tiles, row tile fastest inside a group, so that the ~64
-// workgroups an XCD runs together form a SQUARE-ish block of tiles (8 x 8 instead of 4 x 16): every K-slice of A is then shared by
-// 8 and every K-slice of B by 8 of them in that XCD's L2, instead of 16 / 4. A bijection of the same tile set: results unchanged.
-__device__ __forceinline__ void tile_mn(int v, int mtiles, int ntiles, int group_m, int& mt, int& nt) {
-  if (group_m <= 0 || ntiles == 1) { mt = v / ntiles; nt = v - mt * ntiles; return; }
-  const int gsz = group_m * ntiles;
-  const int g = v / gsz, r = v - g * gsz;
-  const int first = g * group_m;
-  const int rows = mtiles - first < group_m ? mtiles - first : group_m;
-  nt = r / rows;
-  mt = first + (r - nt * rows);
-}
-
 template <bool AFFINE, int VARIANT, int BN>
 __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvArgs p, long long first_tile, long long total_tiles,
                                                                         int tiles_per_batch, int group_m) {
@@ -90,7 +74,7 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
   auto setup_off = [&](long long t, unsigned* ao, unsigned* bo, unsigned& so) {
     const int b = (int)(t / tiles_per_batch);
     const int v = (int)(t - (long long)b * tiles_per_batch);
-    int mt, nt; tile_mn(v, p.mtiles, p.ntiles, group_m, mt, nt);
+    int mt, nt; mss_tile_mn(v, p.mtiles, p.ntiles, group_m, mt, nt);
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       int row = mt * BM + row0 + j * RPP;
@@ -106,7 +90,7 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
     if (VARIANT == 3) { setup_off(t, a_off, b_off, s_off); return; }
     const int b = (int)(t / tiles_per_batch);
     const int v = (int)(t - (long long)b * tiles_per_batch);
-    int mt, nt; tile_mn(v, p.mtiles, p.ntiles, group_m, mt, nt);
+    int mt, nt; mss_tile_mn(v, p.mtiles, p.ntiles, group_m, mt, nt);
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       int row = mt * BM + row0 + j * RPP;
@@ -225,7 +209,7 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
   auto epilogue = [&](long long t) {
     const int b = (int)(t / tiles_per_batch);
     const int v = (int)(t - (long long)b * tiles_per_batch);
-    int mt, nt; tile_mn(v, p.mtiles, p.ntiles, group_m, mt, nt);
+    int mt, nt; mss_tile_mn(v, p.mtiles, p.ntiles, group_m, mt, nt);
     mss_epilogue_store<TM, TN>(acc, p, p.y + (size_t)b * p.y_bs, mt * BM + wm * WTM, nt * BN + wn * WTN, lane);
   };
 
@@ -528,7 +512,9 @@ int launch_gemm(const MssConvArgs& p, hipStream_t stream, long long first = 0, l
 
 }  // namespace
 
-int mss_gemm_nt_bf16x6_launch(MssConvArgs p, void* stream);   // gemm_bf16x6.hip (experimental, opt-in)
+int mss_gemm_nt_bf16x6_launch(MssConvArgs p, void* stream);   // gemm_bf16x6.hip (round 4's first draft, kept for A/B: MSS_GEMM_BF16X6=1)
+bool mss_gemm_nt_bf16x3_eligible(const MssConvArgs& p);       // gemm_bf16x3.hip: the split-bf16 route (MssConvArgs.w_split)
+int mss_gemm_nt_bf16x3_launch(MssConvArgs p, void* stream);
 
 // Shapes this kernel takes from mss_conv2d_forward_f32 (conv_igemm.hip); p.M is set.
 // 33..64 output channels over many rows (the 48-channel heads and bot_fine, 1 M pixels) on the persistent kernel with a 128 x 64
@@ -577,10 +563,8 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
   p.ntiles = mss_cdiv(p.K, 128);
   if (p.Kpad < p.ntiles * 128) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  {
-    // experimental split-bf16 evaluation of the same fp32 GEMM
-    if (MSS_ENV_INT("MSS_GEMM_BF16X6", 0)) return mss_gemm_nt_bf16x6_launch(p, stream);
-  }
+  if (mss_gemm_nt_bf16x3_eligible(p)) return mss_gemm_nt_bf16x3_launch(p, stream);      // the split-bf16 route, chosen by the caller
+  if (MSS_ENV_INT("MSS_GEMM_BF16X6", 0)) return mss_gemm_nt_bf16x6_launch(p, stream);     // round 4's draft of it (A/B only)
   // measured (tools/bench_bgemm.py, tools/bench_1x1.py, r02): variant 2 is +3-7 % on every shape (C = 128: 82.7 -> 86.9,
   // 512: 127 -> 132, 1024 -> 2048: 132 -> 136 TFLOP/s; 1x1 2048 -> 4096 with prologue/residual/statistics: 123 -> 128)
   // r03: variant 3 (32-bit offsets, branch-free advance, loader instructions interleaved with the MFMAs) is +4-6 % from C = 256 up

@@ -1,0 +1,340 @@
+// The fp32 NT GEMM of gemm.hip evaluated on the bf16 matrix cores by operand splitting -- the SECOND, fully pinned GEMM route
+// (round 5; `MssConvArgs.w_split` selects it per call; never silently: mss_conv2d_forward_route answers 3 for it).
+//
+//   x = x_hi + x_mid + x_lo exactly (three round-to-nearest bf16 terms cover fp32's 24 significand bits), so
+//   a * b = a_hi b_hi + (a_hi b_mid + a_mid b_hi) + (a_hi b_lo + a_lo b_hi + a_mid b_mid) + O(2^-26 |a b|)
+// -- six v_mfma_f32_32x32x16_bf16 (fp32 accumulate) per 32 x 32 x 16 block instead of eight v_mfma_f32_32x32x2_f32. The bf16 pipe
+// runs 16x the FLOPs per cycle of the fp32 one, so the six-product form has 2.67x the matrix throughput of the native instruction
+// at fp32 accuracy (against float64: 2e-7 of max|y|, native fp32 MFMA 3-6e-7; tests/test_gpu_ops.py::test_bf16x3_gemm_*).
+//
+// What round 4's first draft (gemm_bf16x6.hip: both operands split on the fly with a scalar chain, 128 x 128 tile, 5.5 VALU per
+// MFMA, pipe 60 % busy) did not have:
+//  * the WEIGHTS are split once, at pack time (mss_gemm_split_weights_bf16x3), into the exact LDS image of a 128-row operand
+//    block per K-step -- [block][K-step][plane hi|mid|lo][128 rows][16 k], 12 KB each, the two 16-byte halves of a row swapped when
+//    bit 3 of the row is set -- so staging B is a linear 16-byte-per-lane copy with no arithmetic at all;
+//  * only the ACTIVATION operand is split in the loader, with v_cvt_pk_bf16_f32 (two conversions per instruction) and mask /
+//    shift re-expansion: 5.5 VALU per element, 8 elements per thread and K-step on the 128 x 256 tile = 0.9 VALU per MFMA;
+//  * gemm_nt_kernel's persistent schedule (variant 3): 32-bit offsets, the loader two K-steps ahead across tile boundaries with
+//    one register set, a branch-free advance, one barrier per K-step, 128 x 256 tiles (48 MFMAs per wave and barrier) at two
+//    workgroups per CU, 128 x 128 at three.
+// LDS per stage: A 3 x 4 KB + B 3 x 4 KB per 128 columns; two stages: 72 KB (128 x 256) / 48 KB (128 x 128).
+#include "mss_epilogue.h"
+#include "mss_gemm_tiles.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int NT = 256, BM = 128, BK = 16;
+constexpr int ROW_B = BK * 2;                 // bytes per row per plane
+constexpr int PLANE = 128 * ROW_B;            // 4 KB: one plane of a 128-row operand block
+constexpr int OPER = 3 * PLANE;               // 12 KB: hi, mid, lo
+constexpr int TM = 2;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {        // v_cvt_pk_bf16_f32: round to nearest even, low half = a
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// (a, b) -> packed hi / mid / lo bf16 pairs; the residuals are exact in fp32 (Sterbenz / aligned-exponent subtraction)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = cvt_pk_bf16(a, b);
+  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+  mid = cvt_pk_bf16(ra, rb);
+  const float qa = ra - __uint_as_float(mid << 16), qb = rb - __uint_as_float(mid & 0xffff0000u);
+  lo = cvt_pk_bf16(qa, qb);
+}
+
+template <bool AFFINE, int BN>
+__global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_bf16x3_kernel(MssConvArgs p, const unsigned char* __restrict__ wpl,
+                                                                               long long total_tiles, int tiles_per_batch,
+                                                                               int group_m, unsigned blk_bytes, int nblk_total) {
+  constexpr int NBLK = BN / 128, TN = BN / 64;          // wave tile 64 x (BN / 2)
+  constexpr int STAGE = (1 + NBLK) * OPER;              // A block, then NBLK B blocks
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int chunk = tid & 3, row0 = tid >> 2;           // A staging: floats [4 chunk, 4 chunk + 4) of rows row0 and row0 + 64
+  const int n_it = p.C / BK;
+  const long long stride = gridDim.x;
+  const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
+
+  // ---- loader state (see gemm_nt_kernel, variant 3) ----
+  unsigned a_off[2], a_nxt[2], b_off[NBLK], b_nxt[NBLK], s_off = 0, s_nxt = 0;
+  long long ld_tile = mss_xcd_remap(blockIdx.x, gridDim.x);
+  int ld_k = 0;
+  auto setup_off = [&](long long t, unsigned* ao, unsigned* bo, unsigned& so) {
+    const int b = (int)(t / tiles_per_batch);
+    const int v = (int)(t - (long long)b * tiles_per_batch);
+    int mt, nt; mss_tile_mn(v, p.mtiles, p.ntiles, group_m, mt, nt);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int row = mt * BM + row0 + j * 64;
+      row = row < p.M ? row : p.M - 1;                  // rows past the end re-read the last row; never stored
+      ao[j] = (unsigned)(((size_t)b * p.x_bs + (size_t)row * p.ldx + chunk * 4) * sizeof(float));
+    }
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j)
+      bo[j] = (unsigned)(b * nblk_total + nt * NBLK + j) * blk_bytes + tid * 16;
+    if (AFFINE) so = (unsigned)(((size_t)((mt * BM) / p.H) * p.in_ss_stride + chunk * 4) * sizeof(float));
+  };
+  auto setup_next = [&]() {
+    const long long t = ld_tile + stride;
+    setup_off(t < total_tiles ? t : ld_tile, a_nxt, b_nxt, s_nxt);
+  };
+  f32x4 areg[2], sreg, hreg;
+  u32x4 breg[NBLK][3];
+  auto issue_loads = [&]() {
+    const char* xb = reinterpret_cast<const char*>(p.x);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) areg[j] = *reinterpret_cast<const f32x4*>(xb + a_off[j]);
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) breg[j][pl] = *reinterpret_cast<const u32x4*>(wpl + b_off[j] + pl * PLANE);
+    if (AFFINE) {
+      sreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in_scale) + s_off);
+      hreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in_shift) + s_off);
+    }
+  };
+  auto advance = [&]() {                 // branch-free: next K-step of this tile, else first K-step of this workgroup's next tile
+    const bool wrap = ++ld_k == n_it;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) a_off[j] = wrap ? a_nxt[j] : a_off[j] + BK * (unsigned)sizeof(float);
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) b_off[j] = wrap ? b_nxt[j] : b_off[j] + (unsigned)OPER;
+    if (AFFINE) s_off = wrap ? s_nxt : s_off + BK * (unsigned)sizeof(float);
+    ld_k = wrap ? 0 : ld_k;
+  };
+  // A: 4 bf16 (8 B) per plane at row r, quarter `chunk` of the 32-byte row, halves swapped when bit 3 of r is set
+  const int st_off = row0 * ROW_B + (((chunk >> 1) ^ ((row0 >> 3) & 1)) * 16) + (chunk & 1) * 8;
+  auto finish_store = [&](int buf) {
+    unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 v = areg[j];
+      if (AFFINE) {
+        v = v * sreg + hreg;
+        v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+      }
+      unsigned hi[2], mid[2], lo[2];
+      split_pair(v.x, v.y, hi[0], mid[0], lo[0]);
+      split_pair(v.z, v.w, hi[1], mid[1], lo[1]);
+      *reinterpret_cast<u32x2*>(base + 0 * PLANE + st_off + j * 64 * ROW_B) = u32x2{hi[0], hi[1]};
+      *reinterpret_cast<u32x2*>(base + 1 * PLANE + st_off + j * 64 * ROW_B) = u32x2{mid[0], mid[1]};
+      *reinterpret_cast<u32x2*>(base + 2 * PLANE + st_off + j * 64 * ROW_B) = u32x2{lo[0], lo[1]};
+    }
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<u32x4*>(base + (1 + j) * OPER + pl * PLANE + tid * 16) = breg[j][pl];
+  };
+
+  // fragment of v_mfma_f32_32x32x16_bf16: lane = (row l % 32, k-block l / 32), 8 consecutive k = 16 B
+  const int frow = lane & 31, fkb = lane >> 5;
+  const int fr_off = frow * ROW_B + ((fkb ^ ((frow >> 3) & 1)) * 16);
+  const int fa_off = wm * 64 * ROW_B + fr_off;
+  const int fb_off = OPER + (BN == 256 ? wn * OPER : wn * 64 * ROW_B) + fr_off;
+
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  auto epilogue = [&](long long t) {
+    const int b = (int)(t / tiles_per_batch);
+    const int v = (int)(t - (long long)b * tiles_per_batch);
+    int mt, nt; mss_tile_mn(v, p.mtiles, p.ntiles, group_m, mt, nt);
+    mss_epilogue_store<TM, TN>(acc, p, p.y + (size_t)b * p.y_bs, mt * BM + wm * 64, nt * BN + wn * (BN / 2), lane);
+  };
+  // One K-step: the products in an order that needs one new operand plane per group of 2 * TN MFMAs
+  //   (A_lo, B_hi) (A_mid, B_hi) (A_hi, B_hi) (A_hi, B_mid) (A_mid, B_mid) (A_hi, B_lo)
+  // (the order inside a K-step is irrelevant for the rounding error: every term is added to an accumulator that already holds the
+  // previous K-steps' sum).
+  auto step = [&](const int buf) {
+    const unsigned char* base = smem + buf * STAGE;
+    auto ld_a = [&](int pl, bf16x8 (&f)[TM]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) f[i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + fa_off + i * 32 * ROW_B);
+    };
+    auto ld_b = [&](int pl, bf16x8 (&f)[TN]) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) f[j] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + fb_off + j * 32 * ROW_B);
+    };
+    auto mm = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    bf16x8 a_hi[TM], a_mid[TM], a_lo[TM], b_hi[TN], b_mid[TN], b_lo[TN];
+    ld_a(2, a_lo); ld_b(0, b_hi);
+    ld_a(1, a_mid); ld_a(0, a_hi);
+    finish_store(buf ^ 1);               // K-step k+1, requested during step k-1
+    issue_loads();                       // K-step k+2 (possibly of the next tile) into the registers just drained
+    advance();
+    mm(a_lo, b_hi);
+    ld_b(1, b_mid);
+    mm(a_mid, b_hi);
+    mm(a_hi, b_hi);
+    ld_b(2, b_lo);
+    mm(a_hi, b_mid);
+    mm(a_mid, b_mid);
+    mm(a_hi, b_lo);
+    __syncthreads();
+  };
+
+  long long cur = ld_tile;               // tile being multiplied (the launch guarantees cur < total_tiles)
+  setup_off(ld_tile, a_off, b_off, s_off);
+  setup_next();
+  issue_loads();
+  finish_store(0);
+  advance();
+  issue_loads();                         // registers now hold K-step 1
+  advance();
+  zero_acc();
+  __syncthreads();
+  int k = 0;
+  auto tile_end = [&]() -> bool {        // true: this workgroup has no tile left
+    if (++k < n_it) return false;
+    epilogue(cur);
+    cur += stride;
+    if (cur >= total_tiles) return true;
+    zero_acc();
+    k = 0;
+    ld_tile = cur;                       // the loader entered `cur` at least one K-step ago (n_it >= 3): prepare the one after it
+    setup_next();
+    return false;
+  };
+  while (true) {                         // unrolled by the two LDS stages: the stage is a compile-time constant in each half
+    step(0);
+    if (tile_end()) break;
+    step(1);
+    if (tile_end()) break;
+  }
+}
+
+// fp32 weights [batch][Kpad][C] -> three bf16 planes in the LDS image order the kernel copies:
+// byte ((b * Kpad/128 + n / 128) * C/16 + s) * 12288 + plane * 4096 + (n % 128) * 32 + ((h ^ ((n >> 3) & 1)) * 16) holds k = 16 s + 8 h .. + 7
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Kpad,
+                                                            int C, long long w_bs, long long total) {
+  const int nk = C / 16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int h = (int)(i & 1);
+    long long r = i >> 1;
+    const int s = (int)(r % nk); r /= nk;
+    const int n = (int)(r % Kpad);
+    const long long b = r / Kpad;
+    const float* src = w + b * w_bs + (size_t)n * C + s * 16 + h * 8;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+    unsigned hi[4], mid[4], lo[4];
+    split_pair(v0.x, v0.y, hi[0], mid[0], lo[0]);
+    split_pair(v0.z, v0.w, hi[1], mid[1], lo[1]);
+    split_pair(v1.x, v1.y, hi[2], mid[2], lo[2]);
+    split_pair(v1.z, v1.w, hi[3], mid[3], lo[3]);
+    unsigned char* dst = out + ((size_t)(b * (Kpad / 128) + n / 128) * nk + s) * OPER + (n & 127) * ROW_B + ((h ^ ((n >> 3) & 1)) * 16);
+    *reinterpret_cast<u32x4*>(dst) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<u32x4*>(dst + PLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+    *reinterpret_cast<u32x4*>(dst + 2 * PLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+  }
+}
+
+template <bool AFFINE, int BN>
+int launch_split(const MssConvArgs& p, hipStream_t stream) {
+  const int batch = p.batch > 1 ? p.batch : 1;
+  const int tiles_per_batch = p.mtiles * p.ntiles;
+  const long long total = (long long)tiles_per_batch * batch;
+  if (total <= 0) return MSS_OK;
+  const size_t smem = (size_t)2 * (1 + BN / 128) * OPER;
+  static int per_cu_max = 0, cus = 256;
+  if (per_cu_max == 0) {
+    int dev = 0, n = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (smem > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16x3_kernel<AFFINE, BN>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_bf16x3_kernel<AFFINE, BN>, NT, smem) != hipSuccess || n < 1) n = BN == 256 ? 2 : 3;
+    const int cap = MSS_ENV_INT("MSS_GEMM_WG_PER_CU", 0);
+    if (cap > 0 && cap < n) n = cap;
+    per_cu_max = n;
+  }
+  // residency (per_cu_max or one less) whose last round of tiles is fuller, as launch_gemm (gemm.hip)
+  int grid = 0;
+  double best = -1.0;
+  for (int per_cu = per_cu_max; per_cu >= (per_cu_max > 1 ? per_cu_max - 1 : 1); --per_cu) {
+    const long long slots = (long long)per_cu * cus;
+    const long long g = total < slots ? total : slots;
+    const long long rounds = (total + g - 1) / g;
+    const double eff = (double)total / (double)(rounds * g);
+    if (eff > best + 0.02) { best = eff; grid = (int)g; }
+  }
+  const int group_m = MSS_ENV_INT("MSS_GEMM_GROUP_M", GEMM_GROUP_M_DEFAULT);
+  const unsigned blk_bytes = (unsigned)(p.C / BK) * OPER;
+  hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN>), dim3(grid), dim3(NT), smem, stream, p,
+                     static_cast<const unsigned char*>(p.w_split), total, tiles_per_batch, group_m, blk_bytes, p.Kpad / 128);
+  return mss_launch_status();
+}
+
+}  // namespace
+
+// Shapes the split route takes: what gemm_nt_kernel's 128- / 256-wide variant-3 kernels take (p.M, p.mtiles set by the caller) with
+// the weights' planes inside 32-bit byte offsets.
+bool mss_gemm_nt_bf16x3_eligible(const MssConvArgs& p) {
+  if (!p.w_split || p.K <= 64 || p.C / BK < 3 || p.Kpad % 128) return false;
+  const long long nb = p.batch > 1 ? p.batch : 1;
+  if (p.batch > 1 && p.w_bs != (long long)p.Kpad * p.C) return false;
+  if ((unsigned long long)((nb - 1) * p.x_bs + (long long)p.M * p.ldx) * 4ull >= 0xffffffffull) return false;
+  if ((unsigned long long)nb * p.Kpad * p.C * 6ull >= 0xffffffffull) return false;
+  return (reinterpret_cast<uintptr_t>(p.w_split) & 15) == 0;
+}
+
+// Called by mss_gemm_nt_dispatch (gemm.hip) with p.H (rows per affine group), p.mtiles set; picks the tile width as the native
+// route does (MSS_GEMM_BN=128|256 forces one).
+int mss_gemm_nt_bf16x3_launch(MssConvArgs p, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int bn = MSS_ENV_INT("MSS_GEMM_BN", 0);
+  const long long nb = p.batch > 1 ? p.batch : 1;
+  const long long tiles256 = (long long)p.mtiles * (p.K / 256) * nb;
+  bool wide = p.K % 256 == 0 && (bn == 256 || (bn == 0 && tiles256 >= 1024 && p.C >= 256));
+  if (wide && bn == 0) {
+    auto eff = [](long long total, long long slots) {
+      const long long rounds = (total + slots - 1) / slots;
+      return (double)total / (double)(rounds * slots);
+    };
+    const double ew = eff(tiles256, 512), en = eff(2 * tiles256, 768);
+    if (ew < 0.8 && en > ew + 0.15) wide = false;
+  }
+  if (wide) {
+    p.ntiles = p.K / 256;
+    return p.in_scale ? launch_split<true, 256>(p, s) : launch_split<false, 256>(p, s);
+  }
+  p.ntiles = mss_cdiv(p.K, 128);
+  return p.in_scale ? launch_split<true, 128>(p, s) : launch_split<false, 128>(p, s);
+}
+
+extern "C" long long mss_gemm_split_weights_bytes(int batch, int Kpad, int C) {
+  if (batch < 1 || Kpad < 128 || Kpad % 128 || C < 16 || C % 16) return 0;
+  return (long long)batch * Kpad * C * 6;
+}
+
+extern "C" int mss_gemm_split_weights_bf16x3(const float* w, void* planes, int batch, int Kpad, int C, long long w_bs, void* stream) {
+  if (!w || !planes || batch < 1 || Kpad % 128 || C % 16 || Kpad < 128 || C < 16) return MSS_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(planes)) & 15 || w_bs % 4) return MSS_ERR_BAD_ARG;
+  const long long total = (long long)batch * Kpad * (C / 16) * 2;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                     static_cast<unsigned char*>(planes), Kpad, C, w_bs, total);
+  return mss_launch_status();
+}

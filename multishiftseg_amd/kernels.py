@@ -62,14 +62,60 @@ class PackedWeight:
     """[R*S][Kpad][Cp] layout consumed by the MFMA kernels. When the output-channel count leaves a
     narrow last 128-wide tile (e.g. 304 = 2*128 + 48, the data gradient of final.0), `tail` holds
     those channels as a separate pack that runs on the 64-wide tile instead of wasting 2/3 of a tile."""
-    __slots__ = ("t", "K", "C", "R", "S", "Kpad", "Cp", "tail")
+    __slots__ = ("t", "K", "C", "R", "S", "Kpad", "Cp", "tail", "planes")
 
     def __init__(self, t, K, C, R, S, Kpad, Cp, tail=None):
         self.t, self.K, self.C, self.R, self.S, self.Kpad, self.Cp, self.tail = t, K, C, R, S, Kpad, Cp, tail
+        self.planes = None         # split-bf16 form, made on first use under that route (w_split_of)
 
 
 def _round_up(v, m):
     return (v + m - 1) // m * m
+
+
+# ---- the split-bf16 GEMM route (csrc/gemm_bf16x3.hip) ---------------------------------------------------------------------------
+# MSS_GEMM_SPLIT=1 (or set_gemm_route("bf16x3")): every product the persistent GEMM kernel takes runs as six bf16 MFMAs on operands
+# split into three bf16 terms (fp32 accumulate, fp32 accuracy); the weights' planes are made once per packed weight.
+_route_override = None
+
+
+def set_gemm_route(route):
+    """"native" (fp32 MFMA), "bf16x3" (split-bf16) or None (back to the MSS_GEMM_SPLIT environment switch)."""
+    global _route_override
+    assert route in (None, "native", "bf16x3")
+    _route_override = route
+
+
+def gemm_route():
+    if _route_override is not None:
+        return _route_override
+    return "bf16x3" if os.environ.get("MSS_GEMM_SPLIT", "0") == "1" else "native"
+
+
+def split_planes(t, Kpad, C):
+    """The three-bf16-plane form (MssConvArgs.w_split) of packed fp32 weights t [batch][Kpad][C]; None where the route does not
+    apply (Kpad not a multiple of 128: the <= 64-channel packs run on the native narrow tile)."""
+    batch = t.numel() // (Kpad * C)
+    nbytes = _lib.value("mss_gemm_split_weights_bytes", batch, Kpad, C)
+    if nbytes <= 0:
+        return None
+    planes = torch.empty(nbytes, device=t.device, dtype=torch.uint8)
+    call("mss_gemm_split_weights_bf16x3", ptr(t), ptr(planes), batch, Kpad, C, Kpad * C)
+    return planes
+
+
+def w_split_of(pw):
+    """Pointer for MssConvArgs.w_split of a PackedWeight / WinoWeight under the current route (None: native). The planes are cached
+    on the pack object, which is itself re-made whenever the parameter changes (_cached_pack)."""
+    if gemm_route() != "bf16x3":
+        return None
+    if pw.planes is None:
+        if getattr(pw, "R", 1) * getattr(pw, "S", 1) != 1:
+            return None
+        pw.planes = split_planes(pw.t, pw.Kpad, pw.Cp)
+        if pw.planes is None:
+            pw.planes = False
+    return ptr(pw.planes) if pw.planes is not False else None
 
 
 def pack_weight(w, flip=False, min_c=16):
@@ -190,7 +236,7 @@ def _fwd_kind(a):
     """Profiling label of a forward launch: which of the two MFMA kernels the C side picks."""
     if _profile is None:
         return "conv_igemm"
-    return ("conv_igemm", "gemm_nt", "gemm_few_rows")[_lib.value("mss_conv2d_forward_route", ctypes.byref(a))]
+    return ("conv_igemm", "gemm_nt", "gemm_few_rows", "gemm_nt_bf16x3")[_lib.value("mss_conv2d_forward_route", ctypes.byref(a))]
 
 
 def conv_out_size(h, r, stride, dil, pad):
@@ -200,6 +246,7 @@ def conv_out_size(h, r, stride, dil, pad):
 def _conv_args(x, pw, y, stride, dil, pad, in_affine, in_relu, out_affine, out_relu, res, res_mask=False):
     a = MssConvArgs()
     a.x, a.w, a.y = x.ptr, ptr(pw.t), (y.ptr if y is not None else None)
+    a.w_split = w_split_of(pw)
     if in_affine is not None:
         sc, sh = in_affine
         a.in_scale, a.in_shift = ptr(sc), ptr(sh)
@@ -289,10 +336,11 @@ def conv2d_wgrad(x, dy, K, C, R, S, stride=1, dil=1, pad=0, in_affine=None, in_r
 
 class WinoWeight:
     """Winograd-domain filter U [(tile+2)^2][Kpad][Cp] of a 3x3 weight."""
-    __slots__ = ("t", "K", "C", "Kpad", "Cp", "tile")
+    __slots__ = ("t", "K", "C", "Kpad", "Cp", "tile", "planes")
 
     def __init__(self, t, K, C, Kpad, Cp, tile):
         self.t, self.K, self.C, self.Kpad, self.Cp, self.tile = t, K, C, Kpad, Cp, tile
+        self.planes = None
 
 
 def pack_weight_wino(w, flip=False, tile=2):
@@ -429,6 +477,7 @@ def _wino_gemm_and_output(xt, ww, N, H, W, dil, res, out, keep_xt, want_stats):
     yt = torch.empty((P, T, K), device=dev, dtype=torch.float32)
     a = MssConvArgs()
     a.x, a.w, a.y = ptr(xt), ptr(ww.t), ptr(yt)
+    a.w_split = w_split_of(ww)
     a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
     a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, K, ww.Kpad, K
     a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
@@ -441,6 +490,7 @@ def _wino_gemm_and_output(xt, ww, N, H, W, dil, res, out, keep_xt, want_stats):
         call("mss_conv2d_forward_f32", ctypes.byref(a))
         if split:
             a.K, a.Kpad = rem, ww.Kpad - split
+            a.w_split = None                                  # the <= 64-channel tail runs on the native narrow tile
             a.w = ctypes.c_void_p(ww.t.data_ptr() + 4 * split * ww.Cp)
             a.y = ctypes.c_void_p(yt.data_ptr() + 4 * split)
             call("mss_conv2d_forward_f32", ctypes.byref(a))
@@ -525,6 +575,7 @@ def conv3x3_pair(x, w1, w2, dil1, dil2, out1, out2, tile, want_stats=False, xt=N
         yt = torch.empty((2 * P, T, Ko), device=dev, dtype=torch.float32)
         a = MssConvArgs()
         a.x, a.w, a.y = ptr(xt), ptr(ww.t), ptr(yt)
+        a.w_split = w_split_of(ww)
         a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
         a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, Ko, ww.Kpad, Ko
         a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
