@@ -49,8 +49,8 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
   lo = cvt_pk_bf16(qa, qb);
 }
 
-template <bool AFFINE, int BN>
-__global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_bf16x3_kernel(MssConvArgs p, const unsigned char* __restrict__ wpl,
+template <bool AFFINE, int BN, bool SCHED>
+__global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf16x3_kernel(MssConvArgs p, const unsigned char* __restrict__ wpl,
                                                                                long long total_tiles, int tiles_per_batch,
                                                                                int group_m, unsigned blk_bytes, int nblk_total) {
   constexpr int NBLK = BN / 128, TN = BN / 64;          // wave tile 64 x (BN / 2)
@@ -88,19 +88,27 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_bf16x3_kernel(M
   };
   f32x4 areg[2], sreg, hreg;
   u32x4 breg[NBLK][3];
-  auto issue_loads = [&]() {
+  // one uniform base per plane (kept opaque, or the compiler folds them back into wpl + 4096 / 8192, which do not fit the 13-bit
+  // instruction offset and cost a 64-bit VALU address per load): every load is `global_load_dwordx4 v, v_off, s[base]`
+  typedef const unsigned char __attribute__((address_space(1)))* gptr_t;     // stays a GLOBAL pointer through the asm (else: flat loads)
+  gptr_t wbase[3] = {(gptr_t)wpl, (gptr_t)wpl + PLANE, (gptr_t)wpl + 2 * PLANE};
+  asm volatile("" : "+s"(wbase[1]), "+s"(wbase[2]));
+  auto issue_loads_a = [&]() {
     const char* xb = reinterpret_cast<const char*>(p.x);
 #pragma unroll
     for (int j = 0; j < 2; ++j) areg[j] = *reinterpret_cast<const f32x4*>(xb + a_off[j]);
-#pragma unroll
-    for (int j = 0; j < NBLK; ++j)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) breg[j][pl] = *reinterpret_cast<const u32x4*>(wpl + b_off[j] + pl * PLANE);
     if (AFFINE) {
       sreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in_scale) + s_off);
       hreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in_shift) + s_off);
     }
   };
+  auto issue_loads_b = [&]() {
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) breg[j][pl] = *reinterpret_cast<const u32x4 __attribute__((address_space(1)))*>(wbase[pl] + b_off[j]);
+  };
+  auto issue_loads = [&]() { issue_loads_a(); issue_loads_b(); };
   auto advance = [&]() {                 // branch-free: next K-step of this tile, else first K-step of this workgroup's next tile
     const bool wrap = ++ld_k == n_it;
 #pragma unroll
@@ -112,28 +120,38 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_bf16x3_kernel(M
   };
   // A: 4 bf16 (8 B) per plane at row r, quarter `chunk` of the 32-byte row, halves swapped when bit 3 of r is set
   const int st_off = row0 * ROW_B + (((chunk >> 1) ^ ((row0 >> 3) & 1)) * 16) + (chunk & 1) * 8;
-  auto finish_store = [&](int buf) {
+  auto split_row = [&](int j, unsigned (&hi)[2], unsigned (&mid)[2], unsigned (&lo)[2]) {
+    f32x4 v = areg[j];
+    if (AFFINE) {
+      v = v * sreg + hreg;
+      v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+    }
+    split_pair(v.x, v.y, hi[0], mid[0], lo[0]);
+    split_pair(v.z, v.w, hi[1], mid[1], lo[1]);
+  };
+  auto store_row = [&](int buf, int j, const unsigned (&hi)[2], const unsigned (&mid)[2], const unsigned (&lo)[2]) {
     unsigned char* base = smem + buf * STAGE;
+    *reinterpret_cast<u32x2*>(base + 0 * PLANE + st_off + j * 64 * ROW_B) = u32x2{hi[0], hi[1]};
+    *reinterpret_cast<u32x2*>(base + 1 * PLANE + st_off + j * 64 * ROW_B) = u32x2{mid[0], mid[1]};
+    *reinterpret_cast<u32x2*>(base + 2 * PLANE + st_off + j * 64 * ROW_B) = u32x2{lo[0], lo[1]};
+  };
+  auto finish_store_a = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      f32x4 v = areg[j];
-      if (AFFINE) {
-        v = v * sreg + hreg;
-        v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
-      }
       unsigned hi[2], mid[2], lo[2];
-      split_pair(v.x, v.y, hi[0], mid[0], lo[0]);
-      split_pair(v.z, v.w, hi[1], mid[1], lo[1]);
-      *reinterpret_cast<u32x2*>(base + 0 * PLANE + st_off + j * 64 * ROW_B) = u32x2{hi[0], hi[1]};
-      *reinterpret_cast<u32x2*>(base + 1 * PLANE + st_off + j * 64 * ROW_B) = u32x2{mid[0], mid[1]};
-      *reinterpret_cast<u32x2*>(base + 2 * PLANE + st_off + j * 64 * ROW_B) = u32x2{lo[0], lo[1]};
+      split_row(j, hi, mid, lo);
+      store_row(buf, j, hi, mid, lo);
     }
+  };
+  auto finish_store_b = [&](int buf) {
+    unsigned char* base = smem + buf * STAGE;
 #pragma unroll
     for (int j = 0; j < NBLK; ++j)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
         *reinterpret_cast<u32x4*>(base + (1 + j) * OPER + pl * PLANE + tid * 16) = breg[j][pl];
   };
+  auto finish_store = [&](int buf) { finish_store_a(buf); finish_store_b(buf); };
 
   // fragment of v_mfma_f32_32x32x16_bf16: lane = (row l % 32, k-block l / 32), 8 consecutive k = 16 B
   const int frow = lane & 31, fkb = lane >> 5;
@@ -177,19 +195,69 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_bf16x3_kernel(M
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     };
     bf16x8 a_hi[TM], a_mid[TM], a_lo[TM], b_hi[TN], b_mid[TN], b_lo[TN];
-    ld_a(2, a_lo); ld_b(0, b_hi);
-    ld_a(1, a_mid); ld_a(0, a_hi);
-    finish_store(buf ^ 1);               // K-step k+1, requested during step k-1
-    issue_loads();                       // K-step k+2 (possibly of the next tile) into the registers just drained
-    advance();
-    mm(a_lo, b_hi);
-    ld_b(1, b_mid);
-    mm(a_mid, b_hi);
-    mm(a_hi, b_hi);
-    ld_b(2, b_lo);
-    mm(a_hi, b_mid);
-    mm(a_mid, b_mid);
-    mm(a_hi, b_lo);
+    if (!SCHED) {
+      ld_a(2, a_lo); ld_b(0, b_hi);
+      ld_a(1, a_mid); ld_a(0, a_hi);
+      finish_store(buf ^ 1);               // K-step k+1, requested during step k-1
+      issue_loads();                       // K-step k+2 (possibly of the next tile) into the registers just drained
+      advance();
+      mm(a_lo, b_hi);
+      ld_b(1, b_mid);
+      mm(a_mid, b_hi);
+      mm(a_hi, b_hi);
+      ld_b(2, b_lo);
+      mm(a_hi, b_mid);
+      mm(a_mid, b_mid);
+      mm(a_hi, b_lo);
+    } else {
+      // Left alone, hipcc sinks the global loads of step k+2 to the END of step k and meets them with an `s_waitcnt vmcnt(0)` at the
+      // top of step k+1 (the two-steps-ahead loader degenerates to none), and clumps the split arithmetic in front of the MFMAs.
+      // Here the step is cut into six segments the scheduler may not move instructions across, one group of 2 * TN MFMAs each,
+      // with the loader's work of that segment asked to go one (or a few) behind each MFMA:
+      //   1: B's LDS writes (data requested a whole step ago)   2: B's global loads for step k+2 + the b_mid fragments
+      //   3: split of A row 0 + its LDS writes                  4: split of A row 1 + its LDS writes + A's global loads + b_lo
+      //   5: the loader's bookkeeping                           6: nothing
+      constexpr int NB = 3 * NBLK, G = TM * TN;
+      auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+      // n x (one MFMA, then `per` instructions of class `mask`); the segment's remaining MFMAs follow
+#define MSS_PAIR_UP(mask, n, per)                                                                                             \
+  _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                          \
+    __builtin_amdgcn_sched_group_barrier((mask), (per), 0);                                                                   \
+  }
+      ld_a(2, a_lo); ld_b(0, b_hi);
+      ld_a(1, a_mid); ld_a(0, a_hi);
+      fence();
+      finish_store_b(buf ^ 1);
+      mm(a_lo, b_hi);
+      MSS_PAIR_UP(0x200, NB < G ? NB : G, NB <= G ? 1 : 2);
+      fence();
+      issue_loads_b();
+      ld_b(1, b_mid);
+      mm(a_mid, b_hi);
+      MSS_PAIR_UP(0x20, NB < G ? NB : G, 1);
+      MSS_PAIR_UP(0x100, G - NB > 0 ? (G - NB < TN ? G - NB : TN) : 0, 1);
+      fence();
+      unsigned hi[2], mid[2], lo[2];
+      split_row(0, hi, mid, lo);
+      store_row(buf ^ 1, 0, hi, mid, lo);
+      mm(a_hi, b_hi);
+      MSS_PAIR_UP(0x2, G - 1, ((AFFINE ? 30 : 22) + G - 2) / (G - 1));
+      fence();
+      split_row(1, hi, mid, lo);
+      store_row(buf ^ 1, 1, hi, mid, lo);
+      issue_loads_a();
+      ld_b(2, b_lo);
+      mm(a_hi, b_mid);
+      MSS_PAIR_UP(0x2, G - 1, ((AFFINE ? 30 : 22) + G - 2) / (G - 1));
+      fence();
+      advance();
+      mm(a_mid, b_mid);
+      MSS_PAIR_UP(0x6, G - 1, 3);
+      fence();
+      mm(a_hi, b_lo);
+#undef MSS_PAIR_UP
+    }
     __syncthreads();
   };
 
@@ -248,7 +316,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   }
 }
 
-template <bool AFFINE, int BN>
+template <bool AFFINE, int BN, bool SCHED>
 int launch_split(const MssConvArgs& p, hipStream_t stream) {
   const int batch = p.batch > 1 ? p.batch : 1;
   const int tiles_per_batch = p.mtiles * p.ntiles;
@@ -261,11 +329,11 @@ int launch_split(const MssConvArgs& p, hipStream_t stream) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (smem > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16x3_kernel<AFFINE, BN>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_bf16x3_kernel<AFFINE, BN>, NT, smem) != hipSuccess || n < 1) n = BN == 256 ? 2 : 3;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED>, NT, smem) != hipSuccess || n < 1) n = BN == 256 ? 2 : 3;
     const int cap = MSS_ENV_INT("MSS_GEMM_WG_PER_CU", 0);
     if (cap > 0 && cap < n) n = cap;
     per_cu_max = n;
@@ -282,7 +350,7 @@ int launch_split(const MssConvArgs& p, hipStream_t stream) {
   }
   const int group_m = MSS_ENV_INT("MSS_GEMM_GROUP_M", GEMM_GROUP_M_DEFAULT);
   const unsigned blk_bytes = (unsigned)(p.C / BK) * OPER;
-  hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN>), dim3(grid), dim3(NT), smem, stream, p,
+  hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED>), dim3(grid), dim3(NT), smem, stream, p,
                      static_cast<const unsigned char*>(p.w_split), total, tiles_per_batch, group_m, blk_bytes, p.Kpad / 128);
   return mss_launch_status();
 }
@@ -316,12 +384,15 @@ int mss_gemm_nt_bf16x3_launch(MssConvArgs p, void* stream) {
     const double ew = eff(tiles256, 512), en = eff(2 * tiles256, 768);
     if (ew < 0.8 && en > ew + 0.15) wide = false;
   }
+  const bool sched = MSS_ENV_INT("MSS_GEMM_SPLIT_SCHED", 1) != 0;      // A/B: 0 = the compiler's own order of the K-step
   if (wide) {
     p.ntiles = p.K / 256;
-    return p.in_scale ? launch_split<true, 256>(p, s) : launch_split<false, 256>(p, s);
+    if (!sched) return p.in_scale ? launch_split<true, 256, false>(p, s) : launch_split<false, 256, false>(p, s);
+    return p.in_scale ? launch_split<true, 256, true>(p, s) : launch_split<false, 256, true>(p, s);
   }
   p.ntiles = mss_cdiv(p.K, 128);
-  return p.in_scale ? launch_split<true, 128>(p, s) : launch_split<false, 128>(p, s);
+  if (!sched) return p.in_scale ? launch_split<true, 128, false>(p, s) : launch_split<false, 128, false>(p, s);
+  return p.in_scale ? launch_split<true, 128, true>(p, s) : launch_split<false, 128, true>(p, s);
 }
 
 extern "C" long long mss_gemm_split_weights_bytes(int batch, int Kpad, int C) {
