@@ -512,7 +512,6 @@ int launch_gemm(const MssConvArgs& p, hipStream_t stream, long long first = 0, l
 
 }  // namespace
 
-int mss_gemm_nt_bf16x6_launch(MssConvArgs p, void* stream);   // gemm_bf16x6.hip (round 4's first draft, kept for A/B: MSS_GEMM_BF16X6=1)
 bool mss_gemm_nt_bf16x3_eligible(const MssConvArgs& p);       // gemm_bf16x3.hip: the split-bf16 route (MssConvArgs.w_split)
 int mss_gemm_nt_bf16x3_launch(MssConvArgs p, void* stream);
 
@@ -564,7 +563,6 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
   if (p.Kpad < p.ntiles * 128) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (mss_gemm_nt_bf16x3_eligible(p)) return mss_gemm_nt_bf16x3_launch(p, stream);      // the split-bf16 route, chosen by the caller
-  if (MSS_ENV_INT("MSS_GEMM_BF16X6", 0)) return mss_gemm_nt_bf16x6_launch(p, stream);     // round 4's draft of it (A/B only)
   // measured (tools/bench_bgemm.py, tools/bench_1x1.py, r02): variant 2 is +3-7 % on every shape (C = 128: 82.7 -> 86.9,
   // 512: 127 -> 132, 1024 -> 2048: 132 -> 136 TFLOP/s; 1x1 2048 -> 4096 with prologue/residual/statistics: 123 -> 128)
   // r03: variant 3 (32-bit offsets, branch-free advance, loader instructions interleaved with the MFMAs) is +4-6 % from C = 256 up

@@ -40,7 +40,7 @@ def test_decoder_state_dict_contract_cpu():
 
 
 @pytest.mark.gpu
-def test_decoder_forward_features_golden():
+def test_decoder_forward_features_golden(gemm_route):
     dec, g = build()
     dec = dec.cuda()
     rng = np.random.default_rng(int(g["seed"]))
@@ -60,7 +60,7 @@ def test_decoder_forward_features_golden():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fixture", ["m2f_decoder_704", "m2f_decoder_1024x2048"])
-def test_decoder_forward_features_fullsize_golden(fixture):
+def test_decoder_forward_features_fullsize_golden(fixture, gemm_route):
     """Row a-11 at the BASELINE sizes: forward_features with the shipped depth (6 encoder layers) on
     the feature pyramid of one 704x704 crop (C4: 10 164 tokens) and of one 1024x2048 image (C5: 43 008 tokens) against the
     reference class's own outputs (tools/gen_golden.py decoder_704 / decoder_c5): strided slices, one full row, float64
@@ -163,7 +163,7 @@ def test_groupnorm_layernorm_upsample_ops_vs_oracle():
 
 
 @pytest.mark.gpu
-def test_decoder_backward_golden():
+def test_decoder_backward_golden(gemm_route):
     """Parameter and feature gradients of L = <mask, G> + sum_i <ms[i], G_i> against the reference class's own autograd
     (tools/gen_golden.py decoder): relative L2 of every gradient <= 2e-3, L2 norms within 1e-3, and two identical runs
     give bit-identical gradients (no float atomics on the path)."""
@@ -221,7 +221,7 @@ def test_decoder_backward_golden():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fixture", ["m2f_decoder_704", "m2f_decoder_1024x2048"])
-def test_decoder_backward_fullsize_golden(fixture):
+def test_decoder_backward_fullsize_golden(fixture, gemm_route):
     """The M2F training path at the BASELINE sizes (VERDICT r03 missing #3 / weak #2): gradients of every parameter and of
     the four feature maps of L = <mask, G> + sum_i <ms[i], G_i>, 6 encoder layers, one 704x704 crop (10 164 tokens) and one
     1024x2048 image (43 008 tokens), against the reference class's own autograd (tools/gen_golden.py decoder_704 /

@@ -19,7 +19,7 @@ def model(deeplab_params):
 
 
 @pytest.mark.parametrize("tag", ["eval_1x64x128", "eval_2x96x96"])
-def test_eval_forward_golden(model, tag):
+def test_eval_forward_golden(model, tag, gemm_route):
     from multishiftseg_amd import synth
     g = golden("deepwv3plus_" + tag)
     n, h, w = (int(v) for v in g["shape"])
@@ -46,7 +46,7 @@ def test_state_dict_contract(model, deeplab_params):
 
 @pytest.mark.parametrize("stage,names,lr", [("stage1", ["ood_head"], 1e-4),
                                             ("stage2", ["aspp", "bot_fine", "bot_aspp", "ood_head"], 1e-6)])
-def test_train_step_golden(deeplab_params, stage, names, lr):
+def test_train_step_golden(deeplab_params, stage, names, lr, gemm_route):
     """a-7: one optimizer step with train-mode BN on the frozen trunk, the reference's Dropout2d
     masks and loss permutations injected -- run through trainer.TrainStep, i.e. the fused loss route and the HIP Adam
     (multishiftseg_amd/optim.py) that bench.py times, not torch.optim."""
@@ -138,7 +138,7 @@ def test_train_step_golden(deeplab_params, stage, names, lr):
     from conftest import ROOT
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", f"train_step_golden_{stage}.json"), "w") as f:
+        with open(os.path.join(ROOT, "gpurun_out", f"train_step_golden_{stage}_{gemm_route}.json"), "w") as f:
             json.dump(report, f, indent=1, sort_keys=True)
     except OSError:
         pass
@@ -146,7 +146,7 @@ def test_train_step_golden(deeplab_params, stage, names, lr):
 
 @pytest.mark.parametrize("n,h,w,train", [(1, 200, 264, False), (3, 72, 104, False), (2, 88, 120, True), (1, 90, 150, False),
                                           (2, 70, 70, True)])
-def test_forward_vs_oracle_ragged_sizes(model, deeplab_params, n, h, w, train):
+def test_forward_vs_oracle_ragged_sizes(model, deeplab_params, n, h, w, train, gemm_route):
     """Sizes whose /2, /4, /8 maps are odd / not multiples of the tiles (25x33, 9x13, 11x15), sizes that are not
     multiples of 8 (90x150 -> 45x75 -> 23x38 -> 12x19; 70x70, the 700x700 crop scaled down), batch 3,
     and train-mode BatchNorm (batch statistics) + injected Dropout2d masks, against the numpy oracle."""

@@ -40,7 +40,7 @@ ROUTES = {"winograd": {}, "direct3x3": {"MSS_WINOGRAD": "0"},
 # fp32-on-bf16-matrix-cores GEMM has to pass the same reference fixtures to be reported at all
 # winograd_fast is the round-2 policy (no accuracy caps: F(6x6) wherever it is cheapest), still a supported switch
 ROUTES_X = dict(ROUTES, winograd_f4={"MSS_WINO_MAX_TILE": "4"}, winograd_fast={"MSS_WINO_ACCURACY": "fast"},
-                bf16x6={"MSS_GEMM_BF16X6": "1"})
+                bf16x3={"MSS_GEMM_SPLIT": "1"})       # the split-bf16 GEMM route (csrc/gemm_bf16x3.hip): same fixtures, same bounds
 _report = {}
 
 
@@ -60,7 +60,7 @@ class _Env:
         self.env = env
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ("MSS_WINOGRAD", "MSS_GEMM", "MSS_WINO_TILE", "MSS_WINO_MAX_TILE", "MSS_STEM_IM2COL", "MSS_GEMM_BF16X6",
+        self.old = {k: os.environ.get(k) for k in ("MSS_WINOGRAD", "MSS_GEMM", "MSS_WINO_TILE", "MSS_WINO_MAX_TILE", "MSS_STEM_IM2COL", "MSS_GEMM_SPLIT",
                                                           "MSS_WINO_ACCURACY")}
         for k in self.old:
             os.environ.pop(k, None)
@@ -93,7 +93,7 @@ def _rel_l2(a, b):
 
 
 # ------------------------------------------------------------------------------------------------ eval
-def test_c1_eval_512x1024_vs_torch_oracle(model, deeplab_params):
+def test_c1_eval_512x1024_vs_torch_oracle(model, deeplab_params, gemm_route):
     """BASELINE config 1: logits and OOD scores within 1e-3, argmax bit-exact where the oracle's top-2 margin > 1e-3."""
     from multishiftseg_amd import kernels as K, synth
     from oracle import deepv3_torch
@@ -105,7 +105,7 @@ def test_c1_eval_512x1024_vs_torch_oracle(model, deeplab_params):
     rs, rl = deepv3_torch.forward(deeplab_params, img)
     logit, score = logit.cpu().numpy(), score.cpu().numpy()
     e_l, e_s = float(np.abs(logit - rl).max()), float(np.abs(score - rs).max())
-    _note("c1_eval", {"max_abs_logit_err": e_l, "max_abs_score_err": e_s})
+    _note(f"c1_eval[{gemm_route}]", {"max_abs_logit_err": e_l, "max_abs_score_err": e_s})
     assert e_l < 1e-3 and e_s < 1e-3
     top2 = np.sort(rl, axis=1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 1e-3
@@ -235,7 +235,8 @@ def test_train_step_golden_2x592x600(deeplab_params, route):
 
 
 # ---------------------------------------------------------------------- the headline configuration vs the REFERENCE
-def test_eval_golden_c3_1x1024x2048(model):
+@pytest.mark.parametrize("route", ["winograd", "bf16x3"])
+def test_eval_golden_c3_1x1024x2048(model, route):
     """BASELINE's metric resolution, eval mode (test_deeplab.py:86-96): outputs of the reference model itself
     (tools/gen_golden.py deeplab_c3) against the DEFAULT route. Bound 5e-4 = half the 1e-3 bar; argmax flips counted over
     ALL pixels, none allowed where the reference's own top-2 margin exceeds the bar."""
@@ -245,13 +246,13 @@ def test_eval_golden_c3_1x1024x2048(model):
     ss, ls = int(g["score_stride"]), int(g["logit_stride"])
     img = torch.from_numpy(synth.synth_image(int(g["image_seed"]), n, h, w)).cuda()
     model.eval()
-    with _Env({}):
+    with _Env(ROUTES_X[route]):
         with torch.no_grad():
             score, logit = model(img)
     e_l = float((logit[:, :, ::ls, ::ls].cpu() - torch.from_numpy(g["logit_sub"])).abs().max())
     e_s = float((score[:, ::ss, ::ss].cpu() - torch.from_numpy(g["score_sub"])).abs().max())
     rep = {"max_abs_logit_err": e_l, "max_abs_score_err": e_s, "argmax": _flip_report(logit, g, "", n, h, w)}
-    _note("eval_c3_1x1024x2048[default]", rep)
+    _note("eval_c3_1x1024x2048[" + ("default" if route == "winograd" else route) + "]", rep)
     assert e_l < 5e-4 and e_s < 5e-4, rep
     assert float((logit[:, :, h // 3].cpu() - torch.from_numpy(g["logit_row"])).abs().max()) < 5e-4
     assert float((score[:, h // 3].cpu() - torch.from_numpy(g["score_row"])).abs().max()) < 5e-4
@@ -260,13 +261,14 @@ def test_eval_golden_c3_1x1024x2048(model):
     assert rep["argmax"]["flips_where_ref_margin_gt_1e3"] == 0, rep
 
 
-def test_train_step_golden_c3_2x1024x2048(deeplab_params):
+@pytest.mark.parametrize("route", ["winograd", "bf16x3"])
+def test_train_step_golden_c3_2x1024x2048(deeplab_params, route):
     """THE headline configuration (BASELINE config 3, per GPU: one orig+aug pair of 1024x2048, stage 2, train-mode BN /
     Dropout2d): one optimizer step of the reference itself (train_deeplab.py:189-204 with lib/loss.py:34-156; fixture from
     tools/gen_golden.py train_c3) against the DEFAULT route bench.py times. Logits and scores within 5e-4 of the reference
     (half the bar), loss, target mutation, running statistics, every stage-2 gradient; argmax flips over ALL 4.2 M pixels
     are counted and none is allowed where the reference's top-2 margin exceeds 1e-3."""
-    rep = _train_step_vs_golden(deeplab_params, "deepwv3plus_train_step_2x1024x2048", "winograd", [6, 6, 6, 6, 6, 4], 5e-4)
+    rep = _train_step_vs_golden(deeplab_params, "deepwv3plus_train_step_2x1024x2048", route, [6, 6, 6, 6, 6, 4], 5e-4)
     assert rep["argmax"]["flips_where_ref_margin_gt_1e3"] == 0, rep["argmax"]
     # flips can only sit on pixels the reference itself decided by less than the fp32 noise of ANY implementation:
     # the direct-kernel route flips 118 of 4.2 M (profiles/r03/wino_attribution_*.txt)

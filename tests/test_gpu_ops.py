@@ -415,39 +415,164 @@ def test_conv_paths_random_shapes(K):
     assert all(v >= 4 for v in checked.values()), checked
 
 
-@pytest.mark.parametrize("rows,c,k,batch", [(300, 64, 128, 1), (1000, 256, 192, 1), (257, 512, 256, 3), (4096, 1024, 128, 2)])
-def test_bf16x6_gemm_is_fp32_accurate(K, monkeypatch, rows, c, k, batch):
-    """EXPERIMENTAL opt-in (MSS_GEMM_BF16X6=1): the fp32 GEMM evaluated with six bf16 MFMAs per block on operands split
-    into three bf16 terms. Against float64 it must be as accurate as the native fp32 MFMA kernel (both ~1e-7 of max|y|)."""
+def _bf16_planes_decode(planes, batch, kpad, c):
+    """The three bf16 planes of mss_gemm_split_weights_bf16x3 (include/mss_hip.h) back as float64 [3][batch][kpad][c]."""
+    nk = c // 16
+    raw = planes.view(torch.int16).view(batch, kpad // 128, nk, 3, 128, 2, 8)       # [b][block][K-step][plane][row][half][8 k]
+    row = torch.arange(128, device=planes.device)
+    swap = ((row >> 3) & 1).bool()
+    raw = torch.where(swap.view(1, 1, 1, 1, 128, 1, 1), raw.flip(5), raw)            # the two 16-byte halves are swapped when bit 3 of the row is set
+    bits = (raw.to(torch.int32) & 0xffff) << 16
+    vals = bits.view(torch.float32).double()                                        # bf16 -> fp32 is exact
+    return vals.permute(3, 0, 1, 4, 2, 5, 6).reshape(3, batch, kpad, c)
+
+
+@pytest.mark.parametrize("batch,kpad,c", [(1, 128, 16), (3, 256, 80), (2, 384, 512)])
+def test_bf16x3_weight_planes_are_an_exact_three_term_split(K, batch, kpad, c):
+    """hi + mid + lo == w exactly, each term a bf16 (16 low bits zero by construction of the format), |mid| <= 2^-8 |hi|-ish and
+    |lo| <= 2^-16: the layout of include/mss_hip.h and the exactness the six-product form relies on."""
+    torch.manual_seed(kpad + c)
+    w = torch.randn(batch, kpad, c, device="cuda") * torch.exp(torch.randn(batch, kpad, 1, device="cuda") * 3)
+    w[0, 0, :4] = torch.tensor([0.0, 1.0, -3.0e-30, 65504.0], device="cuda")
+    planes = K.split_planes(w, kpad, c)
+    assert planes.numel() == batch * kpad * c * 6
+    hi, mid, lo = _bf16_planes_decode(planes, batch, kpad, c)
+    assert torch.equal(hi + mid + lo, w.double())
+    nz = w != 0
+    assert (mid.abs()[nz] <= w.double().abs()[nz] * 2.0 ** -8).all() and (lo.abs()[nz] <= w.double().abs()[nz] * 2.0 ** -16).all()
+
+
+def _run_gemm(K, x, w, k, split, in_affine=None, out_affine=None, out_relu=False, res=None, res_mask=False, want_stats=False):
+    """x [batch][rows][c], w [batch][kpad][c] (rows >= k zero) through mss_conv2d_forward_f32 on the chosen GEMM route."""
     import ctypes
     from multishiftseg_amd import _lib
     from multishiftseg_amd._lib import MssConvArgs, call, ptr
+    batch, rows, c = x.shape
+    kpad = w.shape[1]
+    y = torch.full((batch, rows, k), float("nan"), device="cuda")
+    a = MssConvArgs()
+    a.x, a.w, a.y = ptr(x), ptr(w), ptr(y)
+    planes = K.split_planes(w, kpad, c) if split else None
+    a.w_split = ptr(planes)
+    if in_affine is not None:
+        a.in_scale, a.in_shift, a.in_relu = ptr(in_affine[0]), ptr(in_affine[1]), 1
+    if out_affine is not None:
+        a.out_scale, a.out_shift = ptr(out_affine[0]), ptr(out_affine[1])
+    a.out_relu = int(out_relu)
+    if res is not None:
+        a.res, a.ldres, a.res_mask = ptr(res), k, int(res_mask)
+    stats = None
+    if want_stats:
+        stats = torch.empty((-(-rows // 64), 2, k), device="cuda")
+        a.stats = ptr(stats)
+    a.N, a.H, a.W, a.C, a.ldx = 1, 1, rows, c, c
+    a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, rows, k, kpad, k
+    a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+    if batch > 1:
+        a.batch, a.x_bs, a.w_bs, a.y_bs = batch, rows * c, kpad * c, rows * k
+    assert _lib.value("mss_conv2d_forward_route", ctypes.byref(a)) == (3 if split else 1)
+    call("mss_conv2d_forward_f32", ctypes.byref(a))
+    return y, stats
+
+
+@pytest.mark.parametrize("rows,c,k,batch", [(300, 64, 128, 1), (1000, 256, 192, 1), (257, 512, 256, 3), (4096, 1024, 128, 2), (70000, 48, 512, 1),
+                                            (131, 2048, 1024, 1), (66000, 256, 256, 2)])
+def test_bf16x3_gemm_is_fp32_accurate(K, rows, c, k, batch):
+    """The split-bf16 route (MssConvArgs.w_split; six bf16 MFMAs per block on operands split into three bf16 terms): against
+    float64 it must be as accurate as the native fp32 MFMA kernel (both ~1e-7 of max|y|). Shapes cover both tile widths
+    (128 / 256), ragged row counts, channel counts that leave a padded column tile, the shortest reduction (3 K-steps) and
+    batched products; the operands span 2^+-10 in scale so the low planes are exercised."""
+    from multishiftseg_amd import _lib
     torch.manual_seed(rows + c)
-    x = torch.relu(torch.randn(batch, rows, c, device="cuda")) * (torch.rand(1, 1, c, device="cuda") * 4 + 0.25)
+    x = torch.relu(torch.randn(batch, rows, c, device="cuda")) * torch.exp2(torch.randint(-10, 11, (1, 1, c), device="cuda").float())
     kpad = _lib.value("mss_conv2d_kpad", k)
     w = torch.zeros(batch, kpad, c, device="cuda")
-    w[:, :k] = torch.randn(batch, k, c, device="cuda") / c ** 0.5
-    ref = torch.einsum("bmc,bkc->bmk", x.double(), w[:, :k].double())
+    w[:, :k] = torch.randn(batch, k, c, device="cuda") / c ** 0.5 * torch.exp2(-torch.randint(-10, 11, (1, 1, c), device="cuda").float())
+    sel = torch.randint(0, rows, (min(rows, 2048),), device="cuda")
+    ref = torch.einsum("bmc,bkc->bmk", x[:, sel].double(), w[:, :k].double())
+    y32, _ = _run_gemm(K, x, w, k, split=False)
+    y3, _ = _run_gemm(K, x, w, k, split=True)
+    assert torch.isfinite(y3).all()
+    scale = ref.abs().max().item()
+    e32 = (y32[:, sel].double() - ref).abs().max().item() / scale
+    e3 = (y3[:, sel].double() - ref).abs().max().item() / scale
+    assert e32 < 2e-6 and e3 < 2e-6 and e3 < 2 * e32 + 1e-7, (e32, e3)
+    assert (y3.double() - y32.double()).abs().max().item() < 4e-6 * scale       # every element, not only the sampled rows
+    assert not torch.equal(y32, y3)          # it really is a different evaluation
 
-    def run():
-        y = torch.empty(batch, rows, k, device="cuda")
+
+@pytest.mark.parametrize("rows,c,k,per_sample", [(1500, 256, 384, False), (3 * 128 * 5, 128, 256, True), (40000, 512, 1024, False)])
+def test_bf16x3_gemm_fused_prologue_and_epilogue(K, rows, c, k, per_sample):
+    """Everything gemm_nt_kernel fuses, on the split route: BatchNorm + ReLU prologue (one affine, or one per sample = the Dropout2d
+    fold), per-channel output affine + residual + ReLU, the ReLU-gate form of the residual (res_mask), and the per-64-row partial
+    sums for the next layer's BatchNorm statistics -- against float64, and against the native route to fp32 rounding."""
+    from multishiftseg_amd import _lib
+    torch.manual_seed(rows)
+    x = torch.randn(1, rows, c, device="cuda")
+    kpad = _lib.value("mss_conv2d_kpad", k)
+    w = torch.zeros(1, kpad, c, device="cuda")
+    w[:, :k] = torch.randn(1, k, c, device="cuda") / c ** 0.5
+    n_img = 3 if per_sample else 1
+    sc, sh = torch.rand(n_img, c, device="cuda") + 0.5, torch.randn(n_img, c, device="cuda") * 0.3
+    osc, osh = torch.rand(k, device="cuda") + 0.5, torch.randn(k, device="cuda")
+    res = torch.randn(rows, k, device="cuda")
+    img_of_row = torch.arange(rows, device="cuda") // (rows // n_img)
+    xa = torch.relu(x[0].double() * sc.double()[img_of_row] + sh.double()[img_of_row])
+    lin = (xa @ w[0, :k].double().T) * osc.double() + osh.double()
+
+    def run(split, **kw):
+        import ctypes
+        from multishiftseg_amd._lib import MssConvArgs, call, ptr
+        y = torch.full((rows, k), float("nan"), device="cuda")
         a = MssConvArgs()
         a.x, a.w, a.y = ptr(x), ptr(w), ptr(y)
-        a.N, a.H, a.W, a.C, a.ldx = 1, 1, rows, c, c
-        a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, rows, k, kpad, k
+        planes = K.split_planes(w, kpad, c) if split else None
+        a.w_split = ptr(planes)
+        a.in_scale, a.in_shift, a.in_relu = ptr(sc), ptr(sh), 1
+        a.in_ss_stride = c if per_sample else 0
+        a.out_scale, a.out_shift, a.out_relu = ptr(osc), ptr(osh), int(kw.get("relu", False))
+        a.res, a.ldres, a.res_mask = ptr(res), k, int(kw.get("mask", False))
+        stats = torch.empty((-(-rows // 64), 2, k), device="cuda")
+        a.stats = ptr(stats)
+        hw = rows // n_img
+        a.N, a.H, a.W, a.C, a.ldx = n_img, 1, hw, c, c
+        a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, hw, k, kpad, k
         a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
-        a.batch, a.x_bs, a.w_bs, a.y_bs = batch, rows * c, kpad * c, rows * k
+        assert _lib.value("mss_conv2d_forward_route", ctypes.byref(a)) == (3 if split else 1)
         call("mss_conv2d_forward_f32", ctypes.byref(a))
-        return y
-    y32 = run()
-    monkeypatch.setenv("MSS_GEMM_BF16X6", "1")
-    y6 = run()
-    monkeypatch.delenv("MSS_GEMM_BF16X6")
-    scale = ref.abs().max().item()
-    e32 = (y32.double() - ref).abs().max().item() / scale
-    e6 = (y6.double() - ref).abs().max().item() / scale
-    assert e32 < 2e-6 and e6 < 2e-6 and e6 < 3 * e32 + 2e-7, (e32, e6)
-    assert not torch.equal(y32, y6)          # it really is a different evaluation
+        return y, stats
+    for kw, ref in (({"relu": True}, torch.relu(lin + res.double())), ({"mask": True}, torch.where(res.double() > 0, lin, torch.zeros_like(lin)))):
+        y32, st32 = run(False, **kw)
+        y3, st3 = run(True, **kw)
+        scale = ref.abs().max().item()
+        e32, e3 = (y32.double() - ref).abs().max().item() / scale, (y3.double() - ref).abs().max().item() / scale
+        assert e32 < 2e-6 and e3 < 2e-6 and e3 < 2 * e32 + 1e-7, (kw, e32, e3)
+        pad = (-rows) % 64
+        yp = torch.cat([y3.double(), torch.zeros(pad, k, device="cuda", dtype=torch.float64)]).view(-1, 64, k)
+        np.testing.assert_allclose(st3[:, 0].double().cpu().numpy(), yp.sum(1).cpu().numpy(), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(st3[:, 1].double().cpu().numpy(), (yp * yp).sum(1).cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_bf16x3_route_is_taken_by_the_layer_wrappers(K):
+    """kernels.set_gemm_route("bf16x3") / MSS_GEMM_SPLIT=1 must reach the kernel through every wrapper that builds MssConvArgs: a 1x1
+    layer, a Winograd layer (with the 304 = 256 + 48 output split, whose 48-channel tail stays on the native narrow tile) and a
+    Linear -- checked by the outputs differing in the last bits from the native route while agreeing to fp32 rounding."""
+    from multishiftseg_amd import linear as L
+    torch.manual_seed(3)
+    x = K.Act(torch.randn(2, 40, 56, 256, device="cuda"))
+    w1 = torch.randn(512, 256, 1, 1, device="cuda") / 16
+    w3 = torch.randn(304, 256, 3, 3, device="cuda") / 48
+    wl = torch.nn.Parameter(torch.randn(192, 256, device="cuda") / 16)
+    outs = {}
+    for route in ("native", "bf16x3"):
+        K.set_gemm_route(route)
+        try:
+            outs[route] = (K.conv2d(x, K.pack_weight(w1)).buf.clone(), K.conv3x3(x, w3).buf.clone(), L.linear(x.buf.view(-1, 256), wl).detach().clone())
+        finally:
+            K.set_gemm_route(None)
+    for a, b in zip(outs["native"], outs["bf16x3"]):
+        assert not torch.equal(a, b)
+        assert (a - b).abs().max().item() < 1e-5 * a.abs().max().item()
 
 
 @pytest.mark.parametrize("mode", ["0", "1", "2", "4", "5", "6", "7"])

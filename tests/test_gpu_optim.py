@@ -72,7 +72,7 @@ def test_adam_bias_corrections_are_formed_in_double():
 
 
 @pytest.mark.parametrize("stage,lr", [("stage1", 1e-4), ("stage2", 1e-6)])
-def test_three_reference_steps_through_trainstep(deeplab_params, stage, lr):
+def test_three_reference_steps_through_trainstep(deeplab_params, stage, lr, gemm_route):
     """Three optimizer steps of the reference loop replayed through TrainStep (fused loss route + HIP Adam): losses of all
     three steps, and after the third: parameter deltas, exp_avg and exp_avg_sq of every trainable tensor."""
     from multishiftseg_amd import synth

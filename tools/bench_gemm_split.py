@@ -1,6 +1,7 @@
 """The split-bf16 GEMM route (csrc/gemm_bf16x3.hip, MssConvArgs.w_split) against the native fp32 MFMA kernel on the step's products:
 error of both against float64 on a sample of rows, and time (alternating A B A B after a long warm-up, best round of each).
-python tools/bench_gemm_split.py [--affine] [--draft]     (--draft: also round 4's first draft, MSS_GEMM_BF16X6=1)"""
+python tools/bench_gemm_split.py [--affine] [--quick]     (round 4's first draft of the route, gemm_bf16x6.hip, was timed beside it with
+--draft until it was removed: profiles/r05/split_gemm_vs_draft.jsonl)"""
 import sys, os, json, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
