@@ -165,8 +165,8 @@ def test_groupnorm_layernorm_upsample_ops_vs_oracle():
 @pytest.mark.gpu
 def test_decoder_backward_golden(gemm_route):
     """Parameter and feature gradients of L = <mask, G> + sum_i <ms[i], G_i> against the reference class's own autograd
-    (tools/gen_golden.py decoder): relative L2 of every gradient <= 2e-3, L2 norms within 1e-3, and two identical runs
-    give bit-identical gradients (no float atomics on the path)."""
+    (tools/gen_golden.py decoder): relative L2 of every gradient <= max(2e-3, 2 x the reference's own sensitivity), L2 norms within
+    1e-3, and two identical runs give bit-identical gradients (no float atomics on the path)."""
     dec, g = build()
     dec = dec.cuda()
     rng = np.random.default_rng(int(g["seed"]))
@@ -206,7 +206,10 @@ def test_decoder_backward_golden(gemm_route):
         got = gr.cpu().numpy()
         np.testing.assert_allclose(np.sqrt((got.astype(np.float64) ** 2).sum()), float(g["gl2_feat_" + k]), rtol=1e-3, err_msg=k)
         worst["feat_" + k] = rel(got[:, ::max(1, got.shape[1] // 32)], g["gsub_feat_" + k])
-    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    # bound: 2e-3, or twice what the REFERENCE's own fp32 gradient of that tensor moves by when its inputs are jittered by 1e-5
+    # relative (gsens_*, tools/gen_golden.py decoder): with 2 x 315 queries a single bilinear-cell crossing moves everything
+    # upstream of it by ~1e-3 (the reference: up to 5.6e-3), whichever fp32 implementation or GEMM route computes it
+    bad = {k: (v, float(g["gsens_" + k])) for k, v in worst.items() if v > max(2e-3, 2.0 * float(g["gsens_" + k]))}
     assert not bad, bad
     # determinism
     _, _, pg2, fg2 = run()

@@ -567,7 +567,7 @@ def test_bf16x3_route_is_taken_by_the_layer_wrappers(K):
     for route in ("native", "bf16x3"):
         K.set_gemm_route(route)
         try:
-            outs[route] = (K.conv2d(x, K.pack_weight(w1)).buf.clone(), K.conv3x3(x, w3).buf.clone(), L.linear(x.buf.view(-1, 256), wl).detach().clone())
+            outs[route] = (K.conv2d(x, K.pack_weight(w1)).nchw(), K.conv3x3(x, w3).nchw(), L.linear(x.buf.view(-1, 256), wl).detach().clone())
         finally:
             K.set_gemm_route(None)
     for a, b in zip(outs["native"], outs["bf16x3"]):

@@ -705,6 +705,63 @@ def gen_decoder():
         gk = t2n(t.grad)
         grads["gl2_feat_" + k] = np.float64(np.sqrt((gk.astype(np.float64) ** 2).sum()))
         grads["gsub_feat_" + k] = gk[:, ::max(1, gk.shape[1] // 32)].copy()
+    # conditioning, as in gen_decoder_fullsize (round 5: the small fixture had no floor, and its 3x5 / 6x10 / 12x20 maps put the res4-level
+    # gradients of ANY fp32 implementation ~2e-3 from the fp32 reference): the same computation of the reference in float64
+    dec64 = Dec(shape, transformer_dropout=0.0, transformer_nheads=8, transformer_dim_feedforward=1024, transformer_enc_layers=2,
+                conv_dim=256, mask_dim=256, norm="GN", transformer_in_features=["res3", "res4", "res5"], common_stride=4).eval()
+    dec64.load_state_dict(sd)
+    dec64 = dec64.double()
+    for p in dec64.parameters():
+        p.requires_grad_(True)
+    tf64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in feats.items()}
+    real_float = torch.Tensor.float        # the reference casts its inputs with .float() (msdeformattn.py:314-320): keep them double here
+    torch.Tensor.float = lambda self, *a, **k: self
+    try:
+        m64, _, ms64 = dec64.forward_features(tf64)
+    finally:
+        torch.Tensor.float = real_float
+    sum((t * c.double()).sum() for t, c in zip((m64, *ms64), cot)).backward()
+    rel = lambda a, b: np.float64(np.sqrt(((a.astype(np.float64) - b) ** 2).sum()) / (np.sqrt((b ** 2).sum()) + 1e-300))
+    for k, prm in dec64.named_parameters():
+        g64 = prm.grad.numpy()
+        if "g_" + k in grads:
+            grads["gnoise_" + k] = rel(grads["g_" + k], g64)
+        else:
+            flat = g64.reshape(g64.shape[0], -1)
+            grads["gnoise_" + k] = rel(grads["gsub_" + k], flat[::max(1, flat.shape[0] // 32), ::max(1, flat.shape[1] // 64)])
+    for k, t in tf64.items():
+        g64 = t.grad.numpy()
+        grads["gnoise_feat_" + k] = rel(grads["gsub_feat_" + k], g64[:, ::max(1, g64.shape[1] // 32)])
+    top = sorted(((float(v), k) for k, v in grads.items() if k.startswith("gnoise_")), reverse=True)[:6]
+    print(f"   decoder: largest fp32-vs-fp64 rel-L2 of the REFERENCE's own gradients: {top}")
+    # sensitivity: the reference's own fp32 gradients when its four input maps move by 1e-5 relative -- the size of an fp32
+    # re-implementation's forward deviation (ours: 3.5e-5 absolute on a mask of |max| 3.8). The bilinear sampler's derivative
+    # w.r.t. the location is piecewise constant: a sample that crosses a cell boundary under such a perturbation changes its
+    # location gradient by O(1), and with only 2 x 315 queries one crossing moves every gradient upstream of it by ~1e-3.
+    # gsens_<name> = the largest rel-L2 change over three seeded jitters; tests bound with max(2e-3, 3 x gsens).
+    sens = {}
+    for trial in range(3):
+        jr = np.random.default_rng(640 + trial)
+        for p in dec.parameters():
+            p.grad = None
+        tj = {k: torch.from_numpy(v * (1.0 + 1e-5 * jr.standard_normal(v.shape).astype(np.float32))).requires_grad_(True) for k, v in feats.items()}
+        mj, _, msj = dec.forward_features(tj)
+        sum((t * c).sum() for t, c in zip((mj, *msj), cot)).backward()
+        for k, prm in dec.named_parameters():
+            gk = t2n(prm.grad)
+            if "g_" + k in grads:
+                v = rel(gk, grads["g_" + k].astype(np.float64))
+            else:
+                flat = gk.reshape(gk.shape[0], -1)
+                v = rel(flat[::max(1, flat.shape[0] // 32), ::max(1, flat.shape[1] // 64)], grads["gsub_" + k].astype(np.float64))
+            sens["gsens_" + k] = max(sens.get("gsens_" + k, 0.0), float(v))
+        for k, t in tj.items():
+            gk = t2n(t.grad)
+            v = rel(gk[:, ::max(1, gk.shape[1] // 32)], grads["gsub_feat_" + k].astype(np.float64))
+            sens["gsens_feat_" + k] = max(sens.get("gsens_feat_" + k, 0.0), float(v))
+    grads.update({k: np.float64(v) for k, v in sens.items()})
+    top = sorted(((v, k) for k, v in sens.items()), reverse=True)[:8]
+    print(f"   decoder: largest change of the REFERENCE's gradients under a 1e-5 relative jitter of its inputs: {top}")
     save("m2f_decoder", names=np.array(list(sd.keys())), seed=np.int64(62), hw=np.array([H, W]),
          offsets_bias=t2n(sd["transformer.encoder.layers.0.self_attn.sampling_offsets.bias"]),
          mask_sub=t2n(mask)[:, ::4], mask_abs_sum=np.float64(np.abs(t2n(mask).astype(np.float64)).sum()),
