@@ -34,6 +34,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, dense fp32 matrix
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md, dense bf16 matrix (never the 2:1-sparsity figure)
 FWD_GMAC_1024x2048 = 5827.2            # conv MACs of one forward at 1024x2048
 STAGE2_STEP_OVER_FWD = 1.287           # stage-2 step FLOPs / forward FLOPs
 
@@ -252,8 +253,8 @@ def main():
     ap.add_argument("--no-ood", action="store_true")
     ap.add_argument("--no-m2f", action="store_true", help="skip the Mask2Former legs (`m2f`, N=1 only, ~40 s)")
     ap.add_argument("--no-parity", action="store_true", help="skip the live check against the reference fixture (`parity`)")
-    ap.add_argument("--no-experimental", action="store_true",
-                    help="skip the extra, separately reported run with MSS_GEMM_BF16X6=1 (N=1 only; never part of `value`)")
+    ap.add_argument("--no-split", action="store_true",
+                    help="skip the co-headline run on the split-bf16 GEMM route (`value_fp32_via_bf16x3`, N=1 only; never part of `value`)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -302,6 +303,16 @@ def main():
             parity = parity_check(model, H, W, pairs)
         except Exception as exc:    # never lose the measurement to the checker
             parity = {"error": repr(exc)}
+
+    parity_split = None
+    if parity is not None and world == 1 and not args.no_split:
+        K.set_gemm_route("bf16x3")
+        try:
+            parity_split = parity_check(model, H, W, pairs)
+        except Exception as exc:
+            parity_split = {"error": repr(exc)}
+        finally:
+            K.set_gemm_route(None)
 
     for _ in range(args.warmup):
         one_step()
@@ -454,27 +465,55 @@ def main():
         out["wgrad"] = {"achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                         "kernel_ms_per_step": round(wg["ms"] / max(args.steps, 1), 2)}
 
-    if world == 1 and not args.no_experimental:
-        # EXPERIMENTAL, reported apart from `value`: the same step with the fp32 GEMMs evaluated on the bf16 matrix cores
-        # (three-way operand split, six MFMAs per block, fp32 accumulate; csrc/gemm_bf16x6.hip). Same parity tests pass.
-        os.environ["MSS_GEMM_BF16X6"] = "1"
-        _lib.reset_env_cache()
+    if world == 1 and not args.no_split:
+        # CO-HEADLINE, reported beside `value` and never part of it: the same step with every product the
+        # persistent GEMM kernel takes evaluated on the bf16 matrix cores -- operands as three bf16 terms, six bf16 MFMAs per block,
+        # fp32 accumulation (csrc/gemm_bf16x3.hip; kernels.set_gemm_route). Same timing protocol as `value`, its own parity
+        # against the reference fixture (taken before the first optimizer step) and its own roofline: fp32-equivalent TFLOP/s over
+        # (bf16 dense peak / 6); the weight-gradient and implicit-GEMM kernels stay on the native fp32 MFMA.
+        K.set_gemm_route("bf16x3")
         try:
-            one_step()
+            for _ in range(max(1, args.warmup)):
+                one_step()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 one_step()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / args.steps
-            out["experimental_fp32_via_bf16x6"] = {
-                "images_per_s": round(2 * pairs / dt, 4), "ms_per_step": round(dt * 1e3, 3),
-                "note": "opt-in MSS_GEMM_BF16X6=1, NOT the headline: every gemm_nt launch computes the same fp32 GEMM with "
-                        "operands split into 3 bf16 terms and 6 bf16 MFMAs per block (fp32 accumulate); error against "
-                        "float64 equals the native fp32 MFMA kernel's (tests/test_gpu_ops.py::test_bf16x6_gemm_is_fp32_accurate)"}
+            prof_s = K.ConvProfile()
+            K.set_conv_profile(prof_s)
+            for _ in range(args.steps):
+                one_step()
+            torch.cuda.synchronize()
+            K.set_conv_profile(None)
+            ss_ = prof_s.summary()
+            gs = ss_.get("gemm_nt_bf16x3", dict(launches=0, flops=0.0, ms=1.0))
+            ach = gs["flops"] / (gs["ms"] * 1e-3) / 1e12 if gs["launches"] else 0.0
+            rf = {"bound": "mfma", "kernel": "gemm_nt_bf16x3_kernel (6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block)",
+                  "achieved": round(ach, 2), "peak": round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1), "unit": "TFLOP/s (fp32-equivalent)",
+                  "frac": round(ach / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4), "launches_per_step": gs["launches"] // max(args.steps, 1),
+                  "avg_launch_ms": round(gs["ms"] / max(gs["launches"], 1), 4), "kernel_ms_per_step": round(gs["ms"] / max(args.steps, 1), 2),
+                  "peak_note": "2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md) / 6 MFMA products per fp32 product; under this load the chip "
+                               "holds ~1.7 GHz of the nominal 2.4 (profiles/r05/pmc_split.md: matrix pipe busy share, effective clock)"}
+            ppath = os.path.join(ROOT, "profiles", "split_pmc_latest.json")
+            if os.path.exists(ppath):
+                try:
+                    rf["pmc"] = json.load(open(ppath))
+                except Exception:
+                    pass
+            others = {k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "kernel_ms_per_step": round(v["ms"] / max(args.steps, 1), 2)}
+                      for k, v in ss_.items() if k in ("gemm_nt", "conv_igemm", "conv_wgrad") and v["launches"]}
+            out["value_fp32_via_bf16x3"] = {
+                "value": round(2 * pairs / dt, 4), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3),
+                "dtype": "f32 (operands split into 3 bf16 terms, 6 bf16 MFMAs, fp32 accumulate)",
+                "vs_native_value": round((2 * pairs / dt) / value, 4), "parity": parity_split, "roofline": rf,
+                "native_fp32_mfma_kernels_left_in_the_step": others,
+                "note": "same step, same timing protocol; route = kernels.set_gemm_route('bf16x3') / MSS_GEMM_SPLIT=1; every reference fixture "
+                        "and oracle test that exercises a GEMM runs on both routes with the same bounds (tests/conftest.py gemm_route)"}
         finally:
-            os.environ.pop("MSS_GEMM_BF16X6", None)
-            _lib.reset_env_cache()
+            K.set_gemm_route(None)
+            K.set_conv_profile(None)
 
     if not args.no_ood:
         # OOD-score path (test_deeplab.py:86-90): eval forward -> per-pixel anomaly score
@@ -527,7 +566,16 @@ def main():
         ge = GraphedEval(model, e_img.shape, score_only=True)
         dt_graph = time_eval(lambda: ge(e_img))
         del ge
+        K.set_gemm_route("bf16x3")                # co-headline of the OOD-score path: the same eval forward on the split-bf16 GEMM route
+        try:
+            dt_so3 = time_eval(lambda: ood_scores(model, e_img, score_only=True))
+            dt_b23 = time_eval(lambda: ood_scores(model, e_img2, score_only=True))
+        finally:
+            K.set_gemm_route(None)
         out["ood_score"] = {"end_to_end_mpix_s": round(H * W / dt / 1e6, 3), "end_to_end_ms": round(dt * 1e3, 2),
+                            "bf16x3_route": {"score_only_mpix_s": round(H * W / dt_so3 / 1e6, 3), "score_only_ms": round(dt_so3 * 1e3, 2),
+                                             "score_only_batch2_mpix_s": round(2 * H * W / dt_b23 / 1e6, 3),
+                                             "dtype": "f32 (operands split into 3 bf16 terms, 6 bf16 MFMAs, fp32 accumulate)"},
                             "score_only_mpix_s": round(H * W / dt_so / 1e6, 3), "score_only_ms": round(dt_so * 1e3, 2),
                             "score_only_hipgraph_mpix_s": round(H * W / dt_graph / 1e6, 3), "score_only_hipgraph_ms": round(dt_graph * 1e3, 2),
                             "score_only_batch2_mpix_s": round(2 * H * W / dt_b2 / 1e6, 3), "score_only_batch2_ms": round(dt_b2 * 1e3, 2),
@@ -568,6 +616,29 @@ def main():
                    "numpy_mpix_s": round(512 * 1024 / cpu["c1_numpy_s"] / 1e6, 4),
                    "numpy_vs_torch_max_abs_logit_diff": cpu["c1_numpy_vs_torch_max_abs_logit_diff"]},
             "host": cpu["host"]}
+    # compact summary LAST (the driver keeps the tail of this line): the numbers a reviewer reads first, without the notes
+    summ_out = {"ms_per_step": out["ms_per_step"], "img_s": out["value"], "gemm_frac": out["roofline"]["frac"]}
+    if "value_fp32_via_bf16x3" in out:
+        v3 = out["value_fp32_via_bf16x3"]
+        summ_out["bf16x3"] = {"img_s": v3["value"], "ms": v3["ms_per_step"], "gemm_tflops": v3["roofline"]["achieved"], "frac": v3["roofline"]["frac"],
+                              "logit_err": (v3["parity"] or {}).get("max_abs_logit_err"), "flips": (v3["parity"] or {}).get("argmax_flips_all_pixels")}
+    if "winograd" in out and "transforms" in out["winograd"]:
+        summ_out["wino_transforms_ms"] = out["winograd"]["transforms"]["ms_per_step"]
+    if "wgrad" in out:
+        summ_out["wgrad_tflops"] = out["wgrad"]["achieved"]
+    if "ood_score" in out:
+        o = out["ood_score"]
+        summ_out["ood"] = {"mpix_s": o["score_only_mpix_s"], "b2_mpix_s": o["score_only_batch2_mpix_s"], "bf16x3_mpix_s": o["bf16x3_route"]["score_only_mpix_s"],
+                           "tail_GBs": o["tail_kernel_GBs"], "tail_logits_GBs": o["tail_kernel_with_logits_GBs"]}
+    if isinstance(out.get("m2f"), dict) and "msda" in out["m2f"]:
+        m = out["m2f"]
+        d16 = m["pixel_decoder_forward_features"]["c4_704x704_n16"]
+        summ_out["m2f"] = {"msda_n16_fwd_ms": m["msda"]["c4_n16"]["forward_ms"], "msda_n16_bwd_ms": m["msda"]["c4_n16"]["backward_ms"],
+                           "msda_n16_bwd_frac": m["msda"]["c4_n16"]["backward_frac_of_hbm_peak"], "msda_n1_bwd_ms": m["msda"]["c4_n1"]["backward_ms"],
+                           "decoder_n16_fb_ms": d16["forward_backward_ms"], "decoder_n16_fb_ms_bf16x3": d16.get("bf16x3_route", {}).get("forward_backward_ms"),
+                           "fused_score_ms": m["fused_score"]["fused_score_ms"], "metric_GBs": m["metric_sweep"]["update_GBs_of_12B_per_pixel"],
+                           "metric_b2_GBs": m["metric_sweep"]["update_batch2_GBs_of_12B_per_pixel"]}
+    out["summary"] = summ_out
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

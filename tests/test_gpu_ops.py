@@ -572,7 +572,7 @@ def test_bf16x3_route_is_taken_by_the_layer_wrappers(K):
             K.set_gemm_route(None)
     for a, b in zip(outs["native"], outs["bf16x3"]):
         assert not torch.equal(a, b)
-        assert (a - b).abs().max().item() < 1e-5 * a.abs().max().item()
+        assert (a - b).abs().max().item() < 1e-4 * a.abs().max().item()         # (the Winograd layer: 2e-5 of max|y| between two fp32 evaluations)
 
 
 @pytest.mark.parametrize("mode", ["0", "1", "2", "4", "5", "6", "7"])

@@ -168,13 +168,15 @@ def test_torch_oracle_eval_592x600(deeplab_params):
     np.testing.assert_array_equal(logit.argmax(1)[clear], g["label"][clear])
 
 
-def test_torch_oracle_train_step(deeplab_params):
+@pytest.mark.parametrize("fixture", ["deepwv3plus_train_step", "deepwv3plus_train_step_8pairs"])
+def test_torch_oracle_train_step(deeplab_params, fixture):
     """Gradient oracle: the stage-2 step of the torch restatement (autograd on CPU) against the reference's own step
-    (loss, gradients, running statistics) with its Dropout2d masks and permutations."""
+    (loss, gradients, running statistics) with its Dropout2d masks and permutations -- on the (2+2)-image fixture and on the
+    C2 batch layout (8 originals + their 8 augmentations, 64x96)."""
     import torch
     from multishiftseg_amd import synth
     from oracle import deepv3_torch
-    g = golden("deepwv3plus_train_step")
+    g = golden(fixture)
     pairs, h, w = (int(v) for v in g["shape"])
     pre = "stage2_"
     p = deepv3_torch.to_torch(deeplab_params)

@@ -661,6 +661,52 @@ def import_reference_decoder():
     return mod.MSDeformAttnPixelDecoder, stubs["detectron2.layers"]["ShapeSpec"]
 
 
+def _decoder_grad_sensitivity(dec, feats, cot, grads, feat_slice, trials, tag):
+    """gsens_<name> (round 5): what the REFERENCE's own fp32 gradients move by under the deviations of an fp32 re-implementation --
+    its four input maps jittered by 1e-5 relative AND every contraction's output by one layer's rounding: 6e-6 relative behind a 3x3
+    convolution (Winograd F(6x6): 5.8e-6 of the output per layer, tools/wino_matrices.py), 4e-7 behind a 1x1 convolution / Linear.
+    gnoise_* (fp32 vs fp64 of the reference) only sees ~1e-7 deviations; the bilinear sampler's location derivative is piecewise
+    constant and the ReLUs behind the 3x3 output convolutions flip, and the stored slices are small (feat_res2: 32 x 16 x 16 values:
+    one flipped ReLU inside the slice's footprint moves it by ~1.2e-3), so the comparison is only meaningful down to this floor.
+    Largest rel-L2 change over `trials` seeded perturbations; tests bound with max(1e-3, 3 x gnoise, 2 x gsens)."""
+    rel = lambda a, b: np.float64(np.sqrt(((a.astype(np.float64) - b) ** 2).sum()) / (np.sqrt((b ** 2).sum()) + 1e-300))
+    sens = {}
+    for trial in range(trials):
+        jr = np.random.default_rng(650 + trial)
+        tg = torch.Generator().manual_seed(660 + trial)
+
+        def jitter(mod, inp, out, tg=tg):
+            eps = 6e-6 if isinstance(mod, torch.nn.Conv2d) and tuple(mod.kernel_size) == (3, 3) else 4e-7
+            return out * (1.0 + eps * torch.randn(out.shape, generator=tg, dtype=out.dtype))
+        hooks = [m.register_forward_hook(jitter) for m in dec.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear))]
+        try:
+            for p in dec.parameters():
+                p.grad = None
+            tj = {k: torch.from_numpy(v * (1.0 + 1e-5 * jr.standard_normal(v.shape).astype(np.float32))).requires_grad_(True) for k, v in feats.items()}
+            mj, _, msj = dec.forward_features(tj)
+            sum((t * c).sum() for t, c in zip((mj, *msj), cot)).backward()
+        finally:
+            for h in hooks:
+                h.remove()
+        for k, prm in dec.named_parameters():
+            gk = t2n(prm.grad)
+            if "g_" + k in grads:
+                v = rel(gk, grads["g_" + k].astype(np.float64))
+            else:
+                flat = gk.reshape(gk.shape[0], -1)
+                v = rel(flat[::max(1, flat.shape[0] // 32), ::max(1, flat.shape[1] // 64)], grads["gsub_" + k].astype(np.float64))
+            sens["gsens_" + k] = max(sens.get("gsens_" + k, 0.0), float(v))
+        for k, t in tj.items():
+            v = rel(feat_slice(t2n(t.grad)), grads["gsub_feat_" + k].astype(np.float64))
+            sens["gsens_feat_" + k] = max(sens.get("gsens_feat_" + k, 0.0), float(v))
+        del tj, mj, msj
+    for p in dec.parameters():
+        p.grad = None
+    grads.update({k: np.float64(v) for k, v in sens.items()})
+    top = sorted(((v, k) for k, v in sens.items()), reverse=True)[:8]
+    print(f"   {tag}: largest change of the REFERENCE's gradients under the perturbations of an fp32 re-implementation: {top}")
+
+
 def gen_decoder():
     """a-11: MSDeformAttnPixelDecoder.forward_features of the reference (2 encoder layers, the anomaly_ft.yaml geometry:
     res2..res5 = 256/512/1024/2048 channels at strides 4..32, GN norm, common_stride 4) on a 2-image batch, CPU."""
@@ -734,34 +780,7 @@ def gen_decoder():
         grads["gnoise_feat_" + k] = rel(grads["gsub_feat_" + k], g64[:, ::max(1, g64.shape[1] // 32)])
     top = sorted(((float(v), k) for k, v in grads.items() if k.startswith("gnoise_")), reverse=True)[:6]
     print(f"   decoder: largest fp32-vs-fp64 rel-L2 of the REFERENCE's own gradients: {top}")
-    # sensitivity: the reference's own fp32 gradients when its four input maps move by 1e-5 relative -- the size of an fp32
-    # re-implementation's forward deviation (ours: 3.5e-5 absolute on a mask of |max| 3.8). The bilinear sampler's derivative
-    # w.r.t. the location is piecewise constant: a sample that crosses a cell boundary under such a perturbation changes its
-    # location gradient by O(1), and with only 2 x 315 queries one crossing moves every gradient upstream of it by ~1e-3.
-    # gsens_<name> = the largest rel-L2 change over three seeded jitters; tests bound with max(2e-3, 3 x gsens).
-    sens = {}
-    for trial in range(3):
-        jr = np.random.default_rng(640 + trial)
-        for p in dec.parameters():
-            p.grad = None
-        tj = {k: torch.from_numpy(v * (1.0 + 1e-5 * jr.standard_normal(v.shape).astype(np.float32))).requires_grad_(True) for k, v in feats.items()}
-        mj, _, msj = dec.forward_features(tj)
-        sum((t * c).sum() for t, c in zip((mj, *msj), cot)).backward()
-        for k, prm in dec.named_parameters():
-            gk = t2n(prm.grad)
-            if "g_" + k in grads:
-                v = rel(gk, grads["g_" + k].astype(np.float64))
-            else:
-                flat = gk.reshape(gk.shape[0], -1)
-                v = rel(flat[::max(1, flat.shape[0] // 32), ::max(1, flat.shape[1] // 64)], grads["gsub_" + k].astype(np.float64))
-            sens["gsens_" + k] = max(sens.get("gsens_" + k, 0.0), float(v))
-        for k, t in tj.items():
-            gk = t2n(t.grad)
-            v = rel(gk[:, ::max(1, gk.shape[1] // 32)], grads["gsub_feat_" + k].astype(np.float64))
-            sens["gsens_feat_" + k] = max(sens.get("gsens_feat_" + k, 0.0), float(v))
-    grads.update({k: np.float64(v) for k, v in sens.items()})
-    top = sorted(((v, k) for k, v in sens.items()), reverse=True)[:8]
-    print(f"   decoder: largest change of the REFERENCE's gradients under a 1e-5 relative jitter of its inputs: {top}")
+    _decoder_grad_sensitivity(dec, feats, cot, grads, lambda gk: gk[:, ::max(1, gk.shape[1] // 32)], 4, "decoder")
     save("m2f_decoder", names=np.array(list(sd.keys())), seed=np.int64(62), hw=np.array([H, W]),
          offsets_bias=t2n(sd["transformer.encoder.layers.0.self_attn.sampling_offsets.bias"]),
          mask_sub=t2n(mask)[:, ::4], mask_abs_sum=np.float64(np.abs(t2n(mask).astype(np.float64)).sum()),
@@ -833,19 +852,30 @@ def gen_decoder_fullsize(tag="m2f_decoder_704", n=1, H=704, W=704, layers=6, wit
             torch.Tensor.float = real_float
         sum((t * c.double()).sum() for t, c in zip((m64, *ms64), cot)).backward()
         rel = lambda a, b: np.float64(np.sqrt(((a.astype(np.float64) - b) ** 2).sum()) / (np.sqrt((b ** 2).sum()) + 1e-300))
+        # round 5: where the reference's two precisions disagree by more than 1e-4, its float64 gradient is stored too (rounded to
+        # fp32, g64*_<name>): the two runs took different sides of a knife edge (a sample on a bilinear cell boundary, a ReLU at 0),
+        # and an fp32 re-implementation may land on either -- tests compare with whichever of the two is nearer
         for k, prm in dec64.named_parameters():
             g64 = prm.grad.numpy()
             if "g_" + k in grads:
+                sl, key = g64, "g64_" + k
                 grads["gnoise_" + k] = rel(grads["g_" + k], g64)
             else:
                 flat = g64.reshape(g64.shape[0], -1)
-                grads["gnoise_" + k] = rel(grads["gsub_" + k], flat[::max(1, flat.shape[0] // 32), ::max(1, flat.shape[1] // 64)])
+                sl, key = flat[::max(1, flat.shape[0] // 32), ::max(1, flat.shape[1] // 64)], "g64sub_" + k
+                grads["gnoise_" + k] = rel(grads["gsub_" + k], sl)
+            if grads["gnoise_" + k] > 1e-4:
+                grads[key] = sl.astype(np.float32)
         for k, t in tf64.items():
             g64 = t.grad.numpy()
-            grads["gnoise_feat_" + k] = rel(grads["gsub_feat_" + k],
-                                            g64[:, ::max(1, g64.shape[1] // 32), ::max(1, g64.shape[2] // 16), ::max(1, g64.shape[3] // 16)])
+            sl = g64[:, ::max(1, g64.shape[1] // 32), ::max(1, g64.shape[2] // 16), ::max(1, g64.shape[3] // 16)]
+            grads["gnoise_feat_" + k] = rel(grads["gsub_feat_" + k], sl)
+            if grads["gnoise_feat_" + k] > 1e-4:
+                grads["g64sub_feat_" + k] = sl.astype(np.float32)
         top = sorted(((float(v), k) for k, v in grads.items() if k.startswith("gnoise_")), reverse=True)[:6]
         print(f"   {tag}: {len(grads)} gradient entries; largest fp32-vs-fp64 rel-L2 of the REFERENCE: {top}")
+        _decoder_grad_sensitivity(dec, feats, cot, grads,
+                                  lambda gk: gk[:, ::max(1, gk.shape[1] // 32), ::max(1, gk.shape[2] // 16), ::max(1, gk.shape[3] // 16)], 4, tag)
     save(tag, names=np.array(list(sd.keys())), seed=np.int64(64), nhw=np.array([n, H, W]), layers=np.int64(layers), **grads,
          mask_sub=t2n(mask)[:, ::8, ::4, ::4], mask_abs_sum=absum(mask), mask_row=t2n(mask)[:, :, mask.shape[2] // 3],
          out0_sub=t2n(out0)[:, ::4], out0_abs_sum=absum(out0), ms1_sub=t2n(ms[1])[:, ::8, ::2, ::2], ms1_abs_sum=absum(ms[1]),
@@ -854,17 +884,29 @@ def gen_decoder_fullsize(tag="m2f_decoder_704", n=1, H=704, W=704, layers=6, wit
     print(f"   {tag}: mask {tuple(mask.shape)} |max| {float(mask.abs().max()):.3g}, levels {[tuple(m.shape) for m in ms]}")
 
 
+def reference_get_anomaly_score():
+    """TrainM2FOOD.get_anomaly_score of the reference ITSELF (train_m2f.py:387-407). The module cannot be imported (detectron2 is
+    absent), so the method's own source is cut out of the reference file with `ast` and executed here -- nothing is re-typed
+    (VERDICT r04 missing #3). Returns fn(other_outputs, size) -> score."""
+    import ast
+    import typing
+    path = os.path.join(REF, "train_m2f.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "get_anomaly_score")
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ns = {"torch": torch, "Dict": typing.Dict, "Tuple": typing.Tuple}
+    exec(compile(mod, path, "exec"), ns)
+    return lambda other_outputs, size: ns["get_anomaly_score"](None, other_outputs, size)
+
+
 def gen_m2f():
-    """train_m2f.py:387-407 cannot be imported (detectron2 absent); its five lines of torch
-    arithmetic are evaluated here verbatim on random inputs."""
+    """a-6: the reference's own get_anomaly_score (train_m2f.py:387-407, executed from its source: reference_get_anomaly_score)
+    on random inputs."""
     rng = np.random.default_rng(41)
     cls = rng.standard_normal((2, 100, 20), dtype=np.float32) * 2
     mask = rng.standard_normal((2, 100, 24, 32), dtype=np.float32) * 3
     size = (22, 30)
-    class_probs = torch.softmax(torch.from_numpy(cls), dim=-1)[..., :-1]
-    mask_probs = torch.from_numpy(mask).sigmoid()
-    u = torch.einsum("bqc,bqhw->bchw", class_probs, mask_probs)[:, :, :size[0], :size[1]]
-    score = 1 - torch.max(u, dim=1)[0]
+    score = reference_get_anomaly_score()({"pred_logits_ood": torch.from_numpy(cls), "pred_masks_ood": torch.from_numpy(mask)}, size)
     save("m2f_score", cls=cls, mask=mask, size=np.array(size), score=t2n(score))
     # 8f-2: the chain in front of it -- mask prediction (mask2former_transformer_decoder.py:544-548), the x4 upsample
     # of maskformer_model.py:264-277 and the score -- evaluated with the same torch ops on random inputs
@@ -1014,6 +1056,10 @@ def main():
         print("train"); gen_train_step(DeepWV3Plus, ref_loss)
     if "train" in which or "train3" in which:
         print("train3"); gen_train_steps3(DeepWV3Plus, ref_loss)
+    if "train" in which or "train8" in which:
+        # the C2 batch layout (VERDICT r04 missing #4): 8 (original, augmented) pairs -- [0:8] originals, [8:16] their augmentations,
+        # pairing i <-> i + 8 (train_deeplab.py:190-204, lib/loss.py:59-60,141-145) -- at a small crop, both stages
+        print("train8"); gen_train_step(DeepWV3Plus, ref_loss, pairs=8, h=64, w=96, fixture="deepwv3plus_train_step_8pairs")
     # the two big fixtures take minutes on 8 cores: only on request (python tools/gen_golden.py deeplab_big train_big)
     if "deeplab_big" in which:
         print("deeplab_big"); gen_deeplab_big(DeepWV3Plus)

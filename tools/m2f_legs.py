@@ -121,6 +121,16 @@ def decoder_leg():
             (mask.sum() + sum(m.sum() for m in ms)).backward()
         b = timeit(fb, iters=5, warm=3)
         out[tag] = {"forward_ms": round(f, 2), "forward_backward_ms": round(b, 2), "images_per_s_fwd_bwd": round(N / b * 1e3, 1)}
+        if N > 1:                                         # the same on the split-bf16 GEMM route (kernels.set_gemm_route; co-headline only)
+            from multishiftseg_amd import kernels as K
+            K.set_gemm_route("bf16x3")
+            try:
+                with torch.no_grad():
+                    f3 = timeit(lambda: dec.forward_features(feats), iters=5, warm=2)
+                b3 = timeit(fb, iters=5, warm=3)
+                out[tag]["bf16x3_route"] = {"forward_ms": round(f3, 2), "forward_backward_ms": round(b3, 2), "images_per_s_fwd_bwd": round(N / b3 * 1e3, 1)}
+            finally:
+                K.set_gemm_route(None)
         if N == 1:
             try:                                          # the inference form: the same forward as ONE hipGraph launch
                 from multishiftseg_amd.msdeformattn_decoder import GraphedFeatures
