@@ -166,6 +166,8 @@ typedef struct MssConvArgs {
                            /*   Non-NULL selects the split-bf16 route (6 bf16 MFMAs with fp32 accumulation per product block,       */
                            /*   fp32 accuracy) for every shape the persistent GEMM kernel takes (1x1, > 64 output channels,         */
                            /*   >= 48 input channels); other shapes run the native fp32 kernels on `w` (which must always be set).   */
+  int route;               /* 0: native fp32 MFMA. 1: mss_conv2d_wgrad_f32 evaluates the TN product the same split-bf16 way (both    */
+                           /*   operands split in the loader) where K % 128 == 0 and C % 256 == 0; other shapes stay native.         */
 } MssConvArgs;
 
 int mss_conv2d_forward_f32(MssConvArgs* args, void* stream);

@@ -38,6 +38,7 @@ class MssConvArgs(Structure):
         ("stats", c_void_p),
         ("res_mask", c_int),
         ("w_split", c_void_p),
+        ("route", c_int),
     ]
 
 

@@ -25,6 +25,9 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream);   // gemm.hip: persistent
 bool mss_gemm_nt_eligible(const MssConvArgs& p);
 bool mss_gemm_few_rows(const MssConvArgs& p);
 bool mss_gemm_nt_bf16x3_eligible(const MssConvArgs& p);   // gemm_bf16x3.hip
+bool mss_wgrad_tn_bf16x3_eligible(const MssConvArgs& p, int lddy);
+long long mss_wgrad_tn_bf16x3_ws_bytes(const MssConvArgs& p, int Cp);
+int mss_wgrad_tn_bf16x3_launch(const MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, float* ws, long long ws_bytes, void* stream);
 
 namespace {
 
@@ -1544,6 +1547,10 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
 
 }  // namespace
 
+void mss_wgrad_reduce_launch(const float* ws, float* dwp, long long slab4, int splits, hipStream_t stream) {
+  launch_wgrad_reduce(ws, dwp, slab4, splits, stream);
+}
+
 extern "C" {
 
 int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
@@ -1618,6 +1625,7 @@ long long mss_conv2d_wgrad_workspace_bytes(const MssConvArgs* args, int Cp) {
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return 0;
   long long tn_bytes = 0;
+  if (mss_wgrad_tn_bf16x3_eligible(p, p.K)) return mss_wgrad_tn_bf16x3_ws_bytes(p, Cp);      // args->route == 1: the split-bf16 TN kernel
   if (tn_eligible(p, p.K)) {                 // lddy == K is assumed here and checked again at launch
     const TnPlan pl = tn_plan_for(p);
     tn_bytes = pl.full >= 0 ? tn_tail_bytes(pl) : pl.splits > 1 ? (long long)pl.splits * tn_batch(p) * p.Kpad * Cp * 4 : 0;
@@ -1646,6 +1654,8 @@ int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dw
   if (p.M <= 0) return MSS_OK;
   if (p.batch > 1 && (p.R * p.S != 1 || p.batch > 65535)) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (mss_wgrad_tn_bf16x3_eligible(p, lddy) && ws_bytes >= mss_wgrad_tn_bf16x3_ws_bytes(p, Cp))
+    return mss_wgrad_tn_bf16x3_launch(p, dy, lddy, dwp, Cp, ws, ws_bytes, stream);
   if (tn_eligible(p, lddy)) return launch_wgrad_tn(p, dy, dwp, Cp, ws, ws_bytes, s, lddy);
   if (narrow_eligible(p, dy, lddy, Cp)) return launch_wgrad_narrow(p, dy, lddy, dwp, Cp, ws, ws_bytes, s);
   // output-channel tile: 32 rows (1x4 waves) for the 19-channel heads, 64 for bot_fine's 48, else 128

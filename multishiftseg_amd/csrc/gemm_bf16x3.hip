@@ -291,6 +291,225 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The TN product of the weight gradients on the same route: dW[k][c] = sum_t dy[t][k] * act(x[t][c])  (Winograd-domain batches:
+// dU[p] = dY'[p]^T X'[p]; 1x1 layers and Linears: one position). Both operands are activations, so both are split in the loader;
+// the contraction index t is the ROW of both tensors, so the loader also transposes: a staging task is 8 consecutive rows x 4
+// consecutive columns (8 coalesced 16-byte loads); v_cvt_pk_bf16_f32 pairs rows (2 t', 2 t' + 1) of one column, i.e. the 8 rows
+// of a column leave as ONE 16-byte LDS write per plane -- the k-contiguous row piece the MFMA fragment wants, no shuffles.
+// A 32-row fragment block holds the columns {4 c + i : c = 0..31} of a 128-column group (i = its index in the group): the LDS image is
+// then the NT kernel's ([128-row block][plane][row][16 k], same swizzle, same fragment reads, same MFMA order) and the epilogue
+// interleaves the four blocks of a lane back into 16-byte stores of consecutive columns.
+// Tile 128 (k) x 256 (c) per workgroup, wave 0 stages the 64 dy tasks, waves 1-2 the 128 x tasks (176 VALU each per K-step beside
+// their 48 MFMAs), persistent over (position, split, k tile, c tile); every split walks `tps` rows (a multiple of 16); the last one is
+// shifted back to end at row M and the rows it shares with its predecessor enter as zeros.
+template <bool AFFINE>
+__global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                                float* __restrict__ out, int P, int M, long long a_bs, long long b_bs, int Kpad,
+                                                                int Cp, int ktiles, int ctiles, int splits, int tps, long long total_tiles,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
+  constexpr int NBLK = 2, TN = 4, BN = 256;
+  constexpr int STAGE = (1 + NBLK) * OPER;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // waves 0 AND 3 stage the 64 dy tasks (the same bytes to the same LDS addresses: wave 3 would otherwise idle, and a role that
+  // skips the staging puts a branch into the K-step, which must stay ONE basic block for the interleaving below), waves 1-2 the x tasks
+  const bool is_a = wave == 0 || wave == 3;
+  const int task = is_a ? lane : (wave - 1) * 64 + lane;          // A: 32 column quads x 2 row groups; B: 64 x 2
+  const int cq = is_a ? (task & 31) : (task & 63), rg = is_a ? (task >> 5) : (task >> 6);
+  const int n_it = tps / BK;
+  const long long stride = gridDim.x;
+  const float relu_floor = relu ? 0.f : -__builtin_huge_valf();
+  const int ld = is_a ? lda : ldb;                                 // wave-uniform
+  const unsigned ld_bytes = (unsigned)ld * 4u;
+  typedef const unsigned char __attribute__((address_space(1)))* gptr_t;
+  gptr_t rowbase[8];                                               // operand base + t rows: 8 uniform pointers, one 32-bit offset per thread
+#pragma unroll
+  for (int t = 0; t < 8; ++t) rowbase[t] = (gptr_t)(is_a ? A : B) + (size_t)t * ld_bytes;
+
+  unsigned off = 0, nxt = 0, s_off = 0, s_nxt = 0;
+  int vf = 0, vf_nxt = 0, row_ld = 0, row_nxt = 0;                 // first valid row of the loader's tile; first row of its current step
+  long long ld_tile = mss_xcd_remap(blockIdx.x, gridDim.x);
+  int ld_k = 0;
+  auto decode = [&](long long t, int& pb, int& sp, int& kt, int& ct) {
+    ct = (int)(t % ctiles); t /= ctiles;
+    kt = (int)(t % ktiles); t /= ktiles;
+    sp = (int)(t % splits); pb = (int)(t / splits);
+  };
+  auto setup_off = [&](long long t, unsigned& o, unsigned& so, int& valid_from, int& row0) {
+    int pb, sp, kt, ct; decode(t, pb, sp, kt, ct);
+    valid_from = sp * tps;
+    row0 = valid_from + tps <= M ? valid_from : M - tps;          // the last split is shifted back to end at row M
+    const size_t col = is_a ? (size_t)kt * 128 + 4 * cq : (size_t)ct * BN + 4 * cq;
+    o = (unsigned)((((size_t)pb * (is_a ? a_bs : b_bs)) + (size_t)(row0 + rg * 8) * ld + col) * sizeof(float));
+    if (AFFINE) so = is_a ? 0u : (unsigned)((ct * BN + 4 * cq) * sizeof(float));     // (dy lanes load a valid vector and ignore it)
+  };
+  auto setup_next = [&]() {
+    const long long t = ld_tile + stride;
+    setup_off(t < total_tiles ? t : ld_tile, nxt, s_nxt, vf_nxt, row_nxt);
+  };
+  f32x4 raw[8], sreg, hreg;
+  int raw_mask = 0;                                                // mask_rows of the K-step held in `raw`
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) raw[t] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(rowbase[t] + off);
+    if (AFFINE) {
+      sreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(scale) + s_off);
+      hreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(shift) + s_off);
+    }
+    const int m = vf - row_ld;                                     // rows [row_ld, vf) belong to the previous split (dy rows enter as zeros)
+    raw_mask = is_a && m > 0 ? m : 0;
+  };
+  auto advance = [&]() {
+    const bool wrap = ++ld_k == n_it;
+    off = wrap ? nxt : off + BK * ld_bytes;
+    row_ld = wrap ? row_nxt : row_ld + BK;
+    vf = wrap ? vf_nxt : vf;
+    if (AFFINE) s_off = wrap ? s_nxt : s_off;
+    ld_k = wrap ? 0 : ld_k;
+  };
+  // LDS: 16 bytes (8 k) of row (i * 32 + cq % 32) of the operand block, per plane and column i of the quad
+  const int st_off = (is_a ? 0 : OPER * (1 + (cq >> 5))) + (cq & 31) * ROW_B + ((rg ^ (((cq & 31) >> 3) & 1)) * 16);
+  int st_mask = 0;
+  auto store_comp = [&](int buf, const int i) {                    // column i of the quad: 8 rows -> 3 planes x 16 bytes
+    unsigned char* base = smem + buf * STAGE + st_off;
+    unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int t2 = 0; t2 < 4; ++t2) {
+      float v0 = raw[2 * t2][i], v1 = raw[2 * t2 + 1][i];
+      if (AFFINE) {
+        const float sc = is_a ? 1.f : sreg[i], sh = is_a ? 0.f : hreg[i], fl = is_a ? -__builtin_huge_valf() : relu_floor;
+        v0 = fmaxf(v0 * sc + sh, fl);
+        v1 = fmaxf(v1 * sc + sh, fl);
+      }
+      v0 = rg * 8 + 2 * t2 < st_mask ? 0.f : v0;                  // (st_mask is 0 on the x lanes)
+      v1 = rg * 8 + 2 * t2 + 1 < st_mask ? 0.f : v1;
+      split_pair(v0, v1, hi[t2], mid[t2], lo[t2]);
+    }
+    *reinterpret_cast<u32x4*>(base + 0 * PLANE + i * 32 * ROW_B) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<u32x4*>(base + 1 * PLANE + i * 32 * ROW_B) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+    *reinterpret_cast<u32x4*>(base + 2 * PLANE + i * 32 * ROW_B) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+  };
+  auto finish_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_comp(buf, i);
+  };
+
+  const int frow = lane & 31, fkb = lane >> 5;
+  const int fr_off = frow * ROW_B + ((fkb ^ ((frow >> 3) & 1)) * 16);
+  const int fa_off = wm * 64 * ROW_B + fr_off;
+  const int fb_off = OPER + wn * OPER + fr_off;
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  auto epilogue = [&](long long t) {
+    int pb, sp, kt, ct; decode(t, pb, sp, kt, ct);
+    float* o = out + ((size_t)sp * P + pb) * Kpad * Cp + (size_t)(kt * 128) * Cp + (size_t)(ct * BN + wn * 128 + 4 * frow);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * fkb;
+        const f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        *reinterpret_cast<f32x4*>(o + (size_t)(4 * m + 2 * wm + i) * Cp) = v;
+      }
+  };
+  auto step = [&](const int buf) {
+    const unsigned char* base = smem + buf * STAGE;
+    auto ld_a = [&](int pl, bf16x8 (&f)[TM]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) f[i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + fa_off + i * 32 * ROW_B);
+    };
+    auto ld_b = [&](int pl, bf16x8 (&f)[TN]) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) f[j] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + fb_off + j * 32 * ROW_B);
+    };
+    auto mm = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    bf16x8 a_hi[TM], a_mid[TM], a_lo[TM], b_hi[TN], b_mid[TN], b_lo[TN];
+    // six fenced segments of 8 MFMAs, as in the NT kernel; the split / transpose of K-step k+1 (one quad column = 44 VALU + 3 LDS
+    // writes per segment) rides behind the MFMAs of segments 2-5, the loads of step k+2 behind the last one
+#define MSS_PAIR_UP(mask, n, per)                                                                                             \
+  _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                          \
+    __builtin_amdgcn_sched_group_barrier((mask), (per), 0);                                                                   \
+  }
+    constexpr int PER = AFFINE ? 10 : 8;
+    ld_a(2, a_lo); ld_b(0, b_hi);
+    ld_a(1, a_mid); ld_a(0, a_hi);
+    __builtin_amdgcn_sched_barrier(0);
+    st_mask = raw_mask;
+    mm(a_lo, b_hi);
+    __builtin_amdgcn_sched_barrier(0);
+    store_comp(buf ^ 1, 0);
+    ld_b(1, b_mid);
+    mm(a_mid, b_hi);
+    MSS_PAIR_UP(0x2, 7, PER);
+    __builtin_amdgcn_sched_barrier(0);
+    store_comp(buf ^ 1, 1);
+    mm(a_hi, b_hi);
+    MSS_PAIR_UP(0x2, 7, PER);
+    __builtin_amdgcn_sched_barrier(0);
+    store_comp(buf ^ 1, 2);
+    ld_b(2, b_lo);
+    mm(a_hi, b_mid);
+    MSS_PAIR_UP(0x2, 7, PER);
+    __builtin_amdgcn_sched_barrier(0);
+    store_comp(buf ^ 1, 3);
+    mm(a_mid, b_mid);
+    MSS_PAIR_UP(0x2, 7, PER);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_loads();                       // K-step k+2 into the registers just drained
+    advance();
+    mm(a_hi, b_lo);
+    MSS_PAIR_UP(0x20, 8, 1);
+#undef MSS_PAIR_UP
+    __syncthreads();
+  };
+
+  long long cur = ld_tile;
+  setup_off(ld_tile, off, s_off, vf, row_ld);
+  setup_next();
+  issue_loads();
+  st_mask = raw_mask;
+  finish_store(0);
+  advance();
+  issue_loads();
+  advance();
+  zero_acc();
+  __syncthreads();
+  int k = 0;
+  auto tile_end = [&]() -> bool {
+    if (++k < n_it) return false;
+    epilogue(cur);
+    cur += stride;
+    if (cur >= total_tiles) return true;
+    zero_acc();
+    k = 0;
+    ld_tile = cur;
+    setup_next();
+    return false;
+  };
+  while (true) {
+    step(0);
+    if (tile_end()) break;
+    step(1);
+    if (tile_end()) break;
+  }
+}
+
 // fp32 weights [batch][Kpad][C] -> three bf16 planes in the LDS image order the kernel copies:
 // byte ((b * Kpad/128 + n / 128) * C/16 + s) * 12288 + plane * 4096 + (n % 128) * 32 + ((h ^ ((n >> 3) & 1)) * 16) holds k = 16 s + 8 h .. + 7
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Kpad,
@@ -393,6 +612,86 @@ int mss_gemm_nt_bf16x3_launch(MssConvArgs p, void* stream) {
   p.ntiles = mss_cdiv(p.K, 128);
   if (!sched) return p.in_scale ? launch_split<true, 128, false>(p, s) : launch_split<false, 128, false>(p, s);
   return p.in_scale ? launch_split<true, 128, true>(p, s) : launch_split<false, 128, true>(p, s);
+}
+
+
+// ---- host side of the TN weight-gradient route ------------------------------------------------------------------------------------
+void mss_wgrad_reduce_launch(const float* ws, float* dwp, long long slab4, int splits, hipStream_t stream);   // conv_igemm.hip
+
+namespace {
+struct TnSplitPlan { int ktiles, ctiles, splits, tps; long long total; };
+// 512 workgroup slots (two per CU); the row range is cut so that the tiles fill whole rounds, every split a multiple of 16 rows,
+// at least 48 (the loader runs two K-steps ahead) and at most M
+TnSplitPlan tn_split_plan(const MssConvArgs& p) {
+  TnSplitPlan pl;
+  pl.ktiles = p.K / 128; pl.ctiles = p.C / 256;
+  const long long base = (long long)(p.batch > 1 ? p.batch : 1) * pl.ktiles * pl.ctiles;
+  const int slots = 512;
+  int max_splits = p.M / 256;
+  const int cap = p.batch > 1 ? 64 : 256;
+  if (max_splits > cap) max_splits = cap;
+  if (max_splits < 1) max_splits = 1;
+  int splits = 1;
+  double best = 0.0;
+  for (int sp = 1; sp <= max_splits; ++sp) {
+    const long long total = base * sp;
+    const double eff = (double)total / (double)(((total + slots - 1) / slots) * slots);
+    if (eff > best + 1e-9) { best = eff; splits = sp; }
+    if (eff >= 0.95 && total >= slots) break;
+  }
+  pl.tps = mss_cdiv(mss_cdiv(p.M, splits), 16) * 16;
+  if (pl.tps > p.M) pl.tps = (p.M / 16) * 16;
+  pl.splits = mss_cdiv(p.M, pl.tps);
+  pl.total = base * pl.splits;
+  return pl;
+}
+}  // namespace
+
+// p as mss_conv2d_wgrad_f32 sees it (p.M set); lddy = row stride of dy
+bool mss_wgrad_tn_bf16x3_eligible(const MssConvArgs& p, int lddy) {
+  if (p.route != 1 || p.R * p.S != 1 || p.K % 128 || p.C % 256 || p.K < 128 || p.ldx != p.C || lddy < p.K || lddy % 4 || p.M < 64) return false;
+  if (p.batch > 1 && (lddy != p.K || p.x_bs % 4 || p.y_bs % 4 || p.N != 1 || p.H != 1)) return false;
+  if (p.batch <= 1 && (p.stride != 1 || p.pad != 0 || p.OH != p.H || p.OW != p.W)) return false;
+  if ((p.in_scale || p.in_shift || p.in_relu) && (p.batch > 1 || p.in_ss_stride != 0 || !p.in_scale || !p.in_shift)) return false;
+  if (p.in_scale && ((reinterpret_cast<uintptr_t>(p.in_scale) | reinterpret_cast<uintptr_t>(p.in_shift)) & 15)) return false;
+  const long long nb = p.batch > 1 ? p.batch : 1;
+  if ((unsigned long long)((nb - 1) * (p.batch > 1 ? p.x_bs : 0) + (long long)p.M * p.C) * 4ull >= 0xffffffffull) return false;
+  if ((unsigned long long)((nb - 1) * (p.batch > 1 ? p.y_bs : 0) + (long long)p.M * lddy) * 4ull >= 0xffffffffull) return false;
+  return tn_split_plan(p).total >= 256;          // small products (fewer tiles than half the workgroup slots) stay on the native one-wave kernels
+}
+
+long long mss_wgrad_tn_bf16x3_ws_bytes(const MssConvArgs& p, int Cp) {
+  const TnSplitPlan pl = tn_split_plan(p);
+  return pl.splits > 1 ? (long long)pl.splits * (p.batch > 1 ? p.batch : 1) * p.Kpad * Cp * 4 : 0;
+}
+
+int mss_wgrad_tn_bf16x3_launch(const MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, float* ws, long long ws_bytes, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const TnSplitPlan pl = tn_split_plan(p);
+  const int P = p.batch > 1 ? p.batch : 1;
+  if (p.Kpad != p.K || Cp != p.C) return MSS_ERR_BAD_ARG;          // whole tiles: no padding rows / columns to clear
+  const long long slab = (long long)P * p.Kpad * Cp;
+  if (pl.splits > 1 && (!ws || ws_bytes < (long long)pl.splits * slab * 4)) return MSS_ERR_BAD_ARG;
+  float* out = pl.splits > 1 ? ws : dwp;
+  const size_t smem = (size_t)2 * 3 * OPER;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  const long long slots = 512;
+  const int grid = (int)(pl.total < slots ? pl.total : slots);
+  const long long a_bs = p.batch > 1 ? p.y_bs : 0, b_bs = p.batch > 1 ? p.x_bs : 0;
+  if (p.in_scale)
+    hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<true>, dim3(grid), dim3(NT), smem, s, dy, lddy, p.x, p.C, out, P, p.M, a_bs, b_bs, p.Kpad, Cp, pl.ktiles,
+                       pl.ctiles, pl.splits, pl.tps, pl.total, p.in_scale, p.in_shift, p.in_relu);
+  else
+    hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<false>, dim3(grid), dim3(NT), smem, s, dy, lddy, p.x, p.C, out, P, p.M, a_bs, b_bs, p.Kpad, Cp, pl.ktiles,
+                       pl.ctiles, pl.splits, pl.tps, pl.total, (const float*)nullptr, (const float*)nullptr, 0);
+  if (pl.splits > 1) mss_wgrad_reduce_launch(ws, dwp, slab / 4, pl.splits, s);
+  return mss_launch_status();
 }
 
 extern "C" long long mss_gemm_split_weights_bytes(int batch, int Kpad, int C) {

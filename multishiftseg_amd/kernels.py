@@ -326,6 +326,7 @@ def conv2d_wgrad(x, dy, K, C, R, S, stride=1, dil=1, pad=0, in_affine=None, in_r
     a.OH, a.OW, a.K, a.Kpad = dy.H, dy.W, K, Kpad
     a.R, a.S, a.stride, a.dil, a.pad = R, S, stride, dil, pad
     a.in_relu = int(in_relu)
+    a.route = 1 if gemm_route() == "bf16x3" else 0
     ws, ws_bytes = _wgrad_workspace(a, Cp, x.buf.device)
     with _Timed("conv_wgrad", 2.0 * x.N * dy.H * dy.W * K * C * R * S, (x.N, x.H, x.W, C, K, R, stride, dil)):
         call("mss_conv2d_wgrad_f32", ctypes.byref(a), dy.ptr, dy.ld, ptr(dwp), Cp, ptr(ws), ws_bytes)
@@ -661,6 +662,7 @@ def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=
         a.OH, a.OW, a.K, a.Kpad = 1, T, K, Kpad
         a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
         a.batch, a.x_bs, a.y_bs = P, T * C, T * K
+        a.route = 1 if gemm_route() == "bf16x3" else 0
         ws, ws_bytes = _wgrad_workspace(a, Cp, dev)
         with _Timed("conv_wgrad", 2.0 * P * T * K * C, (P, 1, T, C, K, 1, 1, 1)):
             call("mss_conv2d_wgrad_f32", ctypes.byref(a), ptr(dyt), K, ptr(du), Cp, ptr(ws), ws_bytes)

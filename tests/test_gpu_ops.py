@@ -106,7 +106,7 @@ def test_conv_channel_slices(K):
     assert np.all(got[:, :48] == 0) and np.all(got[:, 96:] == 0)
 
 
-def test_dgrad_and_wgrad(K):
+def test_dgrad_and_wgrad(K, gemm_route):
     rng = np.random.default_rng(5)
     for (cin, cout, r, dil, n, h, w) in [(64, 128, 3, 1, 2, 14, 13), (256, 48, 1, 1, 1, 9, 8), (128, 64, 3, 12, 1, 20, 18)]:
         pad = dil if r == 3 else 0
@@ -260,7 +260,7 @@ def test_winograd_conv_vs_oracle(K, cin, cout, dil, n, h, w, tile, monkeypatch):
 
 @pytest.mark.parametrize("tile", [2, 4, 6])
 @pytest.mark.parametrize("cin,cout,dil,n,h,w", [(32, 64, 1, 2, 12, 14), (64, 32, 2, 1, 13, 17), (48, 36, 12, 2, 16, 22)])
-def test_winograd_wgrad_vs_autograd(K, cin, cout, dil, n, h, w, tile):
+def test_winograd_wgrad_vs_autograd(K, cin, cout, dil, n, h, w, tile, gemm_route):
     rng = np.random.default_rng(cin * 3 + cout + dil)
     x = torch.from_numpy(rng.standard_normal((n, cin, h, w), dtype=np.float32))
     wt = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) / np.sqrt(cin * 9)).astype(np.float32)).requires_grad_(True)
@@ -575,6 +575,53 @@ def test_bf16x3_route_is_taken_by_the_layer_wrappers(K):
         assert (a - b).abs().max().item() < 1e-4 * a.abs().max().item()         # (the Winograd layer: 2e-5 of max|y| between two fp32 evaluations)
 
 
+@pytest.mark.parametrize("P,T,C,Ko,affine,ld_extra", [(36, 1100, 512, 256, False, 0), (1, 162629, 256, 128, False, 32), (1, 70000, 1280, 256, True, 0),
+                                                      (64, 1936, 256, 256, False, 0), (2, 40000, 256, 384, False, 0)])
+def test_bf16x3_wgrad_tn_vs_float64(K, P, T, C, Ko, affine, ld_extra):
+    """The TN weight-gradient product on the split-bf16 route (MssConvArgs.route = 1, gemm_tn_bf16x3_kernel: both operands split and
+    transposed in the loader) against float64 and against the native kernels: row counts that are not multiples of 16 (the last
+    split is shifted back and the rows it shares with its predecessor enter as zeros -- up to 52 of them here), batched positions,
+    a dy that is a channel slice of a wider buffer, the BatchNorm + ReLU prologue on x. Deterministic (two runs bit-identical)."""
+    import ctypes
+    from multishiftseg_amd._lib import MssConvArgs, call, ptr
+    torch.manual_seed(T + C)
+    xt = torch.randn(P, T, C, device="cuda")
+    ldy = Ko + ld_extra
+    dy_buf = torch.randn(P, T, ldy, device="cuda")
+    sc = sh = None
+    if affine:
+        sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.3
+    outs = {}
+    for route in (0, 1, 1):
+        du = torch.full((P, Ko, C), float("nan"), device="cuda")
+        a = MssConvArgs()
+        a.x = ptr(xt)
+        a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
+        a.OH, a.OW, a.K, a.Kpad = 1, T, Ko, Ko
+        a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+        a.route = route
+        if affine:
+            a.in_scale, a.in_shift, a.in_relu = ptr(sc), ptr(sh), 1
+        if P > 1:
+            a.batch, a.x_bs, a.y_bs = P, T * C, T * ldy
+        ws, wsb = K._wgrad_workspace(a, C, "cuda")
+        call("mss_conv2d_wgrad_f32", ctypes.byref(a), ptr(dy_buf), ldy, ptr(du), C, ptr(ws), wsb)
+        outs.setdefault(route, []).append(du)
+    assert torch.equal(outs[1][0], outs[1][1])                      # deterministic
+    assert not torch.equal(outs[0][0], outs[1][0])                  # it really ran the other kernel
+    rows = torch.randint(0, Ko, (32,), device="cuda")
+    xa = xt.double()
+    if affine:
+        xa = torch.relu(xa * sc.double() + sh.double())
+    for b in {0, P - 1}:
+        ref = dy_buf[b][:, rows].double().T @ xa[b]
+        scale = ref.abs().max().item()
+        e0 = (outs[0][0][b, rows].double() - ref).abs().max().item() / scale
+        e1 = (outs[1][0][b, rows].double() - ref).abs().max().item() / scale
+        assert e0 < 5e-6 and e1 < 5e-6 and e1 < 2 * e0 + 2e-7, (e0, e1)
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-5 * outs[0][0].abs().max().item()
+
+
 @pytest.mark.parametrize("mode", ["0", "1", "2", "4", "5", "6", "7"])
 @pytest.mark.parametrize("P,T,C,Ko", [(3, 700, 512, 128), (2, 1000, 256, 72), (4, 37, 768, 256)])
 def test_batched_wgrad_routes_vs_float64(K, monkeypatch, mode, P, T, C, Ko):
@@ -638,7 +685,7 @@ def test_narrow_wgrad_direct_kernel_vs_float64(K, monkeypatch, n, h, w, cin, k, 
 
 
 @pytest.mark.parametrize("n,h,w,cin,k,relu", [(2, 128, 256, 1280, 256, True), (1, 200, 333, 256, 128, True), (1, 128, 256, 512, 256, False)])
-def test_direct_wgrad_with_bn_relu_prologue_vs_float64(K, monkeypatch, n, h, w, cin, k, relu):
+def test_direct_wgrad_with_bn_relu_prologue_vs_float64(K, monkeypatch, n, h, w, cin, k, relu, gemm_route):
     """r04: a 1x1 layer's weight gradient whose forward reads relu(x * scale + shift) (bot_aspp over the five ASPP branches'
     BatchNorm + ReLU, deepv3.py:235-240) on the LDS-free kernel, the affine applied to the x registers at consume time, against
     the LDS kernel (MSS_WGRAD_TN_AFFINE=0) and a float64 product; twice with identical bits."""
@@ -851,7 +898,7 @@ def test_winograd_pair_equals_two_separate_layers(K, monkeypatch):
 
 
 @pytest.mark.parametrize("T,C,Ko", [(162624, 256, 256), (50001, 256, 192), (40000, 1024, 256)])
-def test_linear_wgrad_many_rows_vs_float64(K, T, C, Ko):
+def test_linear_wgrad_many_rows_vs_float64(K, T, C, Ko, gemm_route):
     """The decoder's Linear weight gradients: ONE position, a handful of output tiles and very many rows (16 x 10 164 tokens), i.e.
     up to 192 row splits on the TN kernel (the cap was 64: a third of the slots) summed by the ordered reduction; against a
     float64 product on a sample of rows of dW, and twice with identical bits."""
