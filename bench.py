@@ -470,7 +470,8 @@ def main():
         # persistent GEMM kernel takes evaluated on the bf16 matrix cores -- operands as three bf16 terms, six bf16 MFMAs per block,
         # fp32 accumulation (csrc/gemm_bf16x3.hip; kernels.set_gemm_route). Same timing protocol as `value`, its own parity
         # against the reference fixture (taken before the first optimizer step) and its own roofline: fp32-equivalent TFLOP/s over
-        # (bf16 dense peak / 6); the weight-gradient and implicit-GEMM kernels stay on the native fp32 MFMA.
+        # (bf16 dense peak / 6); the weight gradients whose shapes fit (K % 128, C % 256) run the split TN kernel, the implicit-GEMM
+        # layers and the narrow heads stay on the native fp32 MFMA.
         K.set_gemm_route("bf16x3")
         try:
             for _ in range(max(1, args.warmup)):
@@ -504,6 +505,11 @@ def main():
                     pass
             others = {k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "kernel_ms_per_step": round(v["ms"] / max(args.steps, 1), 2)}
                       for k, v in ss_.items() if k in ("gemm_nt", "conv_igemm", "conv_wgrad") and v["launches"]}
+            wg3 = ss_.get("conv_wgrad_bf16x3")
+            if wg3 and wg3["launches"]:
+                a3 = wg3["flops"] / (wg3["ms"] * 1e-3) / 1e12
+                rf["weight_gradient_kernel"] = {"kernel": "gemm_tn_bf16x3_kernel", "achieved": round(a3, 2), "frac": round(a3 / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
+                                                "launches_per_step": wg3["launches"] // max(args.steps, 1), "kernel_ms_per_step": round(wg3["ms"] / max(args.steps, 1), 2)}
             out["value_fp32_via_bf16x3"] = {
                 "value": round(2 * pairs / dt, 4), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3),
                 "dtype": "f32 (operands split into 3 bf16 terms, 6 bf16 MFMAs, fp32 accumulate)",

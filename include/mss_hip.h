@@ -200,6 +200,9 @@ int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dw
                          long long ws_bytes, void* stream);
 int mss_conv2d_unpack_wgrad_f32(const float* packed, float* grad, int K, int C, int R, int S, int Kpad,
                                 int Cp, int accumulate, void* stream);
+/* 1 when mss_conv2d_wgrad_f32 runs these arguments on the split-bf16 TN kernel (args->route == 1, K % 128 == 0, C % 256 == 0, enough
+ * tiles to fill half the chip), else 0 (native fp32 MFMA kernels). Profiling label only. */
+int mss_conv2d_wgrad_route(const MssConvArgs* args, int lddy);
 
 /* Winograd F(m x m, 3x3) path, m = `tile` = 2 or 4, P = (m+2)^2 positions, for stride-1 3x3 convolutions with
  * many channels (csrc/winograd.hip): weights [K][C][3][3] -> U [P][Kpad][Cp]; x -> X' [P][T][C]

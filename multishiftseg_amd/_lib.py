@@ -86,6 +86,7 @@ SIGNATURES = {
     "mss_conv2d_pack_weights_f32": [P, P, I, I, I, I, I, I, I, P],
     "mss_conv2d_wgrad_workspace_bytes": [POINTER(MssConvArgs), I],
     "mss_conv2d_wgrad_f32": [POINTER(MssConvArgs), P, I, P, I, P, L, P],
+    "mss_conv2d_wgrad_route": [POINTER(MssConvArgs), I],
     "mss_conv2d_unpack_wgrad_f32": [P, P, I, I, I, I, I, I, I, P],
     "mss_nchw_to_nhwc_pad_f32": [P, P, I, I, I, I, I, P],
     "mss_im2col3x3_c3_f32": [P, P, I, I, I, P],
@@ -168,7 +169,7 @@ SIGNATURES = {
     "mss_peak_scatter_f32": [P, P, L, I, I, L, P],
 }
 # entry points that return a plain value rather than a status code
-_VALUE_RETURNING = {"mss_gemm_split_weights_bytes", "mss_abi_version", "mss_env_reset", "mss_env_generation", "mss_rcl_workspace_bytes", "mss_msda_backward_workspace_bytes", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
+_VALUE_RETURNING = {"mss_conv2d_wgrad_route", "mss_gemm_split_weights_bytes", "mss_abi_version", "mss_env_reset", "mss_env_generation", "mss_rcl_workspace_bytes", "mss_msda_backward_workspace_bytes", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
                     "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts",
                     "mss_conv2d_wgrad_workspace_bytes", "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
                     "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats",

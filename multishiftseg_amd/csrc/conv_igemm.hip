@@ -1619,6 +1619,13 @@ int mss_conv2d_unpack_wgrad_f32(const float* packed, float* grad, int K, int C, 
   return mss_launch_status();
 }
 
+// 1 when mss_conv2d_wgrad_f32 evaluates these arguments with the split-bf16 TN kernel (args->route == 1 and the shape eligible), else 0.
+int mss_conv2d_wgrad_route(const MssConvArgs* args, int lddy) {
+  MssConvArgs p = *args;
+  p.M = p.N * p.OH * p.OW;
+  return p.M > 0 && mss_wgrad_tn_bf16x3_eligible(p, lddy) ? 1 : 0;
+}
+
 // Bytes of scratch mss_conv2d_wgrad_f32 needs for these arguments (0: the pixel range is not split).
 long long mss_conv2d_wgrad_workspace_bytes(const MssConvArgs* args, int Cp) {
   MssConvArgs p = *args;

@@ -239,6 +239,13 @@ def _fwd_kind(a):
     return ("conv_igemm", "gemm_nt", "gemm_few_rows", "gemm_nt_bf16x3")[_lib.value("mss_conv2d_forward_route", ctypes.byref(a))]
 
 
+def _wgrad_kind(a, lddy):
+    """Profiling label of a weight-gradient launch: the split-bf16 TN kernel or one of the native fp32 MFMA kernels."""
+    if _profile is None or not a.route:
+        return "conv_wgrad"
+    return "conv_wgrad_bf16x3" if _lib.value("mss_conv2d_wgrad_route", ctypes.byref(a), lddy) else "conv_wgrad"
+
+
 def conv_out_size(h, r, stride, dil, pad):
     return (h + 2 * pad - dil * (r - 1) - 1) // stride + 1
 
@@ -328,7 +335,7 @@ def conv2d_wgrad(x, dy, K, C, R, S, stride=1, dil=1, pad=0, in_affine=None, in_r
     a.in_relu = int(in_relu)
     a.route = 1 if gemm_route() == "bf16x3" else 0
     ws, ws_bytes = _wgrad_workspace(a, Cp, x.buf.device)
-    with _Timed("conv_wgrad", 2.0 * x.N * dy.H * dy.W * K * C * R * S, (x.N, x.H, x.W, C, K, R, stride, dil)):
+    with _Timed(_wgrad_kind(a, dy.ld), 2.0 * x.N * dy.H * dy.W * K * C * R * S, (x.N, x.H, x.W, C, K, R, stride, dil)):
         call("mss_conv2d_wgrad_f32", ctypes.byref(a), dy.ptr, dy.ld, ptr(dwp), Cp, ptr(ws), ws_bytes)
     grad = torch.empty((K, C, R, S), device=x.buf.device, dtype=torch.float32)
     call("mss_conv2d_unpack_wgrad_f32", ptr(dwp), ptr(grad), K, C, R, S, Kpad, Cp, 0)
@@ -664,7 +671,7 @@ def conv2d_wgrad_winograd(x, dy, K, C, dil=1, in_affine=None, in_relu=False, xt=
         a.batch, a.x_bs, a.y_bs = P, T * C, T * K
         a.route = 1 if gemm_route() == "bf16x3" else 0
         ws, ws_bytes = _wgrad_workspace(a, Cp, dev)
-        with _Timed("conv_wgrad", 2.0 * P * T * K * C, (P, 1, T, C, K, 1, 1, 1)):
+        with _Timed(_wgrad_kind(a, K), 2.0 * P * T * K * C, (P, 1, T, C, K, 1, 1, 1)):
             call("mss_conv2d_wgrad_f32", ctypes.byref(a), ptr(dyt), K, ptr(du), Cp, ptr(ws), ws_bytes)
         grad = torch.empty((K, C, 3, 3), device=dev, dtype=torch.float32)
         call("mss_wino_weight_grad_transform_f32", ptr(du), ptr(grad), K, C, Kpad, Cp, ts)

@@ -575,7 +575,7 @@ def test_bf16x3_route_is_taken_by_the_layer_wrappers(K):
         assert (a - b).abs().max().item() < 1e-4 * a.abs().max().item()         # (the Winograd layer: 2e-5 of max|y| between two fp32 evaluations)
 
 
-@pytest.mark.parametrize("P,T,C,Ko,affine,ld_extra", [(36, 1100, 512, 256, False, 0), (1, 162629, 256, 128, False, 32), (1, 70000, 1280, 256, True, 0),
+@pytest.mark.parametrize("P,T,C,Ko,affine,ld_extra", [(36, 1100, 512, 256, False, 0), (1, 162629, 256, 256, False, 32), (1, 70000, 1280, 256, True, 0),
                                                       (64, 1936, 256, 256, False, 0), (2, 40000, 256, 384, False, 0)])
 def test_bf16x3_wgrad_tn_vs_float64(K, P, T, C, Ko, affine, ld_extra):
     """The TN weight-gradient product on the split-bf16 route (MssConvArgs.route = 1, gemm_tn_bf16x3_kernel: both operands split and
