@@ -238,6 +238,7 @@ def launch_check(args):
 
 
 def main():
+    os.environ.setdefault("MSS_LINEAR_STRICT", "1")      # a Linear outside the MFMA kernels' shapes must not reach the library GEMM unnoticed in a benchmark
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)

@@ -228,7 +228,8 @@ int mss_wino_input_transform_upcat_f32(const float* a, int lda, int c_split, con
                                        int H, int W, int C, int tile, float* xt, void* stream);
 /* ASPP (deepv3.py:84-92: three 3x3 branches of rates d, 2d, 3d on the SAME 4096-channel map): X' for all three dilations from
  * ONE read of x. xt_m = exactly what mss_wino_input_transform_f32(x, ..., dil = (m+1)*d, tile = tiles[m], no prologue) writes.
- * tiles: host array of 3 tile edges, each 4 or 6. MSS_ERR_UNSUPPORTED when a base residue sub-grid does not fit in LDS or a
+ * tiles: a HOST pointer (the one exception to this header's "every pointer is a device pointer" rule; read before the launch, so
+ * the call may be captured into a hipGraph) to 3 tile edges, each 4 or 6. MSS_ERR_UNSUPPORTED when a base residue sub-grid does not fit in LDS or a
  * tile edge is 2 (the caller then runs the three transforms separately). */
 int mss_wino_input_transform_aspp3_f32(const float* x, int ldx, int N, int H, int W, int C, int d, const int* tiles, float* xt0,
                                        float* xt1, float* xt2, void* stream);

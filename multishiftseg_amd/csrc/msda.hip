@@ -790,6 +790,12 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_fast_kernel(
         const int i = j + t * LPH;
         d[t] = i < LP ? a[i] * (ga[i] - dot) : 0.f;
       }
+      // every lane of the group has read all of ga[] (for `dot`) before any lane overwrites its entries: the same
+      // release / wave barrier / acquire the other phases of this kernel put between LDS reads and writes (lockstep
+      // execution and LDS op order must not be what makes this correct)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const int i = j + t * LPH;

@@ -166,6 +166,12 @@ def init_from_env():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
         ndev = torch.cuda.device_count()
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        if local_world > ndev and os.environ.get("MSS_DIST_BACKEND") != "gloo":
+            # a mis-sized launch: ranks would silently share GPUs (local_rank % ndev below) and the "per-GPU" numbers mean nothing
+            import warnings
+            warnings.warn(f"multishiftseg_amd.ddp: {local_world} local ranks on {ndev} visible GPU(s): ranks share devices "
+                          f"(rank {rank} -> cuda:{local_rank % ndev}); launch with --nproc-per-node <= {ndev}", RuntimeWarning, stacklevel=2)
         torch.cuda.set_device(local_rank % ndev)
         device = torch.device("cuda", local_rank % ndev)
         backend = "nccl"

@@ -288,7 +288,8 @@ class DeepWV3Plus(nn.Module):
         pair_tile = 0 if keep else K.conv3x3_pair_tile(x, asp.features[1][0].weight, asp.features[2][0].weight, *_ASPP_RATES[:2])
         # the three dilated branches read the same 1 GB map: ONE kernel makes all three Winograd-domain inputs from a single read
         # (kernels.aspp_input_transforms); None: shapes / policy outside it, each branch transforms for itself as before
-        pre_xt = K.aspp_input_transforms(x, _ASPP_RATES, [asp.features[i][0].weight for i in (1, 2, 3)], pair_tile)
+        pre_xt = K.aspp_input_transforms(x, _ASPP_RATES, [asp.features[i][0].weight for i in (1, 2, 3)], pair_tile,
+                                         max_bytes=None if (keep and xt_bytes < (40 << 30)) else (40 << 30))
         for i, feat in enumerate(asp.features):
             rate = 1 if i == 0 else _ASPP_RATES[i - 1]
             sl = raw.slice(256 * (i + 1), 256)

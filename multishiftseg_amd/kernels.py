@@ -602,7 +602,7 @@ def conv3x3_pair(x, w1, w2, dil1, dil2, out1, out2, tile, want_stats=False, xt=N
     return out1, out2
 
 
-def aspp_input_transforms(x, rates, weights, pair_tile=0):
+def aspp_input_transforms(x, rates, weights, pair_tile=0, max_bytes=None):
     """X' of the ONE map `x` for the three dilated 3x3 branches of ASPP (deepv3.py:84-92; rates d, 2d, 3d) from a single read of x
     (mss_wino_input_transform_aspp3_f32): bit-identical to the three separate input transforms, 1 x instead of 3 x 1.07 GB read at
     2 x 128 x 256 x 4096. Returns [xt_d, xt_2d, xt_3d] -- with pair_tile (conv3x3_pair_tile) the first two are the halves of ONE
@@ -621,6 +621,10 @@ def aspp_input_transforms(x, rates, weights, pair_tile=0):
     dev = x.buf.device
     Ts = [_lib.value("mss_wino_num_tiles", N, H, W, r, t) for r, t in zip(rates, tiles)]
     Ps = [(t + 2) ** 2 for t in tiles]
+    # all three X' are live at once here (2.25-4x the map each: 10.6 GB at 2 x 1024 x 2048); a caller that does not keep them for the
+    # backward passes its budget, beyond which each branch transforms for itself again with one X' live at a time
+    if max_bytes is not None and 4.0 * sum(p * t for p, t in zip(Ps, Ts)) * C > max_bytes:
+        return None
     if pair_tile:
         assert Ts[0] == Ts[1]
         both = torch.empty((2 * Ps[0], Ts[0], C), device=dev, dtype=torch.float32)

@@ -171,12 +171,19 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
                 raise ValueError("forward_tokens needs pos_embeds or pe_layer")
             key = ("sine", tuple(tuple(int(v) for v in hw) for hw in shapes), str(src.device), pe_layer.num_pos_feats,
                    pe_layer.temperature, pe_layer.normalize, pe_layer.scale)
-            cache = self.__dict__.setdefault("_index_cache", {})
-            sine = cache.get(key)
+            # the sine tokens are MEGABYTES per shape (10 MB at 704^2, 44 MB at 1024x2048), unlike the index tensors below: their own,
+            # bounded cache (least recently used of 4 shapes is dropped), so a sweep over many image sizes does not grow device
+            # memory without bound. A captured hipGraph is unaffected: `pos` below is a fresh tensor made from them,
+            # and GraphedFeatures keeps its own references.
+            cache = self.__dict__.setdefault("_sine_cache", {})
+            sine = cache.pop(key, None)
             if sine is None:
                 with torch.no_grad():
-                    sine = cache[key] = [pe_layer(torch.empty((1, 1, int(h), int(w)), device=src.device)).flatten(2).transpose(1, 2).contiguous()
-                                         for h, w in shapes]
+                    sine = [pe_layer(torch.empty((1, 1, int(h), int(w)), device=src.device)).flatten(2).transpose(1, 2).contiguous()
+                            for h, w in shapes]
+                while len(cache) >= 4:
+                    cache.pop(next(iter(cache)))
+            cache[key] = sine                                        # (re)inserted last = most recently used
             pos = torch.cat([p + self.level_embed[lvl].view(1, 1, -1) for lvl, p in enumerate(sine)], 1)
         else:
             pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)

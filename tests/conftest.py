@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+os.environ.setdefault("MSS_LINEAR_STRICT", "1")   # tests: a float32 CUDA Linear outside the MFMA kernels' shapes raises (linear._library_route)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
