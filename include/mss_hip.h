@@ -553,6 +553,9 @@ int mss_data_pair_f32(const uint8_t* img, const uint8_t* gen, const uint8_t* tgt
  * each), out >= blocks*256 floats. mss_peak_stream_f32: float4 copy of n floats (8*n bytes moved);
  * variant 0..3 = plain / 4 loads in flight / + nontemporal / + contiguous 16-KB chunks per workgroup. */
 int mss_peak_mfma_f32(float* out, int blocks, int iters, void* stream);
+/* The same for the bf16 matrix cores under load (the split-bf16 GEMM route's ceiling): register-only loops on pseudo-random operands,
+ * blocks x 4 waves x iters x 1 572 864 FLOP; shape 0 = 48 x v_mfma_f32_32x32x16_bf16 per iteration, 1 = 96 x v_mfma_f32_16x16x32_bf16. */
+int mss_peak_mfma_bf16(float* out, int blocks, int iters, int shape, void* stream);
 int mss_peak_stream_f32(const float* src, float* dst, long long n, int variant, void* stream);
 /* layout experiment behind the Winograd-domain layout: one coalesced float4 read, ns (16|36) float4 writes
  * into ns slabs that are n floats apart (blocked = 0) or adjacent per block of blk_floats floats (blocked = 1). */

@@ -26,6 +26,84 @@ __global__ __launch_bounds__(256) void peak_mfma_kernel(float* __restrict__ out,
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// bf16 matrix rate under load (round 5, the split-bf16 GEMM route's ceiling): register-only loops on pseudo-random operands (the chip
+// lowers its clock under bf16 MFMA load on random data, MI355X_MICROARCH.md "DVFS give-back": the datasheet 2.5 PFLOP/s is not what a
+// loop can deliver). SHAPE 0: v_mfma_f32_32x32x16_bf16 on the 64 x 128 wave tile of gemm_nt_bf16x3_kernel (2 x 4 blocks, 6 products each
+// = 48 MFMAs per K-step); SHAPE 1: v_mfma_f32_16x16x32_bf16 on the same tile (4 x 8 blocks, 3 K=32 products each = 96 MFMAs).
+typedef __bf16 pk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float pk_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pk_bf16x8 peak_rand_frag(unsigned& st) {
+  unsigned w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    st = st * 1664525u + 1013904223u;
+    // two bf16 in [-2, 2) with random mantissas: sign | exponent 0x3f / 0x3e.. | 7 random bits
+    const unsigned lo = ((st >> 3) & 0x807fu) | 0x3f00u, hi = ((st >> 11) & 0x807fu) | 0x3e80u;
+    w[i] = lo | (hi << 16);
+  }
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(pk_bf16x8, u4{w[0], w[1], w[2], w[3]});
+}
+template <int SHAPE>
+__global__ __launch_bounds__(256, 2) void peak_mfma_bf16_kernel(float* __restrict__ out, int iters, unsigned seed) {
+  unsigned st = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+  float s = 0.f;
+  if (SHAPE == 0) {
+    pk_bf16x8 a[3][2], b[3][4];
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      for (int i = 0; i < 2; ++i) a[p][i] = peak_rand_frag(st);
+      for (int j = 0; j < 4; ++j) b[p][j] = peak_rand_frag(st);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int PA[6] = {2, 1, 0, 0, 1, 0}, PB[6] = {0, 0, 0, 1, 1, 2};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  } else {
+    pk_bf16x8 a[2][4], b[3][8];
+    pk_f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[0][i] = peak_rand_frag(st); a[1][i] = peak_rand_frag(st); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { b[0][j] = peak_rand_frag(st); b[1][j] = peak_rand_frag(st); b[2][j] = peak_rand_frag(st); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = pk_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t == 2 ? 1 : 0][i], b[t][j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  }
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // variant 0: one 16-B load and store per thread and iteration (round 1: 4.8 TB/s)
 // variant 1: four independent loads in flight per thread before the four stores
 // variant 2: as 1 with nontemporal loads and stores (streaming data is read and written once)
@@ -105,6 +183,15 @@ int mss_peak_scatter_f32(const float* src, float* dst, long long n, int ns, int 
 int mss_peak_mfma_f32(float* out, int blocks, int iters, void* stream) {
   if (!out || blocks <= 0 || iters <= 0) return MSS_ERR_BAD_ARG;
   hipLaunchKernelGGL(peak_mfma_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), out, iters, 1.0f);
+  return mss_launch_status();
+}
+
+// out: at least blocks*256 floats. bf16 FLOPs performed = blocks * 4 waves * iters * 48 * 32768 (shape 0: 32x32x16) or
+// blocks * 4 * iters * 96 * 16384 (shape 1: 16x16x32) -- the same per iteration.
+int mss_peak_mfma_bf16(float* out, int blocks, int iters, int shape, void* stream) {
+  if (!out || blocks <= 0 || iters <= 0 || shape < 0 || shape > 1) return MSS_ERR_BAD_ARG;
+  if (shape == 0) hipLaunchKernelGGL(peak_mfma_bf16_kernel<0>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), out, iters, 12345u);
+  else hipLaunchKernelGGL(peak_mfma_bf16_kernel<1>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), out, iters, 12345u);
   return mss_launch_status();
 }
 

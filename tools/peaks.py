@@ -19,6 +19,17 @@ def measure():
         e.record()
         torch.cuda.synchronize()
         res[f"mfma_f32_tflops_{waves_per_simd}w"] = blocks * 4 * iters * 16 * 4096 / (s.elapsed_time(e) * 1e-3) / 1e12
+    # bf16 matrix cores under load, random operands, two waves per SIMD: the delivered ceiling of the split-bf16 GEMM route
+    for shape, name in ((0, "32x32x16"), (1, "16x16x32")):
+        blocks, iters = 512, 4000
+        call("mss_peak_mfma_bf16", ptr(out), blocks, 200, shape)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        call("mss_peak_mfma_bf16", ptr(out), blocks, iters, shape)
+        e.record()
+        torch.cuda.synchronize()
+        res[f"mfma_bf16_{name}_tflops_2w"] = blocks * 4 * iters * 1572864.0 / (s.elapsed_time(e) * 1e-3) / 1e12
     n = 1 << 28   # 1 GiB source, 1 GiB destination: far beyond the 256 MiB Infinity Cache
     a = torch.empty(n, device="cuda").normal_()
     b = torch.empty(n, device="cuda")
