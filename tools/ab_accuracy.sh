@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 for mode in fast balanced strict; do
   export MSS_WINO_ACCURACY=$mode
   python tools/attribute_wino_error.py --totals-only --tag _$mode > gpurun_out/attr_$mode.log 2>&1
-  python bench.py --steps 5 --no-cpu-baseline --no-ood --no-experimental > gpurun_out/bench_$mode.json 2>/dev/null
+  python bench.py --steps 5 --no-cpu-baseline --no-ood --no-split > gpurun_out/bench_$mode.json 2>/dev/null
   python - <<PY
 import json
 d=json.load(open("gpurun_out/bench_$mode.json")); a=json.load(open("gpurun_out/wino_attribution_$mode.json"))
@@ -12,7 +12,7 @@ PY
 done
 export MSS_WINO_ACCURACY=balanced MSS_WINO_F4_MIN_CHANNELS=64
 python tools/attribute_wino_error.py --totals-only --tag _balanced_f4c64 > gpurun_out/attr_b64.log 2>&1
-python bench.py --steps 5 --no-cpu-baseline --no-ood --no-experimental > gpurun_out/bench_balanced_f4c64.json 2>/dev/null
+python bench.py --steps 5 --no-cpu-baseline --no-ood --no-split > gpurun_out/bench_balanced_f4c64.json 2>/dev/null
 python - <<PY
 import json
 d=json.load(open("gpurun_out/bench_balanced_f4c64.json")); a=json.load(open("gpurun_out/wino_attribution_balanced_f4c64.json"))

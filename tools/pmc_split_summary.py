@@ -6,6 +6,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 out = sys.argv[1]
+KERNEL = "gemm_tn_bf16x3_kernel" if os.environ.get("PMC_SPLIT_TN") == "1" else "gemm_nt_bf16x3_kernel"
 PER_CASE = 8          # launches of the kernel per product: 3 warm-up + 5 timed (tools/pmc_split.py default)
 
 
@@ -21,7 +22,7 @@ for f in sorted(glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv
     per_dispatch = defaultdict(dict)
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            if "gemm_nt_bf16x3_kernel" not in r.get("Kernel_Name", ""):
+            if KERNEL not in r.get("Kernel_Name", ""):
                 continue
             d = int(r["Dispatch_Id"])
             per_dispatch[d][r["Counter_Name"]] = float(r["Counter_Value"])
@@ -34,7 +35,7 @@ for f in sorted(glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv
         for c, v in per_dispatch[d].items():
             if c != "_meta":
                 cases[ci][c].append(v)
-print("# gemm_nt_bf16x3_kernel -- SQ counters, rocprofv3 --pmc, three separate passes (tools/pmc_split.sh); means per launch, in millions\n")
+print(f"# {KERNEL} -- SQ counters, rocprofv3 --pmc, three separate passes (tools/pmc_split.sh); means per launch, in millions\n")
 print("un-profiled timings of the same products, split route:", json.dumps(bench), "\n")
 print("native fp32 MFMA route:", json.dumps(native), "\n")
 summary = []

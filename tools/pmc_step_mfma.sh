@@ -7,7 +7,7 @@ OUT="$GRAFT_REPO_ROOT/gpurun_out/$1"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$GRAFT_REPO_ROOT/bench.py"
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-ood --no-experimental --no-m2f --no-parity"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-ood --no-split --no-m2f --no-parity"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq" -- python3 "$B" $ARGS > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$B" $ARGS > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$B" $ARGS > /dev/null 2>&1

@@ -3,7 +3,7 @@
 set -u
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --memory-copy-trace --output-format csv -d $R/gpurun_out/copies -- python3 $R/bench.py --no-m2f --no-parity --no-cpu-baseline --no-ood --no-experimental --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --memory-copy-trace --output-format csv -d $R/gpurun_out/copies -- python3 $R/bench.py --no-m2f --no-parity --no-cpu-baseline --no-ood --no-split --steps 3 --warmup 1 > /dev/null 2>&1
 cd $R
 python - <<'PY'
 import csv, glob, collections

@@ -8,10 +8,10 @@ OUT="$GRAFT_REPO_ROOT/gpurun_out/$1"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$GRAFT_REPO_ROOT/bench.py"
-BARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-ood --no-experimental --no-m2f --no-parity"
+BARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-ood --no-split --no-m2f --no-parity"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$B" $BARGS > "$OUT/bench_under_rocprof.json" 2> /dev/null
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$B" --steps 2 --warmup 1 --no-cpu-baseline --no-ood --no-experimental --no-m2f --no-parity > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$B" --steps 2 --warmup 1 --no-cpu-baseline --no-ood --no-experimental --no-m2f --no-parity > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$B" --steps 2 --warmup 1 --no-cpu-baseline --no-ood --no-split --no-m2f --no-parity > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$B" --steps 2 --warmup 1 --no-cpu-baseline --no-ood --no-split --no-m2f --no-parity > /dev/null 2>&1
 export MSS_BENCH_SKIP_WINO=1
 M="$GRAFT_REPO_ROOT/tools/microbench_hbm.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/hbm_stats" -- python3 "$M" > /dev/null 2>&1

@@ -4,7 +4,7 @@
 set -u
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_copies -- python3 $R/bench.py --no-m2f --no-parity --no-cpu-baseline --no-ood --no-experimental --steps 1 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_copies -- python3 $R/bench.py --no-m2f --no-parity --no-cpu-baseline --no-ood --no-split --steps 1 --warmup 1 > /dev/null 2>&1
 cd $R
 python3 - <<'PY'
 import csv, glob
