@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
 // Tile 128 (k) x 256 (c) per workgroup, wave 0 stages the 64 dy tasks, waves 1-2 the 128 x tasks (176 VALU each per K-step beside
 // their 48 MFMAs), persistent over (position, split, k tile, c tile); every split walks `tps` rows (a multiple of 16); the last one is
 // shifted back to end at row M and the rows it shares with its predecessor enter as zeros.
-template <bool AFFINE>
+template <bool AFFINE, bool MASKED>
 __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                                 float* __restrict__ out, int P, int M, long long a_bs, long long b_bs, int Kpad,
                                                                 int Cp, int ktiles, int ctiles, int splits, int tps, long long total_tiles,
@@ -317,9 +317,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
   // waves 0 AND 3 stage the 64 dy tasks (the same bytes to the same LDS addresses: wave 3 would otherwise idle, and a role that
   // skips the staging puts a branch into the K-step, which must stay ONE basic block for the interleaving below), waves 1-2 the x tasks
   const bool is_a = wave == 0 || wave == 3;
-  const int task = is_a ? lane : (wave - 1) * 64 + lane;          // A: 32 column quads x 2 row groups; B: 64 x 2
-  const int cq = is_a ? (task & 31) : (task & 63), rg = is_a ? (task >> 5) : (task >> 6);
-  const int n_it = tps / BK;
+  // lane pairs own the two 8-row groups of ONE column quad: the two 16-byte halves of an LDS row come from adjacent lanes, so a
+  // wave's staging write is 1 KB of consecutive LDS bytes (with lane = quad + 32 * row group the 16-byte writes sat 32 bytes apart:
+  // 113 M bank-conflict cycles per launch, profiles/r05/pmc_split_tn.md first version)
+  const int cq = (is_a ? 0 : (wave - 1) * 32) + (lane >> 1), rg = lane & 1;   // A: 32 column quads x 2 row groups; B: 64 x 2
+  // MASKED (M not a multiple of 16): every split walks tps / 16 K-steps, the last one shifted back to end at row M, and the dy rows it
+  // shares with its predecessor enter as zeros (2 VALU per element on every lane). Otherwise (the usual case) the last split simply
+  // has fewer K-steps and nothing is masked.
+  const int nit_full = tps / BK, nit_last = MASKED ? nit_full : (M - (splits - 1) * tps) / BK;
   const long long stride = gridDim.x;
   const float relu_floor = relu ? 0.f : -__builtin_huge_valf();
   const int ld = is_a ? lda : ldb;                                 // wave-uniform
@@ -331,6 +336,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
 
   unsigned off = 0, nxt = 0, s_off = 0, s_nxt = 0;
   int vf = 0, vf_nxt = 0, row_ld = 0, row_nxt = 0;                 // first valid row of the loader's tile; first row of its current step
+  int ld_nit = nit_full, nit_nxt = nit_full;                       // K-steps of the loader's tile / of the one after it
   long long ld_tile = mss_xcd_remap(blockIdx.x, gridDim.x);
   int ld_k = 0;
   auto decode = [&](long long t, int& pb, int& sp, int& kt, int& ct) {
@@ -338,17 +344,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
     kt = (int)(t % ktiles); t /= ktiles;
     sp = (int)(t % splits); pb = (int)(t / splits);
   };
-  auto setup_off = [&](long long t, unsigned& o, unsigned& so, int& valid_from, int& row0) {
+  auto setup_off = [&](long long t, unsigned& o, unsigned& so, int& valid_from, int& row0, int& nit) {
     int pb, sp, kt, ct; decode(t, pb, sp, kt, ct);
     valid_from = sp * tps;
-    row0 = valid_from + tps <= M ? valid_from : M - tps;          // the last split is shifted back to end at row M
+    nit = sp == splits - 1 ? nit_last : nit_full;
+    row0 = (!MASKED || valid_from + tps <= M) ? valid_from : M - tps;   // MASKED: the last split is shifted back to end at row M
     const size_t col = is_a ? (size_t)kt * 128 + 4 * cq : (size_t)ct * BN + 4 * cq;
     o = (unsigned)((((size_t)pb * (is_a ? a_bs : b_bs)) + (size_t)(row0 + rg * 8) * ld + col) * sizeof(float));
     if (AFFINE) so = is_a ? 0u : (unsigned)((ct * BN + 4 * cq) * sizeof(float));     // (dy lanes load a valid vector and ignore it)
   };
   auto setup_next = [&]() {
     const long long t = ld_tile + stride;
-    setup_off(t < total_tiles ? t : ld_tile, nxt, s_nxt, vf_nxt, row_nxt);
+    setup_off(t < total_tiles ? t : ld_tile, nxt, s_nxt, vf_nxt, row_nxt, nit_nxt);
   };
   f32x4 raw[8], sreg, hreg;
   int raw_mask = 0;                                                // mask_rows of the K-step held in `raw`
@@ -359,11 +366,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
       sreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(scale) + s_off);
       hreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(shift) + s_off);
     }
-    const int m = vf - row_ld;                                     // rows [row_ld, vf) belong to the previous split (dy rows enter as zeros)
-    raw_mask = is_a && m > 0 ? m : 0;
+    if (MASKED) {
+      const int m = vf - row_ld;                                   // rows [row_ld, vf) belong to the previous split (dy rows enter as zeros)
+      raw_mask = is_a && m > 0 ? m : 0;
+    }
   };
   auto advance = [&]() {
-    const bool wrap = ++ld_k == n_it;
+    const bool wrap = ++ld_k == ld_nit;
+    ld_nit = wrap ? nit_nxt : ld_nit;
     off = wrap ? nxt : off + BK * ld_bytes;
     row_ld = wrap ? row_nxt : row_ld + BK;
     vf = wrap ? vf_nxt : vf;
@@ -384,8 +394,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
         v0 = fmaxf(v0 * sc + sh, fl);
         v1 = fmaxf(v1 * sc + sh, fl);
       }
-      v0 = rg * 8 + 2 * t2 < st_mask ? 0.f : v0;                  // (st_mask is 0 on the x lanes)
-      v1 = rg * 8 + 2 * t2 + 1 < st_mask ? 0.f : v1;
+      if (MASKED) {
+        v0 = rg * 8 + 2 * t2 < st_mask ? 0.f : v0;                // (st_mask is 0 on the x lanes)
+        v1 = rg * 8 + 2 * t2 + 1 < st_mask ? 0.f : v1;
+      }
       split_pair(v0, v1, hi[t2], mid[t2], lo[t2]);
     }
     *reinterpret_cast<u32x4*>(base + 0 * PLANE + i * 32 * ROW_B) = u32x4{hi[0], hi[1], hi[2], hi[3]};
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                          \
     __builtin_amdgcn_sched_group_barrier((mask), (per), 0);                                                                   \
   }
-    constexpr int PER = AFFINE ? 10 : 8;
+    constexpr int PER = (AFFINE ? 8 : 6) + (MASKED ? 2 : 0);
     ld_a(2, a_lo); ld_b(0, b_hi);
     ld_a(1, a_mid); ld_a(0, a_hi);
     __builtin_amdgcn_sched_barrier(0);
@@ -480,7 +492,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
   };
 
   long long cur = ld_tile;
-  setup_off(ld_tile, off, s_off, vf, row_ld);
+  setup_off(ld_tile, off, s_off, vf, row_ld, ld_nit);
   setup_next();
   issue_loads();
   st_mask = raw_mask;
@@ -490,14 +502,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
   advance();
   zero_acc();
   __syncthreads();
-  int k = 0;
+  int k = 0, cur_nit = ld_nit;
   auto tile_end = [&]() -> bool {
-    if (++k < n_it) return false;
+    if (++k < cur_nit) return false;
     epilogue(cur);
     cur += stride;
     if (cur >= total_tiles) return true;
     zero_acc();
     k = 0;
+    cur_nit = (int)((cur / ((long long)ktiles * ctiles)) % splits) == splits - 1 ? nit_last : nit_full;
     ld_tile = cur;
     setup_next();
     return false;
@@ -642,6 +655,12 @@ TnSplitPlan tn_split_plan(const MssConvArgs& p) {
   pl.tps = mss_cdiv(mss_cdiv(p.M, splits), 16) * 16;
   if (pl.tps > p.M) pl.tps = (p.M / 16) * 16;
   pl.splits = mss_cdiv(p.M, pl.tps);
+  // unmasked kernel (M % 16 == 0): the last split is shorter; it needs its three K-steps too (the loader runs two ahead)
+  if (p.M % 16 == 0 && pl.splits > 1 && p.M - (pl.splits - 1) * pl.tps < 48) {
+    pl.splits -= 1;
+    pl.tps = mss_cdiv(mss_cdiv(p.M, pl.splits), 16) * 16;
+    pl.splits = mss_cdiv(p.M, pl.tps);
+  }
   pl.total = base * pl.splits;
   return pl;
 }
@@ -676,20 +695,27 @@ int mss_wgrad_tn_bf16x3_launch(const MssConvArgs& p, const float* dy, int lddy, 
   const size_t smem = (size_t)2 * 3 * OPER;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
+    const void* ks[4] = {reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<false, false>), reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<false, true>),
+                         reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<true, false>), reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<true, true>)};
+    for (const void* kf : ks) {
+      hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+    }
     attr = true;
   }
   const long long slots = 512;
   const int grid = (int)(pl.total < slots ? pl.total : slots);
   const long long a_bs = p.batch > 1 ? p.y_bs : 0, b_bs = p.batch > 1 ? p.x_bs : 0;
-  if (p.in_scale)
-    hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<true>, dim3(grid), dim3(NT), smem, s, dy, lddy, p.x, p.C, out, P, p.M, a_bs, b_bs, p.Kpad, Cp, pl.ktiles,
-                       pl.ctiles, pl.splits, pl.tps, pl.total, p.in_scale, p.in_shift, p.in_relu);
-  else
-    hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<false>, dim3(grid), dim3(NT), smem, s, dy, lddy, p.x, p.C, out, P, p.M, a_bs, b_bs, p.Kpad, Cp, pl.ktiles,
-                       pl.ctiles, pl.splits, pl.tps, pl.total, (const float*)nullptr, (const float*)nullptr, 0);
+  const bool masked = p.M % 16 != 0 || (pl.splits > 1 && p.M - (pl.splits - 1) * pl.tps < 48);
+#define TN_LAUNCH(AFF, MSK, SC, SH, RL)                                                                                                      \
+  hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<AFF, MSK>), dim3(grid), dim3(NT), smem, s, dy, lddy, p.x, p.C, out, P, p.M, a_bs, b_bs, p.Kpad, Cp, \
+                     pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, SC, SH, RL)
+  if (p.in_scale) {
+    if (masked) TN_LAUNCH(true, true, p.in_scale, p.in_shift, p.in_relu); else TN_LAUNCH(true, false, p.in_scale, p.in_shift, p.in_relu);
+  } else {
+    if (masked) TN_LAUNCH(false, true, (const float*)nullptr, (const float*)nullptr, 0); else TN_LAUNCH(false, false, (const float*)nullptr, (const float*)nullptr, 0);
+  }
+#undef TN_LAUNCH
   if (pl.splits > 1) mss_wgrad_reduce_launch(ws, dwp, slab / 4, pl.splits, s);
   return mss_launch_status();
 }
