@@ -174,7 +174,7 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream);
 int mss_conv2d_kpad(int K);
 /* 1 if mss_conv2d_forward_f32 runs these arguments on the persistent GEMM kernel (csrc/gemm.hip: 1x1, stride 1,
  * more than 64 output channels, or 33..64 of them over >= 16 384 rows), 2 for the few-rows kernel (1x1 over <= 8 pixels, nothing fused), 3 for the
- * split-bf16 form of the persistent GEMM kernel (args->w_split set and the shape eligible), 0 for the implicit-GEMM kernel. Profiling label only. */
+ * split-bf16 form of the persistent GEMM kernel (args->w_split set and the shape eligible), 4 for its implicit-GEMM form, 0 for the native implicit-GEMM kernel. Profiling label only. */
 int mss_conv2d_forward_route(const MssConvArgs* args);
 /* The split-bf16 form of packed weights for MssConvArgs.w_split: w [batch][Kpad][C] fp32 (batch stride w_bs floats; what
  * mss_conv2d_pack_weights_f32 with R = S = 1 or mss_wino_pack_weights_f32 produce, Kpad % 128 == 0, C % 16 == 0) -> `planes`,
@@ -185,6 +185,10 @@ int mss_conv2d_forward_route(const MssConvArgs* args);
  * (deepv3.py:47-92,258-285, wider_resnet.py:169-182), at fp32 accuracy. mss_conv2d_forward_route answers 3 when a call runs it. */
 long long mss_gemm_split_weights_bytes(int batch, int Kpad, int C);
 int mss_gemm_split_weights_bf16x3(const float* w, void* planes, int batch, int Kpad, int C, long long w_bs, void* stream);
+/* The same for an implicit-GEMM layer (3x3 with stride 2 or few input channels, 1x1 with stride 2: what conv_igemm_kernel takes, with
+ * > 64 output channels and one prologue affine): w [taps][Kpad][C] from mss_conv2d_pack_weights_f32 (taps = R*S <= 9) -> planes of
+ * mss_gemm_split_weights_bytes(taps, Kpad, C) bytes with the taps folded into ONE reduction of taps*C; mss_conv2d_forward_route answers 4. */
+int mss_conv_split_weights_bf16x3(const float* w, void* planes, int taps, int Kpad, int C, void* stream);
 /* w [K][C][R][S] (nn.Conv2d.weight) -> packed [R*S][Kpad][Cp] (zero padded).
  * flip=1 packs the data-gradient filter instead (K<->C swapped, taps rotated 180 degrees);
  * then Kpad/Cp refer to the swapped roles. */

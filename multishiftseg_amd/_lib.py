@@ -83,6 +83,7 @@ SIGNATURES = {
     "mss_conv2d_forward_route": [POINTER(MssConvArgs)],
     "mss_gemm_split_weights_bytes": [I, I, I],
     "mss_gemm_split_weights_bf16x3": [P, P, I, I, I, L, P],
+    "mss_conv_split_weights_bf16x3": [P, P, I, I, I, P],
     "mss_conv2d_pack_weights_f32": [P, P, I, I, I, I, I, I, I, P],
     "mss_conv2d_wgrad_workspace_bytes": [POINTER(MssConvArgs), I],
     "mss_conv2d_wgrad_f32": [POINTER(MssConvArgs), P, I, P, I, P, L, P],

@@ -25,6 +25,8 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream);   // gemm.hip: persistent
 bool mss_gemm_nt_eligible(const MssConvArgs& p);
 bool mss_gemm_few_rows(const MssConvArgs& p);
 bool mss_gemm_nt_bf16x3_eligible(const MssConvArgs& p);   // gemm_bf16x3.hip
+bool mss_conv_bf16x3_eligible(const MssConvArgs& p);
+int mss_conv_bf16x3_launch(MssConvArgs p, void* stream);
 bool mss_wgrad_tn_bf16x3_eligible(const MssConvArgs& p, int lddy);
 long long mss_wgrad_tn_bf16x3_ws_bytes(const MssConvArgs& p, int Cp);
 int mss_wgrad_tn_bf16x3_launch(const MssConvArgs& p, const float* dy, int lddy, float* dwp, int Cp, float* ws, long long ws_bytes, void* stream);
@@ -1574,6 +1576,7 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
     const int rc = mss_gemm_nt_dispatch(p, stream);
     if (rc >= 0) return rc;
   }
+  if (mss_conv_bf16x3_eligible(p)) return mss_conv_bf16x3_launch(p, stream);     // the split-bf16 route (args->w_split): gemm_bf16x3.hip, CONV
   // K-step: 16 (41 KB LDS, 144 registers -> 3 workgroups/CU, 3 waves/SIMD) is the faster choice except
   // for the ASPP shape (4096 input channels, 256 output channels), where the 32-deep step wins
   // (measured: 128 vs 119 TFLOP/s); MSS_CONV_BK=16|32 overrides for experiments.
@@ -1591,7 +1594,7 @@ int mss_conv2d_forward_route(const MssConvArgs* args) {
   p.M = p.N * p.OH * p.OW;
   if (!MSS_ENV_INT("MSS_GEMM", 1)) return 0;
   if (mss_gemm_few_rows(p)) return 2;                  // (0 implicit-GEMM kernel, 1 gemm_nt_kernel, 2 gemm_few_rows_kernel)
-  if (!mss_gemm_nt_eligible(p)) return 0;
+  if (!mss_gemm_nt_eligible(p)) return mss_conv_bf16x3_eligible(p) ? 4 : 0;
   p.mtiles = (p.M + 127) / 128;
   return mss_gemm_nt_bf16x3_eligible(p) ? 3 : 1;
 }

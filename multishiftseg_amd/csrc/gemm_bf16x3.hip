@@ -49,7 +49,13 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
   lo = cvt_pk_bf16(qa, qb);
 }
 
-template <bool AFFINE, int BN, bool SCHED>
+// CONV (round 5): the same kernel as an IMPLICIT GEMM for the layers conv_igemm_kernel takes (3x3 with stride 2 or few input channels, 1x1
+// with stride 2): the reduction runs over (tap, channel) -- the weights' planes are packed with the taps folded into one long reduction
+// (mss_gemm_split_weights_bf16x3 on [taps][Kpad][C] with taps > 1: B needs no tap logic at all) -- and only the A side changes: a staged
+// row is an output pixel, its address per tap = pixel base + a uniform tap offset, taps that fall into the zero padding read a valid
+// dummy address and enter as zeros AFTER the BatchNorm + ReLU prologue (the reference pads the activated tensor). Branch-free like
+// the rest of the K-step: the tap state advances with selects.
+template <bool AFFINE, int BN, bool SCHED, bool CONV = false>
 __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf16x3_kernel(MssConvArgs p, const unsigned char* __restrict__ wpl,
                                                                                long long total_tiles, int tiles_per_batch,
                                                                                int group_m, unsigned blk_bytes, int nblk_total) {
@@ -59,7 +65,8 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int chunk = tid & 3, row0 = tid >> 2;           // A staging: floats [4 chunk, 4 chunk + 4) of rows row0 and row0 + 64
-  const int n_it = p.C / BK;
+  const int nk = p.C / BK;                               // K-steps per tap
+  const int n_it = CONV ? nk * p.R * p.S : nk;
   const long long stride = gridDim.x;
   const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
 
@@ -67,6 +74,15 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   unsigned a_off[2], a_nxt[2], b_off[NBLK], b_nxt[NBLK], s_off = 0, s_nxt = 0;
   long long ld_tile = mss_xcd_remap(blockIdx.x, gridDim.x);
   int ld_k = 0;
+  // CONV: per staged row the byte offset of its (possibly virtual) top-left input pixel and the 9-bit map of in-image taps, for the
+  // loader's tile and for the one after it; the loader's tap, its K-step inside the tap, the in-image bits of the K-step in flight
+  int pix[2] = {0, 0}, pix_nxt[2] = {0, 0}, okb[2] = {0, 0}, okb_nxt[2] = {0, 0};
+  int ld_tap = 0, ld_c = 0;
+  unsigned raw_ok = 3u, cur_ok = 3u;
+  auto tap_offset = [&](int tap) {                        // uniform: ((tap / S) * dil * W + (tap % S) * dil) pixels, in bytes
+    const int r = p.S == 1 ? tap : (tap * 43) >> 7, sx = tap - r * p.S;
+    return (r * p.dil * p.W + sx * p.dil) * p.ldx * (int)sizeof(float);
+  };
   auto setup_off = [&](long long t, unsigned* ao, unsigned* bo, unsigned& so) {
     const int b = (int)(t / tiles_per_batch);
     const int v = (int)(t - (long long)b * tiles_per_batch);
@@ -74,13 +90,31 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int row = mt * BM + row0 + j * 64;
+      if (CONV) {
+        int* px = ao == a_off ? pix : pix_nxt;
+        int* ok = ao == a_off ? okb : okb_nxt;
+        const int ohw = p.OH * p.OW;
+        const bool in = row < p.M;
+        row = in ? row : 0;
+        const int n = row / ohw, rem = row - n * ohw, oy = rem / p.OW, ox = rem - oy * p.OW;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        px[j] = (((n * p.H + iy0) * p.W + ix0) * p.ldx + chunk * 4) * (int)sizeof(float);
+        int bits = 0;
+        for (int t = 0; t < p.R * p.S; ++t) {
+          const int r = t / p.S, iy = iy0 + r * p.dil, ix = ix0 + (t - r * p.S) * p.dil;
+          bits |= ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? 1 << t : 0;
+        }
+        ok[j] = in ? bits : 0;                            // rows past the end: every tap "outside" (zeros, never stored)
+        ao[j] = (ok[j] & 1) ? (unsigned)px[j] : (unsigned)(chunk * 4 * sizeof(float));     // tap 0
+        continue;
+      }
       row = row < p.M ? row : p.M - 1;                  // rows past the end re-read the last row; never stored
       ao[j] = (unsigned)(((size_t)b * p.x_bs + (size_t)row * p.ldx + chunk * 4) * sizeof(float));
     }
 #pragma unroll
     for (int j = 0; j < NBLK; ++j)
       bo[j] = (unsigned)(b * nblk_total + nt * NBLK + j) * blk_bytes + tid * 16;
-    if (AFFINE) so = (unsigned)(((size_t)((mt * BM) / p.H) * p.in_ss_stride + chunk * 4) * sizeof(float));
+    if (AFFINE) so = CONV ? (unsigned)(chunk * 4 * sizeof(float)) : (unsigned)(((size_t)((mt * BM) / p.H) * p.in_ss_stride + chunk * 4) * sizeof(float));
   };
   auto setup_next = [&]() {
     const long long t = ld_tile + stride;
@@ -101,6 +135,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
       sreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in_scale) + s_off);
       hreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in_shift) + s_off);
     }
+    if (CONV) raw_ok = cur_ok;
   };
   auto issue_loads_b = [&]() {
 #pragma unroll
@@ -111,6 +146,28 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   auto issue_loads = [&]() { issue_loads_a(); issue_loads_b(); };
   auto advance = [&]() {                 // branch-free: next K-step of this tile, else first K-step of this workgroup's next tile
     const bool wrap = ++ld_k == n_it;
+    if (CONV) {
+      const bool tap_end = ++ld_c == nk;
+      ld_c = tap_end ? 0 : ld_c;
+      ld_tap = wrap ? 0 : (tap_end ? ld_tap + 1 : ld_tap);
+      const int toff = tap_offset(ld_tap);
+      unsigned ok2 = 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        pix[j] = wrap ? pix_nxt[j] : pix[j];
+        okb[j] = wrap ? okb_nxt[j] : okb[j];
+        const bool in = (okb[j] >> ld_tap) & 1;
+        ok2 |= in ? 1u << j : 0u;
+        const unsigned fresh = in ? (unsigned)(pix[j] + toff) : (unsigned)(chunk * 4 * sizeof(float));
+        a_off[j] = tap_end ? fresh : a_off[j] + BK * (unsigned)sizeof(float);
+      }
+      cur_ok = ok2;
+      if (AFFINE) s_off = tap_end ? (unsigned)(chunk * 4 * sizeof(float)) : s_off + BK * (unsigned)sizeof(float);
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) b_off[j] = wrap ? b_nxt[j] : b_off[j] + (unsigned)OPER;
+      ld_k = wrap ? 0 : ld_k;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) a_off[j] = wrap ? a_nxt[j] : a_off[j] + BK * (unsigned)sizeof(float);
 #pragma unroll
@@ -120,11 +177,16 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   };
   // A: 4 bf16 (8 B) per plane at row r, quarter `chunk` of the 32-byte row, halves swapped when bit 3 of r is set
   const int st_off = row0 * ROW_B + (((chunk >> 1) ^ ((row0 >> 3) & 1)) * 16) + (chunk & 1) * 8;
+  unsigned st_ok = 3u;                   // (CONV) in-image bits of the K-step being split
   auto split_row = [&](int j, unsigned (&hi)[2], unsigned (&mid)[2], unsigned (&lo)[2]) {
     f32x4 v = areg[j];
     if (AFFINE) {
       v = v * sreg + hreg;
       v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+    }
+    if (CONV) {                                          // a tap in the zero padding: zeros after the prologue
+      const bool in = (st_ok >> j) & 1;
+      v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
     }
     split_pair(v.x, v.y, hi[0], mid[0], lo[0]);
     split_pair(v.z, v.w, hi[1], mid[1], lo[1]);
@@ -198,6 +260,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
     if (!SCHED) {
       ld_a(2, a_lo); ld_b(0, b_hi);
       ld_a(1, a_mid); ld_a(0, a_hi);
+      st_ok = raw_ok;
       finish_store(buf ^ 1);               // K-step k+1, requested during step k-1
       issue_loads();                       // K-step k+2 (possibly of the next tile) into the registers just drained
       advance();
@@ -239,6 +302,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
       MSS_PAIR_UP(0x100, G - NB > 0 ? (G - NB < TN ? G - NB : TN) : 0, 1);
       fence();
       unsigned hi[2], mid[2], lo[2];
+      st_ok = raw_ok;
       split_row(0, hi, mid, lo);
       store_row(buf ^ 1, 0, hi, mid, lo);
       mm(a_hi, b_hi);
@@ -263,8 +327,10 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
 
   long long cur = ld_tile;               // tile being multiplied (the launch guarantees cur < total_tiles)
   setup_off(ld_tile, a_off, b_off, s_off);
+  if (CONV) cur_ok = (unsigned)((okb[0] & 1) | ((okb[1] & 1) << 1));
   setup_next();
   issue_loads();
+  st_ok = raw_ok;
   finish_store(0);
   advance();
   issue_loads();                         // registers now hold K-step 1
@@ -525,16 +591,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
 
 // fp32 weights [batch][Kpad][C] -> three bf16 planes in the LDS image order the kernel copies:
 // byte ((b * Kpad/128 + n / 128) * C/16 + s) * 12288 + plane * 4096 + (n % 128) * 32 + ((h ^ ((n >> 3) & 1)) * 16) holds k = 16 s + 8 h .. + 7
+// taps > 1 (implicit-GEMM layers: w is [taps][Kpad][C]): ONE plane set whose reduction index is tap * C + c (K-step s = tap * C/16 + ...)
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Kpad,
-                                                            int C, long long w_bs, long long total) {
-  const int nk = C / 16;
+                                                            int C, long long w_bs, long long total, int taps) {
+  const int nk = C / 16 * taps;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int h = (int)(i & 1);
     long long r = i >> 1;
     const int s = (int)(r % nk); r /= nk;
     const int n = (int)(r % Kpad);
     const long long b = r / Kpad;
-    const float* src = w + b * w_bs + (size_t)n * C + s * 16 + h * 8;
+    const int tap = s / (C / 16), sc = s - tap * (C / 16);
+    const float* src = w + b * w_bs + (size_t)tap * Kpad * C + (size_t)n * C + sc * 16 + h * 8;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
     unsigned hi[4], mid[4], lo[4];
     split_pair(v0.x, v0.y, hi[0], mid[0], lo[0]);
@@ -548,7 +616,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   }
 }
 
-template <bool AFFINE, int BN, bool SCHED>
+template <bool AFFINE, int BN, bool SCHED, bool CONV = false>
 int launch_split(const MssConvArgs& p, hipStream_t stream) {
   const int batch = p.batch > 1 ? p.batch : 1;
   const int tiles_per_batch = p.mtiles * p.ntiles;
@@ -561,11 +629,11 @@ int launch_split(const MssConvArgs& p, hipStream_t stream) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (smem > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED>, NT, smem) != hipSuccess || n < 1) n = BN == 256 ? 2 : 3;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV>, NT, smem) != hipSuccess || n < 1) n = BN == 256 ? 2 : 3;
     const int cap = MSS_ENV_INT("MSS_GEMM_WG_PER_CU", 0);
     if (cap > 0 && cap < n) n = cap;
     per_cu_max = n;
@@ -581,8 +649,8 @@ int launch_split(const MssConvArgs& p, hipStream_t stream) {
     if (eff > best + 0.02) { best = eff; grid = (int)g; }
   }
   const int group_m = MSS_ENV_INT("MSS_GEMM_GROUP_M", GEMM_GROUP_M_DEFAULT);
-  const unsigned blk_bytes = (unsigned)(p.C / BK) * OPER;
-  hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED>), dim3(grid), dim3(NT), smem, stream, p,
+  const unsigned blk_bytes = (unsigned)(p.C / BK) * (CONV ? p.R * p.S : 1) * OPER;     // CONV: the taps are part of one long reduction
+  hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV>), dim3(grid), dim3(NT), smem, stream, p,
                      static_cast<const unsigned char*>(p.w_split), total, tiles_per_batch, group_m, blk_bytes, p.Kpad / 128);
   return mss_launch_status();
 }
@@ -720,17 +788,51 @@ int mss_wgrad_tn_bf16x3_launch(const MssConvArgs& p, const float* dy, int lddy, 
   return mss_launch_status();
 }
 
+// The implicit-GEMM layers on the split route: what conv_igemm_kernel takes with > 64 output channels and ONE prologue affine
+bool mss_conv_bf16x3_eligible(const MssConvArgs& p) {
+  if (!p.w_split || p.K <= 64 || p.Kpad % 128 || p.C % BK || p.batch > 1 || p.res_mask) return false;
+  const int taps = p.R * p.S;
+  if ((p.S != 1 && p.S != 3) || taps > 9 || taps * (p.C / BK) < 3) return false;
+  if (taps == 1 && p.stride == 1 && p.pad == 0) return false;                       // a plain GEMM: the NT route takes it
+  if (p.in_scale && p.in_ss_stride) return false;                                   // per-sample affines (Dropout2d fold): native
+  if (p.in_relu && !p.in_scale) return false;
+  if ((unsigned long long)p.N * p.H * p.W * p.ldx * 4ull >= 0x7fffffffull) return false;   // signed 32-bit pixel offsets
+  if ((unsigned long long)taps * p.Kpad * p.C * 6ull >= 0xffffffffull) return false;
+  return (reinterpret_cast<uintptr_t>(p.w_split) & 15) == 0 && MSS_ENV_INT("MSS_CONV_SPLIT", 1) != 0;
+}
+
+int mss_conv_bf16x3_launch(MssConvArgs p, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  p.mtiles = mss_cdiv(p.M, BM);
+  const long long tiles256 = (long long)p.mtiles * (p.K / 256);
+  const bool wide = p.K % 256 == 0 && tiles256 >= 1024;
+  if (wide) {
+    p.ntiles = p.K / 256;
+    return p.in_scale ? launch_split<true, 256, true, true>(p, s) : launch_split<false, 256, true, true>(p, s);
+  }
+  p.ntiles = mss_cdiv(p.K, 128);
+  return p.in_scale ? launch_split<true, 128, true, true>(p, s) : launch_split<false, 128, true, true>(p, s);
+}
+
 extern "C" long long mss_gemm_split_weights_bytes(int batch, int Kpad, int C) {
   if (batch < 1 || Kpad < 128 || Kpad % 128 || C < 16 || C % 16) return 0;
   return (long long)batch * Kpad * C * 6;
 }
 
-extern "C" int mss_gemm_split_weights_bf16x3(const float* w, void* planes, int batch, int Kpad, int C, long long w_bs, void* stream) {
-  if (!w || !planes || batch < 1 || Kpad % 128 || C % 16 || Kpad < 128 || C < 16) return MSS_ERR_BAD_ARG;
+static int split_weights(const float* w, void* planes, int batch, int taps, int Kpad, int C, long long w_bs, void* stream) {
+  if (!w || !planes || batch < 1 || taps < 1 || Kpad % 128 || C % 16 || Kpad < 128 || C < 16) return MSS_ERR_BAD_ARG;
   if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(planes)) & 15 || w_bs % 4) return MSS_ERR_BAD_ARG;
-  const long long total = (long long)batch * Kpad * (C / 16) * 2;
+  const long long total = (long long)batch * Kpad * (C / 16) * taps * 2;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w,
-                     static_cast<unsigned char*>(planes), Kpad, C, w_bs, total);
+                     static_cast<unsigned char*>(planes), Kpad, C, w_bs, total, taps);
   return mss_launch_status();
+}
+extern "C" int mss_gemm_split_weights_bf16x3(const float* w, void* planes, int batch, int Kpad, int C, long long w_bs, void* stream) {
+  return split_weights(w, planes, batch, 1, Kpad, C, w_bs, stream);
+}
+// w [taps][Kpad][C] (mss_conv2d_pack_weights_f32 with R * S = taps > 1) -> planes for MssConvArgs.w_split of an implicit-GEMM layer:
+// taps * Kpad * C * 6 bytes, the taps folded into one reduction of taps * C
+extern "C" int mss_conv_split_weights_bf16x3(const float* w, void* planes, int taps, int Kpad, int C, void* stream) {
+  return split_weights(w, planes, 1, taps, Kpad, C, (long long)taps * Kpad * C, stream);
 }

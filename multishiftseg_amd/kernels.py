@@ -110,9 +110,15 @@ def w_split_of(pw):
     if gemm_route() != "bf16x3":
         return None
     if pw.planes is None:
-        if getattr(pw, "R", 1) * getattr(pw, "S", 1) != 1:
-            return None
-        pw.planes = split_planes(pw.t, pw.Kpad, pw.Cp)
+        taps = getattr(pw, "R", 1) * getattr(pw, "S", 1)
+        if taps != 1 and isinstance(pw, PackedWeight):
+            # an implicit-GEMM layer: the taps folded into one long reduction (mss_conv_split_weights_bf16x3)
+            nbytes = _lib.value("mss_gemm_split_weights_bytes", taps, pw.Kpad, pw.Cp)
+            if nbytes > 0:
+                pw.planes = torch.empty(nbytes, device=pw.t.device, dtype=torch.uint8)
+                call("mss_conv_split_weights_bf16x3", ptr(pw.t), ptr(pw.planes), taps, pw.Kpad, pw.Cp)
+        else:
+            pw.planes = split_planes(pw.t, pw.Kpad, pw.Cp)
         if pw.planes is None:
             pw.planes = False
     return ptr(pw.planes) if pw.planes is not False else None
@@ -236,7 +242,7 @@ def _fwd_kind(a):
     """Profiling label of a forward launch: which of the two MFMA kernels the C side picks."""
     if _profile is None:
         return "conv_igemm"
-    return ("conv_igemm", "gemm_nt", "gemm_few_rows", "gemm_nt_bf16x3")[_lib.value("mss_conv2d_forward_route", ctypes.byref(a))]
+    return ("conv_igemm", "gemm_nt", "gemm_few_rows", "gemm_nt_bf16x3", "conv_igemm_bf16x3")[_lib.value("mss_conv2d_forward_route", ctypes.byref(a))]
 
 
 def _wgrad_kind(a, lddy):

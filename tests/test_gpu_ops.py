@@ -26,7 +26,7 @@ def run_conv(K, x, w, stride=1, dil=1, pad=0, **kw):
     return y.nchw().cpu().numpy()
 
 
-def test_conv_classes_golden(K):
+def test_conv_classes_golden(K, gemm_route):
     g = golden("ops")
     x = g["conv_x"]
     for tag, (stride, dil) in {"1x1": (1, 1), "3x3_d1": (1, 1), "3x3_d2": (1, 2), "3x3_d4": (1, 4), "3x3_d12": (1, 12),
@@ -47,7 +47,7 @@ def test_conv_classes_golden(K):
     (512, 19 + 29, 1, 1, 1, 2, 9, 7),   # heads-like K = 48
     (64, 304, 3, 1, 1, 1, 12, 10),      # K = 2*128 + 48: main + narrow tail launch
 ])
-def test_conv_vs_oracle(K, cin, cout, r, stride, dil, n, h, w):
+def test_conv_vs_oracle(K, cin, cout, r, stride, dil, n, h, w, gemm_route):
     rng = np.random.default_rng(cin * 7 + cout)
     x = rng.standard_normal((n, cin, h, w), dtype=np.float32)
     wt = (rng.standard_normal((cout, cin, r, r), dtype=np.float32) / np.sqrt(cin * r * r)).astype(np.float32)
@@ -57,7 +57,7 @@ def test_conv_vs_oracle(K, cin, cout, r, stride, dil, n, h, w):
     np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)
 
 
-def test_conv_fusions(K):
+def test_conv_fusions(K, gemm_route):
     """prologue BN+ReLU (shared and per-sample), epilogue affine + residual + ReLU."""
     rng = np.random.default_rng(3)
     n, c, k, h, w = 2, 64, 128, 12, 15
@@ -91,7 +91,7 @@ def test_conv_fusions(K):
     np.testing.assert_allclose(y.nchw().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
 
 
-def test_conv_channel_slices(K):
+def test_conv_channel_slices(K, gemm_route):
     """read from / write into slices of a wider NHWC buffer (in-place concat)."""
     rng = np.random.default_rng(4)
     n, h, w = 1, 10, 11
@@ -338,7 +338,7 @@ def test_m2f_fused_equals_unfused_at_full_size(K):
     (64, 32, 3, 1, 2, 1, 13, 17, 6),           # ... four tiles per wave
     (16, 272, 3, 1, 1, 1, 9, 8, 6),            # ... one tile per wave, two channel groups (the second ragged)
 ])
-def test_batchnorm_statistics_from_the_producing_kernel(K, cin, cout, r, stride, dil, n, h, w, wino):
+def test_batchnorm_statistics_from_the_producing_kernel(K, cin, cout, r, stride, dil, n, h, w, wino, gemm_route):
     """want_stats: the conv epilogue / Winograd output transform leaves per-channel partial sums; bn_fold(train=True)
     built from them must equal bn_fold on a statistics pass over the stored activation (residual included)."""
     rng = np.random.default_rng(cin + cout + r + dil)
@@ -367,7 +367,7 @@ def test_batchnorm_statistics_from_the_producing_kernel(K, cin, cout, r, stride,
     np.testing.assert_allclose(got.cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
-def test_conv_paths_random_shapes(K):
+def test_conv_paths_random_shapes(K, gemm_route):
     """Seeded sweep over the three forward paths (persistent GEMM, implicit GEMM, Winograd m = 2 / 4) with odd image
     sizes, channel counts around the tile edges, every dilation of the network, prologue / residual / ReLU / statistics
     switches -- against torch's CPU convolution."""
@@ -551,6 +551,51 @@ def test_bf16x3_gemm_fused_prologue_and_epilogue(K, rows, c, k, per_sample):
         yp = torch.cat([y3.double(), torch.zeros(pad, k, device="cuda", dtype=torch.float64)]).view(-1, 64, k)
         np.testing.assert_allclose(st3[:, 0].double().cpu().numpy(), yp.sum(1).cpu().numpy(), rtol=1e-4, atol=1e-3)
         np.testing.assert_allclose(st3[:, 1].double().cpu().numpy(), (yp * yp).sum(1).cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("cin,cout,r,stride,dil,n,h,w,affine", [
+    (64, 128, 3, 1, 1, 2, 70, 94, True),       # mod2.block1.conv1: 64 input channels stay off Winograd F(4x4); BN + ReLU prologue
+    (256, 512, 3, 2, 1, 2, 61, 59, True),      # mod4.block1.conv1: stride 2, odd size, wide tile when large
+    (256, 512, 1, 2, 1, 2, 61, 59, True),      # mod4.block1.proj_conv: 1x1 stride 2
+    (32, 200, 3, 1, 2, 1, 40, 33, False),      # K = 200 (padded column tile), dilation 2, no prologue
+    (128, 256, 3, 1, 12, 1, 16, 32, False),    # rate 12 on a small map: most taps in the padding
+])
+def test_bf16x3_implicit_gemm_vs_float64(K, cin, cout, r, stride, dil, n, h, w, affine):
+    """The implicit-GEMM layers on the split route (gemm_nt_bf16x3_kernel<..., CONV>; mss_conv2d_forward_route answers 4): taps folded
+    into one long reduction on the weight side, per-tap pixel addressing with zero padding AFTER the BatchNorm + ReLU prologue on
+    the activation side -- against a float64 convolution and against the native implicit-GEMM kernel."""
+    import ctypes
+    from multishiftseg_amd import _lib
+    torch.manual_seed(cin + cout + r)
+    x = K.Act(torch.randn(n, h, w, cin, device="cuda"))
+    wt = torch.randn(cout, cin, r, r, device="cuda") / (cin * r * r) ** 0.5
+    aff = (torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.3) if affine else None
+    pad = dil if r == 3 else 0
+    outs = {}
+    for route in ("native", "bf16x3"):
+        K.set_gemm_route(route)
+        try:
+            pw = K.pack_weight(wt)
+            a = K._conv_args(x, pw, None, stride, dil, pad, aff, affine, None, False, None)
+            a.OH, a.OW = K.conv_out_size(h, r, stride, dil, pad), K.conv_out_size(w, r, stride, dil, pad)
+            assert _lib.value("mss_conv2d_forward_route", ctypes.byref(a)) == (4 if route == "bf16x3" else 0)
+            outs[route] = K.conv2d(x, pw, stride=stride, dil=dil, pad=pad, in_affine=aff, in_relu=affine, want_stats=True)
+        finally:
+            K.set_gemm_route(None)
+    xa = x.nchw().double()
+    if affine:
+        xa = torch.relu(xa * aff[0].double().view(1, -1, 1, 1) + aff[1].double().view(1, -1, 1, 1))
+    ref = torch.nn.functional.conv2d(xa, wt.double(), stride=stride, dilation=dil, padding=pad)
+    scale = ref.abs().max().item()
+    e0 = (outs["native"].nchw().double() - ref).abs().max().item() / scale
+    e1 = (outs["bf16x3"].nchw().double() - ref).abs().max().item() / scale
+    assert e0 < 2e-6 and e1 < 2e-6 and e1 < 2 * e0 + 1e-7, (e0, e1)
+    assert not torch.equal(outs["native"].nchw(), outs["bf16x3"].nchw())
+    st = outs["bf16x3"].stats                                     # the BatchNorm partial sums of the epilogue, per 64 output rows
+    y = outs["bf16x3"].buf.view(-1, cout).double()
+    padr = (-y.shape[0]) % 64
+    yp = torch.cat([y, torch.zeros(padr, cout, device="cuda", dtype=torch.float64)]).view(-1, 64, cout)
+    np.testing.assert_allclose(st[:, 0].double().cpu().numpy(), yp.sum(1).cpu().numpy(), rtol=1e-4, atol=1e-3)
 
 
 def test_bf16x3_route_is_taken_by_the_layer_wrappers(K):
