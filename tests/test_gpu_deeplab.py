@@ -94,7 +94,12 @@ def test_train_step_golden(deeplab_params, stage, names, lr, gemm_route, fixture
     pd = dict(m.named_parameters())
     report = {}
 
-    def close(got, ref, name):
+    def close(got, ref, name, typical=0.0):
+        # typical: rms of the WHOLE tensor (from its stored L2 norm) when `ref` is a slice of it. Round 5: the stored slice of the
+        # dilated ASPP weights (tap (0, 0) of every 64th channel) is EXACTLY zero in the reference -- at dilation 12 on a 12 x 16 map
+        # that tap never meets the image -- and so is the native route's (equal terms of the Winograd-domain sum cancel exactly),
+        # while the split-bf16 route leaves 5e-8 there = 2e-6 of the tensor's rms. A slice is therefore judged against
+        # max(its own norm, 1e-3 of what a slice of that size typically weighs), not against a zero.
         # A single ReLU-threshold flip (pre-activation within 1e-6 of zero) moves one summand of a BN/conv gradient:
         # judge by relative L2 and by the median error, and bound the worst element loosely. Some of these sums are
         # ill-conditioned on this tiny batch (768-pixel BatchNorm batches in ASPP); tools/gen_golden.py measures that on
@@ -103,9 +108,9 @@ def test_train_step_golden(deeplab_params, stage, names, lr, gemm_route, fixture
         # (one Winograd F(4x4) layer's rounding; up to 1.2e-2). No bound is asked to be tighter than those.
         noise = float(g[pre + "gradnoise_" + name]) if pre + "gradnoise_" + name in g.files else 0.0
         sens = float(g[pre + "gradsens_" + name]) if pre + "gradsens_" + name in g.files else 0.0
-        scale = np.abs(ref).max() + 1e-12
+        scale = max(np.abs(ref).max(), 1e-3 * typical) + 1e-12
         err = np.abs(got - ref)
-        rel_l2 = np.sqrt((err.astype(np.float64) ** 2).sum()) / (np.sqrt((ref.astype(np.float64) ** 2).sum()) + 1e-30)
+        rel_l2 = np.sqrt((err.astype(np.float64) ** 2).sum()) / (max(np.sqrt((ref.astype(np.float64) ** 2).sum()), 1e-3 * typical * np.sqrt(ref.size)) + 1e-30)
         # round 2 (deterministic, atomic-free weight gradients): rel-L2 <= max(2e-3, 2 x fp32-vs-fp64 noise of the REFERENCE,
         # 3 x its sensitivity to a 4e-6 jitter of the trunk outputs); round 1 asked for max(1e-2, 5 x, 3 x)
         bound = max(2e-3, 2 * noise, 3 * sens)
@@ -124,7 +129,7 @@ def test_train_step_golden(deeplab_params, stage, names, lr, gemm_route, fixture
         np.testing.assert_allclose(got, float(g[k]), rtol=5e-3, err_msg=name)
         flat = pd[name].grad.cpu().numpy().reshape(pd[name].shape[0], -1)
         sub = flat[:, ::max(1, flat.shape[1] // 64)][:, :64]
-        close(sub, g[pre + "grad_sub_" + name], name)
+        close(sub, g[pre + "grad_sub_" + name], name, typical=float(g[k]) / np.sqrt(flat.size))
     for k in [k for k in g.files if k.startswith(pre + "delta_")]:
         name = k[len(pre) + 6:]
         got = (pd[name].detach() - before[name]).cpu().numpy()

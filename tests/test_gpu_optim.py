@@ -112,15 +112,25 @@ def test_three_reference_steps_through_trainstep(deeplab_params, stage, lr, gemm
         ref_m1, ref_m2, ref_d = g[pre + "exp_avg_" + n], g[pre + "exp_avg_sq_" + n], g[pre + "delta_" + n]
         got_m1, got_m2, got_d = sub(m1), sub(m2), sub(p.detach() - before[n])
 
-        def rel(a, b):
-            return float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum()) / (np.sqrt((b.astype(np.float64) ** 2).sum()) + 1e-300))
+        def rel(a, b, full):
+            # against the slice's own norm, or -- where the stored slice is (nearly) zero against the rest of its tensor: the
+            # dilated ASPP weights' tap (0, 0) never meets the 12 x 16 map, its moments come from the weight decay alone, and
+            # a 2e-6-of-rms rounding residue of the gradient there (split-bf16 route) is 5 % of THAT -- 1e-3 of what a slice of
+            # this size typically weighs in this tensor
+            typical = float(full.double().norm()) * np.sqrt(b.size / full.numel())
+            return float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum()) / (max(np.sqrt((b.astype(np.float64) ** 2).sum()), 1e-3 * typical) + 1e-300))
         # moments are running means of the gradients: they carry the gradients' own parity (measured round 4: stage 1 4e-5,
         # stage 2 at most 6.7e-3 / 5.3e-3 on this tiny batch, whose ASPP BatchNorm sums are ill-conditioned --
         # test_train_step_golden); bound 2e-2
-        r1, r2 = rel(got_m1, ref_m1), rel(got_m2, ref_m2)
+        r1, r2 = rel(got_m1, ref_m1, m1), rel(got_m2, ref_m2, m2)
         # deltas: elements whose normalised step |m|/sqrt(v) is well defined, i.e. the last gradient is not rounding noise
         lastg = g[pre + "lastgrad_" + n]
         solid = np.abs(ref_m1) > 0.05 * np.sqrt(np.maximum(ref_m2, 1e-30) / (1 - 0.999 ** steps))
+        # ... and not where the reference's own raw gradient is EXACTLY zero (round 5): tap (0, 0) of the dilated ASPP weights never meets
+        # the 12 x 16 map, so those elements move by Adam's normalised weight decay alone, sign(1e-4 p) -- a step any rounding residue of
+        # the gradient (5e-8 = 2e-6 of the tensor's rms on the split-bf16 route; the native Winograd sum cancels exactly) redirects
+        # wherever |p| < 5e-4. Their moments are still compared above.
+        solid &= lastg != 0
         ok = np.abs(got_d - ref_d) <= 0.05 * lr * steps
         frac = float(ok[solid].mean()) if solid.any() else 1.0
         report[n] = dict(exp_avg_rel_l2=r1, exp_avg_sq_rel_l2=r2, delta_ok_frac=frac, solid=int(solid.sum()), size=int(solid.size),
