@@ -1626,7 +1626,7 @@ int mss_conv2d_unpack_wgrad_f32(const float* packed, float* grad, int K, int C, 
 int mss_conv2d_wgrad_route(const MssConvArgs* args, int lddy) {
   MssConvArgs p = *args;
   p.M = p.N * p.OH * p.OW;
-  return p.M > 0 && mss_wgrad_tn_bf16x3_eligible(p, lddy) ? 1 : 0;
+  return p.M > 0 && p.Kpad == p.K && mss_wgrad_tn_bf16x3_eligible(p, lddy) ? 1 : 0;     // (and Cp == C at the call)
 }
 
 // Bytes of scratch mss_conv2d_wgrad_f32 needs for these arguments (0: the pixel range is not split).
@@ -1635,7 +1635,7 @@ long long mss_conv2d_wgrad_workspace_bytes(const MssConvArgs* args, int Cp) {
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return 0;
   long long tn_bytes = 0;
-  if (mss_wgrad_tn_bf16x3_eligible(p, p.K)) return mss_wgrad_tn_bf16x3_ws_bytes(p, Cp);      // args->route == 1: the split-bf16 TN kernel
+  if (Cp == p.C && p.Kpad == p.K && mss_wgrad_tn_bf16x3_eligible(p, p.K)) return mss_wgrad_tn_bf16x3_ws_bytes(p, Cp);   // args->route == 1: the split-bf16 TN kernel
   if (tn_eligible(p, p.K)) {                 // lddy == K is assumed here and checked again at launch
     const TnPlan pl = tn_plan_for(p);
     tn_bytes = pl.full >= 0 ? tn_tail_bytes(pl) : pl.splits > 1 ? (long long)pl.splits * tn_batch(p) * p.Kpad * Cp * 4 : 0;
@@ -1664,7 +1664,8 @@ int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dw
   if (p.M <= 0) return MSS_OK;
   if (p.batch > 1 && (p.R * p.S != 1 || p.batch > 65535)) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (mss_wgrad_tn_bf16x3_eligible(p, lddy) && ws_bytes >= mss_wgrad_tn_bf16x3_ws_bytes(p, Cp))
+  // (whole 128 x 256 tiles only: a caller that pads dwp beyond K x C keeps the native kernels, which clear the padding)
+  if (Cp == p.C && p.Kpad == p.K && mss_wgrad_tn_bf16x3_eligible(p, lddy) && ws_bytes >= mss_wgrad_tn_bf16x3_ws_bytes(p, Cp))
     return mss_wgrad_tn_bf16x3_launch(p, dy, lddy, dwp, Cp, ws, ws_bytes, stream);
   if (tn_eligible(p, lddy)) return launch_wgrad_tn(p, dy, dwp, Cp, ws, ws_bytes, s, lddy);
   if (narrow_eligible(p, dy, lddy, Cp)) return launch_wgrad_narrow(p, dy, lddy, dwp, Cp, ws, ws_bytes, s);
