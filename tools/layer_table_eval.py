@@ -21,7 +21,7 @@ print(f"forward {s.elapsed_time(e):.2f} ms")
 agg = {}
 for kind, tag, ms, tf in rows:
     d = agg.setdefault((kind, tag), [0, 0.0, 0.0]); d[0] += 1; d[1] += ms; d[2] += ms * tf
-for kind in ("gemm_nt", "conv_igemm", "wino_transform"):
+for kind in ("gemm_nt", "gemm_nt_bf16x3", "conv_igemm", "conv_igemm_bf16x3", "wino_transform"):
     sub = {k: v for k, v in agg.items() if k[0] == kind}
     t = sum(v[1] for v in sub.values()); w = sum(v[2] for v in sub.values())
     print(f"== {kind}: {t:.2f} ms, {w / t if t else 0:.1f} {'TB/s' if kind == 'wino_transform' else 'TF/s'}")
