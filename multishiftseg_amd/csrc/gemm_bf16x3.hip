@@ -13,7 +13,7 @@
 //    block per K-step -- [block][K-step][plane hi|mid|lo][128 rows][16 k], 12 KB each, the two 16-byte halves of a row swapped when
 //    bit 3 of the row is set -- so staging B is a linear 16-byte-per-lane copy with no arithmetic at all;
 //  * only the ACTIVATION operand is split in the loader, with v_cvt_pk_bf16_f32 (two conversions per instruction) and mask /
-//    shift re-expansion: 5.5 VALU per element, 8 elements per thread and K-step on the 128 x 256 tile = 0.9 VALU per MFMA;
+//    shift re-expansion: 5.5 VALU per element, 8 elements per thread and K-step on the 128 x 256 tile = 1.2 VALU per MFMA measured;
 //  * gemm_nt_kernel's persistent schedule (variant 3): 32-bit offsets, the loader two K-steps ahead across tile boundaries with
 //    one register set, a branch-free advance, one barrier per K-step, 128 x 256 tiles (48 MFMAs per wave and barrier) at two
 //    workgroups per CU, 128 x 128 at three.
@@ -55,7 +55,9 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
 // row is an output pixel, its address per tap = pixel base + a uniform tap offset, taps that fall into the zero padding read a valid
 // dummy address and enter as zeros AFTER the BatchNorm + ReLU prologue (the reference pads the activated tensor). Branch-free like
 // the rest of the K-step: the tap state advances with selects.
-template <bool AFFINE, int BN, bool SCHED, bool CONV = false>
+// ROWAFF: the prologue affine differs per SAMPLE (the Dropout2d fold of mod6 / mod7, wider_resnet.py:139-140,161-162) and a 128-row tile
+// may straddle two images (88 x 88 maps at 700 x 700): every staged row then loads the affine of its own image.
+template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false>
 __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf16x3_kernel(MssConvArgs p, const unsigned char* __restrict__ wpl,
                                                                                long long total_tiles, int tiles_per_batch,
                                                                                int group_m, unsigned blk_bytes, int nblk_total) {
@@ -71,7 +73,11 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   const float relu_floor = p.in_relu ? 0.f : -__builtin_huge_valf();
 
   // ---- loader state (see gemm_nt_kernel, variant 3) ----
-  unsigned a_off[2], a_nxt[2], b_off[NBLK], b_nxt[NBLK], s_off = 0, s_nxt = 0;
+  unsigned a_off[2], a_nxt[2], b_off[NBLK], b_nxt[NBLK], s_off = 0, s_nxt = 0, s_off1 = 0, s_nxt1 = 0;   // (s_off1: row 1's affine, ROWAFF)
+  // the A operand of batch entry b starts at p.x + b * x_bs: a UNIFORM 64-bit base per tile (scalar registers) + 32-bit offsets inside
+  // the entry, so a batched product may exceed 4 GB as a whole (16 x 700 x 700: the ASPP X' is 5.4 / 12 GB) while each entry stays below
+  const char* xb_cur = reinterpret_cast<const char*>(p.x);
+  const char* xb_nxt = xb_cur;
   long long ld_tile = mss_xcd_remap(blockIdx.x, gridDim.x);
   int ld_k = 0;
   // CONV: per staged row the byte offset of its (possibly virtual) top-left input pixel and the 9-bit map of in-image taps, for the
@@ -83,8 +89,9 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
     const int r = p.S == 1 ? tap : (tap * 43) >> 7, sx = tap - r * p.S;
     return (r * p.dil * p.W + sx * p.dil) * p.ldx * (int)sizeof(float);
   };
-  auto setup_off = [&](long long t, unsigned* ao, unsigned* bo, unsigned& so) {
+  auto setup_off = [&](long long t, unsigned* ao, unsigned* bo, unsigned& so, unsigned& so1) {
     const int b = (int)(t / tiles_per_batch);
+    (ao == a_off ? xb_cur : xb_nxt) = reinterpret_cast<const char*>(p.x) + (size_t)b * p.x_bs * sizeof(float);
     const int v = (int)(t - (long long)b * tiles_per_batch);
     int mt, nt; mss_tile_mn(v, p.mtiles, p.ntiles, group_m, mt, nt);
 #pragma unroll
@@ -109,18 +116,23 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
         continue;
       }
       row = row < p.M ? row : p.M - 1;                  // rows past the end re-read the last row; never stored
-      ao[j] = (unsigned)(((size_t)b * p.x_bs + (size_t)row * p.ldx + chunk * 4) * sizeof(float));
+      ao[j] = (unsigned)(((size_t)row * p.ldx + chunk * 4) * sizeof(float));
     }
 #pragma unroll
     for (int j = 0; j < NBLK; ++j)
       bo[j] = (unsigned)(b * nblk_total + nt * NBLK + j) * blk_bytes + tid * 16;
     if (AFFINE) so = CONV ? (unsigned)(chunk * 4 * sizeof(float)) : (unsigned)(((size_t)((mt * BM) / p.H) * p.in_ss_stride + chunk * 4) * sizeof(float));
+    if (ROWAFF) {                                        // p.H = rows per image; rows past the end take the last image's affine
+      const int r0 = min(mt * BM + row0, p.M - 1), r1 = min(mt * BM + row0 + 64, p.M - 1);
+      so = (unsigned)(((size_t)(r0 / p.H) * p.in_ss_stride + chunk * 4) * sizeof(float));
+      so1 = (unsigned)(((size_t)(r1 / p.H) * p.in_ss_stride + chunk * 4) * sizeof(float));
+    }
   };
   auto setup_next = [&]() {
     const long long t = ld_tile + stride;
-    setup_off(t < total_tiles ? t : ld_tile, a_nxt, b_nxt, s_nxt);
+    setup_off(t < total_tiles ? t : ld_tile, a_nxt, b_nxt, s_nxt, s_nxt1);
   };
-  f32x4 areg[2], sreg, hreg;
+  f32x4 areg[2], sreg, hreg, sreg1, hreg1;
   u32x4 breg[NBLK][3];
   // one uniform base per plane (kept opaque, or the compiler folds them back into wpl + 4096 / 8192, which do not fit the 13-bit
   // instruction offset and cost a 64-bit VALU address per load): every load is `global_load_dwordx4 v, v_off, s[base]`
@@ -128,12 +140,15 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   gptr_t wbase[3] = {(gptr_t)wpl, (gptr_t)wpl + PLANE, (gptr_t)wpl + 2 * PLANE};
   asm volatile("" : "+s"(wbase[1]), "+s"(wbase[2]));
   auto issue_loads_a = [&]() {
-    const char* xb = reinterpret_cast<const char*>(p.x);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) areg[j] = *reinterpret_cast<const f32x4*>(xb + a_off[j]);
+    for (int j = 0; j < 2; ++j) areg[j] = *reinterpret_cast<const f32x4*>(xb_cur + a_off[j]);
     if (AFFINE) {
       sreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in_scale) + s_off);
       hreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in_shift) + s_off);
+    }
+    if (ROWAFF) {
+      sreg1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in_scale) + s_off1);
+      hreg1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.in_shift) + s_off1);
     }
     if (CONV) raw_ok = cur_ok;
   };
@@ -146,6 +161,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   auto issue_loads = [&]() { issue_loads_a(); issue_loads_b(); };
   auto advance = [&]() {                 // branch-free: next K-step of this tile, else first K-step of this workgroup's next tile
     const bool wrap = ++ld_k == n_it;
+    xb_cur = wrap ? xb_nxt : xb_cur;
     if (CONV) {
       const bool tap_end = ++ld_c == nk;
       ld_c = tap_end ? 0 : ld_c;
@@ -173,6 +189,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) b_off[j] = wrap ? b_nxt[j] : b_off[j] + (unsigned)OPER;
     if (AFFINE) s_off = wrap ? s_nxt : s_off + BK * (unsigned)sizeof(float);
+    if (ROWAFF) s_off1 = wrap ? s_nxt1 : s_off1 + BK * (unsigned)sizeof(float);
     ld_k = wrap ? 0 : ld_k;
   };
   // A: 4 bf16 (8 B) per plane at row r, quarter `chunk` of the 32-byte row, halves swapped when bit 3 of r is set
@@ -181,7 +198,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   auto split_row = [&](int j, unsigned (&hi)[2], unsigned (&mid)[2], unsigned (&lo)[2]) {
     f32x4 v = areg[j];
     if (AFFINE) {
-      v = v * sreg + hreg;
+      v = (ROWAFF && j == 1) ? v * sreg1 + hreg1 : v * sreg + hreg;
       v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
     }
     if (CONV) {                                          // a tap in the zero padding: zeros after the prologue
@@ -326,7 +343,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   };
 
   long long cur = ld_tile;               // tile being multiplied (the launch guarantees cur < total_tiles)
-  setup_off(ld_tile, a_off, b_off, s_off);
+  setup_off(ld_tile, a_off, b_off, s_off, s_off1);
   if (CONV) cur_ok = (unsigned)((okb[0] & 1) | ((okb[1] & 1) << 1));
   setup_next();
   issue_loads();
@@ -401,6 +418,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
   for (int t = 0; t < 8; ++t) rowbase[t] = (gptr_t)(is_a ? A : B) + (size_t)t * ld_bytes;
 
   unsigned off = 0, nxt = 0, s_off = 0, s_nxt = 0;
+  size_t slab = 0, slab_nxt = 0;                                   // byte offset of the loader's position (uniform, 64-bit): a batch may exceed 4 GB
   int vf = 0, vf_nxt = 0, row_ld = 0, row_nxt = 0;                 // first valid row of the loader's tile; first row of its current step
   int ld_nit = nit_full, nit_nxt = nit_full;                       // K-steps of the loader's tile / of the one after it
   long long ld_tile = mss_xcd_remap(blockIdx.x, gridDim.x);
@@ -410,24 +428,25 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
     kt = (int)(t % ktiles); t /= ktiles;
     sp = (int)(t % splits); pb = (int)(t / splits);
   };
-  auto setup_off = [&](long long t, unsigned& o, unsigned& so, int& valid_from, int& row0, int& nit) {
+  auto setup_off = [&](long long t, unsigned& o, unsigned& so, int& valid_from, int& row0, int& nit, size_t& sl) {
     int pb, sp, kt, ct; decode(t, pb, sp, kt, ct);
+    sl = (size_t)pb * (is_a ? a_bs : b_bs) * sizeof(float);
     valid_from = sp * tps;
     nit = sp == splits - 1 ? nit_last : nit_full;
     row0 = (!MASKED || valid_from + tps <= M) ? valid_from : M - tps;   // MASKED: the last split is shifted back to end at row M
     const size_t col = is_a ? (size_t)kt * 128 + 4 * cq : (size_t)ct * BN + 4 * cq;
-    o = (unsigned)((((size_t)pb * (is_a ? a_bs : b_bs)) + (size_t)(row0 + rg * 8) * ld + col) * sizeof(float));
+    o = (unsigned)(((size_t)(row0 + rg * 8) * ld + col) * sizeof(float));
     if (AFFINE) so = is_a ? 0u : (unsigned)((ct * BN + 4 * cq) * sizeof(float));     // (dy lanes load a valid vector and ignore it)
   };
   auto setup_next = [&]() {
     const long long t = ld_tile + stride;
-    setup_off(t < total_tiles ? t : ld_tile, nxt, s_nxt, vf_nxt, row_nxt, nit_nxt);
+    setup_off(t < total_tiles ? t : ld_tile, nxt, s_nxt, vf_nxt, row_nxt, nit_nxt, slab_nxt);
   };
   f32x4 raw[8], sreg, hreg;
   int raw_mask = 0;                                                // mask_rows of the K-step held in `raw`
   auto issue_loads = [&]() {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) raw[t] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(rowbase[t] + off);
+    for (int t = 0; t < 8; ++t) raw[t] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(rowbase[t] + slab + off);
     if (AFFINE) {
       sreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(scale) + s_off);
       hreg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(shift) + s_off);
@@ -440,6 +459,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
   auto advance = [&]() {
     const bool wrap = ++ld_k == ld_nit;
     ld_nit = wrap ? nit_nxt : ld_nit;
+    slab = wrap ? slab_nxt : slab;
     off = wrap ? nxt : off + BK * ld_bytes;
     row_ld = wrap ? row_nxt : row_ld + BK;
     vf = wrap ? vf_nxt : vf;
@@ -558,7 +578,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
   };
 
   long long cur = ld_tile;
-  setup_off(ld_tile, off, s_off, vf, row_ld, ld_nit);
+  setup_off(ld_tile, off, s_off, vf, row_ld, ld_nit, slab);
   setup_next();
   issue_loads();
   st_mask = raw_mask;
@@ -616,7 +636,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   }
 }
 
-template <bool AFFINE, int BN, bool SCHED, bool CONV = false>
+template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false>
 int launch_split(const MssConvArgs& p, hipStream_t stream) {
   const int batch = p.batch > 1 ? p.batch : 1;
   const int tiles_per_batch = p.mtiles * p.ntiles;
@@ -629,11 +649,11 @@ int launch_split(const MssConvArgs& p, hipStream_t stream) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (smem > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV>, NT, smem) != hipSuccess || n < 1) n = BN == 256 ? 2 : 3;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF>, NT, smem) != hipSuccess || n < 1) n = BN == 256 ? 2 : 3;
     const int cap = MSS_ENV_INT("MSS_GEMM_WG_PER_CU", 0);
     if (cap > 0 && cap < n) n = cap;
     per_cu_max = n;
@@ -650,7 +670,7 @@ int launch_split(const MssConvArgs& p, hipStream_t stream) {
   }
   const int group_m = MSS_ENV_INT("MSS_GEMM_GROUP_M", GEMM_GROUP_M_DEFAULT);
   const unsigned blk_bytes = (unsigned)(p.C / BK) * (CONV ? p.R * p.S : 1) * OPER;     // CONV: the taps are part of one long reduction
-  hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV>), dim3(grid), dim3(NT), smem, stream, p,
+  hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF>), dim3(grid), dim3(NT), smem, stream, p,
                      static_cast<const unsigned char*>(p.w_split), total, tiles_per_batch, group_m, blk_bytes, p.Kpad / 128);
   return mss_launch_status();
 }
@@ -663,7 +683,7 @@ bool mss_gemm_nt_bf16x3_eligible(const MssConvArgs& p) {
   if (!p.w_split || p.K <= 64 || p.C / BK < 3 || p.Kpad % 128) return false;
   const long long nb = p.batch > 1 ? p.batch : 1;
   if (p.batch > 1 && p.w_bs != (long long)p.Kpad * p.C) return false;
-  if ((unsigned long long)((nb - 1) * p.x_bs + (long long)p.M * p.ldx) * 4ull >= 0xffffffffull) return false;
+  if ((unsigned long long)p.M * p.ldx * 4ull >= 0xffffffffull) return false;             // per batch entry (the entries' bases are 64-bit)
   if ((unsigned long long)nb * p.Kpad * p.C * 6ull >= 0xffffffffull) return false;
   return (reinterpret_cast<uintptr_t>(p.w_split) & 15) == 0;
 }
@@ -741,9 +761,7 @@ bool mss_wgrad_tn_bf16x3_eligible(const MssConvArgs& p, int lddy) {
   if (p.batch <= 1 && (p.stride != 1 || p.pad != 0 || p.OH != p.H || p.OW != p.W)) return false;
   if ((p.in_scale || p.in_shift || p.in_relu) && (p.batch > 1 || p.in_ss_stride != 0 || !p.in_scale || !p.in_shift)) return false;
   if (p.in_scale && ((reinterpret_cast<uintptr_t>(p.in_scale) | reinterpret_cast<uintptr_t>(p.in_shift)) & 15)) return false;
-  const long long nb = p.batch > 1 ? p.batch : 1;
-  if ((unsigned long long)((nb - 1) * (p.batch > 1 ? p.x_bs : 0) + (long long)p.M * p.C) * 4ull >= 0xffffffffull) return false;
-  if ((unsigned long long)((nb - 1) * (p.batch > 1 ? p.y_bs : 0) + (long long)p.M * lddy) * 4ull >= 0xffffffffull) return false;
+  if ((unsigned long long)p.M * p.C * 4ull >= 0xffffffffull || (unsigned long long)p.M * lddy * 4ull >= 0xffffffffull) return false;   // per position
   return tn_split_plan(p).total >= 256;          // small products (fewer tiles than half the workgroup slots) stay on the native one-wave kernels
 }
 
@@ -788,8 +806,10 @@ int mss_wgrad_tn_bf16x3_launch(const MssConvArgs& p, const float* dy, int lddy, 
   return mss_launch_status();
 }
 
+static bool rowaff_eligible(const MssConvArgs& p);
 // The implicit-GEMM layers on the split route: what conv_igemm_kernel takes with > 64 output channels and ONE prologue affine
 bool mss_conv_bf16x3_eligible(const MssConvArgs& p) {
+  if (rowaff_eligible(p)) return true;
   if (!p.w_split || p.K <= 64 || p.Kpad % 128 || p.C % BK || p.batch > 1 || p.res_mask) return false;
   const int taps = p.R * p.S;
   if ((p.S != 1 && p.S != 3) || taps > 9 || taps * (p.C / BK) < 3) return false;
@@ -801,9 +821,23 @@ bool mss_conv_bf16x3_eligible(const MssConvArgs& p) {
   return (reinterpret_cast<uintptr_t>(p.w_split) & 15) == 0 && MSS_ENV_INT("MSS_CONV_SPLIT", 1) != 0;
 }
 
+// 1x1 / stride-1 layers whose prologue affine is per sample while 128-row tiles straddle images ((OH * OW) % 128 != 0: mod6 / mod7's
+// last convolutions at 16 x 700 x 700) -- the one GEMM shape mss_gemm_nt_dispatch leaves to conv_igemm_kernel's PER_SAMPLE path
+static bool rowaff_eligible(const MssConvArgs& p) {
+  if (!p.w_split || p.R * p.S != 1 || p.stride != 1 || p.pad != 0 || p.H != p.OH || p.W != p.OW || p.batch > 1) return false;
+  if (!p.in_scale || !p.in_ss_stride || (p.OH * p.OW) % BM == 0 || p.K <= 64 || p.Kpad % 128 || p.C % BK || p.C / BK < 3) return false;
+  if ((unsigned long long)p.M * p.ldx * 4ull >= 0xffffffffull || (unsigned long long)p.Kpad * p.C * 6ull >= 0xffffffffull) return false;
+  return (reinterpret_cast<uintptr_t>(p.w_split) & 15) == 0 && MSS_ENV_INT("MSS_CONV_SPLIT", 1) != 0;
+}
+
 int mss_conv_bf16x3_launch(MssConvArgs p, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   p.mtiles = mss_cdiv(p.M, BM);
+  if (rowaff_eligible(p)) {
+    p.H = p.OH * p.OW;                                   // rows per image
+    p.ntiles = mss_cdiv(p.K, 128);
+    return launch_split<true, 128, true, false, true>(p, s);
+  }
   const long long tiles256 = (long long)p.mtiles * (p.K / 256);
   const bool wide = p.K % 256 == 0 && tiles256 >= 1024;
   if (wide) {

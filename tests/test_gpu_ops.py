@@ -501,7 +501,8 @@ def test_bf16x3_gemm_is_fp32_accurate(K, rows, c, k, batch):
     assert not torch.equal(y32, y3)          # it really is a different evaluation
 
 
-@pytest.mark.parametrize("rows,c,k,per_sample", [(1500, 256, 384, False), (3 * 128 * 5, 128, 256, True), (40000, 512, 1024, False)])
+@pytest.mark.parametrize("rows,c,k,per_sample", [(1500, 256, 384, False), (3 * 128 * 5, 128, 256, True), (40000, 512, 1024, False),
+                                                 (3 * 1320, 256, 384, True)])     # 1320 rows per image: 128-row tiles straddle images (ROWAFF kernel)
 def test_bf16x3_gemm_fused_prologue_and_epilogue(K, rows, c, k, per_sample):
     """Everything gemm_nt_kernel fuses, on the split route: BatchNorm + ReLU prologue (one affine, or one per sample = the Dropout2d
     fold), per-channel output affine + residual + ReLU, the ReLU-gate form of the residual (res_mask), and the per-64-row partial
@@ -538,7 +539,8 @@ def test_bf16x3_gemm_fused_prologue_and_epilogue(K, rows, c, k, per_sample):
         a.N, a.H, a.W, a.C, a.ldx = n_img, 1, hw, c, c
         a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, hw, k, kpad, k
         a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
-        assert _lib.value("mss_conv2d_forward_route", ctypes.byref(a)) == (3 if split else 1)
+        straddle = per_sample and (rows // n_img) % 128 != 0       # native: conv_igemm_kernel's per-sample path; split: the ROWAFF kernel
+        assert _lib.value("mss_conv2d_forward_route", ctypes.byref(a)) == ((4 if split else 0) if straddle else (3 if split else 1))
         call("mss_conv2d_forward_f32", ctypes.byref(a))
         return y, stats
     for kw, ref in (({"relu": True}, torch.relu(lin + res.double())), ({"mask": True}, torch.where(res.double() > 0, lin, torch.zeros_like(lin)))):
