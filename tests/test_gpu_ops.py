@@ -476,7 +476,8 @@ def _run_gemm(K, x, w, k, split, in_affine=None, out_affine=None, out_relu=False
 
 
 @pytest.mark.parametrize("rows,c,k,batch", [(300, 64, 128, 1), (1000, 256, 192, 1), (257, 512, 256, 3), (4096, 1024, 128, 2), (70000, 48, 512, 1),
-                                            (131, 2048, 1024, 1), (66000, 256, 256, 2)])
+                                            (131, 2048, 1024, 1), (66000, 256, 256, 2),
+                                            (9216, 4096, 256, 36)])       # 5.4 GB of X': beyond 32-bit offsets as a whole (16 x 700 x 700 ASPP), 151 MB per entry
 def test_bf16x3_gemm_is_fp32_accurate(K, rows, c, k, batch):
     """The split-bf16 route (MssConvArgs.w_split; six bf16 MFMAs per block on operands split into three bf16 terms): against
     float64 it must be as accurate as the native fp32 MFMA kernel (both ~1e-7 of max|y|). Shapes cover both tile widths
@@ -623,7 +624,8 @@ def test_bf16x3_route_is_taken_by_the_layer_wrappers(K):
 
 
 @pytest.mark.parametrize("P,T,C,Ko,affine,ld_extra", [(36, 1100, 512, 256, False, 0), (1, 162629, 256, 256, False, 32), (1, 70000, 1280, 256, True, 0),
-                                                      (64, 1936, 256, 256, False, 0), (2, 40000, 256, 384, False, 0)])
+                                                      (64, 1936, 256, 256, False, 0), (2, 40000, 256, 384, False, 0),
+                                                      (36, 9216, 4096, 256, False, 0)])     # 5.4 GB of X' in all: 64-bit position bases
 def test_bf16x3_wgrad_tn_vs_float64(K, P, T, C, Ko, affine, ld_extra):
     """The TN weight-gradient product on the split-bf16 route (MssConvArgs.route = 1, gemm_tn_bf16x3_kernel: both operands split and
     transposed in the loader) against float64 and against the native kernels: row counts that are not multiples of 16 (the last
