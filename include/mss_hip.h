@@ -560,6 +560,9 @@ int mss_peak_mfma_f32(float* out, int blocks, int iters, void* stream);
 /* The same for the bf16 matrix cores under load (the split-bf16 GEMM route's ceiling): register-only loops on pseudo-random operands,
  * blocks x 4 waves x iters x 1 572 864 FLOP; shape 0 = 48 x v_mfma_f32_32x32x16_bf16 per iteration, 1 = 96 x v_mfma_f32_16x16x32_bf16. */
 int mss_peak_mfma_bf16(float* out, int blocks, int iters, int shape, void* stream);
+/* Clock calibration: one wave spins for `ticks` of s_memrealtime; out[0] = s_memrealtime ticks, out[1] = s_memtime ticks of the span
+ * (out: 2 x uint64 on the device). Timed from the host it gives the frequency of both counters. */
+int mss_peak_clock(unsigned long long* out, unsigned long long ticks, void* stream);
 int mss_peak_stream_f32(const float* src, float* dst, long long n, int variant, void* stream);
 /* layout experiment behind the Winograd-domain layout: one coalesced float4 read, ns (16|36) float4 writes
  * into ns slabs that are n floats apart (blocked = 0) or adjacent per block of blk_floats floats (blocked = 1). */

@@ -167,6 +167,7 @@ SIGNATURES = {
     "mss_data_pair_f32": [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, P, P],
     "mss_peak_mfma_f32": [P, I, I, P],
     "mss_peak_mfma_bf16": [P, I, I, I, P],
+    "mss_peak_clock": [P, ctypes.c_ulonglong, P],
     "mss_peak_stream_f32": [P, P, L, I, P],
     "mss_peak_scatter_f32": [P, P, L, I, I, L, P],
 }

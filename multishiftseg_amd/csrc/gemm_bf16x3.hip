@@ -22,8 +22,41 @@
 #include "mss_gemm_tiles.h"
 #include <stdlib.h>
 
+#ifdef MSS_SPLIT_STAMPS
+// DIAGNOSTIC BUILD ONLY (never in libmss_hip.so as shipped): per workgroup-wave the summed s_memtime deltas of the K-step's eight
+// stretches -- top (fragment reads), segments 1..6, barrier -- plus the step count; read back with mss_debug_read_stamps.
+__device__ unsigned long long mss_dbg_stamps[4096 * 12];
+extern "C" int mss_debug_read_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mss_dbg_stamps), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#define MSS_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); dbg_sum[i] += t_ - dbg_last; dbg_last = t_; }
+#else
+#define MSS_STAMP(i)
+#endif
+
+// Dynamic tile scheduling of the persistent kernels (round 5): 64 self-resetting (ticket, done) counter pairs in device memory, one pair
+// per launch in rotation (launches on a stream run in order and every launch zeroes its pair when its last workgroup leaves).
+int* mss_sched_slot() {
+  static int* ring = nullptr;
+  static unsigned seq = 0;
+  if (!ring) {
+    if (hipMalloc(reinterpret_cast<void**>(&ring), 64 * 2 * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(ring, 0, 64 * 2 * sizeof(int)) != hipSuccess) return nullptr;
+  }
+  return ring + 2 * (seq++ % 64);
+}
+
 namespace {
 
+// The tile order of the persistent kernels: the static walk t, t + grid, ... unless built with -DMSS_SPLIT_DYNAMIC_TILES (tickets, see
+// gemm_nt_bf16x3_kernel; `make dynamic_tiles` builds that library for A/B). A compile-time switch: as a run-time one it cost 100
+// spilled registers. Measured (profiles/r05/dynamic_tiles.md): the ticket order equalises the workgroups' lifetimes and changes the
+// launch time by +1 % .. -8 %, because the workgroup the static order leaves alone on its SIMDs runs almost twice as fast there.
+#ifdef MSS_SPLIT_DYNAMIC_TILES
+constexpr bool DYN_TILES = true;
+#else
+constexpr bool DYN_TILES = false;
+#endif
 constexpr int NT = 256, BM = 128, BK = 16;
 constexpr int ROW_B = BK * 2;                 // bytes per row per plane
 constexpr int PLANE = 128 * ROW_B;            // 4 KB: one plane of a 128-row operand block
@@ -60,7 +93,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
 template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false>
 __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf16x3_kernel(MssConvArgs p, const unsigned char* __restrict__ wpl,
                                                                                long long total_tiles, int tiles_per_batch,
-                                                                               int group_m, unsigned blk_bytes, int nblk_total) {
+                                                                               int group_m, unsigned blk_bytes, int nblk_total, int* __restrict__ sched) {
   constexpr int NBLK = BN / 128, TN = BN / 64;          // wave tile 64 x (BN / 2)
   constexpr int STAGE = (1 + NBLK) * OPER;              // A block, then NBLK B blocks
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -128,8 +161,21 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
       so1 = (unsigned)(((size_t)(r1 / p.H) * p.in_ss_stride + chunk * 4) * sizeof(float));
     }
   };
+  // DYNAMIC TILE ORDER (DYN_TILES, an experiment kept for A/B). With the static walk t, t + grid, ... every workgroup has the same
+  // number of tiles, but the two workgroups of a CU do not run at the same speed: the SIMD issues the OLDER wave first, so the
+  // first-dispatched workgroup of each CU finishes its tiles in 3.3 ms and the second one in 4.9 (in-kernel stamps,
+  // profiles/r05/stamps_split.txt). With DYN_TILES the first tile is the static one and every further tile is the next ticket of a
+  // device counter: wave 0 draws a ticket per tile, two tiles ahead (the loader needs the tile after the current one), and hands
+  // it over through two LDS words behind the staging buffers; the fast workgroup simply takes more tiles. Which workgroup
+  // computes a tile does not change a bit of it. It also does not change the launch time: see the note at DYN_TILES.
+  int* tk_slot = reinterpret_cast<int*>(smem + 2 * STAGE);
+  long long nxt_tile = 0;
+  int tiles_done = 0;
+  auto draw_ticket = [&](int slot) {
+    if (DYN_TILES && tid == 0) tk_slot[slot] = (int)gridDim.x + atomicAdd(sched, 1);
+  };
   auto setup_next = [&]() {
-    const long long t = ld_tile + stride;
+    const long long t = DYN_TILES ? nxt_tile : ld_tile + stride;
     setup_off(t < total_tiles ? t : ld_tile, a_nxt, b_nxt, s_nxt, s_nxt1);
   };
   f32x4 areg[2], sreg, hreg, sreg1, hreg1;
@@ -238,6 +284,10 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   const int fa_off = wm * 64 * ROW_B + fr_off;
   const int fb_off = OPER + (BN == 256 ? wn * OPER : wn * 64 * ROW_B) + fr_off;
 
+#ifdef MSS_SPLIT_STAMPS
+  unsigned long long dbg_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dbg_last = 0;
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();   // shader clock / constant 100 MHz
+#endif
   f32x16 acc[TM][TN];
   auto zero_acc = [&]() {
 #pragma unroll
@@ -308,16 +358,19 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
       ld_a(2, a_lo); ld_b(0, b_hi);
       ld_a(1, a_mid); ld_a(0, a_hi);
       fence();
+      MSS_STAMP(0)
       finish_store_b(buf ^ 1);
       mm(a_lo, b_hi);
       MSS_PAIR_UP(0x200, NB < G ? NB : G, NB <= G ? 1 : 2);
       fence();
+      MSS_STAMP(1)
       issue_loads_b();
       ld_b(1, b_mid);
       mm(a_mid, b_hi);
       MSS_PAIR_UP(0x20, NB < G ? NB : G, 1);
       MSS_PAIR_UP(0x100, G - NB > 0 ? (G - NB < TN ? G - NB : TN) : 0, 1);
       fence();
+      MSS_STAMP(2)
       unsigned hi[2], mid[2], lo[2];
       st_ok = raw_ok;
       split_row(0, hi, mid, lo);
@@ -325,6 +378,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
       mm(a_hi, b_hi);
       MSS_PAIR_UP(0x2, G - 1, ((AFFINE ? 30 : 22) + G - 2) / (G - 1));
       fence();
+      MSS_STAMP(3)
       split_row(1, hi, mid, lo);
       store_row(buf ^ 1, 1, hi, mid, lo);
       issue_loads_a();
@@ -332,17 +386,31 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
       mm(a_hi, b_mid);
       MSS_PAIR_UP(0x2, G - 1, ((AFFINE ? 30 : 22) + G - 2) / (G - 1));
       fence();
+      MSS_STAMP(4)
       advance();
       mm(a_mid, b_mid);
       MSS_PAIR_UP(0x6, G - 1, 3);
       fence();
+      MSS_STAMP(5)
       mm(a_hi, b_lo);
+      fence();
+      MSS_STAMP(6)
 #undef MSS_PAIR_UP
     }
     __syncthreads();
+    MSS_STAMP(7)
+#ifdef MSS_SPLIT_STAMPS
+    dbg_sum[8] += 1;
+#endif
   };
 
   long long cur = ld_tile;               // tile being multiplied (the launch guarantees cur < total_tiles)
+  if constexpr (DYN_TILES) {
+    draw_ticket(0);
+    __syncthreads();
+    nxt_tile = __builtin_amdgcn_readfirstlane(tk_slot[0]);
+    draw_ticket(1);                      // read at the end of the first tile, many barriers from here
+  }
   setup_off(ld_tile, a_off, b_off, s_off, s_off1);
   if (CONV) cur_ok = (unsigned)((okb[0] & 1) | ((okb[1] & 1) << 1));
   setup_next();
@@ -355,11 +423,25 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   zero_acc();
   __syncthreads();
   int k = 0;
+#ifdef MSS_SPLIT_STAMPS
+  dbg_last = __builtin_amdgcn_s_memtime();
+#endif
   auto tile_end = [&]() -> bool {        // true: this workgroup has no tile left
     if (++k < n_it) return false;
     epilogue(cur);
-    cur += stride;
-    if (cur >= total_tiles) return true;
+#ifdef MSS_SPLIT_STAMPS
+    dbg_last = __builtin_amdgcn_s_memtime();      // (the epilogue is not part of any stretch)
+#endif
+    if constexpr (DYN_TILES) {
+      cur = nxt_tile;
+      nxt_tile = __builtin_amdgcn_readfirstlane(tk_slot[(tiles_done + 1) & 1]);        // drawn during the tile that just ended
+      if (cur >= total_tiles) return true;
+      draw_ticket(tiles_done & 1);                      // (that word was read a whole tile ago)
+      ++tiles_done;
+    } else {
+      cur += stride;
+      if (cur >= total_tiles) return true;
+    }
     zero_acc();
     k = 0;
     ld_tile = cur;                       // the loader entered `cur` at least one K-step ago (n_it >= 3): prepare the one after it
@@ -372,6 +454,18 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
     step(1);
     if (tile_end()) break;
   }
+  if (DYN_TILES && tid == 0 && atomicAdd(sched + 1, 1) == (int)gridDim.x - 1) {   // the last workgroup out zeroes the pair for its next launch
+    __atomic_store_n(sched, 0, __ATOMIC_RELAXED);
+    __atomic_store_n(sched + 1, 0, __ATOMIC_RELAXED);
+  }
+#ifdef MSS_SPLIT_STAMPS
+  if (lane == 0 && blockIdx.x < 1024) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) mss_dbg_stamps[(blockIdx.x * 4 + wave) * 12 + i] = dbg_sum[i];
+    mss_dbg_stamps[(blockIdx.x * 4 + wave) * 12 + 9] = __builtin_amdgcn_s_memtime() - dbg_t0;
+    mss_dbg_stamps[(blockIdx.x * 4 + wave) * 12 + 10] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -390,7 +484,8 @@ template <bool AFFINE, bool MASKED>
 __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                                 float* __restrict__ out, int P, int M, long long a_bs, long long b_bs, int Kpad,
                                                                 int Cp, int ktiles, int ctiles, int splits, int tps, long long total_tiles,
-                                                                const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
+                                                                const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                                int* __restrict__ sched) {
   constexpr int NBLK = 2, TN = 4, BN = 256;
   constexpr int STAGE = (1 + NBLK) * OPER;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -438,8 +533,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
     o = (unsigned)(((size_t)(row0 + rg * 8) * ld + col) * sizeof(float));
     if (AFFINE) so = is_a ? 0u : (unsigned)((ct * BN + 4 * cq) * sizeof(float));     // (dy lanes load a valid vector and ignore it)
   };
+  // dynamic tile order, as in gemm_nt_bf16x3_kernel
+  int* tk_slot = reinterpret_cast<int*>(smem + 2 * STAGE);
+  long long nxt_tile = 0;
+  int tiles_done = 0;
+  auto draw_ticket = [&](int slot) {
+    if (DYN_TILES && tid == 0) tk_slot[slot] = (int)gridDim.x + atomicAdd(sched, 1);
+  };
   auto setup_next = [&]() {
-    const long long t = ld_tile + stride;
+    const long long t = DYN_TILES ? nxt_tile : ld_tile + stride;
     setup_off(t < total_tiles ? t : ld_tile, nxt, s_nxt, vf_nxt, row_nxt, nit_nxt, slab_nxt);
   };
   f32x4 raw[8], sreg, hreg;
@@ -578,6 +680,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
   };
 
   long long cur = ld_tile;
+  if constexpr (DYN_TILES) {
+    draw_ticket(0);
+    __syncthreads();
+    nxt_tile = __builtin_amdgcn_readfirstlane(tk_slot[0]);
+    draw_ticket(1);
+  }
   setup_off(ld_tile, off, s_off, vf, row_ld, ld_nit, slab);
   setup_next();
   issue_loads();
@@ -592,8 +700,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
   auto tile_end = [&]() -> bool {
     if (++k < cur_nit) return false;
     epilogue(cur);
-    cur += stride;
-    if (cur >= total_tiles) return true;
+    if constexpr (DYN_TILES) {
+      cur = nxt_tile;
+      nxt_tile = __builtin_amdgcn_readfirstlane(tk_slot[(tiles_done + 1) & 1]);
+      if (cur >= total_tiles) return true;
+      draw_ticket(tiles_done & 1);
+      ++tiles_done;
+    } else {
+      cur += stride;
+      if (cur >= total_tiles) return true;
+    }
     zero_acc();
     k = 0;
     cur_nit = (int)((cur / ((long long)ktiles * ctiles)) % splits) == splits - 1 ? nit_last : nit_full;
@@ -606,6 +722,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
     if (tile_end()) break;
     step(1);
     if (tile_end()) break;
+  }
+  if (DYN_TILES && tid == 0 && atomicAdd(sched + 1, 1) == (int)gridDim.x - 1) {
+    __atomic_store_n(sched, 0, __ATOMIC_RELAXED);
+    __atomic_store_n(sched + 1, 0, __ATOMIC_RELAXED);
   }
 }
 
@@ -642,7 +762,7 @@ int launch_split(const MssConvArgs& p, hipStream_t stream) {
   const int tiles_per_batch = p.mtiles * p.ntiles;
   const long long total = (long long)tiles_per_batch * batch;
   if (total <= 0) return MSS_OK;
-  const size_t smem = (size_t)2 * (1 + BN / 128) * OPER;
+  const size_t smem = (size_t)2 * (1 + BN / 128) * OPER + 16;          // + the two ticket words of the dynamic tile order
   static int per_cu_max = 0, cus = 256;
   if (per_cu_max == 0) {
     int dev = 0, n = 0;
@@ -670,8 +790,10 @@ int launch_split(const MssConvArgs& p, hipStream_t stream) {
   }
   const int group_m = MSS_ENV_INT("MSS_GEMM_GROUP_M", GEMM_GROUP_M_DEFAULT);
   const unsigned blk_bytes = (unsigned)(p.C / BK) * (CONV ? p.R * p.S : 1) * OPER;     // CONV: the taps are part of one long reduction
+  int* sched = DYN_TILES ? mss_sched_slot() : nullptr;
+  if (DYN_TILES && !sched) return 2;
   hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF>), dim3(grid), dim3(NT), smem, stream, p,
-                     static_cast<const unsigned char*>(p.w_split), total, tiles_per_batch, group_m, blk_bytes, p.Kpad / 128);
+                     static_cast<const unsigned char*>(p.w_split), total, tiles_per_batch, group_m, blk_bytes, p.Kpad / 128, sched);
   return mss_launch_status();
 }
 
@@ -778,7 +900,7 @@ int mss_wgrad_tn_bf16x3_launch(const MssConvArgs& p, const float* dy, int lddy, 
   const long long slab = (long long)P * p.Kpad * Cp;
   if (pl.splits > 1 && (!ws || ws_bytes < (long long)pl.splits * slab * 4)) return MSS_ERR_BAD_ARG;
   float* out = pl.splits > 1 ? ws : dwp;
-  const size_t smem = (size_t)2 * 3 * OPER;
+  const size_t smem = (size_t)2 * 3 * OPER + 16;
   static bool attr = false;
   if (!attr) {
     const void* ks[4] = {reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<false, false>), reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<false, true>),
@@ -793,9 +915,11 @@ int mss_wgrad_tn_bf16x3_launch(const MssConvArgs& p, const float* dy, int lddy, 
   const int grid = (int)(pl.total < slots ? pl.total : slots);
   const long long a_bs = p.batch > 1 ? p.y_bs : 0, b_bs = p.batch > 1 ? p.x_bs : 0;
   const bool masked = p.M % 16 != 0 || (pl.splits > 1 && p.M - (pl.splits - 1) * pl.tps < 48);
+  int* sched = DYN_TILES ? mss_sched_slot() : nullptr;
+  if (DYN_TILES && !sched) return 2;
 #define TN_LAUNCH(AFF, MSK, SC, SH, RL)                                                                                                      \
   hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<AFF, MSK>), dim3(grid), dim3(NT), smem, s, dy, lddy, p.x, p.C, out, P, p.M, a_bs, b_bs, p.Kpad, Cp, \
-                     pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, SC, SH, RL)
+                     pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, SC, SH, RL, sched)
   if (p.in_scale) {
     if (masked) TN_LAUNCH(true, true, p.in_scale, p.in_shift, p.in_relu); else TN_LAUNCH(true, false, p.in_scale, p.in_shift, p.in_relu);
   } else {

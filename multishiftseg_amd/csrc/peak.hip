@@ -186,6 +186,21 @@ int mss_peak_mfma_f32(float* out, int blocks, int iters, void* stream) {
   return mss_launch_status();
 }
 
+// Clock calibration: one wave spins until s_memrealtime has advanced by `ticks`; out[0] = ticks seen, out[1] = s_memtime ticks in the
+// same span. With the launch timed from the host this gives the frequency of BOTH counters (tools/peaks.py: realtime_MHz, and what
+// s_memtime counts on an otherwise idle chip).
+__global__ void peak_clock_kernel(unsigned long long* out, unsigned long long ticks) {
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r = r0;
+  while (r - r0 < ticks) { __builtin_amdgcn_s_sleep(8); r = __builtin_amdgcn_s_memrealtime(); }
+  if (threadIdx.x == 0) { out[0] = r - r0; out[1] = __builtin_amdgcn_s_memtime() - t0; }
+}
+int mss_peak_clock(unsigned long long* out, unsigned long long ticks, void* stream) {
+  if (!out || ticks == 0) return MSS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(peak_clock_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), out, ticks);
+  return mss_launch_status();
+}
+
 // out: at least blocks*256 floats. bf16 FLOPs performed = blocks * 4 waves * iters * 48 * 32768 (shape 0: 32x32x16) or
 // blocks * 4 * iters * 96 * 16384 (shape 1: 16x16x32) -- the same per iteration.
 int mss_peak_mfma_bf16(float* out, int blocks, int iters, int shape, void* stream) {
