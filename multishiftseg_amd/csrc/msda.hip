@@ -1370,6 +1370,356 @@ __global__ __launch_bounds__(256) void msda_bin_merge_kernel(MsdaBinGeom g, cons
 }
 
 // ------------------------------------------------------------------------------------------
+// grad_value, CELL-SORTED path (round 5). The binned kernel above spends 15 of its 19 VALU slots per
+// sample on making the accumulation order-independent (two 64-bit fixed-point conversions + two LDS atomics per lane).
+// Here the counting sort's key is the CELL: key = (image, head, level, home cell, q mod sub) -- `sub` sub-keys per cell
+// on the levels that receive many samples per cell, so that a key holds ~5 - 25 records -- and one WAVE owns one ROW of
+// cells of one (image, head, level):
+//   msda_cell_kernel<0>      per-key record counts (one global atomic per in-image sample)
+//   msda_scan_*_kernel       exclusive scan of the keys (two launches)
+//   msda_cell_kernel<1>      the 16-byte records to their keys' runs (position inside a run = arrival order)
+//   msda_bwd_value_rows_kernel  a wave walks its row's keys in blocks of whole runs with <= 64 records: lane = record
+//                            computes the four corner weights and the RANK of its record among its run's records by
+//                            (query, point) -- the run is consumed in that order, so the fp32 sums do not depend on the
+//                            arrival order --, stages weights / grad_out row offsets in LDS at the ranked position, then
+//                            lanes = (column, channel) add the records one by one (two FMAs per record) into two
+//                            registers. At a cell boundary the left column's sums and the previous cell's right-column
+//                            sums give the cell's "upper" part (stored to grad_value) and the "lower" part of the cell
+//                            below (stored to a side tensor, the next row belongs to another wave).
+//   msda_rows_merge_kernel   grad_value += lower parts
+// A run longer than 64 records (never at uniform locations) is added in 64-bit fixed point scaled by its own per-lane
+// maximum, which is order-independent too. No LDS atomics, no fixed-point conversion on the common path, bit-reproducible.
+// MEASURED AND NOT ADOPTED (opt-in, MSS_MSDA_BWD_ROWS=1; profiles/r05/msda_bwd_rows.md): at C4 N = 16 the per-sample global
+// atomics of the two sort passes cost 0.53 + 0.98 ms (the binned path's chunk-level LDS histograms: 0.08 + 0.14 -- a chunk
+// of 4096 samples meets 54 x 8 tile keys but 93 k cell keys, nothing to aggregate), and the row kernel takes 0.65 ms, what
+// the binned accumulation takes: the two FMAs per record come with ~15 instructions of run bookkeeping, rank loop and
+// staging per record, and three dependent global latencies per block of 64 records.
+constexpr int MSDA_ROW_MAXL = 8;
+// sh: log2(sub-keys per cell); kstart: first key inside one (image, head); cstart: first cell inside one image of the side tensor
+struct MsdaRowLevel { int H, W, sh, kstart, cstart, item0; };
+struct MsdaRowGeom { MsdaRowLevel lv[MSDA_ROW_MAXL]; int L, KS, rows, cells; };
+
+static bool msda_row_geom(const int64_t* hs, int L, int Lq, int P, MsdaRowGeom& g) {
+  if (L < 1 || L > MSDA_ROW_MAXL) return false;
+  g.L = L;
+  long long ks = 0, rows = 0, cells = 0;
+  double weight[MSDA_ROW_MAXL];
+  for (int l = 0; l < L; ++l) {
+    const long long H = hs[2 * l], W = hs[2 * l + 1];
+    if (H < 1 || W < 1 || H > 32767 || W > 32767) return false;
+    const double density = (double)Lq * P / ((double)H * W);
+    int sh = 0;
+    while (sh < 4 && density / (1 << sh) > 24.0) ++sh;
+    g.lv[l].H = (int)H; g.lv[l].W = (int)W; g.lv[l].sh = sh;
+    if (ks + ((H * W) << sh) >= (1ll << 30)) return false;
+    g.lv[l].kstart = (int)ks;
+    g.lv[l].cstart = (int)cells;
+    ks += (H * W) << sh;
+    cells += H * W;
+    weight[l] = density * (double)W;                        // records per row: the heaviest rows are handed out first
+    rows += H;
+  }
+  bool done[MSDA_ROW_MAXL] = {false};
+  int item0 = 0;
+  for (int k = 0; k < L; ++k) {
+    int best = -1;
+    for (int l = 0; l < L; ++l) if (!done[l] && (best < 0 || weight[l] > weight[best])) best = l;
+    done[best] = true;
+    g.lv[best].item0 = item0;
+    item0 += g.lv[best].H;
+  }
+  for (int l = L; l < MSDA_ROW_MAXL; ++l) { g.lv[l] = g.lv[L - 1]; g.lv[l].item0 = 0x7fffffff; }
+  g.KS = (int)ks;
+  g.rows = (int)rows;
+  g.cells = (int)cells;
+  return true;
+}
+
+// A record: header = kill << 31 | query << 4 | point, then A, B, lw as in the binned path (corners outside the image folded
+// into the weights, so the consumer adds all four unconditionally). MODE 0: count. MODE 1: scatter.
+template <int MODE>
+__global__ __launch_bounds__(256) void msda_cell_kernel(MsdaRowGeom g, const float* __restrict__ loc, const float* __restrict__ attn,
+                                                        int M, int Lq, int P, long long per_image, int* __restrict__ counts_or_cursor,
+                                                        f32x4* __restrict__ records) {
+  __shared__ MsdaRowLevel lv[MSDA_ROW_MAXL];
+  const int tid = threadIdx.x, n = blockIdx.y;
+  if (tid < g.L) lv[tid] = g.lv[tid];
+  __syncthreads();
+  const int L = g.L;
+  int* gk = counts_or_cursor + (size_t)n * M * g.KS;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const long long s = ((long long)blockIdx.x * 4 + it) * 256 + tid;
+    if (s >= per_image) break;
+    const long long gs = (long long)n * per_image + s;
+    const float lx = loc[gs * 2], ly = loc[gs * 2 + 1];
+    const unsigned su = (unsigned)s;                         // per_image < 2^31 (host-checked)
+    const unsigned sp = su / (unsigned)P, p = su - sp * (unsigned)P;
+    const unsigned l = sp % (unsigned)L;
+    const unsigned sm = sp / (unsigned)L;
+    const unsigned m = sm % (unsigned)M, q = sm / (unsigned)M;
+    const MsdaRowLevel v = lv[l];
+    const float w_im = __fmaf_rn(lx, (float)v.W, -0.5f), h_im = __fmaf_rn(ly, (float)v.H, -0.5f);   // one rounding in both modes
+    if (!(h_im > -1.f && w_im > -1.f && h_im < (float)v.H && w_im < (float)v.W)) continue;
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    int h0 = (int)hf, w0 = (int)wf;
+    const int hc = max(h0, 0), wc = max(w0, 0);
+    const int key = (int)m * g.KS + v.kstart + ((hc * v.W + wc) << v.sh) + (int)(q & ((1u << v.sh) - 1u));
+    if (MODE == 0) {
+      (void)__hip_atomic_fetch_add(gk + key, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const int pos = __hip_atomic_fetch_add(gk + key, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float aw = attn[gs];
+      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+      float A, B, lwq;
+      unsigned kill;
+      if (h0 < 0) { A = aw * lh; B = 0.f; }                               // row -1 is outside: row 0 moves up
+      else { A = aw * hh; B = (h0 + 1 <= v.H - 1) ? aw * lh : 0.f; }
+      if (w0 < 0) { lwq = hw; kill = 1u; }                                // column 0 takes 1 - (1 - lw)
+      else { lwq = lw; kill = (w0 + 1 <= v.W - 1) ? 0u : 1u; }
+      f32x4 r;
+      r.x = __uint_as_float((kill << 31) | (q << 4) | p);
+      r.y = A; r.z = B; r.w = lwq;
+      records[pos] = r;
+    }
+  }
+}
+
+// exclusive scan of counts[n] -> offsets[n + 1] and cursor[n], 4096 elements per workgroup: block sums, then each
+// workgroup adds up the sums in front of it (a few hundred) and scans its own elements
+__global__ __launch_bounds__(1024) void msda_scan_sums_kernel(const int* __restrict__ counts, int n, int* __restrict__ bsum) {
+  __shared__ int red[16];
+  const int tid = threadIdx.x, base = blockIdx.x * 4096 + tid * 4;
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sum += base + i < n ? counts[base + i] : 0;
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+    for (int i = 0; i < 16; ++i) t += red[i];
+    bsum[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(1024) void msda_scan_apply_kernel(const int* __restrict__ counts, int n, const int* __restrict__ bsum,
+                                                               int* __restrict__ offsets, int* __restrict__ cursor) {
+  __shared__ int part[1024];
+  __shared__ int red[16];
+  const int tid = threadIdx.x, base = blockIdx.x * 4096 + tid * 4;
+  int pre = 0;
+  for (int i = tid; i < (int)blockIdx.x; i += 1024) pre += bsum[i];
+#pragma unroll
+  for (int o = 32; o; o >>= 1) pre += __shfl_xor(pre, o);
+  if ((tid & 63) == 0) red[tid >> 6] = pre;
+  int c[4], sum = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { c[i] = base + i < n ? counts[base + i] : 0; sum += c[i]; }
+  part[tid] = sum;
+  __syncthreads();
+  int front = 0;
+  for (int i = 0; i < 16; ++i) front += red[i];
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = front + part[tid] - sum;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (base + i < n) { offsets[base + i] = run; cursor[base + i] = run; }
+    run += c[i];
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 1023) offsets[n] = front + part[1023];
+}
+
+template <int UN>
+__global__ __launch_bounds__(256) void msda_bwd_value_rows_kernel(MsdaRowGeom g, const int64_t* __restrict__ starts,
+                                                                  const float* __restrict__ gout, const f32x4* __restrict__ records,
+                                                                  const int* __restrict__ offsets, int* __restrict__ ticket, int S, int M,
+                                                                  int Lq, int N, float* __restrict__ gvalue, float* __restrict__ gbot) {
+  constexpr int D = 32;
+  __shared__ MsdaRowLevel slv[MSDA_ROW_MAXL];
+  __shared__ f32x4 sw_all[4][64];
+  __shared__ unsigned srow_all[4][64];
+  __shared__ unsigned skey_all[4][64];
+  __shared__ int soff_all[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, d = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < g.L) slv[tid] = g.lv[tid];
+  __syncthreads();
+  f32x4* sw = sw_all[wave];
+  unsigned* srow = srow_all[wave];
+  unsigned* skey = skey_all[wave];
+  int* soff = soff_all[wave];
+  const float* swf = reinterpret_cast<const float*>(sw) + half * 2;        // this lane's column: (upper, lower) weight of record i at swf[4 i]
+  const int NM = N * M, nitems = g.rows * NM;
+  const size_t rs = (size_t)M * D;
+  const unsigned rs4 = (unsigned)(rs * sizeof(float)), d4 = (unsigned)d * 4u;
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(gout), 0, (int)(unsigned)min((unsigned long long)N * Lq * rs * 4ull, 0xffffffffull), 0x00020000);
+  const f32x4 zero_rec = {0.f, 0.f, 0.f, 0.f};
+  const int swap_addr = (lane ^ 32) << 2;
+  for (;;) {
+    int item = 0;
+    if (lane == 0) item = atomicAdd(ticket, 1);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= nitems) break;
+    const int irow = item / NM, nm = item - irow * NM;       // row-major over the levels, heaviest level first
+    int l = 0;
+    for (int k = 1; k < g.L; ++k) if (irow >= slv[k].item0 && irow < slv[k].item0 + slv[k].H) l = k;
+    const MsdaRowLevel v = slv[l];
+    const int r = irow - v.item0, n = nm / M, m = nm - n * M;
+    const int nk = v.W << v.sh;
+    const unsigned submask = (1u << v.sh) - 1u;
+    const int* offp = offsets + (size_t)nm * g.KS + v.kstart + (size_t)((r * v.W) << v.sh);
+    const unsigned go_nm = (unsigned)(((size_t)n * Lq * M + m) * D * sizeof(float));
+    float* gv = gvalue + ((size_t)n * S + (size_t)starts[l] + (size_t)r * v.W) * rs + (size_t)m * D + d;
+    float* gb = gbot + ((size_t)n * g.cells + (size_t)v.cstart + (size_t)(r + 1) * v.W) * rs + (size_t)m * D + d;
+    const bool below = r + 1 < v.H;
+    float accT = 0.f, accB = 0.f, prevT = 0.f, prevB = 0.f;
+    int c = 0, kpos = 0;
+    // the cell is complete: lanes 0-31 hold its left-column sums (its own upper part and the lower part of the cell below),
+    // lanes 32-63 the right-column sums, which belong to the NEXT cell of this row and the one below that
+    auto flush = [&]() {
+      const float pT = __int_as_float(__builtin_amdgcn_ds_bpermute(swap_addr, __float_as_int(prevT)));
+      const float pB = __int_as_float(__builtin_amdgcn_ds_bpermute(swap_addr, __float_as_int(prevB)));
+      if (half == 0) {
+        gv[(size_t)c * rs] = accT + pT;
+        if (below) gb[(size_t)c * rs] = accB + pB;
+      }
+      prevT = accT; prevB = accB;
+      accT = 0.f; accB = 0.f;
+      ++c;
+    };
+    // record -> staging slot `pos`: the four corner weights and the byte offset of its grad_out row
+    auto stage = [&](const f32x4& rec, int pos) {
+      const unsigned hd = __float_as_uint(rec.x);
+      const float lwv = rec.w, lwk = (hd >> 31) ? 0.f : lwv, hwv = 1.f - lwv;
+      f32x4 w;
+      w.x = rec.y * hwv; w.y = rec.z * hwv;                  // left column: upper, lower
+      w.z = rec.y * lwk; w.w = rec.z * lwk;                  // right column
+      sw[pos] = w;
+      srow[pos] = ((hd >> 4) & 0x7ffffffu) * rs4;
+    };
+    while (kpos < nk) {
+      const int o = offp[min(kpos + lane, nk)];
+      const int o0 = __builtin_amdgcn_readfirstlane(o);
+      const int rem = min(63, nk - kpos);
+      const unsigned long long fits = __ballot(lane <= rem && o - o0 <= 64);        // a prefix of the lanes (lane 0 always)
+      int t = __popcll(fits) - 1;
+      if (t == 0) {
+        // ---- one key with more than 64 records: order-independent 64-bit fixed-point sums, scaled per lane ----
+        const int beg = o0, end = __builtin_amdgcn_readlane(o, 1);
+        float mx = 0.f;
+        bool bad = false;
+        long long sT = 0, sB = 0;
+        double to_fixed = 0.0, from_fixed = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {
+          for (int b = beg; b < end; b += 64) {
+            stage(b + lane < end ? records[b + lane] : zero_rec, lane);
+            const int cntb = min(64, end - b);
+            for (int i = 0; i < cntb; ++i) {
+              const float gq = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, srow[i] + d4, go_nm, 0));
+              const float cT = swf[4 * i] * gq, cB = swf[4 * i + 1] * gq;
+              if (pass == 0) {
+                mx = fmaxf(mx, fmaxf(fabsf(cT), fabsf(cB)));
+                // (an exponent test, not c - c == 0: the compiler contracts that with the product above into an fma = the rounding error)
+                bad |= (__float_as_uint(cT) & 0x7f800000u) == 0x7f800000u || (__float_as_uint(cB) & 0x7f800000u) == 0x7f800000u;
+              } else {
+                sT += __double_as_longlong(fma((double)cT, to_fixed, 6755399441055744.0)) - 0x4338000000000000ll;
+                sB += __double_as_longlong(fma((double)cB, to_fixed, 6755399441055744.0)) - 0x4338000000000000ll;
+              }
+            }
+          }
+          if (pass == 0) {
+            int e = 0;
+            if (mx > 0.f && !bad) (void)frexpf(mx, &e);
+            to_fixed = bad ? 0.0 : ldexp(1.0, 30 - e);
+            from_fixed = ldexp(1.0, e - 30);
+          }
+        }
+        accT += bad ? __builtin_nanf("") : (float)((double)sT * from_fixed);
+        accB += bad ? __builtin_nanf("") : (float)((double)sB * from_fixed);
+        if (((unsigned)(kpos + 1) & submask) == 0u) flush();
+        kpos += 1;
+        continue;
+      }
+      const int cnt = __builtin_amdgcn_readlane(o, t) - o0;
+      if (cnt > 0) {
+        soff[lane] = o - o0;
+        const f32x4 rec = lane < cnt ? records[o0 + lane] : zero_rec;
+        // this record's key: the last one that starts at or before it
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step; step >>= 1) {
+          const int mid = lo + step;
+          if (mid < t && soff[mid] <= lane) lo = mid;
+        }
+        const int rs_ = soff[lo], re_ = soff[lo + 1];
+        const unsigned mykey = lane < cnt ? (__float_as_uint(rec.x) & 0x7fffffffu) : 0xffffffffu;
+        skey[lane] = mykey;
+        int len = lane < cnt ? re_ - rs_ : 0;
+#pragma unroll
+        for (int of = 32; of; of >>= 1) len = max(len, __shfl_xor(len, of));
+        const int maxr = __builtin_amdgcn_readfirstlane(len);
+        int rank = 0;
+        for (int j = 0; j < maxr; ++j) {
+          const int pj = rs_ + j;
+          rank += (pj < re_ && skey[pj & 63] < mykey) ? 1 : 0;
+        }
+        stage(rec, lane < cnt ? rs_ + rank : lane);
+      }
+      // the records in (key, query, point) order: two FMAs per record and lane
+      int kk = 0;
+      int e_u = __builtin_amdgcn_readlane(o, 1) - o0;
+      auto end_key = [&]() {
+        if (((unsigned)(kpos + kk + 1) & submask) == 0u) flush();
+        ++kk;
+        e_u = kk < t ? __builtin_amdgcn_readlane(o, kk + 1) - o0 : 0x7fffffff;
+      };
+      for (int i0 = 0; i0 < cnt; i0 += UN) {
+        float gq[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+          if (i0 + u < cnt) gq[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, srow[i0 + u] + d4, go_nm, 0));
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int i = i0 + u;
+          if (i < cnt) {
+            while (i == e_u) end_key();
+            accT = __fmaf_rn(swf[4 * i], gq[u], accT);
+            accB = __fmaf_rn(swf[4 * i + 1], gq[u], accB);
+          }
+        }
+      }
+      while (kk < t) end_key();
+      kpos += t;
+    }
+  }
+}
+
+// grad_value[rows 1 .. H-1 of every level] += the lower parts the rows above them left in `gbot`
+__global__ __launch_bounds__(256) void msda_rows_merge_kernel(MsdaRowGeom g, const int64_t* __restrict__ starts, int S, int M, int N,
+                                                            const float* __restrict__ gbot, float* __restrict__ gvalue) {
+  const int l = blockIdx.z, n = blockIdx.y;
+  const MsdaRowLevel v = g.lv[l];
+  const size_t rs4 = (size_t)M * 8;                          // float4s per cell
+  const size_t total = (size_t)(v.H - 1) * v.W * rs4;
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(gbot) + ((size_t)n * g.cells + (size_t)v.cstart + (size_t)v.W) * rs4;
+  f32x4* g4 = reinterpret_cast<f32x4*>(gvalue) + ((size_t)n * S + (size_t)starts[l] + (size_t)v.W) * rs4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    f32x4 a = g4[i];
+    const f32x4 b = b4[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    g4[i] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Operand preparation of the MSDeformAttn module (ops/modules/ms_deform_attn.py:100-109) in one pass:
 //   attn = softmax over the L*P logits of a (query, head);  loc = reference_point[l] + offset / (W_l, H_l)
 // instead of softmax + view + stack + div + add as five elementwise library kernels over the 12-36 values per (q, m).
@@ -1619,6 +1969,83 @@ int msda_backward(const T* value, const int64_t* shapes, const int64_t* starts, 
   return mss_launch_status();
 }
 
+// grad_loc / grad_attn (and, with goff / glog, the module's backward): the gather pass (no atomics)
+static int msda_launch_gather(const float* value, const int64_t* shapes, const int64_t* starts, const float* loc, const float* attn,
+                              const float* gout, int N, int S, int M, int L, int Lq, int P, float* gloc, float* gattn, float* goff,
+                              long long ldo, float* glog, long long ldl, hipStream_t stream) {
+  const long long npairs = (long long)N * Lq * M;
+  const size_t smem_gather = (size_t)4 * 8 * L * P * 4 * sizeof(float);
+  const long long nblocks = (npairs + 31) / 32;
+  const bool buf = (unsigned long long)N * S * M * 32 * 4ull < 0xffffffffull && MSS_ENV_INT("MSS_MSDA_BUF", 1) != 0;
+  if (buf)
+    hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<true>, dim3((unsigned)nblocks), dim3(256), smem_gather, stream, value, shapes, starts,
+                       loc, attn, gout, npairs, S, M, L, Lq, P, gloc, gattn, goff, ldo, glog, ldl);
+  else
+    hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<false>, dim3((unsigned)nblocks), dim3(256), smem_gather, stream, value, shapes, starts,
+                       loc, attn, gout, npairs, S, M, L, Lq, P, gloc, gattn, goff, ldo, glog, ldl);
+  return mss_launch_status();
+}
+
+// workspace of the cell-sorted backward: [header 64 B: ticket][counts][offsets + 1][cursor][block sums] | records | lower parts
+struct MsdaRowWs { size_t counts, offsets, cursor, bsum, records, gbot, total; long long nkeys; int nblk; };
+static bool msda_row_layout(const MsdaRowGeom& g, int N, int M, int L, int Lq, int P, MsdaRowWs& w) {
+  const long long per_image = (long long)Lq * M * L * P;
+  if (per_image >= (1ll << 31) || (long long)N * per_image >= (1ll << 31)) return false;
+  if (P > 16 || Lq >= (1 << 27)) return false;                       // record header: query << 4 | point
+  w.nkeys = (long long)N * M * g.KS;
+  if (w.nkeys >= (1ll << 30) || (long long)g.rows * N * M >= (1ll << 30)) return false;
+  w.nblk = (int)((w.nkeys + 4095) / 4096);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  w.counts = 64;
+  w.offsets = up(w.counts + (size_t)w.nkeys * 4);
+  w.cursor = up(w.offsets + (size_t)(w.nkeys + 1) * 4);
+  w.bsum = up(w.cursor + (size_t)w.nkeys * 4);
+  w.records = up(w.bsum + (size_t)w.nblk * 4);
+  w.gbot = up(w.records + (size_t)N * per_image * 16);
+  w.total = up(w.gbot + (size_t)N * g.cells * M * 32 * 4);
+  return true;
+}
+
+// MSS_ERR_UNSUPPORTED: shapes this path does not take (the caller goes on to the binned path)
+static int msda_backward_rows(const float* value, const int64_t* shapes, const int64_t* starts, const int64_t* host_shapes,
+                              const float* loc, const float* attn, const float* gout, int N, int S, int M, int L, int Lq, int P,
+                              float* gvalue, float* gloc, float* gattn, void* ws, size_t ws_bytes, hipStream_t stream, float* goff,
+                              long long ldo, float* glog, long long ldl) {
+  MsdaRowGeom g;
+  MsdaRowWs w;
+  if (!msda_row_geom(host_shapes, L, Lq, P, g) || !msda_row_layout(g, N, M, L, Lq, P, w)) return MSS_ERR_UNSUPPORTED;
+  if (ws_bytes < w.total || (reinterpret_cast<uintptr_t>(gvalue) & 15)) return MSS_ERR_UNSUPPORTED;
+  long long cells = 0;
+  for (int l = 0; l < L; ++l) cells += host_shapes[2 * l] * host_shapes[2 * l + 1];
+  if (cells < S) {          // rows of the value tensor outside the L levels come back zero (ms_deform_attn_cuda.cu:126)
+    hipError_t ez = hipMemsetAsync(gvalue, 0, (size_t)N * S * M * 32 * sizeof(float), stream);
+    if (ez != hipSuccess) return (int)ez;
+  }
+  char* base = static_cast<char*>(ws);
+  int* ticket = reinterpret_cast<int*>(base);
+  int* counts = reinterpret_cast<int*>(base + w.counts);
+  int* offsets = reinterpret_cast<int*>(base + w.offsets);
+  int* cursor = reinterpret_cast<int*>(base + w.cursor);
+  int* bsum = reinterpret_cast<int*>(base + w.bsum);
+  f32x4* records = reinterpret_cast<f32x4*>(base + w.records);
+  float* gbot = reinterpret_cast<float*>(base + w.gbot);
+  hipError_t e = hipMemsetAsync(base, 0, w.counts + (size_t)w.nkeys * 4, stream);
+  if (e != hipSuccess) return (int)e;
+  const long long per_image = (long long)Lq * M * L * P;
+  const unsigned chunks = (unsigned)((per_image + 1023) / 1024);
+  hipLaunchKernelGGL(msda_cell_kernel<0>, dim3(chunks, (unsigned)N), dim3(256), 0, stream, g, loc, attn, M, Lq, P, per_image, counts, records);
+  hipLaunchKernelGGL(msda_scan_sums_kernel, dim3((unsigned)w.nblk), dim3(1024), 0, stream, counts, (int)w.nkeys, bsum);
+  hipLaunchKernelGGL(msda_scan_apply_kernel, dim3((unsigned)w.nblk), dim3(1024), 0, stream, counts, (int)w.nkeys, bsum, offsets, cursor);
+  hipLaunchKernelGGL(msda_cell_kernel<1>, dim3(chunks, (unsigned)N), dim3(256), 0, stream, g, loc, attn, M, Lq, P, per_image, cursor, records);
+  const long long nitems = (long long)g.rows * N * M;
+  const long long want = (nitems + 3) / 4;
+  const unsigned nwg = (unsigned)(want < 256 * 8 ? want : 256 * 8);        // up to eight 4-wave workgroups per CU, a row per wave
+  hipLaunchKernelGGL(msda_bwd_value_rows_kernel<8>, dim3(nwg), dim3(256), 0, stream, g, starts, gout, records, offsets, ticket, S, M, Lq, N,
+                     gvalue, gbot);
+  hipLaunchKernelGGL(msda_rows_merge_kernel, dim3(128, (unsigned)N, (unsigned)L), dim3(256), 0, stream, g, starts, S, M, N, gbot, gvalue);
+  return msda_launch_gather(value, shapes, starts, loc, attn, gout, N, S, M, L, Lq, P, gloc, gattn, goff, ldo, glog, ldl, stream);
+}
+
 // workspace of the binned backward: [header 64 B: ticket, max|grad_out|, max|attn|][counts][offsets + 1][cursor] | records | halo
 struct MsdaBinWs { size_t counts, offsets, cursor, records, halo, total; long long nkeys; };
 static bool msda_bin_layout(const MsdaBinGeom& g, int N, int M, int L, int Lq, int P, MsdaBinWs& w) {
@@ -1654,12 +2081,20 @@ static int msda_backward_binned(const float* value, const int64_t* shapes, const
   if (!gvalue || !gout || !ws || (!goff && (!gloc || !gattn))) return MSS_ERR_BAD_ARG;
   const size_t smem_gather = (size_t)4 * 8 * L * P * 4 * sizeof(float);
   if (((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(gout)) & 15) != 0 || smem_gather > 65536) return MSS_ERR_UNSUPPORTED;
-  MsdaBinGeom g;
-  MsdaBinWs w;
-  if (!msda_bin_geom(host_shapes, L, Lq, P, (long long)N * Lq * M * L * P, g) || !msda_bin_layout(g, N, M, L, Lq, P, w)) return MSS_ERR_UNSUPPORTED;
   long long cells = 0;
   for (int l = 0; l < L; ++l) cells += host_shapes[2 * l] * host_shapes[2 * l + 1];
   if (cells > S) return MSS_ERR_BAD_ARG;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return MSS_ERR_BAD_ARG;
+  // round 5: the cell-sorted path, opt-in (MSS_MSDA_BWD_ROWS=1; tests and A/B): parity-green and bit-reproducible, but slower than
+  // the binned path at every size measured -- 2.71 ms against 1.35 at C4 N = 16 (profiles/r05/msda_bwd_rows.md)
+  if (MSS_ENV_INT("MSS_MSDA_BWD_ROWS", 0) != 0) {
+    rc = msda_backward_rows(value, shapes, starts, host_shapes, loc, attn, gout, N, S, M, L, Lq, P, gvalue, gloc, gattn, ws, ws_bytes, stream,
+                            goff, ldo, glog, ldl);
+    if (rc != MSS_ERR_UNSUPPORTED) return rc;
+  }
+  MsdaBinGeom g;
+  MsdaBinWs w;
+  if (!msda_bin_geom(host_shapes, L, Lq, P, (long long)N * Lq * M * L * P, g) || !msda_bin_layout(g, N, M, L, Lq, P, w)) return MSS_ERR_UNSUPPORTED;
   if (ws_bytes < w.total || (reinterpret_cast<uintptr_t>(ws) & 255)) return MSS_ERR_BAD_ARG;
   if (cells < S) {
     // the tiles plain-store exactly the rows of the L levels; a value tensor with more rows than the levels cover
@@ -1696,16 +2131,7 @@ static int msda_backward_binned(const float* value, const int64_t* shapes, const
                      Lq, N, gvalue, halo);
   hipLaunchKernelGGL(msda_bin_merge_kernel, dim3((unsigned)g.ntiles, (unsigned)(N * M)), dim3(256), 0, stream, g, starts, S, M, N,
                      halo, gvalue);
-  // grad_loc / grad_attn: the gather pass (no atomics)
-  const long long nblocks = (npairs + 31) / 32;
-  const bool buf = (unsigned long long)N * S * M * D * 4ull < 0xffffffffull && MSS_ENV_INT("MSS_MSDA_BUF", 1) != 0;
-  if (buf)
-    hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<true>, dim3((unsigned)nblocks), dim3(256), smem_gather, stream, value, shapes, starts,
-                       loc, attn, gout, npairs, S, M, L, Lq, P, gloc, gattn, goff, ldo, glog, ldl);
-  else
-    hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<false>, dim3((unsigned)nblocks), dim3(256), smem_gather, stream, value, shapes, starts,
-                       loc, attn, gout, npairs, S, M, L, Lq, P, gloc, gattn, goff, ldo, glog, ldl);
-  return mss_launch_status();
+  return msda_launch_gather(value, shapes, starts, loc, attn, gout, N, S, M, L, Lq, P, gloc, gattn, goff, ldo, glog, ldl, stream);
 }
 
 }  // namespace
@@ -1830,6 +2256,11 @@ long long mss_msda_backward_workspace_bytes(const int64_t* host_shapes, int N, i
   if ((unsigned long long)N * Lq * M * D * 4ull >= 0xffffffffull) return 0;
   if ((size_t)4 * 8 * L * P * 4 * sizeof(float) > 65536) return 0;
   if (!msda_bin_geom(host_shapes, L, Lq, P, (long long)N * Lq * M * L * P, g) || !msda_bin_layout(g, N, M, L, Lq, P, w)) return 0;
+  MsdaRowGeom gr;
+  MsdaRowWs wr;
+  if (MSS_ENV_INT("MSS_MSDA_BWD_ROWS", 0) != 0 && msda_row_geom(host_shapes, L, Lq, P, gr) && msda_row_layout(gr, N, M, L, Lq, P, wr) &&
+      wr.total > w.total)
+    return (long long)wr.total;
   return (long long)w.total;
 }
 

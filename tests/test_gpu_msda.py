@@ -201,8 +201,9 @@ def test_module_golden():
 @pytest.fixture
 def force_bwd(monkeypatch):
     def set_mode(mode):          # "0": atomic scatter kernel, "2": re-scanning owner-computes LDS tiles at any size,
-        if mode == "b":          # "b": binned owner-computes path (round 3, the default whenever fp32 / D = 32)
+        if mode in ("b", "r"):   # "b": binned owner-computes path (round 3), "r": cell-sorted rows (round 5, opt-in)
             monkeypatch.setenv("MSS_MSDA_BWD_BINNED", "1")
+            monkeypatch.setenv("MSS_MSDA_BWD_ROWS", "1" if mode == "r" else "0")
             monkeypatch.delenv("MSS_MSDA_BWD_LDS", raising=False)
         else:
             monkeypatch.setenv("MSS_MSDA_BWD_BINNED", "0")
@@ -210,17 +211,18 @@ def force_bwd(monkeypatch):
     return set_mode
 
 
-@pytest.mark.parametrize("mode", ["0", "2", "b"])
+@pytest.mark.parametrize("mode", ["0", "2", "b", "r"])
 @pytest.mark.parametrize("N,Lq,shapes", [
     (2, 1500, [(22, 22), (44, 44), (88, 88)]),          # C4 geometry
     (1, 900, [(32, 64), (64, 128)]),                     # wide levels: several column tiles
     (2, 257, [(1, 300), (300, 1), (17, 17), (5, 3)]),    # thin and tiny levels, ragged tiles
-    (1, 40000, [(9, 9), (33, 20)]),                      # dense sampling of small levels: 8 x 8 tiles, every halo kind
+    (1, 40000, [(9, 9), (33, 20)]),                      # dense sampling of small levels: 8 x 8 tiles, every halo kind; runs > 64 records
 ])
 def test_backward_formulations_vs_oracle(F, force_bwd, mode, N, Lq, shapes):
-    """The three grad_value formulations (memory-side atomics; tiles owned by a workgroup that re-scans its level, 64-bit
-    fixed point in LDS; the same tiles fed from records binned once by a counting sort, halos merged afterwards) and both
-    gather passes against the numpy oracle, with locations spilling over every border."""
+    """The four grad_value formulations (memory-side atomics; tiles owned by a workgroup that re-scans its level, 64-bit
+    fixed point in LDS; the same tiles fed from records binned once by a counting sort, halos merged afterwards; records
+    sorted by cell and added in (query, point) order by the wave that owns the row) and both gather passes against the
+    numpy oracle, with locations spilling over every border."""
     force_bwd(mode)
     rng = np.random.default_rng(len(shapes) * 100 + N)
     shp = np.array(shapes, dtype=np.int64)
@@ -238,7 +240,7 @@ def test_backward_formulations_vs_oracle(F, force_bwd, mode, N, Lq, shapes):
     np.testing.assert_allclose(a.grad.cpu().numpy(), ga, rtol=1e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("mode", ["0", "2", "b"])
+@pytest.mark.parametrize("mode", ["0", "2", "b", "r"])
 def test_backward_zero_fills_rows_no_level_covers(F, force_bwd, mode):
     """a value tensor with more rows than the levels cover -- padding behind the last level and a gap between two
     levels in level_start_index (the functional API allows both) -- must get ZERO gradient on the uncovered rows on every
@@ -284,11 +286,15 @@ def test_owner_backward_is_order_independent_and_matches_atomics_at_full_size(F,
     g[:, ::7] *= 1e-4                                      # 1e4 dynamic range between queries
     from multishiftseg_amd import MultiScaleDeformableAttention as MSDA
     res = {}
-    for mode in ("0", "2", "2b", "b", "bb"):
+    for mode in ("0", "2", "2b", "b", "bb", "r", "rr"):
         force_bwd(mode[0])
         res[mode] = MSDA.ms_deform_attn_backward(v, shapes, starts, loc, attn, g, 64)
     assert torch.equal(res["2"][0], res["2b"][0])          # integer accumulation: same bits every time
     assert torch.equal(res["b"][0], res["bb"][0])          # ... also when the records arrive in a different order
+    assert torch.equal(res["r"][0], res["rr"][0])          # fp32 sums in (query, point) order: same bits whatever the arrival order
+    assert (res["r"][0] - res["2"][0]).abs().max().item() < 2e-5 * res["0"][0].abs().max().item()
+    for i in (1, 2):
+        assert torch.equal(res["r"][i], res["2"][i])
     scale = res["0"][0].abs().max().item()
     assert (res["0"][0] - res["2"][0]).abs().max().item() < 2e-5 * scale
     # the two owner-computes routes add the same fixed-point integers; only cells on a tile's first row / column differ,
@@ -300,7 +306,7 @@ def test_owner_backward_is_order_independent_and_matches_atomics_at_full_size(F,
     torch.testing.assert_close(res["0"][2], res["2"][2], rtol=1e-3, atol=1e-4 * res["0"][2].abs().max().item())
 
 
-@pytest.mark.parametrize("mode", ["2", "b"])
+@pytest.mark.parametrize("mode", ["2", "b", "r"])
 def test_owner_backward_propagates_non_finite_gradients(F, force_bwd, mode):
     """Fixed-point accumulation cannot represent inf/NaN: a non-finite grad_out must still surface as NaN."""
     force_bwd(mode)

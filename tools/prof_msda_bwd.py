@@ -17,6 +17,6 @@ loc = (ref[:, :, None, :, None, :] + off / shp.flip(-1)[None, None, None, :, Non
 attn = torch.softmax(torch.randn(N, S, 8, 12, device="cuda"), -1).view(N, S, 8, 3, 4).contiguous()
 g = torch.randn(N, S, 256, device="cuda")
 shp._mss_host = shapes
-for _ in range(3):
+for _ in range(8):
     MSDA.ms_deform_attn_backward(value, shp, starts, loc, attn, g, 128)
 torch.cuda.synchronize()
