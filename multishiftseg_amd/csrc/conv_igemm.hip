@@ -1622,11 +1622,26 @@ int mss_conv2d_unpack_wgrad_f32(const float* packed, float* grad, int K, int C, 
   return mss_launch_status();
 }
 
+// K = 128 j + r output channels with 0 < r <= 64 over many pixels (the pixel decoder's merged 288-wide projection = 256 + 32: as ONE
+// product its third 128-row tile is 3/4 padding, 71 - 79 TFLOP/s): the first 128 j channels as one product on the wide kernels and
+// the last r on the narrow streaming kernel, each writing its own rows of dwp. Returns the wide part's channel count, 0 = no split.
+static int wgrad_wide_part(const MssConvArgs& p, int Cp) {
+  if (MSS_ENV_INT("MSS_WGRAD_KSPLIT", 1) == 0) return 0;
+  const int r = p.K % 128;
+  if (p.batch > 1 || p.K <= 128 || r == 0 || r > 64 || Cp != p.C || p.Kpad < p.K) return 0;
+  MssConvArgs t = p;
+  t.K = r; t.Kpad = p.Kpad - (p.K - r);
+  return narrow_shape_ok(t, Cp) && (r <= 32 || r % 2 == 0) ? p.K - r : 0;
+}
+
 // 1 when mss_conv2d_wgrad_f32 evaluates these arguments with the split-bf16 TN kernel (args->route == 1 and the shape eligible), else 0.
 int mss_conv2d_wgrad_route(const MssConvArgs* args, int lddy) {
   MssConvArgs p = *args;
   p.M = p.N * p.OH * p.OW;
-  return p.M > 0 && p.Kpad == p.K && mss_wgrad_tn_bf16x3_eligible(p, lddy) ? 1 : 0;     // (and Cp == C at the call)
+  if (p.M <= 0) return 0;
+  const int wide = wgrad_wide_part(p, p.C);
+  if (wide) p.K = p.Kpad = wide;
+  return p.Kpad == p.K && mss_wgrad_tn_bf16x3_eligible(p, lddy) ? 1 : 0;     // (and Cp == C at the call)
 }
 
 // Bytes of scratch mss_conv2d_wgrad_f32 needs for these arguments (0: the pixel range is not split).
@@ -1634,6 +1649,13 @@ long long mss_conv2d_wgrad_workspace_bytes(const MssConvArgs* args, int Cp) {
   MssConvArgs p = *args;
   p.M = p.N * p.OH * p.OW;
   if (p.M <= 0) return 0;
+  if (const int wide = wgrad_wide_part(p, Cp)) {           // both parts run one after the other on the same scratch
+    MssConvArgs a = p, b = p;
+    a.K = a.Kpad = wide;
+    b.K = p.K - wide; b.Kpad = p.Kpad - wide;
+    const long long wa = mss_conv2d_wgrad_workspace_bytes(&a, Cp), wb = mss_conv2d_wgrad_workspace_bytes(&b, Cp);
+    return wa > wb ? wa : wb;
+  }
   long long tn_bytes = 0;
   if (Cp == p.C && p.Kpad == p.K && mss_wgrad_tn_bf16x3_eligible(p, p.K)) return mss_wgrad_tn_bf16x3_ws_bytes(p, Cp);   // args->route == 1: the split-bf16 TN kernel
   if (tn_eligible(p, p.K)) {                 // lddy == K is assumed here and checked again at launch
@@ -1664,6 +1686,18 @@ int mss_conv2d_wgrad_f32(MssConvArgs* args, const float* dy, int lddy, float* dw
   if (p.M <= 0) return MSS_OK;
   if (p.batch > 1 && (p.R * p.S != 1 || p.batch > 65535)) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (const int wide = wgrad_wide_part(p, Cp)) {
+    MssConvArgs a = *args, b = *args;
+    a.K = a.Kpad = wide;
+    b.K = p.K - wide; b.Kpad = p.Kpad - wide;
+    b.route = 0;                                           // (the narrow kernel is a streaming kernel: nothing to split)
+    b.M = p.M;
+    if (!narrow_eligible(b, dy + wide, lddy, Cp)) goto whole;      // pointer alignment, known only here
+    int rc = mss_conv2d_wgrad_f32(&a, dy, lddy, dwp, Cp, ws, ws_bytes, stream);
+    if (rc != MSS_OK) return rc;
+    return mss_conv2d_wgrad_f32(&b, dy + wide, lddy, dwp + (size_t)wide * Cp, Cp, ws, ws_bytes, stream);
+  }
+whole:
   // (whole 128 x 256 tiles only: a caller that pads dwp beyond K x C keeps the native kernels, which clear the padding)
   if (Cp == p.C && p.Kpad == p.K && mss_wgrad_tn_bf16x3_eligible(p, lddy) && ws_bytes >= mss_wgrad_tn_bf16x3_ws_bytes(p, Cp))
     return mss_wgrad_tn_bf16x3_launch(p, dy, lddy, dwp, Cp, ws, ws_bytes, stream);

@@ -520,7 +520,10 @@ int mss_gemm_nt_bf16x3_launch(MssConvArgs p, void* stream);
 // tile instead of conv_igemm's one-tile-per-workgroup 256 x 64 kernel: 0.203 -> 0.184 ms (256 -> 48) and 0.116 -> 0.087 ms
 // (128 -> 48) at 1 x 512 x 1024 (MSS_GEMM_BN64=0 restores the old route)
 static bool gemm_bn64_wanted(const MssConvArgs& p) {
-  return MSS_ENV_INT("MSS_GEMM_BN64", 1) != 0 && p.K <= 64 && p.K > 32 && p.batch <= 1 && p.C / BK >= 3 && p.M >= 16384;
+  // r05: MSS_GEMM_BN64_MINK (default 32 since r05, 33 before): 256 -> 32 over 162 k rows (the tail of the pixel decoder's
+  // 288-wide projection, 31 TFLOP/s on conv_igemm's 256 x 64 tile)
+  return MSS_ENV_INT("MSS_GEMM_BN64", 1) != 0 && p.K <= 64 && p.K >= MSS_ENV_INT("MSS_GEMM_BN64_MINK", 32) && p.batch <= 1 && p.C / BK >= 3 &&
+         p.M >= 16384;
 }
 
 bool mss_gemm_nt_eligible(const MssConvArgs& p) {
