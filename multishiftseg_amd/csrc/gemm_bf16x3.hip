@@ -90,7 +90,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
 // the rest of the K-step: the tap state advances with selects.
 // ROWAFF: the prologue affine differs per SAMPLE (the Dropout2d fold of mod6 / mod7, wider_resnet.py:139-140,161-162) and a 128-row tile
 // may straddle two images (88 x 88 maps at 700 x 700): every staged row then loads the affine of its own image.
-template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false>
+template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false, bool DYN = false>
 __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf16x3_kernel(MssConvArgs p, const unsigned char* __restrict__ wpl,
                                                                                long long total_tiles, int tiles_per_batch,
                                                                                int group_m, unsigned blk_bytes, int nblk_total, int* __restrict__ sched) {
@@ -161,21 +161,21 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
       so1 = (unsigned)(((size_t)(r1 / p.H) * p.in_ss_stride + chunk * 4) * sizeof(float));
     }
   };
-  // DYNAMIC TILE ORDER (DYN_TILES, an experiment kept for A/B). With the static walk t, t + grid, ... every workgroup has the same
+  // DYNAMIC TILE ORDER (DYN, an experiment kept for A/B). With the static walk t, t + grid, ... every workgroup has the same
   // number of tiles, but the two workgroups of a CU do not run at the same speed: the SIMD issues the OLDER wave first, so the
   // first-dispatched workgroup of each CU finishes its tiles in 3.3 ms and the second one in 4.9 (in-kernel stamps,
-  // profiles/r05/stamps_split.txt). With DYN_TILES the first tile is the static one and every further tile is the next ticket of a
+  // profiles/r05/stamps_split.txt). With DYN the first tile is the static one and every further tile is the next ticket of a
   // device counter: wave 0 draws a ticket per tile, two tiles ahead (the loader needs the tile after the current one), and hands
   // it over through two LDS words behind the staging buffers; the fast workgroup simply takes more tiles. Which workgroup
-  // computes a tile does not change a bit of it. It also does not change the launch time: see the note at DYN_TILES.
+  // computes a tile does not change a bit of it. It also does not change the launch time: see the note at DYN.
   int* tk_slot = reinterpret_cast<int*>(smem + 2 * STAGE);
   long long nxt_tile = 0;
   int tiles_done = 0;
   auto draw_ticket = [&](int slot) {
-    if (DYN_TILES && tid == 0) tk_slot[slot] = (int)gridDim.x + atomicAdd(sched, 1);
+    if (DYN && tid == 0) tk_slot[slot] = (int)gridDim.x + atomicAdd(sched, 1);
   };
   auto setup_next = [&]() {
-    const long long t = DYN_TILES ? nxt_tile : ld_tile + stride;
+    const long long t = DYN ? nxt_tile : ld_tile + stride;
     setup_off(t < total_tiles ? t : ld_tile, a_nxt, b_nxt, s_nxt, s_nxt1);
   };
   f32x4 areg[2], sreg, hreg, sreg1, hreg1;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   };
 
   long long cur = ld_tile;               // tile being multiplied (the launch guarantees cur < total_tiles)
-  if constexpr (DYN_TILES) {
+  if constexpr (DYN) {
     draw_ticket(0);
     __syncthreads();
     nxt_tile = __builtin_amdgcn_readfirstlane(tk_slot[0]);
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
 #ifdef MSS_SPLIT_STAMPS
     dbg_last = __builtin_amdgcn_s_memtime();      // (the epilogue is not part of any stretch)
 #endif
-    if constexpr (DYN_TILES) {
+    if constexpr (DYN) {
       cur = nxt_tile;
       nxt_tile = __builtin_amdgcn_readfirstlane(tk_slot[(tiles_done + 1) & 1]);        // drawn during the tile that just ended
       if (cur >= total_tiles) return true;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
     step(1);
     if (tile_end()) break;
   }
-  if (DYN_TILES && tid == 0 && atomicAdd(sched + 1, 1) == (int)gridDim.x - 1) {   // the last workgroup out zeroes the pair for its next launch
+  if (DYN && tid == 0 && atomicAdd(sched + 1, 1) == (int)gridDim.x - 1) {   // the last workgroup out zeroes the pair for its next launch
     __atomic_store_n(sched, 0, __ATOMIC_RELAXED);
     __atomic_store_n(sched + 1, 0, __ATOMIC_RELAXED);
   }
@@ -610,16 +610,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
+  // Output row of accumulator register r of block i: 4 m + 2 wm + i with m = (r & 3) + 8 (r >> 2) + 4 fkb, i.e. a per-lane part
+  // (16 fkb rows + the lane's column quad: ONE 32-bit byte offset) and a uniform part (2 wm + 4 (r & 3) + 32 (r >> 2) + i rows: a scalar
+  // add to the tile's base). Written as 32 64-bit per-lane offsets the compiler hoisted them out of the tile loop and spilled them:
+  // 18 scratch reloads, each behind an s_waitcnt vmcnt(0), in front of every tile's stores.
+  typedef unsigned char __attribute__((address_space(1)))* gwptr_t;
+  const unsigned ep_lane = (unsigned)(((size_t)(16 * fkb) * Cp + (size_t)(wn * 128 + 4 * frow)) * sizeof(float));
   auto epilogue = [&](long long t) {
     int pb, sp, kt, ct; decode(t, pb, sp, kt, ct);
-    float* o = out + ((size_t)sp * P + pb) * Kpad * Cp + (size_t)(kt * 128) * Cp + (size_t)(ct * BN + wn * 128 + 4 * frow);
+    gwptr_t tile = (gwptr_t)(out + ((size_t)sp * P + pb) * Kpad * Cp + (size_t)(kt * 128 + 2 * wm) * Cp + (size_t)(ct * BN));
+    const size_t row_b = (size_t)Cp * sizeof(float);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * fkb;
+        gwptr_t rowp = tile + (size_t)(4 * (r & 3) + 32 * (r >> 2) + i) * row_b;          // uniform
+        asm volatile("" : "+s"(rowp));
         const f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-        *reinterpret_cast<f32x4*>(o + (size_t)(4 * m + 2 * wm + i) * Cp) = v;
+        *reinterpret_cast<f32x4 __attribute__((address_space(1)))*>(rowp + ep_lane) = v;
       }
   };
   auto step = [&](const int buf) {
@@ -756,8 +764,16 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   }
 }
 
+// The ticket tile order (DYN) per instantiation: the kernels with a prologue on a 128 x 256 tile. Their static form spills 4 - 12
+// registers into scratch inside the K-loop (whose loads and stores share the vector-memory counter with the tile prefetch), the
+// ticket form none: 187 -> 236 TFLOP/s on 65536 x 2048 -> 4096 with BatchNorm + ReLU on the input (profiles/r05/dynamic_tiles.md).
+// Everywhere else the static walk is as fast or faster (it keeps the XCD grouping of the tiles).
+template <bool AFFINE, int BN, bool CONV>
+constexpr bool split_dyn_tiles() { return DYN_TILES || (AFFINE && BN == 256 && !CONV); }
+
 template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false>
 int launch_split(const MssConvArgs& p, hipStream_t stream) {
+  constexpr bool DYN = split_dyn_tiles<AFFINE, BN, CONV>();
   const int batch = p.batch > 1 ? p.batch : 1;
   const int tiles_per_batch = p.mtiles * p.ntiles;
   const long long total = (long long)tiles_per_batch * batch;
@@ -769,11 +785,11 @@ int launch_split(const MssConvArgs& p, hipStream_t stream) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (smem > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF, DYN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF>, NT, smem) != hipSuccess || n < 1) n = BN == 256 ? 2 : 3;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF, DYN>, NT, smem) != hipSuccess || n < 1) n = BN == 256 ? 2 : 3;
     const int cap = MSS_ENV_INT("MSS_GEMM_WG_PER_CU", 0);
     if (cap > 0 && cap < n) n = cap;
     per_cu_max = n;
@@ -790,9 +806,9 @@ int launch_split(const MssConvArgs& p, hipStream_t stream) {
   }
   const int group_m = MSS_ENV_INT("MSS_GEMM_GROUP_M", GEMM_GROUP_M_DEFAULT);
   const unsigned blk_bytes = (unsigned)(p.C / BK) * (CONV ? p.R * p.S : 1) * OPER;     // CONV: the taps are part of one long reduction
-  int* sched = DYN_TILES ? mss_sched_slot() : nullptr;
-  if (DYN_TILES && !sched) return 2;
-  hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF>), dim3(grid), dim3(NT), smem, stream, p,
+  int* sched = DYN ? mss_sched_slot() : nullptr;
+  if (DYN && !sched) return 2;
+  hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF, DYN>), dim3(grid), dim3(NT), smem, stream, p,
                      static_cast<const unsigned char*>(p.w_split), total, tiles_per_batch, group_m, blk_bytes, p.Kpad / 128, sched);
   return mss_launch_status();
 }
