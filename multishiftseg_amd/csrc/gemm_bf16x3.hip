@@ -21,6 +21,9 @@
 #include "mss_epilogue.h"
 #include "mss_gemm_tiles.h"
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
+#include <utility>
 
 #ifdef MSS_SPLIT_STAMPS
 // DIAGNOSTIC BUILD ONLY (never in libmss_hip.so as shipped): per workgroup-wave the summed s_memtime deltas of the K-step's eight
@@ -34,16 +37,29 @@ extern "C" int mss_debug_read_stamps(unsigned long long* host, int n) {
 #define MSS_STAMP(i)
 #endif
 
-// Dynamic tile scheduling of the persistent kernels (round 5): 64 self-resetting (ticket, done) counter pairs in device memory, one pair
-// per launch in rotation (launches on a stream run in order and every launch zeroes its pair when its last workgroup leaves).
-int* mss_sched_slot() {
-  static int* ring = nullptr;
-  static unsigned seq = 0;
-  if (!ring) {
-    if (hipMalloc(reinterpret_cast<void**>(&ring), 64 * 2 * sizeof(int)) != hipSuccess) return nullptr;
-    if (hipMemset(ring, 0, 64 * 2 * sizeof(int)) != hipSuccess) return nullptr;
+// Dynamic tile scheduling of the persistent kernels (round 5): self-resetting (ticket, done) counter pairs in device memory. A pair
+// may only be shared by launches that cannot overlap, so every STREAM gets its own ring of 8 pairs, used in rotation (launches on a
+// stream run in order and every launch zeroes its pair when its last workgroup leaves). The rings come out of one pool that is
+// allocated and cleared by the first call in the process -- nothing is allocated later, e.g. under a stream capture; a process
+// with more than 64 streams that launch these kernels gets MSS_ERR_UNSUPPORTED from the launcher (nullptr here).
+int* mss_sched_slot(hipStream_t stream) {
+  constexpr int RINGS = 64, PAIRS = 8;
+  static std::mutex mu;
+  static int* pool = nullptr;
+  static std::unordered_map<hipStream_t, std::pair<int, unsigned>> rings;     // stream -> (ring index, launches so far)
+  std::lock_guard<std::mutex> lock(mu);
+  if (!pool) {
+    int* q = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&q), RINGS * PAIRS * 2 * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(q, 0, RINGS * PAIRS * 2 * sizeof(int)) != hipSuccess) { (void)hipFree(q); return nullptr; }
+    pool = q;
   }
-  return ring + 2 * (seq++ % 64);
+  auto it = rings.find(stream);
+  if (it == rings.end()) {
+    if ((int)rings.size() >= RINGS) return nullptr;
+    it = rings.emplace(stream, std::make_pair((int)rings.size(), 0u)).first;
+  }
+  return pool + ((size_t)it->second.first * PAIRS + it->second.second++ % PAIRS) * 2;
 }
 
 namespace {
@@ -806,8 +822,8 @@ int launch_split(const MssConvArgs& p, hipStream_t stream) {
   }
   const int group_m = MSS_ENV_INT("MSS_GEMM_GROUP_M", GEMM_GROUP_M_DEFAULT);
   const unsigned blk_bytes = (unsigned)(p.C / BK) * (CONV ? p.R * p.S : 1) * OPER;     // CONV: the taps are part of one long reduction
-  int* sched = DYN ? mss_sched_slot() : nullptr;
-  if (DYN && !sched) return 2;
+  int* sched = DYN ? mss_sched_slot(stream) : nullptr;
+  if (DYN && !sched) return MSS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF, DYN>), dim3(grid), dim3(NT), smem, stream, p,
                      static_cast<const unsigned char*>(p.w_split), total, tiles_per_batch, group_m, blk_bytes, p.Kpad / 128, sched);
   return mss_launch_status();
@@ -931,8 +947,8 @@ int mss_wgrad_tn_bf16x3_launch(const MssConvArgs& p, const float* dy, int lddy, 
   const int grid = (int)(pl.total < slots ? pl.total : slots);
   const long long a_bs = p.batch > 1 ? p.y_bs : 0, b_bs = p.batch > 1 ? p.x_bs : 0;
   const bool masked = p.M % 16 != 0 || (pl.splits > 1 && p.M - (pl.splits - 1) * pl.tps < 48);
-  int* sched = DYN_TILES ? mss_sched_slot() : nullptr;
-  if (DYN_TILES && !sched) return 2;
+  int* sched = DYN_TILES ? mss_sched_slot(s) : nullptr;
+  if (DYN_TILES && !sched) return MSS_ERR_UNSUPPORTED;
 #define TN_LAUNCH(AFF, MSK, SC, SH, RL)                                                                                                      \
   hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<AFF, MSK>), dim3(grid), dim3(NT), smem, s, dy, lddy, p.x, p.C, out, P, p.M, a_bs, b_bs, p.Kpad, Cp, \
                      pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, SC, SH, RL, sched)

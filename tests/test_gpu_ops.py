@@ -601,6 +601,54 @@ def test_bf16x3_implicit_gemm_vs_float64(K, cin, cout, r, stride, dil, n, h, w, 
     np.testing.assert_allclose(st[:, 0].double().cpu().numpy(), yp.sum(1).cpu().numpy(), rtol=1e-4, atol=1e-3)
 
 
+def test_bf16x3_ticket_tile_order_on_two_streams_at_once(K):
+    """The 128 x 256 split kernels with a prologue walk their tiles off a device ticket counter (gemm_bf16x3.hip, split_dyn_tiles): a
+    counter pair may only be shared by launches that cannot overlap, so every stream has its own ring. Two streams launch such
+    products at the same time, 40 each -- one long, one short, so launches of one stream overlap several of the other -- and
+    every output must be bit-identical to the same product computed alone."""
+    import ctypes
+    from multishiftseg_amd import _lib
+    from multishiftseg_amd._lib import MssConvArgs, call, ptr
+    torch.manual_seed(11)
+
+    def product(rows, c, k):
+        x = torch.randn(rows, c, device="cuda")
+        kpad = _lib.value("mss_conv2d_kpad", k)
+        w = torch.zeros(1, kpad, c, device="cuda")
+        w[:, :k] = torch.randn(1, k, c, device="cuda") / c ** 0.5
+        sc, sh = torch.rand(c, device="cuda") + 0.5, torch.randn(c, device="cuda") * 0.3
+        planes = K.split_planes(w, kpad, c)
+
+        def run(y):
+            a = MssConvArgs()
+            a.x, a.w, a.y, a.w_split = ptr(x), ptr(w), ptr(y), ptr(planes)
+            a.in_scale, a.in_shift, a.in_relu = ptr(sc), ptr(sh), 1
+            a.N, a.H, a.W, a.C, a.ldx = 1, 1, rows, c, c
+            a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, rows, k, kpad, k
+            a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
+            assert _lib.value("mss_conv2d_forward_route", ctypes.byref(a)) == 3
+            call("mss_conv2d_forward_f32", ctypes.byref(a))
+        keep = (x, w, sc, sh, planes)
+        return run, keep, (rows, k)
+    jobs = [product(40000, 512, 512), product(9000, 256, 256)]
+    want = []
+    for run, _, (rows, k) in jobs:
+        y = torch.empty(rows, k, device="cuda")
+        run(y)
+        want.append(y)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[torch.full((rows, k), float("nan"), device="cuda") for _ in range(40)] for _, _, (rows, k) in jobs]
+    for i in range(40):
+        for j, (run, _, _) in enumerate(jobs):
+            with torch.cuda.stream(streams[j]):
+                run(outs[j][i])
+    torch.cuda.synchronize()
+    for j in range(2):
+        for y in outs[j]:
+            assert torch.equal(y, want[j])
+
+
 def test_bf16x3_route_is_taken_by_the_layer_wrappers(K):
     """kernels.set_gemm_route("bf16x3") / MSS_GEMM_SPLIT=1 must reach the kernel through every wrapper that builds MssConvArgs: a 1x1
     layer, a Winograd layer (with the 304 = 256 + 48 output split, whose 48-channel tail stays on the native narrow tile) and a
