@@ -40,26 +40,29 @@ extern "C" int mss_debug_read_stamps(unsigned long long* host, int n) {
 // Dynamic tile scheduling of the persistent kernels (round 5): self-resetting (ticket, done) counter pairs in device memory. A pair
 // may only be shared by launches that cannot overlap, so every STREAM gets its own ring of 8 pairs, used in rotation (launches on a
 // stream run in order and every launch zeroes its pair when its last workgroup leaves). The rings come out of one pool that is
-// allocated and cleared by the first call in the process -- nothing is allocated later, e.g. under a stream capture; a process
+// allocated and cleared by the first call on a device -- nothing is allocated later, e.g. under a stream capture; a process
 // with more than 64 streams that launch these kernels gets MSS_ERR_UNSUPPORTED from the launcher (nullptr here).
 int* mss_sched_slot(hipStream_t stream) {
-  constexpr int RINGS = 64, PAIRS = 8;
+  constexpr int RINGS = 64, PAIRS = 8, MAXDEV = 16;
   static std::mutex mu;
-  static int* pool = nullptr;
-  static std::unordered_map<hipStream_t, std::pair<int, unsigned>> rings;     // stream -> (ring index, launches so far)
+  static int* pools[MAXDEV] = {nullptr};                                      // one pool per device of this process
+  static std::unordered_map<hipStream_t, std::pair<int, unsigned>> rings[MAXDEV];   // stream -> (ring index, launches so far)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
-  if (!pool) {
+  if (!pools[dev]) {
     int* q = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&q), RINGS * PAIRS * 2 * sizeof(int)) != hipSuccess) return nullptr;
     if (hipMemset(q, 0, RINGS * PAIRS * 2 * sizeof(int)) != hipSuccess) { (void)hipFree(q); return nullptr; }
-    pool = q;
+    pools[dev] = q;
   }
-  auto it = rings.find(stream);
-  if (it == rings.end()) {
-    if ((int)rings.size() >= RINGS) return nullptr;
-    it = rings.emplace(stream, std::make_pair((int)rings.size(), 0u)).first;
+  auto& map = rings[dev];
+  auto it = map.find(stream);
+  if (it == map.end()) {
+    if ((int)map.size() >= RINGS) return nullptr;
+    it = map.emplace(stream, std::make_pair((int)map.size(), 0u)).first;
   }
-  return pool + ((size_t)it->second.first * PAIRS + it->second.second++ % PAIRS) * 2;
+  return pools[dev] + ((size_t)it->second.first * PAIRS + it->second.second++ % PAIRS) * 2;
 }
 
 namespace {
