@@ -37,13 +37,14 @@ extern "C" int mss_debug_read_stamps(unsigned long long* host, int n) {
 #define MSS_STAMP(i)
 #endif
 
-// Dynamic tile scheduling of the persistent kernels (round 5): self-resetting (ticket, done) counter pairs in device memory. A pair
-// may only be shared by launches that cannot overlap, so every STREAM gets its own ring of 8 pairs, used in rotation (launches on a
+// Dynamic tile scheduling of the persistent kernels (round 5): self-resetting counter slots in device memory (eight per-XCD ticket
+// counters + a count of finished workgroups, draw_xcd_ticket). A slot
+// may only be shared by launches that cannot overlap, so every STREAM gets its own ring of 8 slots, used in rotation (launches on a
 // stream run in order and every launch zeroes its pair when its last workgroup leaves). The rings come out of one pool that is
 // allocated and cleared by the first call on a device -- nothing is allocated later, e.g. under a stream capture; a process
 // with more than 64 streams that launch these kernels gets MSS_ERR_UNSUPPORTED from the launcher (nullptr here).
 int* mss_sched_slot(hipStream_t stream) {
-  constexpr int RINGS = 64, PAIRS = 8, MAXDEV = 16;
+  constexpr int RINGS = 64, PAIRS = 8, MAXDEV = 16, SLOT = 16;     // a slot: 8 per-XCD ticket counters + the done counter (64 B)
   static std::mutex mu;
   static int* pools[MAXDEV] = {nullptr};                                      // one pool per device of this process
   static std::unordered_map<hipStream_t, std::pair<int, unsigned>> rings[MAXDEV];   // stream -> (ring index, launches so far)
@@ -52,8 +53,8 @@ int* mss_sched_slot(hipStream_t stream) {
   std::lock_guard<std::mutex> lock(mu);
   if (!pools[dev]) {
     int* q = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&q), RINGS * PAIRS * 2 * sizeof(int)) != hipSuccess) return nullptr;
-    if (hipMemset(q, 0, RINGS * PAIRS * 2 * sizeof(int)) != hipSuccess) { (void)hipFree(q); return nullptr; }
+    if (hipMalloc(reinterpret_cast<void**>(&q), RINGS * PAIRS * SLOT * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(q, 0, RINGS * PAIRS * SLOT * sizeof(int)) != hipSuccess) { (void)hipFree(q); return nullptr; }
     pools[dev] = q;
   }
   auto& map = rings[dev];
@@ -62,7 +63,7 @@ int* mss_sched_slot(hipStream_t stream) {
     if ((int)map.size() >= RINGS) return nullptr;
     it = map.emplace(stream, std::make_pair((int)map.size(), 0u)).first;
   }
-  return pools[dev] + ((size_t)it->second.first * PAIRS + it->second.second++ % PAIRS) * 2;
+  return pools[dev] + ((size_t)it->second.first * PAIRS + it->second.second++ % PAIRS) * SLOT;
 }
 
 namespace {
@@ -99,6 +100,22 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
   mid = cvt_pk_bf16(ra, rb);
   const float qa = ra - __uint_as_float(mid << 16), qb = rb - __uint_as_float(mid & 0xffff0000u);
   lo = cvt_pk_bf16(qa, qb);
+}
+
+// One ticket of the dynamic tile order (thread 0 of a workgroup). The static walk gives workgroup b the tiles v, v + grid, v + 2 grid,
+// ... with v = mss_xcd_remap(b): every XCD owns a contiguous range of v, so the tiles in flight on an XCD share their operands
+// through its L2. A single global counter loses that (64 x 2304 x 4096 -> 256: -8 %), so there is one counter per XCD over the list
+// of ITS tiles in the static order (entry j -> v = base + j % cnt, round j / cnt; the first cnt entries are the static first
+// tiles). The lists of the eight XCDs differ by at most one tile per round, so nothing is taken from a neighbour's list.
+// Returns total_tiles when the list is exhausted.
+__device__ __forceinline__ int draw_xcd_ticket(int* __restrict__ sched, long long total_tiles) {
+  const int nwg = (int)gridDim.x, q = nwg >> 3, r = nwg & 7, x = (int)blockIdx.x & 7;
+  const int cnt = q + (x < r ? 1 : 0);                       // >= 1: this workgroup is one of them
+  const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  const unsigned j = (unsigned)(cnt + atomicAdd(sched + x, 1));
+  const unsigned round = j / (unsigned)cnt;
+  const long long t = base + (int)(j - round * (unsigned)cnt) + (long long)round * nwg;
+  return t < total_tiles ? (int)t : (int)total_tiles;
 }
 
 // CONV (round 5): the same kernel as an IMPLICIT GEMM for the layers conv_igemm_kernel takes (3x3 with stride 2 or few input channels, 1x1
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
   long long nxt_tile = 0;
   int tiles_done = 0;
   auto draw_ticket = [&](int slot) {
-    if (DYN && tid == 0) tk_slot[slot] = (int)gridDim.x + atomicAdd(sched, 1);
+    if (DYN && tid == 0) tk_slot[slot] = draw_xcd_ticket(sched, total_tiles);
   };
   auto setup_next = [&]() {
     const long long t = DYN ? nxt_tile : ld_tile + stride;
@@ -473,9 +490,9 @@ __global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf1
     step(1);
     if (tile_end()) break;
   }
-  if (DYN && tid == 0 && atomicAdd(sched + 1, 1) == (int)gridDim.x - 1) {   // the last workgroup out zeroes the pair for its next launch
-    __atomic_store_n(sched, 0, __ATOMIC_RELAXED);
-    __atomic_store_n(sched + 1, 0, __ATOMIC_RELAXED);
+  if (DYN && tid == 0 && atomicAdd(sched + 8, 1) == (int)gridDim.x - 1) {   // the last workgroup out zeroes the counters for their next launch
+#pragma unroll
+    for (int i = 0; i < 9; ++i) __atomic_store_n(sched + i, 0, __ATOMIC_RELAXED);
   }
 #ifdef MSS_SPLIT_STAMPS
   if (lane == 0 && blockIdx.x < 1024) {
@@ -557,7 +574,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
   long long nxt_tile = 0;
   int tiles_done = 0;
   auto draw_ticket = [&](int slot) {
-    if (DYN_TILES && tid == 0) tk_slot[slot] = (int)gridDim.x + atomicAdd(sched, 1);
+    if (DYN_TILES && tid == 0) tk_slot[slot] = draw_xcd_ticket(sched, total_tiles);
   };
   auto setup_next = [&]() {
     const long long t = DYN_TILES ? nxt_tile : ld_tile + stride;
@@ -750,9 +767,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
     step(1);
     if (tile_end()) break;
   }
-  if (DYN_TILES && tid == 0 && atomicAdd(sched + 1, 1) == (int)gridDim.x - 1) {
-    __atomic_store_n(sched, 0, __ATOMIC_RELAXED);
-    __atomic_store_n(sched + 1, 0, __ATOMIC_RELAXED);
+  if (DYN_TILES && tid == 0 && atomicAdd(sched + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) __atomic_store_n(sched + i, 0, __ATOMIC_RELAXED);
   }
 }
 
