@@ -127,7 +127,7 @@ __device__ __forceinline__ int draw_xcd_ticket(int* __restrict__ sched, long lon
 // ROWAFF: the prologue affine differs per SAMPLE (the Dropout2d fold of mod6 / mod7, wider_resnet.py:139-140,161-162) and a 128-row tile
 // may straddle two images (88 x 88 maps at 700 x 700): every staged row then loads the affine of its own image.
 template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false, bool DYN = false>
-__global__ __launch_bounds__(NT, (BN == 256 || AFFINE) ? 2 : 3) void gemm_nt_bf16x3_kernel(MssConvArgs p, const unsigned char* __restrict__ wpl,
+__global__ __launch_bounds__(NT, (BN == 256 || (AFFINE && (CONV || ROWAFF))) ? 2 : 3) void gemm_nt_bf16x3_kernel(MssConvArgs p, const unsigned char* __restrict__ wpl,
                                                                                long long total_tiles, int tiles_per_batch,
                                                                                int group_m, unsigned blk_bytes, int nblk_total, int* __restrict__ sched) {
   constexpr int NBLK = BN / 128, TN = BN / 64;          // wave tile 64 x (BN / 2)
@@ -804,12 +804,14 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 // registers into scratch inside the K-loop (whose loads and stores share the vector-memory counter with the tile prefetch), the
 // ticket form none: 187 -> 236 TFLOP/s on 65536 x 2048 -> 4096 with BatchNorm + ReLU on the input (profiles/r05/dynamic_tiles.md).
 // Everywhere else the static walk is as fast or faster (it keeps the XCD grouping of the tiles).
-template <bool AFFINE, int BN, bool CONV>
-constexpr bool split_dyn_tiles() { return DYN_TILES || (AFFINE && BN == 256 && !CONV); }
+// The 128-wide kernel with a prologue: 175 registers in the static form (two workgroups per CU), 165 in the ticket form -- three
+// workgroups per CU like the plain 128-wide kernel (the per-sample-affine variant spills there and stays as it was).
+template <bool AFFINE, int BN, bool CONV, bool ROWAFF>
+constexpr bool split_dyn_tiles() { return DYN_TILES || (AFFINE && !CONV && !ROWAFF); }
 
 template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false>
 int launch_split(const MssConvArgs& p, hipStream_t stream) {
-  constexpr bool DYN = split_dyn_tiles<AFFINE, BN, CONV>();
+  constexpr bool DYN = split_dyn_tiles<AFFINE, BN, CONV, ROWAFF>();
   const int batch = p.batch > 1 ? p.batch : 1;
   const int tiles_per_batch = p.mtiles * p.ntiles;
   const long long total = (long long)tiles_per_batch * batch;
