@@ -375,6 +375,12 @@ int mss_rcl_pass1_f32(const MssRclArgs* a, float* lse, float* ce_aug, uint8_t* k
  * = {threshold key, n_less, k, n_equal_to_take, tie tickets, ...}. */
 int mss_rcl_select_f32(const float* ce_aug, long long n, const double* counters, float selection_ratio,
                        uint32_t* hist_ws, uint32_t* sel, void* stream);
+/* the same selection, bit-identical sel[0..3], in 5 launches instead of 9 (each pick rides in front of the next byte's histogram
+ * pass): what mss_rcl_loss_device_f32 runs. scratch: MSS_RCL_SELECT_SCRATCH_WORDS uint32 (four histograms + two state buffers),
+ * cleared by the call unless scratch_zeroed != 0. */
+#define MSS_RCL_SELECT_SCRATCH_WORDS (4 * 256 + 16)
+int mss_rcl_select_merged_f32(const float* ce_aug, long long n, const double* counters, float selection_ratio,
+                              uint32_t* scratch, int scratch_zeroed, uint32_t* sel, void* stream);
 /* the same selection one radix pass at a time (shift = 24, 16, 8, 0): a data-parallel caller
  * all-reduces the 256-bin histogram between hist and pick -> exact GLOBAL k-th smallest. */
 int mss_rcl_select_init_f32(const double* counters, float selection_ratio, uint32_t* hist_ws, uint32_t* sel,

@@ -113,6 +113,7 @@ SIGNATURES = {
     "mss_m2f_score_f32": [P, P, I, I, I, I, I, I, I, P, P],
     "mss_rcl_pass1_f32": [POINTER(MssRclArgs), P, P, P, P, P, P],
     "mss_rcl_select_f32": [P, L, P, F, P, P, P],
+    "mss_rcl_select_merged_f32": [P, L, P, F, P, I, P, P],
     "mss_rcl_pass2_f32": [POINTER(MssRclArgs), P, P, P, P, P, F, P, P],
     "mss_rcl_num_compact_blocks": [I, I, I],
     "mss_rcl_compact_f32": [P, I, I, I, P, P, P, P, P, P],

@@ -331,6 +331,94 @@ __global__ void rcl_pick_kernel(uint32_t* sel, uint32_t* hist, int shift) {
   for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
 }
 
+// ---- the selection in 5 launches instead of 9 (round 5): the pick of digit d+1 rides in front of the histogram of digit d ----
+// Every workgroup of the histogram pass of byte `shift` first repeats the pick of the byte above it from the finished
+// histogram of that byte (a 256-lane scan: ~1 us, against a launch of its own), so the chain is hist(24) hist(16) hist(8)
+// hist(0) pick(0). The selection state travels through two alternating 8-word buffers (workgroup 0 writes the state AFTER
+// its pick for the next launch; the others may still be reading the state before it), each pass has its own histogram.
+// FIRST: no pick, the state is the initial one (k from the pass-1 counters, as rcl_select_init_kernel).
+struct RclSelState { uint32_t prefix, less, k, krem; };
+__device__ __forceinline__ RclSelState rcl_pick_digit(const uint32_t* __restrict__ sel_in, const uint32_t* __restrict__ hist_prev,
+                                                      int shift_prev, uint32_t* scan, uint32_t* st) {
+  const uint32_t cnt = hist_prev[threadIdx.x];
+  scan[threadIdx.x] = cnt;
+  if (threadIdx.x == 0) { st[0] = sel_in[0]; st[1] = sel_in[1]; st[2] = sel_in[2]; st[3] = sel_in[5]; }
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const uint32_t t = threadIdx.x >= (unsigned)o ? scan[threadIdx.x - o] : 0u;
+    __syncthreads();
+    scan[threadIdx.x] += t;
+    __syncthreads();
+  }
+  const uint32_t k = st[2], krem = st[3], prefix = st[0], less = st[1];
+  __syncthreads();
+  if (k != 0) {
+    const uint32_t incl = scan[threadIdx.x], excl = incl - cnt;
+    const bool mine = excl < krem && krem <= incl;
+    const bool fallback = threadIdx.x == 255 && krem > incl;     // cannot happen for a consistent k; mirrors rcl_pick_par_kernel
+    if (mine || fallback) { st[0] = prefix | ((uint32_t)threadIdx.x << shift_prev); st[1] = less + excl; st[3] = krem - excl; }
+  }
+  __syncthreads();
+  RclSelState r = {st[0], st[1], st[2], st[3]};
+  return r;
+}
+
+template <bool WAVE_AGG, bool FIRST>
+__global__ __launch_bounds__(256) void rcl_hist_pick_kernel(const float* __restrict__ v, long long n, const double* __restrict__ counters,
+                                                            float ratio, const uint32_t* __restrict__ sel_in, uint32_t* __restrict__ sel_out,
+                                                            const uint32_t* __restrict__ hist_prev, uint32_t* __restrict__ hist_cur, int shift) {
+  __shared__ uint32_t lh[256], scan[256], st[4];
+  lh[threadIdx.x] = 0;
+  RclSelState s;
+  if (FIRST) {
+    const float n_in = (float)counters[CNT_N_IN_AUG];
+    const uint32_t k = (uint32_t)(int)(ratio * n_in);            // int(selection_ratio * total_num), float32 as in torch
+    s.prefix = 0; s.less = 0; s.k = k; s.krem = k;
+    __syncthreads();
+  } else {
+    s = rcl_pick_digit(sel_in, hist_prev, shift + 8, scan, st);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sel_out[0] = s.prefix; sel_out[1] = s.less; sel_out[2] = s.k; sel_out[3] = 0; sel_out[4] = 0; sel_out[5] = s.krem; sel_out[6] = 0;
+  }
+  const uint32_t prefix = s.prefix;
+  const uint32_t mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+  if (s.k != 0) {
+    const long long step = (long long)gridDim.x * blockDim.x;
+    const long long n_round = (n + step - 1) / step * step;     // whole waves stay converged through the ballot loop
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += step) {
+      uint32_t key = 0;
+      bool take = false;
+      if (i < n) { key = f2key(v[i]); take = (key & mask) == (prefix & mask); }
+      const uint32_t digit = (key >> shift) & 255u;
+      if (WAVE_AGG) {
+        unsigned long long todo = __ballot(take);
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const uint32_t d0 = (uint32_t)__shfl((int)digit, leader);
+          const unsigned long long same = __ballot(take && digit == d0) & todo;
+          if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lh[d0], (uint32_t)__popcll(same));
+          todo &= ~same;
+        }
+      } else if (take) {
+        atomicAdd(&lh[digit], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (lh[threadIdx.x]) atomicAdd(&hist_cur[threadIdx.x], lh[threadIdx.x]);
+}
+
+// the last pick (byte 0) -> the canonical selection words (sel[3] = how many elements equal to the threshold are taken)
+__global__ __launch_bounds__(256) void rcl_pick_final_kernel(const uint32_t* __restrict__ sel_in, const uint32_t* __restrict__ hist_prev,
+                                                             uint32_t* __restrict__ sel) {
+  __shared__ uint32_t scan[256], st[4];
+  const RclSelState s = rcl_pick_digit(sel_in, hist_prev, 0, scan, st);
+  if (threadIdx.x == 0) {
+    sel[0] = s.prefix; sel[1] = s.less; sel[2] = s.k; sel[3] = s.k != 0 ? s.krem : 0u; sel[4] = 0; sel[5] = s.krem; sel[6] = 0;
+  }
+}
+
 // ---- pass 2 ---------------------------------------------------------------------------------
 // Selection mode only, augmented half only: which pixels made the easiest-k cut (key < threshold, plus `need_eq` of the
 // ones equal to it, first come first served), their gradient, the target mutation of all the others.
@@ -496,27 +584,28 @@ __global__ __launch_bounds__(256) void rcl_count_kernel(const uint8_t* __restric
 
 // exclusive scan of each of the 3 rows of block_counts (single workgroup), totals to n_out
 __global__ __launch_bounds__(1024) void rcl_scan_kernel(uint32_t* block_counts, int nblocks, uint32_t* n_out) {
-  __shared__ uint32_t part[1024];
-  for (int k = 0; k < 3; ++k) {
-    uint32_t* row = block_counts + (size_t)k * nblocks;
-    const int per = (nblocks + 1023) / 1024;
-    const int b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
-    uint32_t s = 0;
-    for (int i = b0; i < b1; ++i) s += row[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (int o = 1; o < 1024; o <<= 1) {
-      uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
-      __syncthreads();
-      part[threadIdx.x] += v;
-      __syncthreads();
-    }
-    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-    for (int i = b0; i < b1; ++i) { uint32_t c = row[i]; row[i] = run; run += c; }
-    if (threadIdx.x == 1023) n_out[k] = part[1023];
-    __syncthreads();
+  // one workgroup per list (r05: the three lists used to be scanned one after the other by ONE workgroup, 20 barriers each: 12 us);
+  // partial sums per thread, inclusive scan inside each wave with shuffles, then over the 16 wave totals
+  __shared__ uint32_t wave_tot[16];
+  const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* row = block_counts + (size_t)k * nblocks;
+  const int per = (nblocks + 1023) / 1024;
+  const int b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
+  uint32_t s = 0;
+  for (int i = b0; i < b1; ++i) s += row[i];
+  uint32_t incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= o) incl += v;
   }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int w = 0; w < wave; ++w) before += wave_tot[w];
+  uint32_t run = before + incl - s;
+  for (int i = b0; i < b1; ++i) { const uint32_t c = row[i]; row[i] = run; run += c; }
+  if (threadIdx.x == 1023) n_out[k] = before + incl;
 }
 
 __global__ __launch_bounds__(256) void rcl_scatter_kernel(const uint8_t* __restrict__ kind, long long total,
@@ -785,13 +874,21 @@ static bool rcl_vec4(const MssRclArgs* a) {
 
 // dlogit (optional, [B][C][H][W]): pass 1 writes the gradient of every pixel whose weight does not depend on the
 // selection -- the original half always, the augmented half when a->select == 0 (then pass 2 is not needed at all).
+static int rcl_pass1_impl(const MssRclArgs* a, float* lse, float* ce_aug, uint8_t* kind, double* counters, float* dlogit,
+                          void* stream, bool clear_counters);
 int mss_rcl_pass1_f32(const MssRclArgs* a, float* lse, float* ce_aug, uint8_t* kind, double* counters, float* dlogit,
                       void* stream) {
+  return rcl_pass1_impl(a, lse, ce_aug, kind, counters, dlogit, stream, true);
+}
+static int rcl_pass1_impl(const MssRclArgs* a, float* lse, float* ce_aug, uint8_t* kind, double* counters, float* dlogit,
+                          void* stream, bool clear_counters) {
   int rc = rcl_check(a);
   if (rc) return rc;
   if (!lse || !ce_aug || !kind || !counters) return MSS_ERR_BAD_ARG;
-  hipError_t e = hipMemsetAsync(counters, 0, 16 * sizeof(double), S_(stream));
-  if (e != hipSuccess) return (int)e;
+  if (clear_counters) {
+    hipError_t e = hipMemsetAsync(counters, 0, 16 * sizeof(double), S_(stream));
+    if (e != hipSuccess) return (int)e;
+  }
   const long long total = (long long)a->B * a->H * a->W;
   const bool v4 = rcl_vec4(a) && ((reinterpret_cast<uintptr_t>(lse) | reinterpret_cast<uintptr_t>(ce_aug) |
                                    reinterpret_cast<uintptr_t>(kind) | reinterpret_cast<uintptr_t>(dlogit)) & 15) == 0;
@@ -817,6 +914,31 @@ int mss_rcl_select_f32(const float* ce_aug, long long n, const double* counters,
     else hipLaunchKernelGGL(rcl_hist2_kernel<false>, grid, dim3(256), 0, S_(stream), ce_aug, n, sel, shift, hist_ws);
     hipLaunchKernelGGL(rcl_pick_par_kernel, dim3(1), dim3(256), 0, S_(stream), sel, hist_ws, shift);
   }
+  return mss_launch_status();
+}
+
+// The same selection in 5 launches (the picks ride in front of the next byte's histogram, see rcl_hist_pick_kernel). scratch:
+// MSS_RCL_SELECT_SCRATCH_WORDS 32-bit words (four histograms + two state buffers), cleared here unless the caller says it already
+// is (scratch_zeroed != 0: mss_rcl_loss_device_f32 clears it together with the counters).
+int mss_rcl_select_merged_f32(const float* ce_aug, long long n, const double* counters, float selection_ratio, uint32_t* scratch,
+                              int scratch_zeroed, uint32_t* sel, void* stream) {
+  if (!ce_aug || !counters || !scratch || !sel || n <= 0) return MSS_ERR_BAD_ARG;
+  if (!scratch_zeroed) {
+    hipError_t e = hipMemsetAsync(scratch, 0, MSS_RCL_SELECT_SCRATCH_WORDS * sizeof(uint32_t), S_(stream));
+    if (e != hipSuccess) return (int)e;
+  }
+  uint32_t* hist = scratch;                     // [4][256]: bytes 3, 2, 1, 0
+  uint32_t* sb = scratch + 4 * 256;             // [2][8]
+  const dim3 grid(grid_for(n, 1024));
+  hipLaunchKernelGGL((rcl_hist_pick_kernel<true, true>), grid, dim3(256), 0, S_(stream), ce_aug, n, counters, selection_ratio, sb, sb,
+                     hist, hist, 24);
+  hipLaunchKernelGGL((rcl_hist_pick_kernel<false, false>), grid, dim3(256), 0, S_(stream), ce_aug, n, counters, selection_ratio, sb, sb + 8,
+                     hist, hist + 256, 16);
+  hipLaunchKernelGGL((rcl_hist_pick_kernel<false, false>), grid, dim3(256), 0, S_(stream), ce_aug, n, counters, selection_ratio, sb + 8, sb,
+                     hist + 256, hist + 512, 8);
+  hipLaunchKernelGGL((rcl_hist_pick_kernel<false, false>), grid, dim3(256), 0, S_(stream), ce_aug, n, counters, selection_ratio, sb, sb + 8,
+                     hist + 512, hist + 768, 0);
+  hipLaunchKernelGGL(rcl_pick_final_kernel, dim3(1), dim3(256), 0, S_(stream), sb + 8, hist + 768, sel);
   return mss_launch_status();
 }
 
@@ -894,7 +1016,7 @@ int mss_rcl_compact_f32(const uint8_t* kind, int B, int H, int W, int32_t* idx_o
   const long long half = (long long)(B / 2) * H * W;
   const int nb = mss_rcl_num_compact_blocks(B, H, W);
   hipLaunchKernelGGL(rcl_count_kernel, dim3(nb), dim3(256), 0, S_(stream), kind, total, half, block_counts, nb);
-  hipLaunchKernelGGL(rcl_scan_kernel, dim3(1), dim3(1024), 0, S_(stream), block_counts, nb, n_out);
+  hipLaunchKernelGGL(rcl_scan_kernel, dim3(3), dim3(1024), 0, S_(stream), block_counts, nb, n_out);
   hipLaunchKernelGGL(rcl_scatter_kernel, dim3(nb), dim3(256), 0, S_(stream), kind, total, half, block_counts, nb,
                      idx_orig, idx_aug, idx_ood);
   return mss_launch_status();
@@ -954,7 +1076,7 @@ static RclWs rcl_ws_layout(int B, int H, int W) {
   w.counters = up(w.kind + total);
   w.sel = up(w.counters + 16 * 8);
   w.hist = up(w.sel + 8 * 4);
-  w.idx = up(w.hist + 256 * 4);
+  w.idx = up(w.hist + MSS_RCL_SELECT_SCRATCH_WORDS * 4);     // the merged selection's scratch (four histograms + two state buffers)
   w.block_counts = up(w.idx + 3 * total * 4);
   w.n_out = up(w.block_counts + 3 * nb * 4);
   w.total = up(w.n_out + 4 * 4);
@@ -986,10 +1108,19 @@ int mss_rcl_loss_device_f32(const MssRclArgs* a, void* workspace, long long work
   int32_t* idx2 = idx1 + total;
   uint32_t* block_counts = reinterpret_cast<uint32_t*>(base + w.block_counts);
   uint32_t* n_out = reinterpret_cast<uint32_t*>(base + w.n_out);
-  if ((rc = mss_rcl_pass1_f32(a, lse, ce_aug, kind, counters, dlogit, stream))) return rc;
+  // counters, selection words and the selection's scratch lie next to each other: ONE clear for all of them
+  {
+    hipError_t e = hipMemsetAsync(counters, 0, (w.hist - w.counters) + MSS_RCL_SELECT_SCRATCH_WORDS * sizeof(uint32_t), S_(stream));
+    if (e != hipSuccess) return (int)e;
+  }
+  if ((rc = rcl_pass1_impl(a, lse, ce_aug, kind, counters, dlogit, stream, false))) return rc;
   const bool select = a->select != 0;
   if (select) {
-    if ((rc = mss_rcl_select_f32(ce_aug, (long long)(a->B / 2) * a->H * a->W, counters, a->selection_ratio, hist, sel, stream))) return rc;
+    if (MSS_ENV_INT("MSS_RCL_SELECT_MERGED", 1) != 0)
+      rc = mss_rcl_select_merged_f32(ce_aug, (long long)(a->B / 2) * a->H * a->W, counters, a->selection_ratio, hist, 1, sel, stream);
+    else
+      rc = mss_rcl_select_f32(ce_aug, (long long)(a->B / 2) * a->H * a->W, counters, a->selection_ratio, hist, sel, stream);
+    if (rc) return rc;
     if ((rc = mss_rcl_pass2_f32(a, lse, ce_aug, kind, sel, counters, 1.0f, dlogit, stream))) return rc;
   } else {
     hipError_t e = hipMemsetAsync(sel, 0, 8 * sizeof(uint32_t), S_(stream));

@@ -134,3 +134,48 @@ def test_merged_pair_launch_equals_the_two_separate_ones(n_sets, cap):
     np.testing.assert_allclose(c_b.cpu().numpy(), c_a.cpu().numpy(), rtol=2e-6, atol=0)   # float partial sums grouped by another grid
     n = min(cap, n0, n1, n2)
     assert (d_a != 0).sum().item() <= 4 * n and (n == 0 or c_a.abs().sum().item() > 0)
+
+
+@pytest.mark.parametrize("case", ["random", "ties", "inf_nan", "k0", "all", "tiny", "one_exponent"])
+def test_merged_selection_equals_the_nine_launch_one(case):
+    """mss_rcl_select_merged_f32 (each digit's pick in front of the next byte's histogram pass: 5 launches, what the one-call loss
+    runs) against mss_rcl_select_f32 (init + 4 x (histogram, pick)): the same threshold key, count below it, k and number of ties
+    to take, on value sets with many exact ties at the threshold, +inf / NaN entries (ignored pixels are +inf in ce_aug), k = 0,
+    k = n, a single element, and values that share sign and exponent (the first pass sees one digit)."""
+    from multishiftseg_amd import _lib
+    from multishiftseg_amd._lib import call, ptr
+    g = torch.Generator(device="cuda").manual_seed(hash(case) % 1000)
+    n, ratio = 300007, 0.8
+    if case == "random":
+        v = torch.randn(n, device="cuda", generator=g).abs() * 3
+    elif case == "ties":
+        v = (torch.randint(0, 7, (n,), device="cuda", generator=g).float() * 0.25)
+    elif case == "inf_nan":
+        v = torch.randn(n, device="cuda", generator=g).abs()
+        v[::5] = float("inf")
+        v[7::1001] = float("nan")
+    elif case == "k0":
+        v, ratio = torch.rand(n, device="cuda", generator=g), 1e-9
+    elif case == "all":
+        v, ratio = torch.rand(n, device="cuda", generator=g), 1.0
+    elif case == "tiny":
+        n = 1
+        v = torch.tensor([0.37], device="cuda")
+    else:
+        v = 1.0 + torch.rand(n, device="cuda", generator=g) * 0.999
+    n_in = int(torch.isfinite(v).sum()) if case == "inf_nan" else n
+    counters = torch.zeros(16, dtype=torch.float64, device="cuda")
+    counters[2] = n_in                                    # CNT_N_IN_AUG
+    hist = torch.zeros(256, dtype=torch.int32, device="cuda")
+    sel_a = torch.full((8,), -1, dtype=torch.int32, device="cuda")
+    call("mss_rcl_select_f32", ptr(v), n, ptr(counters), ratio, ptr(hist), ptr(sel_a))
+    for zeroed in (0, 1):
+        scratch = torch.full((4 * 256 + 16,), 0 if zeroed else 12345, dtype=torch.int32, device="cuda")
+        sel_b = torch.full((8,), -1, dtype=torch.int32, device="cuda")
+        call("mss_rcl_select_merged_f32", ptr(v), n, ptr(counters), ratio, ptr(scratch), zeroed, ptr(sel_b))
+        assert sel_a[:6].tolist() == sel_b[:6].tolist(), (case, sel_a.tolist(), sel_b.tolist())
+    k = sel_a[2].item()
+    assert k == int(np.float32(ratio) * np.float32(n_in))
+    if k > 0 and case != "inf_nan":
+        kth = torch.sort(v).values[k - 1].item()
+        assert sel_a[1].item() == int((v < kth).sum()) and sel_a[3].item() == k - sel_a[1].item()
