@@ -216,6 +216,10 @@ int mss_conv2d_wgrad_route(const MssConvArgs* args, int lddy);
  * or 4x (m = 4) below the direct form; fp32 rounding error ~1e-6 (m = 2) / ~1e-5 (m = 4) relative per layer. */
 long long mss_wino_num_tiles(int N, int H, int W, int dil, int tile);
 int mss_wino_pack_weights_f32(const float* w, float* u, int K, int C, int Kpad, int Cp, int tile, void* stream);
+/* The same U straight into the split-bf16 planes MssConvArgs.w_split takes ((tile + 2)^2 batch entries of [Kpad][C]; bit-identical to
+ * mss_gemm_split_weights_bf16x3 of the function above with Cp == C) without writing and re-reading U in fp32. Kpad % 128 == 0,
+ * C % 16 == 0, both pointers 16-byte aligned; planes: mss_gemm_split_weights_bytes((tile + 2)^2, Kpad, C) bytes. */
+int mss_wino_pack_split_bf16x3(const float* w, void* planes, int K, int C, int Kpad, int tile, void* stream);
 int mss_wino_input_transform_f32(const float* x, int ldx, int N, int H, int W, int C, int dil, int tile,
                                  const float* scale, const float* shift, int relu, float* xt, void* stream);
 /* The same X', but of dx = the train-mode BatchNorm+ReLU backward of the gradient dy w.r.t. the layer input x2, computed on the fly

@@ -133,6 +133,7 @@ SIGNATURES = {
     "mss_adam_step_f32": [P, P, P, P, L, c_double, c_double, c_double, c_double, c_double, I, P],
     "mss_wino_num_tiles": [I, I, I, I, I],
     "mss_wino_pack_weights_f32": [P, P, I, I, I, I, I, P],
+    "mss_wino_pack_split_bf16x3": [P, P, I, I, I, I, P],
     "mss_wino_input_transform_f32": [P, I, I, I, I, I, I, I, P, P, I, P, P],
     "mss_wino_input_transform_bnbwd_f32": [P, I, P, I, I, I, I, I, I, I, P, P, P, P, P, I, P, P],
     "mss_wino_input_transform_upcat_f32": [P, I, I, P, I, I, I, I, I, I, I, I, P, P],

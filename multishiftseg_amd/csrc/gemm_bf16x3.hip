@@ -20,6 +20,7 @@
 // LDS per stage: A 3 x 4 KB + B 3 x 4 KB per 128 columns; two stages: 72 KB (128 x 256) / 48 KB (128 x 128).
 #include "mss_epilogue.h"
 #include "mss_gemm_tiles.h"
+#include "mss_bf16x3.h"
 #include <stdlib.h>
 #include <mutex>
 #include <unordered_map>
@@ -77,10 +78,13 @@ constexpr bool DYN_TILES = true;
 #else
 constexpr bool DYN_TILES = false;
 #endif
-constexpr int NT = 256, BM = 128, BK = 16;
-constexpr int ROW_B = BK * 2;                 // bytes per row per plane
-constexpr int PLANE = 128 * ROW_B;            // 4 KB: one plane of a 128-row operand block
-constexpr int OPER = 3 * PLANE;               // 12 KB: hi, mid, lo
+constexpr int NT = 256, BM = 128;
+using mss_bf16x3::BK;
+using mss_bf16x3::ROW_B;
+using mss_bf16x3::PLANE;
+using mss_bf16x3::OPER;
+using mss_bf16x3::cvt_pk_bf16;
+using mss_bf16x3::split_pair;
 constexpr int TM = 2;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -88,19 +92,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {        // v_cvt_pk_bf16_f32: round to nearest even, low half = a
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-// (a, b) -> packed hi / mid / lo bf16 pairs; the residuals are exact in fp32 (Sterbenz / aligned-exponent subtraction)
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = cvt_pk_bf16(a, b);
-  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
-  mid = cvt_pk_bf16(ra, rb);
-  const float qa = ra - __uint_as_float(mid << 16), qb = rb - __uint_as_float(mid & 0xffff0000u);
-  lo = cvt_pk_bf16(qa, qb);
-}
 
 // One ticket of the dynamic tile order (thread 0 of a workgroup). The static walk gives workgroup b the tiles v, v + grid, v + 2 grid,
 // ... with v = mss_xcd_remap(b): every XCD owns a contiguous range of v, so the tiles in flight on an XCD share their operands

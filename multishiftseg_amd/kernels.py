@@ -117,6 +117,10 @@ def w_split_of(pw):
             if nbytes > 0:
                 pw.planes = torch.empty(nbytes, device=pw.t.device, dtype=torch.uint8)
                 call("mss_conv_split_weights_bf16x3", ptr(pw.t), ptr(pw.planes), taps, pw.Kpad, pw.Cp)
+        elif isinstance(pw, WinoWeight) and pw._t is None:
+            pw.planes = pw.fused_planes()
+            if pw.planes is None:
+                pw.planes = split_planes(pw.t, pw.Kpad, pw.Cp)
         else:
             pw.planes = split_planes(pw.t, pw.Kpad, pw.Cp)
         if pw.planes is None:
@@ -349,12 +353,35 @@ def conv2d_wgrad(x, dy, K, C, R, S, stride=1, dil=1, pad=0, in_affine=None, in_r
 
 
 class WinoWeight:
-    """Winograd-domain filter U [(tile+2)^2][Kpad][Cp] of a 3x3 weight."""
-    __slots__ = ("t", "K", "C", "Kpad", "Cp", "tile", "planes")
+    """Winograd-domain filter U [(tile+2)^2][Kpad][Cp] of a 3x3 weight. `src` (optional): the contiguous [K][C][3][3] weight it comes
+    from; with it `t` may start as None and is made on first use -- the split-bf16 route fills its planes straight from `src`
+    (w_split_of -> mss_wino_pack_split_bf16x3) and never reads U in fp32 unless the layer has a narrow native tail."""
+    __slots__ = ("_t", "src", "K", "C", "Kpad", "Cp", "tile", "planes")
 
-    def __init__(self, t, K, C, Kpad, Cp, tile):
-        self.t, self.K, self.C, self.Kpad, self.Cp, self.tile = t, K, C, Kpad, Cp, tile
+    def __init__(self, t, K, C, Kpad, Cp, tile, src=None):
+        assert t is not None or src is not None
+        self._t, self.src, self.K, self.C, self.Kpad, self.Cp, self.tile = t, src, K, C, Kpad, Cp, tile
         self.planes = None
+
+    @property
+    def t(self):
+        if self._t is None:
+            t = torch.empty(((self.tile + 2) ** 2, self.Kpad, self.Cp), device=self.src.device, dtype=torch.float32)
+            call("mss_wino_pack_weights_f32", ptr(self.src), ptr(t), self.K, self.C, self.Kpad, self.Cp, self.tile)
+            self._t = t
+        return self._t
+
+    def fused_planes(self):
+        """The split-bf16 planes of U straight from `src` (bit-identical to split_planes(self.t, ...)), or None where that form does
+        not apply (no source weight, a padded Cp, Kpad not a multiple of 128)."""
+        if self.src is None or self.Cp != self.C or self.Kpad % 128 or self.C % 16 or self.src.data_ptr() % 16:
+            return None
+        nbytes = _lib.value("mss_gemm_split_weights_bytes", (self.tile + 2) ** 2, self.Kpad, self.C)
+        if nbytes <= 0:
+            return None
+        planes = torch.empty(nbytes, device=self.src.device, dtype=torch.uint8)
+        call("mss_wino_pack_split_bf16x3", ptr(self.src), ptr(planes), self.K, self.C, self.Kpad, self.tile)
+        return planes
 
 
 def pack_weight_wino(w, flip=False, tile=2):
@@ -367,6 +394,8 @@ def pack_weight_wino(w, flip=False, tile=2):
         raise TypeError("pack_weight_wino needs a float32 CUDA tensor")
     w = w.detach().contiguous()
     Kpad = _lib.value("mss_conv2d_kpad", K)
+    if gemm_route() == "bf16x3" and Kpad % 128 == 0 and os.environ.get("MSS_WINO_PACK_FUSED", "1") != "0":
+        return WinoWeight(None, K, C, Kpad, C, tile, src=w)          # U in fp32 only if somebody asks for it (WinoWeight.t)
     t = torch.empty(((tile + 2) ** 2, Kpad, C), device=w.device, dtype=torch.float32)
     call("mss_wino_pack_weights_f32", ptr(w), ptr(t), K, C, Kpad, C, tile)
     return WinoWeight(t, K, C, Kpad, C, tile)
@@ -478,6 +507,17 @@ def conv2d_winograd(x, ww, dil=1, in_affine=None, in_relu=False, res=None, out=N
         return _wino_gemm_and_output(xt, ww, N, H, W, dil, res, out, keep_xt, want_stats)
 
 
+def _set_wino_w(a, ww):
+    """MssConvArgs.w of a Winograd-domain product. On the split-bf16 route the kernel reads only the planes (a.w_split): when U has not
+    been made in fp32 (WinoWeight._t is None) and the library confirms that exactly these arguments take the split GEMM, U stays
+    unmade and `w` carries the planes' address as a non-null stand-in; in every other case it is U (made on demand)."""
+    if ww._t is None and a.w_split is not None:
+        a.w = a.w_split
+        if _lib.value("mss_conv2d_forward_route", ctypes.byref(a)) == 3:
+            return
+    a.w = ptr(ww.t)
+
+
 def _wino_gemm_and_output(xt, ww, N, H, W, dil, res, out, keep_xt, want_stats):
     """Steps 2 and 3 of the Winograd convolution on a transformed input X' [P][T][C]: the batched MFMA products and the output
     transform (+ residual, + BatchNorm partial sums)."""
@@ -490,7 +530,7 @@ def _wino_gemm_and_output(xt, ww, N, H, W, dil, res, out, keep_xt, want_stats):
         out = Act.empty(N, H, W, K, dev, ld=_round_up(K, 32) if K % 32 else None)
     yt = torch.empty((P, T, K), device=dev, dtype=torch.float32)
     a = MssConvArgs()
-    a.x, a.w, a.y = ptr(xt), ptr(ww.t), ptr(yt)
+    a.x, a.y = ptr(xt), ptr(yt)
     a.w_split = w_split_of(ww)
     a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
     a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, K, ww.Kpad, K
@@ -500,6 +540,7 @@ def _wino_gemm_and_output(xt, ww, N, H, W, dil, res, out, keep_xt, want_stats):
     split = K - rem if (K > 128 and 0 < rem <= 64) else 0     # e.g. 304 = 256 + 48: narrow tail on the 64-wide tile
     if split:
         a.K = split
+    _set_wino_w(a, ww)
     with _Timed(_fwd_kind(a), 2.0 * P * T * C * K, (P, 1, T, C, K, 1, 1, 1)):   # the MFMA work actually executed
         call("mss_conv2d_forward_f32", ctypes.byref(a))
         if split:
@@ -588,12 +629,13 @@ def conv3x3_pair(x, w1, w2, dil1, dil2, out1, out2, tile, want_stats=False, xt=N
             assert tuple(xt.shape) == (2 * P, T, C)
         yt = torch.empty((2 * P, T, Ko), device=dev, dtype=torch.float32)
         a = MssConvArgs()
-        a.x, a.w, a.y = ptr(xt), ptr(ww.t), ptr(yt)
+        a.x, a.y = ptr(xt), ptr(yt)
         a.w_split = w_split_of(ww)
         a.N, a.H, a.W, a.C, a.ldx = 1, 1, T, C, C
         a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, T, Ko, ww.Kpad, Ko
         a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
         a.batch, a.x_bs, a.w_bs, a.y_bs = 2 * P, T * C, ww.Kpad * ww.Cp, T * Ko
+        _set_wino_w(a, ww)
         with _Timed(_fwd_kind(a), 2.0 * 2 * P * T * C * Ko, (2 * P, 1, T, C, Ko, 1, 1, 1)):
             call("mss_conv2d_forward_f32", ctypes.byref(a))
         del xt

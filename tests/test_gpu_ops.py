@@ -601,6 +601,35 @@ def test_bf16x3_implicit_gemm_vs_float64(K, cin, cout, r, stride, dil, n, h, w, 
     np.testing.assert_allclose(st[:, 0].double().cpu().numpy(), yp.sum(1).cpu().numpy(), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("tile", [2, 4, 6])
+@pytest.mark.parametrize("k,c", [(256, 128), (200, 48), (384, 1040)])
+def test_bf16x3_winograd_planes_straight_from_the_weight(K, tile, k, c):
+    """mss_wino_pack_split_bf16x3 (3x3 weight -> the split-bf16 planes of its Winograd-domain form, U never written in fp32) must be
+    bit-identical to mss_wino_pack_weights_f32 followed by mss_gemm_split_weights_bf16x3 -- also on the padding rows (k >= K) -- and a
+    WinoWeight made lazily under the split route must hand out the same U on demand."""
+    from multishiftseg_amd import _lib
+    from multishiftseg_amd._lib import call, ptr
+    torch.manual_seed(tile * 1000 + k + c)
+    w = (torch.randn(k, c, 3, 3, device="cuda") * torch.logspace(-3, 1, k, device="cuda")[:, None, None, None]).contiguous()
+    kpad = _lib.value("mss_conv2d_kpad", k)
+    P = (tile + 2) ** 2
+    u = torch.empty(P, kpad, c, device="cuda")
+    call("mss_wino_pack_weights_f32", ptr(w), ptr(u), k, c, kpad, c, tile)
+    want = K.split_planes(u, kpad, c)
+    got = torch.full_like(want, 0x5a)
+    call("mss_wino_pack_split_bf16x3", ptr(w), ptr(got), k, c, kpad, tile)
+    assert torch.equal(got, want)
+    K.set_gemm_route("bf16x3")
+    try:
+        ww = K.pack_weight_wino(w, tile=tile)
+        assert ww._t is None                                   # nothing in fp32 yet
+        K.w_split_of(ww)
+        assert ww._t is None and torch.equal(ww.planes, want)
+        assert torch.equal(ww.t, u)                            # ... and U on demand
+    finally:
+        K.set_gemm_route(None)
+
+
 def test_bf16x3_ticket_tile_order_on_two_streams_at_once(K):
     """The 128 x 256 split kernels with a prologue walk their tiles off a device ticket counter (gemm_bf16x3.hip, split_dyn_tiles): a
     counter pair may only be shared by launches that cannot overlap, so every stream has its own ring. Two streams launch such
