@@ -261,6 +261,9 @@ def test_eval_golden_c3_1x1024x2048(model, route):
     assert rep["argmax"]["flips_where_ref_margin_gt_1e3"] == 0, rep
 
 
+C3_FLIPS_MAX = {"winograd": 460, "bf16x3": 400}
+
+
 @pytest.mark.parametrize("route", ["winograd", "bf16x3"])
 def test_train_step_golden_c3_2x1024x2048(deeplab_params, route):
     """THE headline configuration (BASELINE config 3, per GPU: one orig+aug pair of 1024x2048, stage 2, train-mode BN /
@@ -272,7 +275,8 @@ def test_train_step_golden_c3_2x1024x2048(deeplab_params, route):
     assert rep["argmax"]["flips_where_ref_margin_gt_1e3"] == 0, rep["argmax"]
     # flips can only sit on pixels the reference itself decided by less than the fp32 noise of ANY implementation:
     # the direct-kernel route flips 118 of 4.2 M (profiles/r03/wino_attribution_*.txt)
-    assert rep["argmax"]["flips_all_pixels"] < 1e-4 * rep["argmax"]["pixels"], rep["argmax"]
+    # <= 2 x what was observed on this fixture (native 230, split 198 of 4 194 304; profiles/r05/fullsize_parity.json) -- VERDICT r04 #6 / r05 #1d
+    assert rep["argmax"]["flips_all_pixels"] <= C3_FLIPS_MAX[route], rep["argmax"]
 
 
 def _stage2_step(m, img, target, masks, seed):
@@ -319,7 +323,9 @@ def test_three_routes_agree_at_bench_size(deeplab_params, tag, pairs, h, w):
     gs = golden("deepwv3plus_train_step_2x592x600")
     sens = {k[len("stage2_gradsens_"):]: float(gs[k]) for k in gs.files if k.startswith("stage2_gradsens_")}
     out = {}
-    for route, env in ROUTES.items():
+    # + the split-bf16 GEMM route as a whole step (VERDICT r05 next #1b): at 16 x 700^2 / 768^2 it needs the 64-bit per-entry bases
+    # (X' beyond 4 GB) and the ROWAFF prologue (Dropout2d tiles straddling images) that only kernel-level tests covered before
+    for route, env in dict(ROUTES, bf16x3=ROUTES_X["bf16x3"]).items():
         m.load_state_dict(saved)
         with _Env(env):
             out[route] = _stage2_step(m, img, target, masks, seed=4242)
@@ -333,7 +339,7 @@ def test_three_routes_agree_at_bench_size(deeplab_params, tag, pairs, h, w):
     ref = out["igemm_only"]
     rep = {"wino_tiles": tiles, "nondeterministic_grads": nondet}
     bad = []
-    for route in ("winograd", "direct3x3", "winograd_f2"):
+    for route in ("winograd", "direct3x3", "winograd_f2", "bf16x3"):
         s, l, loss, grads, tgt = out[route]
         e_s = float((s - ref[0]).abs().max())
         e_l = float((l - ref[1]).abs().max())
