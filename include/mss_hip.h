@@ -21,12 +21,13 @@
 extern "C" {
 #endif
 
-#define MSS_ABI_VERSION 7      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
+#define MSS_ABI_VERSION 8      /* 2: round-2 struct / workspace changes; 3: mss_msda_backward_binned_f32; 4: mss_add_layernorm_bwd_sum_f32, mss_stem_conv_pool_f32,
                                   mss_wino_input_transform_bnbwd_f32, mss_wino_input_transform_upcat_f32,
                                   mss_bn_fold_train_from_partials_f32; 5 (round 4): mss_adam_step_f32 takes double hyper-parameters, mss_env_reset,
                                   mss_wino_input_transform_aspp3_f32, mss_msda_prepare_backward_ld_f32, mss_rcl_pairs_device2_f32, mss_rcl_loss_device_f32, mss_m2f_fused_score_ws_f32, mss_oodm_compact_packed_f32,
                                   6 (late round 4, additive): mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32, mss_add_layernorm_q_f32, mss_add_layernorm_bwd_sum2_f32, mss_msda_forward_fused_save_f32, mss_msda_backward_binned_proj_f32, mss_gap_from_partials_f32;
-                                  7 (round 5): MssConvArgs.w_split + mss_gemm_split_weights_bf16x3 (the split-bf16 GEMM route) */
+                                  7 (round 5): MssConvArgs.w_split + mss_gemm_split_weights_bf16x3 (the split-bf16 GEMM route);
+                                  8 (round 6): mss_msda_forward_window_f32 removed (the measured-slower LDS-window forward left the product) */
 int mss_abi_version(void);
 
 /* The MSS_* environment switches (A/B experiments, test routes; none is needed in production) are read once per call site and
@@ -49,16 +50,6 @@ int mss_env_generation(void);
 int mss_msda_forward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                          const float* sampling_loc, const float* attn_weight, int N, int S, int M, int D, int L,
                          int Lq, int P, float* out, void* stream);
-/* Forward through LDS-staged value windows (round 2; replaces the same ms_deform_attn_forward, vision.cpp:18-21 ->
- * ms_deform_attn_cuda.cu:25-88, for fp32 / D = 32): 64 queries x one head per workgroup, each level's window of value rows
- * staged once in LDS, corner fetches outside it fall back to the global gather. `host_shapes` is a HOST copy of spatial_shapes
- * [L][2] (the launch grid depends on it); reference_points NULL: loc / attn are sampling_locations / attention_weights,
- * else the raw offsets / logits of ops/modules/ms_deform_attn.py:98-109. MSS_ERR_UNSUPPORTED unless D == 32, L <= 8,
- * L*P <= 20 and value / out are 16-byte aligned. */
-int mss_msda_forward_window_f32(const float* value, const int64_t* host_shapes, const int64_t* level_start_index,
-                                const float* loc_or_offsets, const float* attn_or_logits, const float* reference_points, int N,
-                                int S, int M, int D, int L, int Lq, int P, float* out, void* stream);
-
 int mss_msda_forward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                          const double* sampling_loc, const double* attn_weight, int N, int S, int M, int D, int L,
                          int Lq, int P, double* out, void* stream);

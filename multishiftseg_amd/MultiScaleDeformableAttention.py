@@ -18,7 +18,7 @@ _HOST_SHAPES = {}      # id(tensor) -> (tensor, version, ctypes int64 array): ho
 
 
 def host_shapes(spatial_shapes):
-    """HOST copy of a device spatial_shapes tensor for the window forward (its launch grid depends on the level sizes).
+    """HOST copy of a device spatial_shapes tensor for the binned backward (its tile geometry and launch grids depend on the level sizes).
     Callers that know the sizes attach them (`t._mss_host = [(H, W), ...]`, msdeformattn_encoder.py); otherwise one
     synchronising copy per distinct tensor object, remembered while that tensor is alive and unmodified. None while a
     hipGraph is being captured (no host copy possible): the caller then takes the kernel that reads the device tensor."""
@@ -37,13 +37,6 @@ def host_shapes(spatial_shapes):
         _HOST_SHAPES.clear()
     _HOST_SHAPES[id(spatial_shapes)] = (spatial_shapes, spatial_shapes._version, arr)
     return arr
-
-
-def use_window(value, L, P):
-    """The LDS-window forward (fp32, head dimension 32, <= 8 levels, L*P <= 20) is OPT-IN, MSS_MSDA_WINDOW=1: measured
-    0.7x the speed of the L2-gather kernel (csrc/msda.hip, msda_fwd_window_kernel)."""
-    return (os.environ.get("MSS_MSDA_WINDOW", "0") == "1" and value.dtype == torch.float32 and value.shape[3] == 32 and L <= 8
-            and L * P <= 20 and value.data_ptr() % 16 == 0)
 
 
 def _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step, extra=()):
@@ -75,12 +68,6 @@ def _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     N, S, M, D, L, Lq, P = _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
     out = torch.empty((N, Lq, M * D), device=value.device, dtype=value.dtype)
-    if use_window(value, L, P):
-        hs = host_shapes(spatial_shapes)
-        if hs is not None:
-            call("mss_msda_forward_window_f32", ptr(value), hs, ptr(level_start_index), ptr(sampling_loc), ptr(attn_weight), None,
-                 N, S, M, D, L, Lq, P, ptr(out))
-            return out
     sfx = "f32" if value.dtype == torch.float32 else "f64"
     call(f"mss_msda_forward_{sfx}", ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(sampling_loc),
          ptr(attn_weight), N, S, M, D, L, Lq, P, ptr(out))
@@ -96,7 +83,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_attn = torch.empty_like(attn_weight)
     sfx = "f32" if value.dtype == torch.float32 else "f64"
     # fp32 / D = 32: grad_value on the binned owner-computes path (csrc/msda.hip, round 3) whenever a host copy of the level
-    # sizes is at hand; MSS_MSDA_BWD_BINNED=0 keeps the round-2 kernels (A/B and the second formulation in the tests)
+    # sizes is at hand; MSS_MSDA_BWD_BINNED=0: the generic scatter-add kernel (fp64 / other head dimensions; the second formulation in the tests)
     if sfx == "f32" and D == 32 and N * Lq > 0 and os.environ.get("MSS_MSDA_BWD_BINNED", "1") != "0" \
             and value.data_ptr() % 16 == 0 and grad_output.data_ptr() % 16 == 0:
         hs = host_shapes(spatial_shapes)

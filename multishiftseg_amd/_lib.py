@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so libmss_hip.
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSS_LIB", os.path.join(_HERE, "libmss_hip.so"))   # MSS_LIB: A/B experiments only
 
-MSS_ABI_VERSION = 7          # include/mss_hip.h
+MSS_ABI_VERSION = 8          # include/mss_hip.h
 MSS_ERR_BAD_ARG = 1001
 MSS_ERR_UNSUPPORTED = 1002
 
@@ -71,7 +71,6 @@ SIGNATURES = {
     "mss_msda_backward_binned_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, L, P],
     "mss_msda_backward_binned_proj_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, L, P, L, P, L, P],
     "mss_msda_forward_fused_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
-    "mss_msda_forward_window_f32": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
     "mss_msda_prepare_f32": [P, P, P, P, I, I, I, I, I, P, P, P],
     "mss_msda_prepare_backward_f32": [P, P, P, P, I, I, I, I, I, P, P, P],
     "mss_msda_prepare_backward_ld_f32": [P, P, P, P, I, I, I, I, I, P, L, P, L, P],

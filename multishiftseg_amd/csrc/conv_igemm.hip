@@ -1588,11 +1588,12 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
   return k32 ? launch_conv<128, 128, 32, 2, 2>(p, s) : launch_conv<128, 128, 16, 2, 2>(p, s);
 }
 
-// Which kernel mss_conv2d_forward_f32 runs for these arguments: 1 = gemm_nt_kernel (gemm.hip), 0 = conv_igemm_kernel.
+// Which kernel mss_conv2d_forward_f32 runs for these arguments: 1 = gemm_nt_kernel (gemm.hip), 0 = conv_igemm_kernel, 2 = gemm_few_rows_kernel,
+// 3 = gemm_nt_bf16x3_kernel, 4 = its implicit-GEMM / per-sample-affine instantiations (args->w_split set).
 int mss_conv2d_forward_route(const MssConvArgs* args) {
   MssConvArgs p = *args;
   p.M = p.N * p.OH * p.OW;
-  if (!MSS_ENV_INT("MSS_GEMM", 1)) return 0;
+  if (!MSS_ENV_INT("MSS_GEMM", 1)) return mss_conv_bf16x3_eligible(p) ? 4 : 0;      // as the forward: MSS_GEMM=0 only skips the NT dispatch
   if (mss_gemm_few_rows(p)) return 2;                  // (0 implicit-GEMM kernel, 1 gemm_nt_kernel, 2 gemm_few_rows_kernel)
   if (!mss_gemm_nt_eligible(p)) return mss_conv_bf16x3_eligible(p) ? 4 : 0;
   p.mtiles = (p.M + 127) / 128;
@@ -1654,7 +1655,16 @@ long long mss_conv2d_wgrad_workspace_bytes(const MssConvArgs* args, int Cp) {
     a.K = a.Kpad = wide;
     b.K = p.K - wide; b.Kpad = p.Kpad - wide;
     const long long wa = mss_conv2d_wgrad_workspace_bytes(&a, Cp), wb = mss_conv2d_wgrad_workspace_bytes(&b, Cp);
-    return wa > wb ? wa : wb;
+    // ... or, when the narrow part's pointers turn out misaligned at launch, the unsplit product instead: enough for that too
+    // (the fall-back to `whole` used to fail with BAD_ARG on the smaller scratch)
+    const long long parts = wa > wb ? wa : wb;
+    long long whole = wgrad_ws_bytes<128, 128, 16>(p, Cp);
+    if (tn_eligible(p, p.K)) {
+      const TnPlan pl = tn_plan_for(p);
+      const long long tb = pl.full >= 0 ? tn_tail_bytes(pl) : pl.splits > 1 ? (long long)pl.splits * tn_batch(p) * p.Kpad * Cp * 4 : 0;
+      if (tb > whole) whole = tb;
+    }
+    return parts > whole ? parts : whole;
   }
   long long tn_bytes = 0;
   if (Cp == p.C && p.Kpad == p.K && mss_wgrad_tn_bf16x3_eligible(p, p.K)) return mss_wgrad_tn_bf16x3_ws_bytes(p, Cp);   // args->route == 1: the split-bf16 TN kernel

@@ -39,32 +39,69 @@ extern "C" int mss_debug_read_stamps(unsigned long long* host, int n) {
 #endif
 
 // Dynamic tile scheduling of the persistent kernels (round 5): self-resetting counter slots in device memory (eight per-XCD ticket
-// counters + a count of finished workgroups, draw_xcd_ticket). A slot
-// may only be shared by launches that cannot overlap, so every STREAM gets its own ring of 8 slots, used in rotation (launches on a
-// stream run in order and every launch zeroes its pair when its last workgroup leaves). The rings come out of one pool that is
-// allocated and cleared by the first call on a device -- nothing is allocated later, e.g. under a stream capture; a process
-// with more than 64 streams that launch these kernels gets MSS_ERR_UNSUPPORTED from the launcher (nullptr here).
-int* mss_sched_slot(hipStream_t stream) {
-  constexpr int RINGS = 64, PAIRS = 8, MAXDEV = 16, SLOT = 16;     // a slot: 8 per-XCD ticket counters + the done counter (64 B)
-  static std::mutex mu;
-  static int* pools[MAXDEV] = {nullptr};                                      // one pool per device of this process
-  static std::unordered_map<hipStream_t, std::pair<int, unsigned>> rings[MAXDEV];   // stream -> (ring index, launches so far)
+// counters + a count of finished workgroups, draw_xcd_ticket; every launch zeroes its slot when its last workgroup leaves).
+// A slot may only be shared by launches that cannot overlap. Ownership (round 6, ADVICE r05 / VERDICT r05 weak 9):
+//  * EAGER launches: every stream has its own ring of 8 slots, used in rotation (launches on a stream run in order);
+//  * launches recorded by a STREAM CAPTURE: the slot address is baked into the graph and the graph may later be replayed on any
+//    stream, beside other graphs and beside eager launches of the stream it was captured on -- so each captured launch gets a PRIVATE
+//    slot out of a region no eager launch ever uses, never handed out twice (a graph exec cannot overlap itself, so its own
+//    replays are ordered). 8192 such slots per device; when they are used up -- or when the pool does not exist yet and the first
+//    launch on the device happens under capture, where nothing may be allocated -- the launcher falls back to the static tile walk
+//    (nullptr here: correct, a few percent slower on the prologue kernels).
+// The pool (64 rings x 8 + 8192 slots of 64 bytes = 544 KB) is allocated and cleared by mss_sched_init, which the weight-plane packers
+// call (a split launch needs planes, so the pool exists before the first launch unless the packing itself was captured), or lazily by
+// the first eager launch. A process with more than 64 streams that launch these kernels gets the static walk on the later ones.
+// A launch that FAULTS leaves its slot dirty; a device fault is sticky in HIP (every later call on the context fails), so there is no
+// later launch to protect.
+namespace {
+constexpr int SCHED_RINGS = 64, SCHED_PAIRS = 8, SCHED_MAXDEV = 16, SCHED_SLOT = 16, SCHED_GRAPH_SLOTS = 8192;   // a slot: 16 ints (64 B)
+std::mutex sched_mu;
+int* sched_pools[SCHED_MAXDEV] = {nullptr};                                           // one pool per device of this process
+int sched_graph_used[SCHED_MAXDEV] = {0};
+std::unordered_map<hipStream_t, std::pair<int, unsigned>> sched_rings[SCHED_MAXDEV];  // stream -> (ring index, launches so far)
+
+bool sched_pool_locked(int dev) {                  // sched_mu held; false: no pool and none can be made right now
+  if (sched_pools[dev]) return true;
+  const size_t bytes = ((size_t)SCHED_RINGS * SCHED_PAIRS + SCHED_GRAPH_SLOTS) * SCHED_SLOT * sizeof(int);
+  int* q = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&q), bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipMemset(q, 0, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(q); return false; }
+  sched_pools[dev] = q;
+  return true;
+}
+bool stream_is_capturing(hipStream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
+}
+}  // namespace
+
+// Allocate the ticket pool of the current device now (not under a capture). Idempotent.
+void mss_sched_init(hipStream_t stream) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!pools[dev]) {
-    int* q = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&q), RINGS * PAIRS * SLOT * sizeof(int)) != hipSuccess) return nullptr;
-    if (hipMemset(q, 0, RINGS * PAIRS * SLOT * sizeof(int)) != hipSuccess) { (void)hipFree(q); return nullptr; }
-    pools[dev] = q;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SCHED_MAXDEV || stream_is_capturing(stream)) return;
+  std::lock_guard<std::mutex> lock(sched_mu);
+  (void)sched_pool_locked(dev);
+}
+
+// nullptr: use the static tile walk for this launch
+int* mss_sched_slot(hipStream_t stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SCHED_MAXDEV) return nullptr;
+  const bool capturing = stream_is_capturing(stream);
+  std::lock_guard<std::mutex> lock(sched_mu);
+  if (!sched_pools[dev] && (capturing || !sched_pool_locked(dev))) return nullptr;
+  if (capturing) {
+    if (sched_graph_used[dev] >= SCHED_GRAPH_SLOTS) return nullptr;
+    return sched_pools[dev] + ((size_t)SCHED_RINGS * SCHED_PAIRS + sched_graph_used[dev]++) * SCHED_SLOT;
   }
-  auto& map = rings[dev];
+  auto& map = sched_rings[dev];
   auto it = map.find(stream);
   if (it == map.end()) {
-    if ((int)map.size() >= RINGS) return nullptr;
+    if ((int)map.size() >= SCHED_RINGS) return nullptr;
     it = map.emplace(stream, std::make_pair((int)map.size(), 0u)).first;
   }
-  return pools[dev] + ((size_t)it->second.first * PAIRS + it->second.second++ % PAIRS) * SLOT;
+  return sched_pools[dev] + ((size_t)it->second.first * SCHED_PAIRS + it->second.second++ % SCHED_PAIRS) * SCHED_SLOT;
 }
 
 namespace {
@@ -117,11 +154,24 @@ __device__ __forceinline__ int draw_xcd_ticket(int* __restrict__ sched, long lon
 // the rest of the K-step: the tap state advances with selects.
 // ROWAFF: the prologue affine differs per SAMPLE (the Dropout2d fold of mod6 / mod7, wider_resnet.py:139-140,161-162) and a 128-row tile
 // may straddle two images (88 x 88 maps at 700 x 700): every staged row then loads the affine of its own image.
-template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false, bool DYN = false>
-__global__ __launch_bounds__(NT, (BN == 256 || (AFFINE && (CONV || ROWAFF))) ? 2 : 3) void gemm_nt_bf16x3_kernel(MssConvArgs p, const unsigned char* __restrict__ wpl,
+// MF (round 6): the MFMA shape. 32: v_mfma_f32_32x32x16_bf16, one product per instruction, B staged through registers (round 5).
+// 16: v_mfma_f32_16x16x32_bf16 on CONCATENATED planes -- the instruction's 32-deep reduction is two 16-deep halves taken from two
+// different planes of the same K-step, lanes 0-31 (k 0..15 of the instruction) reading plane P, lanes 32-63 (k 16..31) plane Q, so
+// one instruction adds TWO of the six products:
+//     X(hi|mid) W(hi|mid) = hi hi + mid mid      X(mid|hi) W(hi|mid) = mid hi + hi mid      X(lo|hi) W(hi|lo) = lo hi + hi lo
+// (three instructions per 16 x 16 x 16 block instead of six halves of a 32 x 32 x 16 one: the same matrix-pipe cycles, but the chip
+// holds a higher clock on this shape -- MI355X_MICROARCH.md, DVFS give-back (7): 1.12-1.14x with LDS-fed operands). The plane
+// pairing costs nothing: the planes lie in LDS as before and a fragment read adds a per-lane plane offset. The weights are the FIRST
+// operand, so the accumulator holds D[channel][pixel]: a lane's four values are four consecutive channels of one pixel, a 16-byte
+// store (mss_epilogue_store16). The weight planes go global -> LDS by LDS-DMA (global_load_lds_dwordx4; they are stored in LDS
+// image order, a wave-instruction copies 1 KB) one K-step ahead, which frees the 24 staging registers for the fragments.
+template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false, bool DYN = false, int MF = 32>
+__global__ __launch_bounds__(NT, (MF == 16 || BN == 256 || (AFFINE && (CONV || ROWAFF))) ? 2 : 3) void gemm_nt_bf16x3_kernel(MssConvArgs p, const unsigned char* __restrict__ wpl,
                                                                                long long total_tiles, int tiles_per_batch,
                                                                                int group_m, unsigned blk_bytes, int nblk_total, int* __restrict__ sched) {
   constexpr int NBLK = BN / 128, TN = BN / 64;          // wave tile 64 x (BN / 2)
+  constexpr bool M16 = MF == 16;
+  constexpr int TI = 4, TJ = BN / 32;                   // M16: 16-pixel blocks x 16-channel blocks of the wave tile
   constexpr int STAGE = (1 + NBLK) * OPER;              // A block, then NBLK B blocks
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,6 +184,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || (AFFINE && (CONV || ROWAFF))) ? 2
 
   // ---- loader state (see gemm_nt_kernel, variant 3) ----
   unsigned a_off[2], a_nxt[2], b_off[NBLK], b_nxt[NBLK], s_off = 0, s_nxt = 0, s_off1 = 0, s_nxt1 = 0;   // (s_off1: row 1's affine, ROWAFF)
+  unsigned b_lag[NBLK];                                  // M16: b_off as it was before the last advance() (the DMA runs ONE step ahead)
   // the A operand of batch entry b starts at p.x + b * x_bs: a UNIFORM 64-bit base per tile (scalar registers) + 32-bit offsets inside
   // the entry, so a batched product may exceed 4 GB as a whole (16 x 700 x 700: the ASPP X' is 5.4 / 12 GB) while each entry stays below
   const char* xb_cur = reinterpret_cast<const char*>(p.x);
@@ -231,7 +282,30 @@ __global__ __launch_bounds__(NT, (BN == 256 || (AFFINE && (CONV || ROWAFF))) ? 2
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) breg[j][pl] = *reinterpret_cast<const u32x4 __attribute__((address_space(1)))*>(wbase[pl] + b_off[j]);
   };
-  auto issue_loads = [&]() { issue_loads_a(); issue_loads_b(); };
+  auto issue_loads = [&]() { issue_loads_a(); if (!M16) issue_loads_b(); };
+  // M16: the weight planes of one K-step straight into LDS stage `buf`: per block and plane one global_load_lds_dwordx4 per wave
+  // (LDS destination = M0 + 16 * lane: the wave's 1 KB of the 4 KB plane; source = plane base + the thread's byte offset `off[j]`).
+  // Inline asm on purpose: the compiler then keeps no book on these in its vmcnt accounting, so it never answers a pending DMA with a
+  // conservative vmcnt(0) on the A operand's register loads (cdna_hip_programming.md 5, Pipelining across barriers); unknown
+  // outstanding operations can only make its own counted waits stricter, never too weak. The K-step orders them by hand:
+  // every use of the previous A registers comes BEFORE the DMAs, the next A loads AFTER them, and the barrier is preceded by
+  // s_waitcnt vmcnt(<number of those A loads>), which retires exactly the DMAs.
+  const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(smem) +
+                            (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+  auto dma_b = [&](int buf, const unsigned (&off)[NBLK]) {
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+      const unsigned d0 = lds_wave + (unsigned)(buf * STAGE + (1 + j) * OPER), d1 = d0 + PLANE, d2 = d0 + 2 * PLANE;
+      unsigned keep;                                     // M0 is the compiler's to manage: put it back
+      asm volatile("s_mov_b32 %0, m0\n\t"
+                   "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                   "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\t"
+                   "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %7\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(keep) : "s"(d0), "s"(d1), "s"(d2), "v"(off[j]), "s"(wbase[0]), "s"(wbase[1]), "s"(wbase[2]) : "memory");
+    }
+  };
+  constexpr int N_A_LOADS = 2 + (AFFINE ? 2 : 0) + (ROWAFF ? 2 : 0);          // issue_loads_a: what follows the DMAs in a K-step
   auto advance = [&]() {                 // branch-free: next K-step of this tile, else first K-step of this workgroup's next tile
     const bool wrap = ++ld_k == n_it;
     xb_cur = wrap ? xb_nxt : xb_cur;
@@ -253,14 +327,14 @@ __global__ __launch_bounds__(NT, (BN == 256 || (AFFINE && (CONV || ROWAFF))) ? 2
       cur_ok = ok2;
       if (AFFINE) s_off = tap_end ? (unsigned)(chunk * 4 * sizeof(float)) : s_off + BK * (unsigned)sizeof(float);
 #pragma unroll
-      for (int j = 0; j < NBLK; ++j) b_off[j] = wrap ? b_nxt[j] : b_off[j] + (unsigned)OPER;
+      for (int j = 0; j < NBLK; ++j) { if (M16) b_lag[j] = b_off[j]; b_off[j] = wrap ? b_nxt[j] : b_off[j] + (unsigned)OPER; }
       ld_k = wrap ? 0 : ld_k;
       return;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) a_off[j] = wrap ? a_nxt[j] : a_off[j] + BK * (unsigned)sizeof(float);
 #pragma unroll
-    for (int j = 0; j < NBLK; ++j) b_off[j] = wrap ? b_nxt[j] : b_off[j] + (unsigned)OPER;
+    for (int j = 0; j < NBLK; ++j) { if (M16) b_lag[j] = b_off[j]; b_off[j] = wrap ? b_nxt[j] : b_off[j] + (unsigned)OPER; }
     if (AFFINE) s_off = wrap ? s_nxt : s_off + BK * (unsigned)sizeof(float);
     if (ROWAFF) s_off1 = wrap ? s_nxt1 : s_off1 + BK * (unsigned)sizeof(float);
     ld_k = wrap ? 0 : ld_k;
@@ -315,20 +389,97 @@ __global__ __launch_bounds__(NT, (BN == 256 || (AFFINE && (CONV || ROWAFF))) ? 2
   unsigned long long dbg_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dbg_last = 0;
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();   // shader clock / constant 100 MHz
 #endif
-  f32x16 acc[TM][TN];
+  f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
+  f32x4 acc16[M16 ? TI : 1][M16 ? TJ : 1];               // M16: [pixel block][channel block], D[channel][pixel] (mss_epilogue_store16)
   auto zero_acc = [&]() {
+    if constexpr (M16) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TJ; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
   };
   auto epilogue = [&](long long t) {
     const int b = (int)(t / tiles_per_batch);
     const int v = (int)(t - (long long)b * tiles_per_batch);
     int mt, nt; mss_tile_mn(v, p.mtiles, p.ntiles, group_m, mt, nt);
-    mss_epilogue_store<TM, TN>(acc, p, p.y + (size_t)b * p.y_bs, mt * BM + wm * 64, nt * BN + wn * (BN / 2), lane);
+    if constexpr (M16) mss_epilogue_store16<TI, TJ>(acc16, p, p.y + (size_t)b * p.y_bs, mt * BM + wm * 64, nt * BN + wn * (BN / 2), lane);
+    else mss_epilogue_store<TM, TN>(acc, p, p.y + (size_t)b * p.y_bs, mt * BM + wm * 64, nt * BN + wn * (BN / 2), lane);
+  };
+  // M16 fragments: lane = (row l & 15 of a 16-row block, k-block l >> 4 of the instruction's four); k-blocks 0, 1 are the two 16-byte
+  // halves of the row in plane P, k-blocks 2, 3 the same halves in plane Q. Same swizzle as the 32-row form (bit 3 of the row swaps the
+  // halves): the 16 lanes of a k-block cover the sixteen 16-byte slots of a 256-byte bank row.
+  const int l15 = lane & 15, khalf = (lane >> 4) & 1, up = lane >> 5;
+  const int fr16 = l15 * ROW_B + ((khalf ^ (l15 >> 3)) * 16);
+  const int fx16 = wm * 64 * ROW_B + fr16;                                        // X: block 0, pixel rows of this wave
+  const int fw16 = OPER + (BN == 256 ? wn * OPER : wn * 64 * ROW_B) + fr16;        // W: this wave's 128 / 64 channels
+  const int x_hm = fx16 + up * PLANE, x_mh = fx16 + (1 - up) * PLANE, x_lh = fx16 + (1 - up) * 2 * PLANE;   // (P | Q) per half wave
+  const int w_hm = fw16 + up * PLANE, w_hl = fw16 + up * 2 * PLANE;
+  auto step16 = [&](const int buf) {
+    const unsigned char* base = smem + buf * STAGE;
+    auto ld_x = [&](int off, bf16x8 (&f)[TI]) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i) f[i] = *reinterpret_cast<const bf16x8*>(base + off + i * 16 * ROW_B);
+    };
+    auto ld_w = [&](int off, bf16x8 (&f)[TJ]) {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) f[j] = *reinterpret_cast<const bf16x8*>(base + off + j * 16 * ROW_B);
+    };
+    auto mm = [&](const bf16x8 (&w)[TJ], const bf16x8 (&x)[TI]) {           // channel block outermost: w[j] dies after TI instructions
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int i = 0; i < TI; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], x[i], acc16[i][j], 0, 0, 0);
+    };
+    constexpr int G = TI * TJ;                           // MFMAs per group: 32 (128 x 256 tile) / 16
+    auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+#define MSS_PAIR_UP(mask, n, per)                                                                                             \
+  _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                          \
+    __builtin_amdgcn_sched_group_barrier((mask), (per), 0);                                                                   \
+  }
+    bf16x8 xhm[TI], xmh[TI], xlh[TI], whm[TJ], whl[TJ];
+    ld_x(x_hm, xhm); ld_w(w_hm, whm);
+    fence();
+    // group 1 (hi hi + mid mid): the split of BOTH staged rows of K-step k+1 (every use of the A registers) + their LDS writes
+    ld_x(x_mh, xmh);
+    unsigned hi[2], mid[2], lo[2];
+    st_ok = raw_ok;
+    split_row(0, hi, mid, lo);
+    store_row(buf ^ 1, 0, hi, mid, lo);
+    split_row(1, hi, mid, lo);
+    store_row(buf ^ 1, 1, hi, mid, lo);
+    mm(whm, xhm);
+    constexpr int VAL = 2 * (AFFINE ? 30 : 22), S1 = G - TI - 6;      // VALU of the two splits; MFMA slots left after the reads and writes
+    MSS_PAIR_UP(0x100, TI, 1);
+    MSS_PAIR_UP(0x2, S1, (VAL + S1 - 1) / S1);
+    MSS_PAIR_UP(0x200, 6, 1);
+    fence();
+    // group 2 (mid hi + hi mid): the weight planes of K-step k+1 by DMA, then the A loads of K-step k+2, the fragments of group 3
+    dma_b(buf ^ 1, b_lag);
+    issue_loads_a();
+    ld_x(x_lh, xlh); ld_w(w_hl, whl);
+    mm(whm, xmh);
+    MSS_PAIR_UP(0x20, N_A_LOADS, 1);
+    MSS_PAIR_UP(0x100, TI + TJ < G - N_A_LOADS ? TI + TJ : G - N_A_LOADS, 1);
+    fence();
+    // group 3 (lo hi + hi lo): the loader's bookkeeping
+    advance();
+    mm(whl, xlh);
+    MSS_PAIR_UP(0x6, G - 1, 3);
+    fence();
+#undef MSS_PAIR_UP
+    // the DMAs are older than the N_A_LOADS register loads: this retires them (and this wave's LDS writes) and leaves the loads in flight
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(N_A_LOADS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" : : : "memory");                     // nothing of the next step moves above the barrier
   };
   // One K-step: the products in an order that needs one new operand plane per group of 2 * TN MFMAs
   //   (A_lo, B_hi) (A_mid, B_hi) (A_hi, B_hi) (A_hi, B_mid) (A_mid, B_mid) (A_hi, B_lo)
@@ -442,13 +593,20 @@ __global__ __launch_bounds__(NT, (BN == 256 || (AFFINE && (CONV || ROWAFF))) ? 2
   if (CONV) cur_ok = (unsigned)((okb[0] & 1) | ((okb[1] & 1) << 1));
   setup_next();
   issue_loads();
+  if constexpr (M16) dma_b(0, b_off);    // the weight planes of K-step 0 (b_off still describes it)
   st_ok = raw_ok;
-  finish_store(0);
+  if constexpr (M16) finish_store_a(0); else finish_store(0);
   advance();
   issue_loads();                         // registers now hold K-step 1
   advance();
   zero_acc();
-  __syncthreads();
+  if constexpr (M16) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(N_A_LOADS) : "memory");     // the DMAs of K-step 0 (older than K-step 1's A loads)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" : : : "memory");
+  } else {
+    __syncthreads();
+  }
   int k = 0;
 #ifdef MSS_SPLIT_STAMPS
   dbg_last = __builtin_amdgcn_s_memtime();
@@ -476,9 +634,9 @@ __global__ __launch_bounds__(NT, (BN == 256 || (AFFINE && (CONV || ROWAFF))) ? 2
     return false;
   };
   while (true) {                         // unrolled by the two LDS stages: the stage is a compile-time constant in each half
-    step(0);
+    if constexpr (M16) step16(0); else step(0);
     if (tile_end()) break;
-    step(1);
+    if constexpr (M16) step16(1); else step(1);
     if (tile_end()) break;
   }
   if (DYN && tid == 0 && atomicAdd(sched + 8, 1) == (int)gridDim.x - 1) {   // the last workgroup out zeroes the counters for their next launch
@@ -800,34 +958,49 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 template <bool AFFINE, int BN, bool CONV, bool ROWAFF>
 constexpr bool split_dyn_tiles() { return DYN_TILES || (AFFINE && !CONV && !ROWAFF); }
 
-template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false>
-int launch_split(const MssConvArgs& p, hipStream_t stream) {
-  constexpr bool DYN = split_dyn_tiles<AFFINE, BN, CONV, ROWAFF>();
+// occupancy / CU count / the raised dynamic-LDS limit of one kernel instantiation, PER DEVICE (function attributes are per device; a
+// process may drive several): filled on the first launch on that device under a mutex
+struct SplitDevInfo { int occ = 0, cus = 256; };
+template <typename KernelT>
+int split_dev_info(KernelT kern, size_t smem, int fallback_occ, SplitDevInfo (&info)[SCHED_MAXDEV], std::mutex& mu, SplitDevInfo& out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SCHED_MAXDEV) return MSS_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(mu);
+  if (info[dev].occ == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) info[dev].cus = prop.multiProcessorCount;
+    if (smem > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+    }
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, NT, smem) != hipSuccess || n < 1) n = fallback_occ;
+    info[dev].occ = n;
+  }
+  out = info[dev];
+  return MSS_OK;
+}
+
+template <bool AFFINE, int BN, bool SCHED, bool CONV, bool ROWAFF, bool DYN, int MF>
+int launch_split_as(const MssConvArgs& p, hipStream_t stream, int* sched) {
   const int batch = p.batch > 1 ? p.batch : 1;
   const int tiles_per_batch = p.mtiles * p.ntiles;
   const long long total = (long long)tiles_per_batch * batch;
   if (total <= 0) return MSS_OK;
   const size_t smem = (size_t)2 * (1 + BN / 128) * OPER + 16;          // + the two ticket words of the dynamic tile order
-  static int per_cu_max = 0, cus = 256;
-  if (per_cu_max == 0) {
-    int dev = 0, n = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (smem > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF, DYN>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (e != hipSuccess) return (int)e;
-    }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF, DYN>, NT, smem) != hipSuccess || n < 1) n = BN == 256 ? 2 : 3;
-    const int cap = MSS_ENV_INT("MSS_GEMM_WG_PER_CU", 0);
-    if (cap > 0 && cap < n) n = cap;
-    per_cu_max = n;
-  }
+  static SplitDevInfo info[SCHED_MAXDEV];
+  static std::mutex mu;
+  SplitDevInfo di;
+  const int rc = split_dev_info(gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF, DYN, MF>, smem, BN == 256 ? 2 : 3, info, mu, di);
+  if (rc != MSS_OK) return rc;
+  int per_cu_max = di.occ;
+  const int cap = MSS_ENV_INT("MSS_GEMM_WG_PER_CU", 0);                // (A/B) read on every call: mss_env_reset applies
+  if (cap > 0 && cap < per_cu_max) per_cu_max = cap;
   // residency (per_cu_max or one less) whose last round of tiles is fuller, as launch_gemm (gemm.hip)
   int grid = 0;
   double best = -1.0;
   for (int per_cu = per_cu_max; per_cu >= (per_cu_max > 1 ? per_cu_max - 1 : 1); --per_cu) {
-    const long long slots = (long long)per_cu * cus;
+    const long long slots = (long long)per_cu * di.cus;
     const long long g = total < slots ? total : slots;
     const long long rounds = (total + g - 1) / g;
     const double eff = (double)total / (double)(rounds * g);
@@ -835,11 +1008,34 @@ int launch_split(const MssConvArgs& p, hipStream_t stream) {
   }
   const int group_m = MSS_ENV_INT("MSS_GEMM_GROUP_M", GEMM_GROUP_M_DEFAULT);
   const unsigned blk_bytes = (unsigned)(p.C / BK) * (CONV ? p.R * p.S : 1) * OPER;     // CONV: the taps are part of one long reduction
-  int* sched = DYN ? mss_sched_slot(stream) : nullptr;
-  if (DYN && !sched) return MSS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF, DYN>), dim3(grid), dim3(NT), smem, stream, p,
+  hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF, DYN, MF>), dim3(grid), dim3(NT), smem, stream, p,
                      static_cast<const unsigned char*>(p.w_split), total, tiles_per_batch, group_m, blk_bytes, p.Kpad / 128, sched);
   return mss_launch_status();
+}
+
+// what mss_epilogue_store16's 16-byte accesses need
+bool split_mf16_ok(const MssConvArgs& p) {
+  auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (p.K % 4 || p.ldy % 4 || !al(p.y) || (p.batch > 1 && p.y_bs % 4)) return false;
+  if (p.res && (p.ldres % 4 || !al(p.res))) return false;
+  if (p.out_scale && (!al(p.out_scale) || !al(p.out_shift))) return false;
+  return !p.stats || al(p.stats);
+}
+
+template <bool AFFINE, int BN, bool SCHED, bool CONV, bool ROWAFF, int MF>
+int launch_split_mf(const MssConvArgs& p, hipStream_t stream) {
+  if constexpr (split_dyn_tiles<AFFINE, BN, CONV, ROWAFF>()) {
+    int* sched = MSS_ENV_INT("MSS_GEMM_SPLIT_STATIC", 0) ? nullptr : mss_sched_slot(stream);    // (tests: force the fallback)
+    if (sched) return launch_split_as<AFFINE, BN, SCHED, CONV, ROWAFF, true, MF>(p, stream, sched);
+  }
+  return launch_split_as<AFFINE, BN, SCHED, CONV, ROWAFF, false, MF>(p, stream, nullptr);   // no slot to be had: the static walk
+}
+
+template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false>
+int launch_split(const MssConvArgs& p, hipStream_t stream) {
+  // MSS_GEMM_SPLIT_MFMA=32: the round-5 form (one product per v_mfma_f32_32x32x16_bf16) for A/B and for outputs mss_epilogue_store16 cannot take
+  if (SCHED && MSS_ENV_INT("MSS_GEMM_SPLIT_MFMA", 32) == 16 && split_mf16_ok(p)) return launch_split_mf<AFFINE, BN, true, CONV, ROWAFF, 16>(p, stream);
+  return launch_split_mf<AFFINE, BN, SCHED, CONV, ROWAFF, 32>(p, stream);
 }
 
 }  // namespace
@@ -946,15 +1142,19 @@ int mss_wgrad_tn_bf16x3_launch(const MssConvArgs& p, const float* dy, int lddy, 
   if (pl.splits > 1 && (!ws || ws_bytes < (long long)pl.splits * slab * 4)) return MSS_ERR_BAD_ARG;
   float* out = pl.splits > 1 ? ws : dwp;
   const size_t smem = (size_t)2 * 3 * OPER + 16;
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[SCHED_MAXDEV] = {false};                           // function attributes are per device
+  static std::mutex attr_mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SCHED_MAXDEV) return MSS_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> attr_lock(attr_mu);
+  if (!attr[dev]) {
     const void* ks[4] = {reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<false, false>), reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<false, true>),
                          reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<true, false>), reinterpret_cast<const void*>(gemm_tn_bf16x3_kernel<true, true>)};
     for (const void* kf : ks) {
       hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
     }
-    attr = true;
+    attr[dev] = true;
   }
   const long long slots = 512;
   const int grid = (int)(pl.total < slots ? pl.total : slots);
@@ -1025,6 +1225,7 @@ extern "C" long long mss_gemm_split_weights_bytes(int batch, int Kpad, int C) {
 static int split_weights(const float* w, void* planes, int batch, int taps, int Kpad, int C, long long w_bs, void* stream) {
   if (!w || !planes || batch < 1 || taps < 1 || Kpad % 128 || C % 16 || Kpad < 128 || C < 16) return MSS_ERR_BAD_ARG;
   if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(planes)) & 15 || w_bs % 4) return MSS_ERR_BAD_ARG;
+  mss_sched_init(static_cast<hipStream_t>(stream));     // the ticket pool exists before anything can launch on these planes
   const long long total = (long long)batch * Kpad * (C / 16) * taps * 2;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w,

@@ -5,16 +5,15 @@
 //     :38-89   bilinear gather        :242-304 forward kernel
 //     :92-164  bilinear scatter/grads :306-925 backward kernel family
 //
-// Design (not a translation of the reference's 1-thread-per-element / 32-thread-block kernels):
-//  forward fast path (fp32, D = 4*LPH): LPH lanes own one (n,q,m) pair with float4 channels each,
-//    so one wavefront covers 64/LPH consecutive pairs (= all 8 heads of one query at D=32): the
-//    pair's 2*L*P locations + L*P weights are staged once per wave through LDS (coalesced 1-KB
-//    reads) instead of being re-read by every channel thread; each corner gather is one 16-B load
-//    per lane (a full 128-B value row per 8 lanes); the output store is a contiguous 1 KB.
-//  backward: LPP (32 or 64) lanes own one pair, lane = channel, so each grad_value atomic
-//    wave-instruction covers whole 128-B rows (the shape the memory-side atomic units run at full
-//    rate); grad_loc / grad_attn are reduced over the pair's lanes with DPP/shuffles and written
-//    with plain stores (no LDS round trip, no serial thread-0 loop, no zero-init needed).
+// Design (not a translation of the reference's 1-thread-per-element / 32-thread-block kernels). ONE forward and TWO backward
+// formulations ship (round 6; the measured losers are in the git history):
+//  forward (fp32, D = 4*LPH = 16 / 32 / 64): msda_fwd_rec_kernel, per-sample records (below); anything else: msda_fwd_generic_kernel.
+//  backward, default (fp32, D = 32, host copy of the level shapes at hand): grad_value on the BINNED owner-computes path (counting
+//    sort of the samples by home tile, 64-bit fixed-point LDS tiles, halo merge: no float atomic, bit-reproducible) + one gather
+//    pass for grad_loc / grad_attn (msda_bwd_gather_fast_kernel).
+//  backward, generic (fp64, other head dimensions, no host shapes): msda_bwd_kernel -- LPP (32 or 64) lanes own one pair, lane =
+//    channel, so each grad_value atomic wave-instruction covers whole 128-B rows (the shape the memory-side atomic units run at full
+//    rate); grad_loc / grad_attn are reduced over the pair's lanes with DPP/shuffles and written with plain stores.
 #include "mss_common.h"
 #include <stdlib.h>
 #include "../../include/mss_hip.h"
@@ -22,8 +21,6 @@
 namespace {
 
 constexpr int MSDA_MAX_LP = 20;       // prepare kernels: 256 pairs x 3 x L*P floats of LDS per workgroup (60 KB at 20)
-constexpr int MSDA_WIN_MAXL = 8;      // window forward: levels carried by value in the kernel arguments
-constexpr int MSDA_WIN_ROWS = 320;    // window forward: value rows (128 B each) of one level staged per workgroup (40 KB)
 
 template <typename T> struct Vec4;
 template <> struct Vec4<float> { typedef f32x4 type; };
@@ -32,181 +29,18 @@ template <typename T, int LPP>
 __device__ __forceinline__ T pair_reduce(T v);     // sum over the LPP lanes of a pair's group (defined with the backward)
 
 // ------------------------------------------------------------------------------------------
-// forward, fast path
-// FUSED: `loc` / `attn` are the raw sampling offsets and attention logits of the module's two Linears and `ref` the
-// reference points [N,Lq,L,2] (ops/modules/ms_deform_attn.py:100-109): the softmax over the L*P logits and the
-// location arithmetic loc = ref + offset / (W_l, H_l) happen here, on the values the wave has staged in LDS anyway, so
-// the [N,Lq,M,L,P,2] / [N,Lq,M,L,P] tensors (11.7 MB per call at C4, read AND written by a separate kernel) never
-// exist. Same arithmetic as msda_prepare_kernel except the order in which the L*P exponentials are added.
-template <int LPH, bool FUSED, bool BUF>
-__global__ __launch_bounds__(256) void msda_fwd_fast_kernel(
-    const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
-    const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ ref, long long npairs, int S,
-    int M, int L, int Lq, int P, float* __restrict__ out, long long ldo, long long ldl) {
-  constexpr int D = 4 * LPH;
-  constexpr int HPW = 64 / LPH;  // pairs per wave
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LP = L * P;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* sloc = smem + wave * (HPW * LP * 3);  // [HPW][LP][2]
-  float* sattn = sloc + HPW * LP * 2;          // [HPW][LP]
-
-  const long long pair0 = ((long long)blockIdx.x * 4 + wave) * HPW;
-  if (pair0 >= npairs) return;  // whole wave leaves together (no block barrier below)
-  const int npw = (int)min((long long)HPW, npairs - pair0);
-
-  // stage loc/attn of the wave's pairs. ldo / ldl: floats between the rows of consecutive (n, q) -- M*2LP / M*LP when the two
-  // tensors are dense; r04: both projections' outputs side by side in ONE [N*Lq, M*3LP] buffer (a single 288-wide product).
-  // The wave's pairs are contiguous in memory when dense, and also when the wave holds exactly the M heads of one query.
-  if (M == HPW || (ldo == (long long)M * LP * 2 && ldl == (long long)M * LP)) {
-    const float* gl = M == HPW ? loc + pair0 / M * ldo : loc + pair0 * LP * 2;
-    const float* ga = M == HPW ? attn + pair0 / M * ldl : attn + pair0 * LP;
-    for (int i = lane; i < npw * LP * 2; i += 64) sloc[i] = gl[i];
-    for (int i = lane; i < npw * LP; i += 64) sattn[i] = ga[i];
-  } else {
-    for (int i = lane; i < npw * LP * 2; i += 64) {
-      const long long pr = pair0 + i / (LP * 2);
-      sloc[i] = loc[pr / M * ldo + (pr % M) * (LP * 2) + i % (LP * 2)];
-    }
-    for (int i = lane; i < npw * LP; i += 64) {
-      const long long pr = pair0 + i / LP;
-      sattn[i] = attn[pr / M * ldl + (pr % M) * LP + i % LP];
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  const int g = lane / LPH, j = lane % LPH;
-  const bool mine = g < npw;                    // lanes without a pair stay until the wave-level barriers are done
-  const long long pair = pair0 + (mine ? g : 0);
-  const int m = (int)(pair % M);
-  const long long nq = pair / M;
-  const int n = (int)(nq / Lq);
-  const float* myloc = sloc + g * LP * 2;
-  const float* myattn = sattn + g * LP;
-  const size_t row_stride = (size_t)M * D;  // floats between consecutive spatial positions
-  const float* vbase = value + (size_t)n * S * row_stride + (size_t)m * D + 4 * j;
-  if (FUSED && mine) {
-    // The LPH lanes of a pair turn its staged raw values into attention weights and locations IN PLACE, each lane taking
-    // every LPH-th sample (2 exps + 4 divisions per lane at L*P = 12, instead of every lane redoing all 12): the maximum
-    // from LDS, the partial sums of exponentials combined by an LPH-lane shuffle tree. A wave executes in lockstep and
-    // LDS operations of one wave complete in order, so the reads of the raw logits precede the overwriting stores.
-    float* ml = sloc + g * LP * 2;
-    float* ma = sattn + g * LP;
-    float mx = -__builtin_huge_valf();
-    for (int i = 0; i < LP; ++i) mx = fmaxf(mx, ma[i]);
-    constexpr int MAXI = (20 + LPH - 1) / LPH;          // L*P <= 20 (checked by the launcher)
-    float e[MAXI];
-    float part = 0.f;
-#pragma unroll
-    for (int t = 0; t < MAXI; ++t) {
-      const int i = j + t * LPH;
-      e[t] = i < LP ? expf(ma[i] - mx) : 0.f;
-      part += e[t];
-    }
-    const float inv = 1.f / pair_reduce<float, LPH>(part);
-#pragma unroll
-    for (int t = 0; t < MAXI; ++t) {
-      const int i = j + t * LPH;
-      if (i < LP) {
-        const int l = i / P;
-        ma[i] = e[t] * inv;
-        ml[2 * i] = ref[(nq * L + l) * 2] + ml[2 * i] / (float)shapes[2 * l + 1];
-        ml[2 * i + 1] = ref[(nq * L + l) * 2 + 1] + ml[2 * i + 1] / (float)shapes[2 * l];
-      }
-    }
-  }
-  if (FUSED) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-  if (!mine) return;
-
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (BUF) {
-    // PMC showed this kernel issuing 22 VALU instructions per gather (69 % VALU-issue utilisation next to the L2 gather
-    // ceiling; the fused form 89 %): 64-bit address arithmetic per corner and sixteen selects per sample that zero the
-    // out-of-image corners. Here the whole value tensor is ONE buffer resource (host-checked: < 4 GB): a corner is a 32-bit
-    // byte offset, and an out-of-image corner gets an out-of-range offset, for which the hardware returns zeros without a
-    // memory access -- the reference's zero padding, exact even next to non-finite values.
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(value), 0, (int)(unsigned)min((unsigned long long)npairs / M / Lq * S * row_stride * 4ull, 0xffffffffull),
-        0x00020000);
-    const unsigned rs4 = (unsigned)(row_stride * sizeof(float));
-    const unsigned lane_off = (unsigned)(((size_t)n * S * row_stride + (size_t)m * D + 4 * j) * sizeof(float));
-    for (int l = 0; l < L; ++l) {
-      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-      const unsigned lvl_off = lane_off + (unsigned)starts[l] * rs4;
-#pragma unroll 4
-      for (int pt = 0; pt < P; ++pt) {
-        const float lx = myloc[(l * P + pt) * 2], ly = myloc[(l * P + pt) * 2 + 1];
-        const float aw = myattn[l * P + pt];
-        const float w_im = lx * W - 0.5f, h_im = ly * H - 0.5f;
-        const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-        const float hf = floorf(h_im), wf = floorf(w_im);
-        const int h0 = (int)hf, w0 = (int)wf;
-        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-        const bool okh0 = inside && h0 >= 0, okh1 = inside && h0 + 1 <= H - 1;
-        const bool okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
-        const unsigned o00 = lvl_off + (unsigned)(h0 * W + w0) * rs4;          // garbage when out of image: replaced below
-        const unsigned oob = 0xffffffffu;
-        const f32x4 v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (okh0 && okw0) ? o00 : oob, 0, 0));
-        const f32x4 v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (okh0 && okw1) ? o00 + rs4 : oob, 0, 0));
-        const f32x4 v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (okh1 && okw0) ? o00 + W * rs4 : oob, 0, 0));
-        const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (okh1 && okw1) ? o00 + W * rs4 + rs4 : oob, 0, 0));
-        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-        const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-        acc += aw * val;
-      }
-    }
-    *reinterpret_cast<f32x4*>(out + pair * D + 4 * j) = acc;
-    return;
-  }
-  for (int l = 0; l < L; ++l) {
-    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-    const float* vl = vbase + (size_t)starts[l] * row_stride;
-#pragma unroll 4
-    for (int pt = 0; pt < P; ++pt) {
-      const float lx = myloc[(l * P + pt) * 2], ly = myloc[(l * P + pt) * 2 + 1];
-      const float aw = myattn[l * P + pt];
-      const float w_im = lx * W - 0.5f, h_im = ly * H - 0.5f;
-      const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-      const float hf = floorf(h_im), wf = floorf(w_im);
-      const int h0 = (int)hf, w0 = (int)wf;
-      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-      const bool okh0 = inside && h0 >= 0, okh1 = inside && h0 + 1 <= H - 1;
-      const bool okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
-      const int h0c = min(max(h0, 0), H - 1), h1c = min(max(h0 + 1, 0), H - 1);
-      const int w0c = min(max(w0, 0), W - 1), w1c = min(max(w0 + 1, 0), W - 1);
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      f32x4 v1 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h0c * W + w0c) * row_stride);
-      f32x4 v2 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h0c * W + w1c) * row_stride);
-      f32x4 v3 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h1c * W + w0c) * row_stride);
-      f32x4 v4 = *reinterpret_cast<const f32x4*>(vl + (size_t)(h1c * W + w1c) * row_stride);
-      v1 = (okh0 && okw0) ? v1 : z;
-      v2 = (okh0 && okw1) ? v2 : z;
-      v3 = (okh1 && okw0) ? v3 : z;
-      v4 = (okh1 && okw1) ? v4 : z;
-      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-      const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-      acc += aw * val;
-    }
-  }
-  *reinterpret_cast<f32x4*>(out + pair * D + 4 * j) = acc;
-}
-
-// ------------------------------------------------------------------------------------------
-// forward, r04: per-sample RECORDS. In msda_fwd_fast_kernel every one of the LPH lanes that share a (query, head) repeats the
-// sample's location arithmetic (pixel coordinates, floor, four weights, four corner offsets with their in-image tests: ~20 of the
-// ~40 VALU instructions per sample; the kernel is VALU-issue-bound next to the L2 gather ceiling). Here the
-// lanes of a group split the L*P samples between them ONCE: lane j prepares samples j, j + LPH, ... -- it loads their raw values
-// itself (no LDS staging of loc / attn), for the fused form takes part in the group's softmax through shuffles, and leaves a
-// record in LDS: four byte offsets into the value tensor (out-of-image corners: an out-of-range offset, answered with zeros by
-// the buffer hardware), the four bilinear weights, the attention weight. The sampling loop then costs, per sample and lane, three
-// LDS reads (group-uniform addresses: broadcasts), four address adds and the 20 multiply-adds of the accumulation.
-// Arithmetic per output identical to msda_fwd_fast_kernel's (same expressions in the same order): bit-identical results.
+// forward (fp32, D = 4 * LPH): per-sample RECORDS. LPH lanes own one (n, q, m) pair with float4 channels each, so one wavefront
+// covers 64 / LPH consecutive pairs (all 8 heads of one query at D = 32); each corner gather is one 16-byte load per lane (a full
+// 128-byte value row per 8 lanes) through ONE buffer resource (32-bit offsets; an out-of-image corner is an out-of-range offset the
+// hardware answers with zeros: the reference's zero padding, no selects); the output store is a contiguous 1 KB.
+// The lanes of a group split the L*P samples between them ONCE: lane j prepares samples j, j + LPH, ... -- it loads their raw values
+// itself, for the FUSED form (`loc` / `attn` are the raw sampling offsets / attention logits of the module's two Linears and `ref` the
+// reference points [N,Lq,L,2], ops/modules/ms_deform_attn.py:100-109) takes part in the group's softmax through shuffles and does
+// loc = ref + offset / (W_l, H_l), and leaves a record in LDS: four byte offsets into the value tensor, the four bilinear weights,
+// the attention weight. The sampling loop then costs, per sample and lane, three LDS reads (group-uniform addresses: broadcasts),
+// four address adds and the 20 multiply-adds of the accumulation: 16 VALU per sample where round 2's kernel (every lane repeating
+// the location arithmetic: ~40) was VALU-issue-bound next to the L2 gather ceiling. That kernel and round 2's LDS-window forward
+// (0.7x the gather's speed) left the product in round 6 (git history).
 template <int LPH, bool FUSED>
 __global__ __launch_bounds__(256) void msda_fwd_rec_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
@@ -324,239 +158,6 @@ __global__ __launch_bounds__(256) void msda_fwd_rec_kernel(
     acc += aw * val;
   }
   *reinterpret_cast<f32x4*>(out + pair * D + 4 * j) = acc;
-}
-
-// ------------------------------------------------------------------------------------------
-// forward through LDS windows (fp32, D = 32). The fast kernel above sits on the L2 row-gather rate (48 x 128-B rows per
-// (query, head), 16-17 TB/s measured); in the encoder the queries are the pixels of the levels themselves and their
-// samples lie a few pixels around their own position, so neighbouring queries gather the same rows again and again.
-// One workgroup = 64 queries (an 8x8 pixel tile of one level when the queries are the pixel grid, else 64 consecutive
-// queries) x one head. Per level: the bounding box of the tile's samples is reduced in LDS, a window of at most
-// MSDA_WIN_ROWS value rows (the whole box if it fits, else a box of that area around the samples' mean) is staged once
-// with coalesced 128-B loads, and the 4*P corner fetches of every query read LDS; a corner outside the window falls
-// back to the global gather, so the result never depends on where the window lies. Same arithmetic per sample as the
-// fast kernel. Level geometry comes BY VALUE from the host (the grid size depends on it).
-// MEASURED (profiles/r02/m2f/bench_msda_window.jsonl): correct but SLOWER than the gather kernel on MI355X -- 0.66-0.81 ms
-// against 0.46 ms at N = 16 (C4), 0.18-0.22 against 0.107 at C5 -- so it is opt-in (MSS_MSDA_WINDOW=1) and kept as the
-// record of the experiment: 48 LDS b128 reads per (query, head) cost 8 clocks each before bank conflicts (rows of the
-// same parity collide), the per-level barriers and box reductions add to that, and the L2 gather already delivers
-// 17 TB/s = 43 % of the L1 data path; the ceiling of the LDS route is ~2x, the first implementation is 0.7x.
-struct MsdaLevels {
-  int L;
-  int H[MSDA_WIN_MAXL], W[MSDA_WIN_MAXL];
-  int qstart[MSDA_WIN_MAXL];         // first query of the level (grid mode)
-  int tiles_x[MSDA_WIN_MAXL];        // 8x8 tiles per row of the level
-  int tile_start[MSDA_WIN_MAXL + 1]; // prefix sum of the tile counts
-};
-
-template <bool FUSED>
-__global__ __launch_bounds__(256) void msda_fwd_window_kernel(
-    const float* __restrict__ value, const int64_t* __restrict__ starts, const float* __restrict__ loc,
-    const float* __restrict__ attn, const float* __restrict__ ref, const MsdaLevels lv, int grid_mode, int ntiles, int S, int M,
-    int Lq, int P, float* __restrict__ out) {
-  constexpr int D = 32;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ int sq[64];
-  __shared__ int sstat[MSDA_WIN_MAXL][8];
-  const int L = lv.L, LP = L * P;
-  float* swin = smem;                       // [MSDA_WIN_ROWS][32]
-  float* sx = swin + MSDA_WIN_ROWS * D;     // [64][LP] w_im
-  float* sy = sx + 64 * LP;                 // h_im
-  float* sa = sy + 64 * LP;                 // attention weight
-  const int tid = threadIdx.x;
-  int b = blockIdx.x;
-  const int m = b % M;
-  b /= M;
-  const int tile = b % ntiles, n = b / ntiles;
-
-  if (tid < 64) {
-    int q = -1;
-    if (grid_mode) {
-      int lq = 0;
-      while (lq + 1 < L && tile >= lv.tile_start[lq + 1]) ++lq;
-      const int t = tile - lv.tile_start[lq];
-      const int ty = t / lv.tiles_x[lq], tx = t - ty * lv.tiles_x[lq];
-      const int y = ty * 8 + (tid >> 3), x = tx * 8 + (tid & 7);
-      if (y < lv.H[lq] && x < lv.W[lq]) q = lv.qstart[lq] + y * lv.W[lq] + x;
-    } else {
-      q = tile * 64 + tid;
-      if (q >= Lq) q = -1;
-    }
-    sq[tid] = q;
-  }
-  if (tid < L * 8) {
-    const int k = tid & 7;
-    sstat[tid >> 3][k] = (k == 0 || k == 2) ? 0x7fffffff : (k == 1 || k == 3) ? (int)0x80000000 : 0;
-  }
-  __syncthreads();
-
-  // ---- phase 1: the 4 lanes of a query slot turn its L*P raw entries into (w_im, h_im, weight) in LDS
-  {
-    const int slot = tid >> 2, sub = tid & 3;
-    const int q = sq[slot];
-    const long long nq = (long long)n * Lq + max(q, 0);
-    const long long pair = nq * M + m;
-    const float* gl = loc + pair * LP * 2;
-    const float* ga = attn + pair * LP;
-    constexpr int MAXI = (MSDA_MAX_LP + 3) / 4;
-    float lx[MAXI], ly[MAXI], aw[MAXI];
-    float mx = -__builtin_huge_valf();
-#pragma unroll
-    for (int u = 0; u < MAXI; ++u) {
-      const int k = sub + 4 * u;
-      if (k < LP) {
-        lx[u] = gl[2 * k], ly[u] = gl[2 * k + 1], aw[u] = ga[k];
-        mx = fmaxf(mx, aw[u]);
-      }
-    }
-    if (FUSED) {
-      mx = fmaxf(mx, __shfl_xor(mx, 1));
-      mx = fmaxf(mx, __shfl_xor(mx, 2));
-      float part = 0.f;
-#pragma unroll
-      for (int u = 0; u < MAXI; ++u)
-        if (sub + 4 * u < LP) {
-          aw[u] = expf(aw[u] - mx);
-          part += aw[u];
-        }
-      part += __shfl_xor(part, 1);
-      part += __shfl_xor(part, 2);
-      const float inv = 1.f / part;
-#pragma unroll
-      for (int u = 0; u < MAXI; ++u) {
-        const int k = sub + 4 * u;
-        if (k < LP) {
-          const int l = k / P;
-          aw[u] *= inv;
-          lx[u] = ref[(nq * L + l) * 2] + lx[u] / (float)lv.W[l];
-          ly[u] = ref[(nq * L + l) * 2 + 1] + ly[u] / (float)lv.H[l];
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < MAXI; ++u) {
-      const int k = sub + 4 * u;
-      if (k < LP) {
-        const int l = k / P;
-        sx[slot * LP + k] = q >= 0 ? lx[u] * lv.W[l] - 0.5f : -8.f;
-        sy[slot * LP + k] = q >= 0 ? ly[u] * lv.H[l] - 0.5f : -8.f;
-        sa[slot * LP + k] = q >= 0 ? aw[u] : 0.f;
-      }
-    }
-  }
-  __syncthreads();
-
-  const int g = tid >> 3, j = tid & 7;
-  const size_t row_stride = (size_t)M * D;
-  const float* vbase = value + (size_t)n * S * row_stride + (size_t)m * D + 4 * j;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const int q0 = sq[g], q1 = sq[g + 32];
-
-  for (int l = 0; l < L; ++l) {
-    const int H = lv.H[l], W = lv.W[l];
-    // ---- bounding box and mean of the tile's samples on this level
-    {
-      int lo_h = 0x7fffffff, hi_h = (int)0x80000000, lo_w = 0x7fffffff, hi_w = (int)0x80000000, cnt = 0;
-      float sh = 0.f, sw = 0.f;
-      for (int i = tid; i < 64 * P; i += 256) {
-        const int slot = i / P, pt = i - slot * P;
-        const float w_im = sx[slot * LP + l * P + pt], h_im = sy[slot * LP + l * P + pt];
-        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-          const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im);
-          lo_h = min(lo_h, max(h0, 0)), hi_h = max(hi_h, min(h0 + 1, H - 1));
-          lo_w = min(lo_w, max(w0, 0)), hi_w = max(hi_w, min(w0 + 1, W - 1));
-          sh += h_im, sw += w_im, ++cnt;
-        }
-      }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        lo_h = min(lo_h, __shfl_xor(lo_h, o)), hi_h = max(hi_h, __shfl_xor(hi_h, o));
-        lo_w = min(lo_w, __shfl_xor(lo_w, o)), hi_w = max(hi_w, __shfl_xor(hi_w, o));
-        cnt += __shfl_xor(cnt, o), sh += __shfl_xor(sh, o), sw += __shfl_xor(sw, o);
-      }
-      if ((tid & 63) == 0 && cnt > 0) {
-        atomicMin(&sstat[l][0], lo_h), atomicMax(&sstat[l][1], hi_h);
-        atomicMin(&sstat[l][2], lo_w), atomicMax(&sstat[l][3], hi_w);
-        atomicAdd(&sstat[l][4], cnt);
-        atomicAdd(reinterpret_cast<float*>(&sstat[l][5]), sh), atomicAdd(reinterpret_cast<float*>(&sstat[l][6]), sw);
-      }
-    }
-    __syncthreads();
-    // ---- the window (block-uniform)
-    int wh0 = 0, ww0 = 0, nh = 0, nw = 0;
-    {
-      const int cnt = sstat[l][4];
-      if (cnt > 0) {
-        const int lo_h = sstat[l][0], hi_h = sstat[l][1], lo_w = sstat[l][2], hi_w = sstat[l][3];
-        const int bh = hi_h - lo_h + 1, bw = hi_w - lo_w + 1;
-        nh = bh, nw = bw, wh0 = lo_h, ww0 = lo_w;
-        if (bh * bw > MSDA_WIN_ROWS) {
-          const float f = sqrtf((float)MSDA_WIN_ROWS / ((float)bh * (float)bw));
-          nh = min(bh, max(2, (int)(bh * f)));
-          nw = min(bw, MSDA_WIN_ROWS / nh);
-          nh = min(bh, MSDA_WIN_ROWS / nw);
-          const float mh = __int_as_float(sstat[l][5]) / cnt, mw = __int_as_float(sstat[l][6]) / cnt;
-          wh0 = min(max((int)floorf(mh + 1.f) - nh / 2, lo_h), hi_h - nh + 1);
-          ww0 = min(max((int)floorf(mw + 1.f) - nw / 2, lo_w), hi_w - nw + 1);
-        }
-      }
-    }
-    const float* vl = vbase + (size_t)starts[l] * row_stride;
-    {
-      const int rows = nh * nw;
-      constexpr int UN = MSDA_WIN_ROWS / 32;
-      f32x4 t[UN];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int r = g + 32 * u;
-        if (r < rows) {
-          const int hy = r / nw, wx = r - hy * nw;
-          t[u] = *reinterpret_cast<const f32x4*>(vl + (size_t)((wh0 + hy) * W + ww0 + wx) * row_stride);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int r = g + 32 * u;
-        if (r < rows) *reinterpret_cast<f32x4*>(swin + r * D + 4 * j) = t[u];
-      }
-    }
-    __syncthreads();
-    // ---- sampling: the thread's two queries, P points each. (A branch-free variant -- LDS read with a clamped index plus
-    // a buffer load pushed out of range for in-window corners -- was 3x slower: the out-of-range buffer loads still
-    // occupy the address path, 2.04 ms against 0.66 ms at N = 16.)
-    auto fetch = [&](int hc, int wc) -> f32x4 {
-      const int dh = hc - wh0, dw = wc - ww0;
-      if ((unsigned)dh < (unsigned)nh && (unsigned)dw < (unsigned)nw)
-        return *reinterpret_cast<const f32x4*>(swin + (dh * nw + dw) * D + 4 * j);
-      return *reinterpret_cast<const f32x4*>(vl + (size_t)(hc * W + wc) * row_stride);
-    };
-    auto sample = [&](int slot, f32x4& acc) {
-      for (int pt = 0; pt < P; ++pt) {
-        const float w_im = sx[slot * LP + l * P + pt], h_im = sy[slot * LP + l * P + pt];
-        const float aw = sa[slot * LP + l * P + pt];
-        const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-        if (!inside) continue;
-        const float hf = floorf(h_im), wf = floorf(w_im);
-        const int h0 = (int)hf, w0 = (int)wf;
-        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-        const bool okh0 = h0 >= 0, okh1 = h0 + 1 <= H - 1, okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
-        const int h0c = max(h0, 0), h1c = min(h0 + 1, H - 1), w0c = max(w0, 0), w1c = min(w0 + 1, W - 1);
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        f32x4 v1 = fetch(h0c, w0c), v2 = fetch(h0c, w1c), v3 = fetch(h1c, w0c), v4 = fetch(h1c, w1c);
-        v1 = (okh0 && okw0) ? v1 : z;
-        v2 = (okh0 && okw1) ? v2 : z;
-        v3 = (okh1 && okw0) ? v3 : z;
-        v4 = (okh1 && okw1) ? v4 : z;
-        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-        const f32x4 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-        acc += aw * val;
-      }
-    };
-    if (q0 >= 0) sample(g, acc0);
-    if (q1 >= 0) sample(g + 32, acc1);
-  }
-  if (q0 >= 0) *reinterpret_cast<f32x4*>(out + (((long long)n * Lq + q0) * M + m) * D + 4 * j) = acc0;
-  if (q1 >= 0) *reinterpret_cast<f32x4*>(out + (((long long)n * Lq + q1) * M + m) * D + 4 * j) = acc1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -830,38 +431,15 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_fast_kernel(
   }
 }
 
-// grad_value without global atomics (fp32, D = 32). The scatter-add formulation above is bound by memory-side
-// atomics (~1.3 TB/s of added bytes: 6 ms for the 8 GB of a 16-image C4 call). Here a workgroup OWNS a tile of
-// grad_value -- (image n, head m, level l, a band of rows x columns with at most 256 positions) -- scans the level's
-// Lq*P sampling locations of (n, m) (L2-resident, a few hundred KB), and for the samples whose bilinear footprint
-// touches its tile accumulates w_corner * attn * grad_out in LDS; the finished tile is written with plain stores.
-// Every grad_value element belongs to exactly one tile, so there is no memset and no global atomic. Passing samples
-// are compacted with a wave ballot and handled two at a time (32 channels each), four pairs in flight.
-//
-// The LDS accumulators are 64-bit FIXED POINT: ds_add_f32 runs at 0.33 lane-operations per clock per CU on gfx950
-// (measured, tools/hipbench/lds_atomic_rate.hip), ds_add_u64 at 9.2. A pre-pass finds max|grad_out| and max|attn|;
-// with 2^e >= their product every contribution is scaled by 2^(40-e), so |c| <= 2^40, 2^22 of them cannot overflow
-// and the resolution is 2^-40 of the largest possible contribution (fp32 atomics resolve 2^-24 of each partial sum).
-// The result does not depend on the order of the additions.
-constexpr int MSDA_TILE_CELLS = 256;   // x 32 channels x 8 B = 64 KB -> two workgroups per CU
-constexpr int MSDA_TILE_W = 16;
+// The owner-computes formulations of grad_value accumulate in LDS in 64-bit FIXED POINT: ds_add_f32 runs at 0.33 lane-operations
+// per clock per CU on gfx950 (measured, tools/hipbench/lds_atomic_rate.hip), ds_add_u64 at 9.2. With 2^e >= max|grad_out| *
+// max|attn| every contribution is scaled by 2^(40-e), so |c| <= 2^40, 2^22 of them cannot overflow and the resolution is 2^-40
+// of the largest possible contribution (fp32 atomics resolve 2^-24 of each partial sum). The result does not depend on the
+// order of the additions. (Round 2's first form -- every tile re-scanning its level's samples -- and round 5's cell-sorted
+// rows were measured slower than the binned path below at every size and left the product in round 6: git history,
+// profiles/r05/msda_bwd_rows.md.)
 constexpr int MSDA_FIXED_BITS = 40;
 
-__global__ __launch_bounds__(256) void msda_absmax_kernel(const float* __restrict__ a, long long na,
-                                                          const float* __restrict__ b, long long nb,
-                                                          unsigned* __restrict__ out) {
-  float ma = 0.f, mb = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < na; i += (long long)gridDim.x * 256) ma = fmaxf(ma, fabsf(a[i]));
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nb; i += (long long)gridDim.x * 256) mb = fmaxf(mb, fabsf(b[i]));
-  ma = mss_wave_max(ma);
-  mb = mss_wave_max(mb);
-  if ((threadIdx.x & 63) == 0) {       // non-negative floats order like their bit patterns
-    atomicMax(out, __float_as_uint(ma));
-    atomicMax(out + 1, __float_as_uint(mb));
-  }
-}
-
-// one atomicMax per WORKGROUP, and only when it can raise the value (same-address atomics serialise: 8192 of them cost
 // 95 us here). `red`: >= 16 floats of LDS; every thread of the (<= 1024-thread) workgroup calls it.
 __device__ __forceinline__ void msda_block_atomic_max(float m, unsigned* __restrict__ out, float* red) {
   m = mss_wave_max(m);
@@ -873,138 +451,6 @@ __device__ __forceinline__ void msda_block_atomic_max(float m, unsigned* __restr
     for (int i = 1; i < (int)(blockDim.x >> 6); ++i) mm = fmaxf(mm, red[i]);
     const unsigned bits = __float_as_uint(mm);          // non-negative floats order like their bit patterns
     if (bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
-  }
-}
-
-struct MsdaTile { int l, H, W, r0, r1, c0, c1; long long start; bool valid; };
-__device__ __forceinline__ MsdaTile msda_find_tile(const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
-                                                   int L, int t) {
-  MsdaTile k;
-  k.valid = false;
-  for (int l = 0; l < L; ++l) {
-    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-    // ~16 x 16 positions (a bilinear footprint straddles a tile edge with probability ~1/16 per axis; row bands would
-    // duplicate half of the samples); thin levels get wider / taller tiles so that a tile still holds ~256 positions
-    const int BH0 = H < MSDA_TILE_W ? H : MSDA_TILE_W;
-    const int BW = min(W, MSDA_TILE_CELLS / BH0);
-    const int BH = min(H, MSDA_TILE_CELLS / BW);
-    const int nr = (H + BH - 1) / BH, nc = (W + BW - 1) / BW;
-    if (t < nr * nc) {
-      const int br = t / nc, bc = t - br * nc;
-      k.l = l; k.H = H; k.W = W; k.start = starts[l];
-      k.r0 = br * BH; k.r1 = min(H, k.r0 + BH);
-      k.c0 = bc * BW; k.c1 = min(W, k.c0 + BW);
-      k.valid = true;
-      return k;
-    }
-    t -= nr * nc;
-  }
-  return k;
-}
-
-constexpr int MSDA_LDS_NT = 1024;      // 16 waves: the gout gathers are latency-bound, two such workgroups per CU
-template <int UN>                      // UN sample pairs in flight per wave
-__global__ __launch_bounds__(MSDA_LDS_NT) void msda_bwd_value_lds_kernel(
-    const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts, const float* __restrict__ loc,
-    const float* __restrict__ attn, const float* __restrict__ gout, const unsigned* __restrict__ absmax, int S, int M,
-    int L, int Lq, int P, float* __restrict__ gvalue) {
-  constexpr int D = 32, NT = MSDA_LDS_NT;
-  __shared__ unsigned long long tile[MSDA_TILE_CELLS * D];
-  const MsdaTile k = msda_find_tile(shapes, starts, L, blockIdx.x);
-  if (!k.valid) return;                                  // the grid is an upper bound on the tile count
-  const int m = blockIdx.y, n = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, d = lane & 31;
-  const int tw = k.c1 - k.c0, cells = (k.r1 - k.r0) * tw;
-  for (int i = tid; i < cells * D; i += NT) tile[i] = 0ull;
-  // fixed-point scale: 2^(40 - e) with 2^e >= max|grad_out| * max|attn| (bilinear weights are <= 1)
-  const float bound = __uint_as_float(absmax[0]) * __uint_as_float(absmax[1]);
-  int e = 0;
-  if (bound > 0.f && bound < __builtin_huge_valf()) (void)frexpf(bound, &e);      // bound = f * 2^e, f in [0.5, 1)
-  // a non-finite grad_out / attn poisons the whole gradient (the reference's float atomics would poison the cells it
-  // reaches): every element written below becomes NaN instead of a silently wrong finite number
-  const bool finite = bound < __builtin_huge_valf();      // false for inf and NaN
-  const double to_fixed = ldexp(1.0, MSDA_FIXED_BITS - e);
-  const double from_fixed = finite ? ldexp(1.0, e - MSDA_FIXED_BITS) : (double)__builtin_nanf("");
-  __syncthreads();
-  const long long total = (long long)Lq * P;
-  const size_t pair_stride = (size_t)M * L * P;          // (q -> q+1) in units of samples
-  const size_t pair0 = ((size_t)n * Lq * M + m) * L * P + (size_t)k.l * P;
-  const float fH = (float)k.H, fW = (float)k.W;
-  const float* go = gout + ((size_t)n * Lq * M + m) * D + d;       // + q * M * D
-  const size_t go_stride = (size_t)M * D;
-  const int total_i = (int)total;
-  for (int i0 = 0; i0 < total_i; i0 += NT) {
-    const int i = i0 + tid;
-    bool pass = false;
-    int q = 0;
-    float h_im = 0.f, w_im = 0.f, aw = 0.f;
-    if (i < total_i) {
-      q = i / P;
-      const int pt = i - q * P;
-      const size_t sidx = pair0 + (size_t)q * pair_stride + pt;
-      const float lx = loc[sidx * 2], ly = loc[sidx * 2 + 1];
-      w_im = lx * fW - 0.5f;
-      h_im = ly * fH - 0.5f;
-      if (h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW) {
-        const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im);
-        const bool rows = (h0 >= k.r0 && h0 < k.r1) || (h0 + 1 >= k.r0 && h0 + 1 < k.r1);     // h0 = -1 / h0+1 = H never match
-        const bool cols = (w0 >= k.c0 && w0 < k.c1) || (w0 + 1 >= k.c0 && w0 + 1 < k.c1);
-        pass = rows && cols;
-        if (pass) aw = attn[sidx];
-      }
-    }
-    unsigned long long mask = __ballot(pass);
-    while (mask) {
-      // up to UN pairs of passing samples: lanes 0-31 take the even ones, lanes 32-63 the odd ones; all gout rows are
-      // requested before the first LDS atomic
-      int sq[UN];
-      float sh[UN], sw[UN], tgv[UN];
-      bool act[UN];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        int s0 = -1, s1 = -1;
-        if (mask) { s0 = __ffsll((long long)mask) - 1; mask &= mask - 1; }
-        if (mask) { s1 = __ffsll((long long)mask) - 1; mask &= mask - 1; }
-        const int src = half ? s1 : s0;
-        act[u] = src >= 0;
-        const int from = src >= 0 ? src : 0;
-        sq[u] = __shfl(q, from);
-        sh[u] = __shfl(h_im, from);
-        sw[u] = __shfl(w_im, from);
-        tgv[u] = __shfl(aw, from);
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) tgv[u] *= act[u] ? go[(size_t)sq[u] * go_stride] : 0.f;
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        if (act[u]) {
-          const float hf = floorf(sh[u]), wf = floorf(sw[u]);
-          const int h0 = (int)hf, w0 = (int)wf;
-          const float lh = sh[u] - hf, lw = sw[u] - wf, hh = 1.f - lh, hw = 1.f - lw;
-          const bool r_lo = h0 >= k.r0 && h0 < k.r1, r_hi = h0 + 1 >= k.r0 && h0 + 1 < k.r1;
-          const bool c_lo = w0 >= k.c0 && w0 < k.c1, c_hi = w0 + 1 >= k.c0 && w0 + 1 < k.c1;
-          unsigned long long* base = tile + ((h0 - k.r0) * tw + (w0 - k.c0)) * D + d;
-          // round(c * 2^(40-e)) as a two's-complement integer: adding 1.5 * 2^52 leaves it in the low mantissa bits
-          // (|c * to_fixed| <= 2^40); a native double -> int64 conversion does not exist on this ISA
-          auto fx = [&](float c) {
-            const double t = fma((double)c, to_fixed, 6755399441055744.0);
-            return (unsigned long long)(__double_as_longlong(t) - 0x4338000000000000ll);
-          };
-          if (r_lo && c_lo) atomicAdd(base, fx(hh * hw * tgv[u]));
-          if (r_lo && c_hi) atomicAdd(base + D, fx(hh * lw * tgv[u]));
-          if (r_hi && c_lo) atomicAdd(base + tw * D, fx(lh * hw * tgv[u]));
-          if (r_hi && c_hi) atomicAdd(base + tw * D + D, fx(lh * lw * tgv[u]));
-        }
-      }
-    }
-  }
-  __syncthreads();
-  const size_t rs = (size_t)M * D;
-  float* gv = gvalue + (size_t)n * S * rs + (size_t)m * D + (size_t)k.start * rs;
-  for (int i = tid; i < cells * D; i += NT) {
-    const int cell = i >> 5, ch = i & 31;
-    const int r = cell / tw, c = cell - r * tw;
-    gv[(size_t)((k.r0 + r) * k.W + k.c0 + c) * rs + ch] = (float)((double)(long long)tile[i] * from_fixed);
   }
 }
 
@@ -1370,356 +816,6 @@ __global__ __launch_bounds__(256) void msda_bin_merge_kernel(MsdaBinGeom g, cons
 }
 
 // ------------------------------------------------------------------------------------------
-// grad_value, CELL-SORTED path (round 5). The binned kernel above spends 15 of its 19 VALU slots per
-// sample on making the accumulation order-independent (two 64-bit fixed-point conversions + two LDS atomics per lane).
-// Here the counting sort's key is the CELL: key = (image, head, level, home cell, q mod sub) -- `sub` sub-keys per cell
-// on the levels that receive many samples per cell, so that a key holds ~5 - 25 records -- and one WAVE owns one ROW of
-// cells of one (image, head, level):
-//   msda_cell_kernel<0>      per-key record counts (one global atomic per in-image sample)
-//   msda_scan_*_kernel       exclusive scan of the keys (two launches)
-//   msda_cell_kernel<1>      the 16-byte records to their keys' runs (position inside a run = arrival order)
-//   msda_bwd_value_rows_kernel  a wave walks its row's keys in blocks of whole runs with <= 64 records: lane = record
-//                            computes the four corner weights and the RANK of its record among its run's records by
-//                            (query, point) -- the run is consumed in that order, so the fp32 sums do not depend on the
-//                            arrival order --, stages weights / grad_out row offsets in LDS at the ranked position, then
-//                            lanes = (column, channel) add the records one by one (two FMAs per record) into two
-//                            registers. At a cell boundary the left column's sums and the previous cell's right-column
-//                            sums give the cell's "upper" part (stored to grad_value) and the "lower" part of the cell
-//                            below (stored to a side tensor, the next row belongs to another wave).
-//   msda_rows_merge_kernel   grad_value += lower parts
-// A run longer than 64 records (never at uniform locations) is added in 64-bit fixed point scaled by its own per-lane
-// maximum, which is order-independent too. No LDS atomics, no fixed-point conversion on the common path, bit-reproducible.
-// MEASURED AND NOT ADOPTED (opt-in, MSS_MSDA_BWD_ROWS=1; profiles/r05/msda_bwd_rows.md): at C4 N = 16 the per-sample global
-// atomics of the two sort passes cost 0.53 + 0.98 ms (the binned path's chunk-level LDS histograms: 0.08 + 0.14 -- a chunk
-// of 4096 samples meets 54 x 8 tile keys but 93 k cell keys, nothing to aggregate), and the row kernel takes 0.65 ms, what
-// the binned accumulation takes: the two FMAs per record come with ~15 instructions of run bookkeeping, rank loop and
-// staging per record, and three dependent global latencies per block of 64 records.
-constexpr int MSDA_ROW_MAXL = 8;
-// sh: log2(sub-keys per cell); kstart: first key inside one (image, head); cstart: first cell inside one image of the side tensor
-struct MsdaRowLevel { int H, W, sh, kstart, cstart, item0; };
-struct MsdaRowGeom { MsdaRowLevel lv[MSDA_ROW_MAXL]; int L, KS, rows, cells; };
-
-static bool msda_row_geom(const int64_t* hs, int L, int Lq, int P, MsdaRowGeom& g) {
-  if (L < 1 || L > MSDA_ROW_MAXL) return false;
-  g.L = L;
-  long long ks = 0, rows = 0, cells = 0;
-  double weight[MSDA_ROW_MAXL];
-  for (int l = 0; l < L; ++l) {
-    const long long H = hs[2 * l], W = hs[2 * l + 1];
-    if (H < 1 || W < 1 || H > 32767 || W > 32767) return false;
-    const double density = (double)Lq * P / ((double)H * W);
-    int sh = 0;
-    while (sh < 4 && density / (1 << sh) > 24.0) ++sh;
-    g.lv[l].H = (int)H; g.lv[l].W = (int)W; g.lv[l].sh = sh;
-    if (ks + ((H * W) << sh) >= (1ll << 30)) return false;
-    g.lv[l].kstart = (int)ks;
-    g.lv[l].cstart = (int)cells;
-    ks += (H * W) << sh;
-    cells += H * W;
-    weight[l] = density * (double)W;                        // records per row: the heaviest rows are handed out first
-    rows += H;
-  }
-  bool done[MSDA_ROW_MAXL] = {false};
-  int item0 = 0;
-  for (int k = 0; k < L; ++k) {
-    int best = -1;
-    for (int l = 0; l < L; ++l) if (!done[l] && (best < 0 || weight[l] > weight[best])) best = l;
-    done[best] = true;
-    g.lv[best].item0 = item0;
-    item0 += g.lv[best].H;
-  }
-  for (int l = L; l < MSDA_ROW_MAXL; ++l) { g.lv[l] = g.lv[L - 1]; g.lv[l].item0 = 0x7fffffff; }
-  g.KS = (int)ks;
-  g.rows = (int)rows;
-  g.cells = (int)cells;
-  return true;
-}
-
-// A record: header = kill << 31 | query << 4 | point, then A, B, lw as in the binned path (corners outside the image folded
-// into the weights, so the consumer adds all four unconditionally). MODE 0: count. MODE 1: scatter.
-template <int MODE>
-__global__ __launch_bounds__(256) void msda_cell_kernel(MsdaRowGeom g, const float* __restrict__ loc, const float* __restrict__ attn,
-                                                        int M, int Lq, int P, long long per_image, int* __restrict__ counts_or_cursor,
-                                                        f32x4* __restrict__ records) {
-  __shared__ MsdaRowLevel lv[MSDA_ROW_MAXL];
-  const int tid = threadIdx.x, n = blockIdx.y;
-  if (tid < g.L) lv[tid] = g.lv[tid];
-  __syncthreads();
-  const int L = g.L;
-  int* gk = counts_or_cursor + (size_t)n * M * g.KS;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const long long s = ((long long)blockIdx.x * 4 + it) * 256 + tid;
-    if (s >= per_image) break;
-    const long long gs = (long long)n * per_image + s;
-    const float lx = loc[gs * 2], ly = loc[gs * 2 + 1];
-    const unsigned su = (unsigned)s;                         // per_image < 2^31 (host-checked)
-    const unsigned sp = su / (unsigned)P, p = su - sp * (unsigned)P;
-    const unsigned l = sp % (unsigned)L;
-    const unsigned sm = sp / (unsigned)L;
-    const unsigned m = sm % (unsigned)M, q = sm / (unsigned)M;
-    const MsdaRowLevel v = lv[l];
-    const float w_im = __fmaf_rn(lx, (float)v.W, -0.5f), h_im = __fmaf_rn(ly, (float)v.H, -0.5f);   // one rounding in both modes
-    if (!(h_im > -1.f && w_im > -1.f && h_im < (float)v.H && w_im < (float)v.W)) continue;
-    const float hf = floorf(h_im), wf = floorf(w_im);
-    int h0 = (int)hf, w0 = (int)wf;
-    const int hc = max(h0, 0), wc = max(w0, 0);
-    const int key = (int)m * g.KS + v.kstart + ((hc * v.W + wc) << v.sh) + (int)(q & ((1u << v.sh) - 1u));
-    if (MODE == 0) {
-      (void)__hip_atomic_fetch_add(gk + key, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      const int pos = __hip_atomic_fetch_add(gk + key, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float aw = attn[gs];
-      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-      float A, B, lwq;
-      unsigned kill;
-      if (h0 < 0) { A = aw * lh; B = 0.f; }                               // row -1 is outside: row 0 moves up
-      else { A = aw * hh; B = (h0 + 1 <= v.H - 1) ? aw * lh : 0.f; }
-      if (w0 < 0) { lwq = hw; kill = 1u; }                                // column 0 takes 1 - (1 - lw)
-      else { lwq = lw; kill = (w0 + 1 <= v.W - 1) ? 0u : 1u; }
-      f32x4 r;
-      r.x = __uint_as_float((kill << 31) | (q << 4) | p);
-      r.y = A; r.z = B; r.w = lwq;
-      records[pos] = r;
-    }
-  }
-}
-
-// exclusive scan of counts[n] -> offsets[n + 1] and cursor[n], 4096 elements per workgroup: block sums, then each
-// workgroup adds up the sums in front of it (a few hundred) and scans its own elements
-__global__ __launch_bounds__(1024) void msda_scan_sums_kernel(const int* __restrict__ counts, int n, int* __restrict__ bsum) {
-  __shared__ int red[16];
-  const int tid = threadIdx.x, base = blockIdx.x * 4096 + tid * 4;
-  int sum = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) sum += base + i < n ? counts[base + i] : 0;
-#pragma unroll
-  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
-  if ((tid & 63) == 0) red[tid >> 6] = sum;
-  __syncthreads();
-  if (tid == 0) {
-    int t = 0;
-    for (int i = 0; i < 16; ++i) t += red[i];
-    bsum[blockIdx.x] = t;
-  }
-}
-
-__global__ __launch_bounds__(1024) void msda_scan_apply_kernel(const int* __restrict__ counts, int n, const int* __restrict__ bsum,
-                                                               int* __restrict__ offsets, int* __restrict__ cursor) {
-  __shared__ int part[1024];
-  __shared__ int red[16];
-  const int tid = threadIdx.x, base = blockIdx.x * 4096 + tid * 4;
-  int pre = 0;
-  for (int i = tid; i < (int)blockIdx.x; i += 1024) pre += bsum[i];
-#pragma unroll
-  for (int o = 32; o; o >>= 1) pre += __shfl_xor(pre, o);
-  if ((tid & 63) == 0) red[tid >> 6] = pre;
-  int c[4], sum = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { c[i] = base + i < n ? counts[base + i] : 0; sum += c[i]; }
-  part[tid] = sum;
-  __syncthreads();
-  int front = 0;
-  for (int i = 0; i < 16; ++i) front += red[i];
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int v = tid >= o ? part[tid - o] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int run = front + part[tid] - sum;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (base + i < n) { offsets[base + i] = run; cursor[base + i] = run; }
-    run += c[i];
-  }
-  if (blockIdx.x == gridDim.x - 1 && tid == 1023) offsets[n] = front + part[1023];
-}
-
-template <int UN>
-__global__ __launch_bounds__(256) void msda_bwd_value_rows_kernel(MsdaRowGeom g, const int64_t* __restrict__ starts,
-                                                                  const float* __restrict__ gout, const f32x4* __restrict__ records,
-                                                                  const int* __restrict__ offsets, int* __restrict__ ticket, int S, int M,
-                                                                  int Lq, int N, float* __restrict__ gvalue, float* __restrict__ gbot) {
-  constexpr int D = 32;
-  __shared__ MsdaRowLevel slv[MSDA_ROW_MAXL];
-  __shared__ f32x4 sw_all[4][64];
-  __shared__ unsigned srow_all[4][64];
-  __shared__ unsigned skey_all[4][64];
-  __shared__ int soff_all[4][64];
-  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, d = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (tid < g.L) slv[tid] = g.lv[tid];
-  __syncthreads();
-  f32x4* sw = sw_all[wave];
-  unsigned* srow = srow_all[wave];
-  unsigned* skey = skey_all[wave];
-  int* soff = soff_all[wave];
-  const float* swf = reinterpret_cast<const float*>(sw) + half * 2;        // this lane's column: (upper, lower) weight of record i at swf[4 i]
-  const int NM = N * M, nitems = g.rows * NM;
-  const size_t rs = (size_t)M * D;
-  const unsigned rs4 = (unsigned)(rs * sizeof(float)), d4 = (unsigned)d * 4u;
-  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(gout), 0, (int)(unsigned)min((unsigned long long)N * Lq * rs * 4ull, 0xffffffffull), 0x00020000);
-  const f32x4 zero_rec = {0.f, 0.f, 0.f, 0.f};
-  const int swap_addr = (lane ^ 32) << 2;
-  for (;;) {
-    int item = 0;
-    if (lane == 0) item = atomicAdd(ticket, 1);
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= nitems) break;
-    const int irow = item / NM, nm = item - irow * NM;       // row-major over the levels, heaviest level first
-    int l = 0;
-    for (int k = 1; k < g.L; ++k) if (irow >= slv[k].item0 && irow < slv[k].item0 + slv[k].H) l = k;
-    const MsdaRowLevel v = slv[l];
-    const int r = irow - v.item0, n = nm / M, m = nm - n * M;
-    const int nk = v.W << v.sh;
-    const unsigned submask = (1u << v.sh) - 1u;
-    const int* offp = offsets + (size_t)nm * g.KS + v.kstart + (size_t)((r * v.W) << v.sh);
-    const unsigned go_nm = (unsigned)(((size_t)n * Lq * M + m) * D * sizeof(float));
-    float* gv = gvalue + ((size_t)n * S + (size_t)starts[l] + (size_t)r * v.W) * rs + (size_t)m * D + d;
-    float* gb = gbot + ((size_t)n * g.cells + (size_t)v.cstart + (size_t)(r + 1) * v.W) * rs + (size_t)m * D + d;
-    const bool below = r + 1 < v.H;
-    float accT = 0.f, accB = 0.f, prevT = 0.f, prevB = 0.f;
-    int c = 0, kpos = 0;
-    // the cell is complete: lanes 0-31 hold its left-column sums (its own upper part and the lower part of the cell below),
-    // lanes 32-63 the right-column sums, which belong to the NEXT cell of this row and the one below that
-    auto flush = [&]() {
-      const float pT = __int_as_float(__builtin_amdgcn_ds_bpermute(swap_addr, __float_as_int(prevT)));
-      const float pB = __int_as_float(__builtin_amdgcn_ds_bpermute(swap_addr, __float_as_int(prevB)));
-      if (half == 0) {
-        gv[(size_t)c * rs] = accT + pT;
-        if (below) gb[(size_t)c * rs] = accB + pB;
-      }
-      prevT = accT; prevB = accB;
-      accT = 0.f; accB = 0.f;
-      ++c;
-    };
-    // record -> staging slot `pos`: the four corner weights and the byte offset of its grad_out row
-    auto stage = [&](const f32x4& rec, int pos) {
-      const unsigned hd = __float_as_uint(rec.x);
-      const float lwv = rec.w, lwk = (hd >> 31) ? 0.f : lwv, hwv = 1.f - lwv;
-      f32x4 w;
-      w.x = rec.y * hwv; w.y = rec.z * hwv;                  // left column: upper, lower
-      w.z = rec.y * lwk; w.w = rec.z * lwk;                  // right column
-      sw[pos] = w;
-      srow[pos] = ((hd >> 4) & 0x7ffffffu) * rs4;
-    };
-    while (kpos < nk) {
-      const int o = offp[min(kpos + lane, nk)];
-      const int o0 = __builtin_amdgcn_readfirstlane(o);
-      const int rem = min(63, nk - kpos);
-      const unsigned long long fits = __ballot(lane <= rem && o - o0 <= 64);        // a prefix of the lanes (lane 0 always)
-      int t = __popcll(fits) - 1;
-      if (t == 0) {
-        // ---- one key with more than 64 records: order-independent 64-bit fixed-point sums, scaled per lane ----
-        const int beg = o0, end = __builtin_amdgcn_readlane(o, 1);
-        float mx = 0.f;
-        bool bad = false;
-        long long sT = 0, sB = 0;
-        double to_fixed = 0.0, from_fixed = 0.0;
-        for (int pass = 0; pass < 2; ++pass) {
-          for (int b = beg; b < end; b += 64) {
-            stage(b + lane < end ? records[b + lane] : zero_rec, lane);
-            const int cntb = min(64, end - b);
-            for (int i = 0; i < cntb; ++i) {
-              const float gq = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, srow[i] + d4, go_nm, 0));
-              const float cT = swf[4 * i] * gq, cB = swf[4 * i + 1] * gq;
-              if (pass == 0) {
-                mx = fmaxf(mx, fmaxf(fabsf(cT), fabsf(cB)));
-                // (an exponent test, not c - c == 0: the compiler contracts that with the product above into an fma = the rounding error)
-                bad |= (__float_as_uint(cT) & 0x7f800000u) == 0x7f800000u || (__float_as_uint(cB) & 0x7f800000u) == 0x7f800000u;
-              } else {
-                sT += __double_as_longlong(fma((double)cT, to_fixed, 6755399441055744.0)) - 0x4338000000000000ll;
-                sB += __double_as_longlong(fma((double)cB, to_fixed, 6755399441055744.0)) - 0x4338000000000000ll;
-              }
-            }
-          }
-          if (pass == 0) {
-            int e = 0;
-            if (mx > 0.f && !bad) (void)frexpf(mx, &e);
-            to_fixed = bad ? 0.0 : ldexp(1.0, 30 - e);
-            from_fixed = ldexp(1.0, e - 30);
-          }
-        }
-        accT += bad ? __builtin_nanf("") : (float)((double)sT * from_fixed);
-        accB += bad ? __builtin_nanf("") : (float)((double)sB * from_fixed);
-        if (((unsigned)(kpos + 1) & submask) == 0u) flush();
-        kpos += 1;
-        continue;
-      }
-      const int cnt = __builtin_amdgcn_readlane(o, t) - o0;
-      if (cnt > 0) {
-        soff[lane] = o - o0;
-        const f32x4 rec = lane < cnt ? records[o0 + lane] : zero_rec;
-        // this record's key: the last one that starts at or before it
-        int lo = 0;
-#pragma unroll
-        for (int step = 32; step; step >>= 1) {
-          const int mid = lo + step;
-          if (mid < t && soff[mid] <= lane) lo = mid;
-        }
-        const int rs_ = soff[lo], re_ = soff[lo + 1];
-        const unsigned mykey = lane < cnt ? (__float_as_uint(rec.x) & 0x7fffffffu) : 0xffffffffu;
-        skey[lane] = mykey;
-        int len = lane < cnt ? re_ - rs_ : 0;
-#pragma unroll
-        for (int of = 32; of; of >>= 1) len = max(len, __shfl_xor(len, of));
-        const int maxr = __builtin_amdgcn_readfirstlane(len);
-        int rank = 0;
-        for (int j = 0; j < maxr; ++j) {
-          const int pj = rs_ + j;
-          rank += (pj < re_ && skey[pj & 63] < mykey) ? 1 : 0;
-        }
-        stage(rec, lane < cnt ? rs_ + rank : lane);
-      }
-      // the records in (key, query, point) order: two FMAs per record and lane
-      int kk = 0;
-      int e_u = __builtin_amdgcn_readlane(o, 1) - o0;
-      auto end_key = [&]() {
-        if (((unsigned)(kpos + kk + 1) & submask) == 0u) flush();
-        ++kk;
-        e_u = kk < t ? __builtin_amdgcn_readlane(o, kk + 1) - o0 : 0x7fffffff;
-      };
-      for (int i0 = 0; i0 < cnt; i0 += UN) {
-        float gq[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-          if (i0 + u < cnt) gq[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, srow[i0 + u] + d4, go_nm, 0));
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          const int i = i0 + u;
-          if (i < cnt) {
-            while (i == e_u) end_key();
-            accT = __fmaf_rn(swf[4 * i], gq[u], accT);
-            accB = __fmaf_rn(swf[4 * i + 1], gq[u], accB);
-          }
-        }
-      }
-      while (kk < t) end_key();
-      kpos += t;
-    }
-  }
-}
-
-// grad_value[rows 1 .. H-1 of every level] += the lower parts the rows above them left in `gbot`
-__global__ __launch_bounds__(256) void msda_rows_merge_kernel(MsdaRowGeom g, const int64_t* __restrict__ starts, int S, int M, int N,
-                                                            const float* __restrict__ gbot, float* __restrict__ gvalue) {
-  const int l = blockIdx.z, n = blockIdx.y;
-  const MsdaRowLevel v = g.lv[l];
-  const size_t rs4 = (size_t)M * 8;                          // float4s per cell
-  const size_t total = (size_t)(v.H - 1) * v.W * rs4;
-  const f32x4* b4 = reinterpret_cast<const f32x4*>(gbot) + ((size_t)n * g.cells + (size_t)v.cstart + (size_t)v.W) * rs4;
-  f32x4* g4 = reinterpret_cast<f32x4*>(gvalue) + ((size_t)n * S + (size_t)starts[l] + (size_t)v.W) * rs4;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    f32x4 a = g4[i];
-    const f32x4 b = b4[i];
-    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    g4[i] = a;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // Operand preparation of the MSDeformAttn module (ops/modules/ms_deform_attn.py:100-109) in one pass:
 //   attn = softmax over the L*P logits of a (query, head);  loc = reference_point[l] + offset / (W_l, H_l)
 // instead of softmax + view + stack + div + add as five elementwise library kernels over the 12-36 values per (q, m).
@@ -1834,7 +930,7 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* starts, c
 }
 
 template <int LPH>
-int msda_forward_fast(const float* value, const int64_t* shapes, const int64_t* starts, const float* loc,
+int msda_forward_rec(const float* value, const int64_t* shapes, const int64_t* starts, const float* loc,
                       const float* attn, const float* ref, int N, int S, int M, int L, int Lq, int P, float* out,
                       hipStream_t stream, long long ldo = 0, long long ldl = 0, float* loc_out = nullptr, float* attn_out = nullptr) {
   constexpr int HPW = 64 / LPH;
@@ -1842,61 +938,16 @@ int msda_forward_fast(const float* value, const int64_t* shapes, const int64_t* 
   const long long nblocks = (npairs + 4 * HPW - 1) / (4 * HPW);
   if (ldo <= 0) ldo = (long long)M * L * P * 2;
   if (ldl <= 0) ldl = (long long)M * L * P;
-  const size_t smem = (size_t)4 * HPW * L * P * 3 * sizeof(float);
-  // buffer-resource addressing (32-bit offsets, hardware zero fill) when the value tensor is below 4 GB; MSS_MSDA_BUF=0: A/B
-  const bool buf = (unsigned long long)N * S * M * (4 * LPH) * 4ull < 0xffffffffull && MSS_ENV_INT("MSS_MSDA_BUF", 1) != 0;
-#define MSDA_LAUNCH(FUSED_, BUF_)                                                                                              \
-  hipLaunchKernelGGL((msda_fwd_fast_kernel<LPH, FUSED_, BUF_>), dim3((unsigned)nblocks), dim3(256), smem, stream, value, shapes, \
-                     starts, loc, attn, ref, npairs, S, M, L, Lq, P, out, ldo, ldl)
-  // r04: per-sample records prepared once per (query, head) group (msda_fwd_rec_kernel); needs the buffer addressing and, for
-  // the 0xffffff00 out-of-range marker, a tensor below that size. MSS_MSDA_REC=0: the round-2/3 kernel (A/B, tests)
+  // buffer-resource addressing (32-bit offsets, hardware zero fill) and the 0xffffff00 out-of-range marker need a value tensor
+  // below that size; beyond it (and where the records do not fit in LDS) the caller falls back to the generic kernel
   const size_t smem_rec = (size_t)4 * HPW * (L * P + 1) * 9 * sizeof(float);
-  if (buf && (unsigned long long)N * S * M * (4 * LPH) * 4ull < 0xffffff00ull && smem_rec <= 65536 &&
-      MSS_ENV_INT("MSS_MSDA_REC", 1) != 0) {
-    if (ref)
-      hipLaunchKernelGGL((msda_fwd_rec_kernel<LPH, true>), dim3((unsigned)nblocks), dim3(256), smem_rec, stream, value, shapes, starts, loc,
-                         attn, ref, npairs, S, M, L, Lq, P, out, ldo, ldl, L * P + 1, loc_out, attn_out);
-    else
-      hipLaunchKernelGGL((msda_fwd_rec_kernel<LPH, false>), dim3((unsigned)nblocks), dim3(256), smem_rec, stream, value, shapes, starts, loc,
-                         attn, ref, npairs, S, M, L, Lq, P, out, ldo, ldl, L * P + 1);
-    return mss_launch_status();
-  }
-  if (loc_out) return MSS_ERR_UNSUPPORTED;              // only the record kernel hands its locations / weights back
-  if (ref) { if (buf) MSDA_LAUNCH(true, true); else MSDA_LAUNCH(true, false); }
-  else { if (buf) MSDA_LAUNCH(false, true); else MSDA_LAUNCH(false, false); }
-#undef MSDA_LAUNCH
-  return mss_launch_status();
-}
-
-int msda_forward_window(const float* value, const int64_t* starts, const float* loc, const float* attn, const float* ref,
-                        const int64_t* host_shapes, int N, int S, int M, int L, int Lq, int P, float* out, hipStream_t stream) {
-  MsdaLevels lv;
-  lv.L = L;
-  long long sum = 0;
-  int tiles = 0;
-  for (int l = 0; l < L; ++l) {
-    const long long h = host_shapes[2 * l], w = host_shapes[2 * l + 1];
-    if (h <= 0 || w <= 0 || h > 32767 || w > 32767) return MSS_ERR_UNSUPPORTED;
-    lv.H[l] = (int)h, lv.W[l] = (int)w;
-    lv.qstart[l] = (int)sum;
-    lv.tiles_x[l] = (int)((w + 7) / 8);
-    lv.tile_start[l] = tiles;
-    tiles += (int)(((h + 7) / 8) * ((w + 7) / 8));
-    sum += h * w;
-  }
-  lv.tile_start[L] = tiles;
-  for (int l = L; l < MSDA_WIN_MAXL; ++l) lv.H[l] = lv.W[l] = lv.qstart[l] = lv.tiles_x[l] = 0, lv.tile_start[l + 1] = tiles;
-  const int grid_mode = sum == (long long)Lq;          // the queries are the pixels of the levels (encoder self-attention)
-  const int ntiles = grid_mode ? tiles : (Lq + 63) / 64;
-  const long long nblocks = (long long)N * ntiles * M;
-  if (nblocks > 0x7fffffffll) return MSS_ERR_UNSUPPORTED;
-  const size_t smem = ((size_t)MSDA_WIN_ROWS * 32 + (size_t)3 * 64 * L * P) * sizeof(float);
+  if ((unsigned long long)N * S * M * (4 * LPH) * 4ull >= 0xffffff00ull || smem_rec > 65536) return MSS_ERR_UNSUPPORTED;
   if (ref)
-    hipLaunchKernelGGL(msda_fwd_window_kernel<true>, dim3((unsigned)nblocks), dim3(256), smem, stream, value, starts, loc, attn, ref,
-                       lv, grid_mode, ntiles, S, M, Lq, P, out);
+    hipLaunchKernelGGL((msda_fwd_rec_kernel<LPH, true>), dim3((unsigned)nblocks), dim3(256), smem_rec, stream, value, shapes, starts, loc,
+                       attn, ref, npairs, S, M, L, Lq, P, out, ldo, ldl, L * P + 1, loc_out, attn_out);
   else
-    hipLaunchKernelGGL(msda_fwd_window_kernel<false>, dim3((unsigned)nblocks), dim3(256), smem, stream, value, starts, loc, attn, ref,
-                       lv, grid_mode, ntiles, S, M, Lq, P, out);
+    hipLaunchKernelGGL((msda_fwd_rec_kernel<LPH, false>), dim3((unsigned)nblocks), dim3(256), smem_rec, stream, value, shapes, starts, loc,
+                       attn, ref, npairs, S, M, L, Lq, P, out, ldo, ldl, L * P + 1);
   return mss_launch_status();
 }
 
@@ -1908,55 +959,13 @@ int msda_backward(const T* value, const int64_t* shapes, const int64_t* starts, 
   if (rc) return rc;
   if (!gvalue && N > 0) return MSS_ERR_BAD_ARG;
   const long long npairs = (long long)N * Lq * M;
-  const int lds_path = MSS_ENV_INT("MSS_MSDA_BWD_LDS", 1);      // 0: atomic kernel only, 2: owner-computes path at any size (tests)
-  // owner-computes path: fp32, D = 32, at most 2^22 samples per (image, head, level) (fixed-point headroom)
-  const bool owner = lds_path && sizeof(T) == 4 && D == 32 && npairs > 0 && M <= 65535 && N <= 65535 &&
-                     (long long)Lq * P <= (1ll << 22) &&
-                     (lds_path == 2 || npairs * L * P >= (6ll << 20));   // below ~6 M samples the atomic kernel wins
-  if (N > 0 && !owner) {
+  // the generic formulation (any dtype / head dimension, no host copy of the level shapes needed): scatter-add with whole-row atomics
+  if (N > 0) {
     hipError_t e = hipMemsetAsync(gvalue, 0, (size_t)N * S * M * D * sizeof(T), stream);
     if (e != hipSuccess) return (int)e;
   }
   if (npairs == 0) return MSS_OK;
   if (!gout || !gloc || !gattn) return MSS_ERR_BAD_ARG;
-  if (owner) {
-    // grad_value: tiles accumulated in LDS. The first 8 bytes of grad_loc hold max|grad_out|, max|attn| until the
-    // gather pass below overwrites them with the real gradient.
-    unsigned* absmax = reinterpret_cast<unsigned*>(gloc);
-    hipError_t e = hipMemsetAsync(absmax, 0, 2 * sizeof(unsigned), stream);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(msda_absmax_kernel, dim3(1024), dim3(256), 0, stream, reinterpret_cast<const float*>(gout),
-                       npairs * D, reinterpret_cast<const float*>(attn), npairs * L * P, absmax);
-    // an upper bound on the tile count of any set of level shapes with S positions in all (checked exhaustively on
-    // random shape sets up to 600 x 600); surplus workgroups exit at once
-    const unsigned tiles_bound = (unsigned)(S / 32 + 4 * L + 4);
-    // 4 sample pairs in flight per wave (2 and 8 measured within 2 % / 12 % slower)
-    hipLaunchKernelGGL(msda_bwd_value_lds_kernel<4>, dim3(tiles_bound, (unsigned)M, (unsigned)N), dim3(MSDA_LDS_NT), 0, stream, shapes,
-                       starts, reinterpret_cast<const float*>(loc), reinterpret_cast<const float*>(attn),
-                       reinterpret_cast<const float*>(gout), absmax, S, M, L, Lq, P, reinterpret_cast<float*>(gvalue));
-    // grad_loc / grad_attn: the gather pass (no atomics)
-    const size_t smem = (size_t)4 * 8 * L * P * 4 * sizeof(float);
-    const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(gout)) & 15) == 0;
-    if (aligned && smem <= 65536) {
-      const long long nblocks = (npairs + 31) / 32;
-      const bool buf = (unsigned long long)N * S * M * D * 4ull < 0xffffffffull && MSS_ENV_INT("MSS_MSDA_BUF", 1) != 0;
-      if (buf)
-        hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<true>, dim3((unsigned)nblocks), dim3(256), smem, stream,
-                           reinterpret_cast<const float*>(value), shapes, starts, reinterpret_cast<const float*>(loc),
-                           reinterpret_cast<const float*>(attn), reinterpret_cast<const float*>(gout), npairs, S, M, L, Lq, P,
-                           reinterpret_cast<float*>(gloc), reinterpret_cast<float*>(gattn));
-      else
-        hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<false>, dim3((unsigned)nblocks), dim3(256), smem, stream,
-                           reinterpret_cast<const float*>(value), shapes, starts, reinterpret_cast<const float*>(loc),
-                           reinterpret_cast<const float*>(attn), reinterpret_cast<const float*>(gout), npairs, S, M, L, Lq, P,
-                           reinterpret_cast<float*>(gloc), reinterpret_cast<float*>(gattn));
-    } else {
-      const long long nblocks = (npairs + 7) / 8;
-      hipLaunchKernelGGL((msda_bwd_kernel<T, 32, false>), dim3((unsigned)nblocks), dim3(256), 0, stream, value, shapes,
-                         starts, loc, attn, gout, npairs, S, M, D, L, Lq, P, gvalue, gloc, gattn);
-    }
-    return mss_launch_status();
-  }
   if (D <= 32) {
     const long long nblocks = (npairs + 7) / 8;
     hipLaunchKernelGGL((msda_bwd_kernel<T, 32, true>), dim3((unsigned)nblocks), dim3(256), 0, stream, value, shapes,
@@ -1976,7 +985,7 @@ static int msda_launch_gather(const float* value, const int64_t* shapes, const i
   const long long npairs = (long long)N * Lq * M;
   const size_t smem_gather = (size_t)4 * 8 * L * P * 4 * sizeof(float);
   const long long nblocks = (npairs + 31) / 32;
-  const bool buf = (unsigned long long)N * S * M * 32 * 4ull < 0xffffffffull && MSS_ENV_INT("MSS_MSDA_BUF", 1) != 0;
+  const bool buf = (unsigned long long)N * S * M * 32 * 4ull < 0xffffffffull;
   if (buf)
     hipLaunchKernelGGL(msda_bwd_gather_fast_kernel<true>, dim3((unsigned)nblocks), dim3(256), smem_gather, stream, value, shapes, starts,
                        loc, attn, gout, npairs, S, M, L, Lq, P, gloc, gattn, goff, ldo, glog, ldl);
@@ -1986,67 +995,6 @@ static int msda_launch_gather(const float* value, const int64_t* shapes, const i
   return mss_launch_status();
 }
 
-// workspace of the cell-sorted backward: [header 64 B: ticket][counts][offsets + 1][cursor][block sums] | records | lower parts
-struct MsdaRowWs { size_t counts, offsets, cursor, bsum, records, gbot, total; long long nkeys; int nblk; };
-static bool msda_row_layout(const MsdaRowGeom& g, int N, int M, int L, int Lq, int P, MsdaRowWs& w) {
-  const long long per_image = (long long)Lq * M * L * P;
-  if (per_image >= (1ll << 31) || (long long)N * per_image >= (1ll << 31)) return false;
-  if (P > 16 || Lq >= (1 << 27)) return false;                       // record header: query << 4 | point
-  w.nkeys = (long long)N * M * g.KS;
-  if (w.nkeys >= (1ll << 30) || (long long)g.rows * N * M >= (1ll << 30)) return false;
-  w.nblk = (int)((w.nkeys + 4095) / 4096);
-  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  w.counts = 64;
-  w.offsets = up(w.counts + (size_t)w.nkeys * 4);
-  w.cursor = up(w.offsets + (size_t)(w.nkeys + 1) * 4);
-  w.bsum = up(w.cursor + (size_t)w.nkeys * 4);
-  w.records = up(w.bsum + (size_t)w.nblk * 4);
-  w.gbot = up(w.records + (size_t)N * per_image * 16);
-  w.total = up(w.gbot + (size_t)N * g.cells * M * 32 * 4);
-  return true;
-}
-
-// MSS_ERR_UNSUPPORTED: shapes this path does not take (the caller goes on to the binned path)
-static int msda_backward_rows(const float* value, const int64_t* shapes, const int64_t* starts, const int64_t* host_shapes,
-                              const float* loc, const float* attn, const float* gout, int N, int S, int M, int L, int Lq, int P,
-                              float* gvalue, float* gloc, float* gattn, void* ws, size_t ws_bytes, hipStream_t stream, float* goff,
-                              long long ldo, float* glog, long long ldl) {
-  MsdaRowGeom g;
-  MsdaRowWs w;
-  if (!msda_row_geom(host_shapes, L, Lq, P, g) || !msda_row_layout(g, N, M, L, Lq, P, w)) return MSS_ERR_UNSUPPORTED;
-  if (ws_bytes < w.total || (reinterpret_cast<uintptr_t>(gvalue) & 15)) return MSS_ERR_UNSUPPORTED;
-  long long cells = 0;
-  for (int l = 0; l < L; ++l) cells += host_shapes[2 * l] * host_shapes[2 * l + 1];
-  if (cells < S) {          // rows of the value tensor outside the L levels come back zero (ms_deform_attn_cuda.cu:126)
-    hipError_t ez = hipMemsetAsync(gvalue, 0, (size_t)N * S * M * 32 * sizeof(float), stream);
-    if (ez != hipSuccess) return (int)ez;
-  }
-  char* base = static_cast<char*>(ws);
-  int* ticket = reinterpret_cast<int*>(base);
-  int* counts = reinterpret_cast<int*>(base + w.counts);
-  int* offsets = reinterpret_cast<int*>(base + w.offsets);
-  int* cursor = reinterpret_cast<int*>(base + w.cursor);
-  int* bsum = reinterpret_cast<int*>(base + w.bsum);
-  f32x4* records = reinterpret_cast<f32x4*>(base + w.records);
-  float* gbot = reinterpret_cast<float*>(base + w.gbot);
-  hipError_t e = hipMemsetAsync(base, 0, w.counts + (size_t)w.nkeys * 4, stream);
-  if (e != hipSuccess) return (int)e;
-  const long long per_image = (long long)Lq * M * L * P;
-  const unsigned chunks = (unsigned)((per_image + 1023) / 1024);
-  hipLaunchKernelGGL(msda_cell_kernel<0>, dim3(chunks, (unsigned)N), dim3(256), 0, stream, g, loc, attn, M, Lq, P, per_image, counts, records);
-  hipLaunchKernelGGL(msda_scan_sums_kernel, dim3((unsigned)w.nblk), dim3(1024), 0, stream, counts, (int)w.nkeys, bsum);
-  hipLaunchKernelGGL(msda_scan_apply_kernel, dim3((unsigned)w.nblk), dim3(1024), 0, stream, counts, (int)w.nkeys, bsum, offsets, cursor);
-  hipLaunchKernelGGL(msda_cell_kernel<1>, dim3(chunks, (unsigned)N), dim3(256), 0, stream, g, loc, attn, M, Lq, P, per_image, cursor, records);
-  const long long nitems = (long long)g.rows * N * M;
-  const long long want = (nitems + 3) / 4;
-  const unsigned nwg = (unsigned)(want < 256 * 8 ? want : 256 * 8);        // up to eight 4-wave workgroups per CU, a row per wave
-  hipLaunchKernelGGL(msda_bwd_value_rows_kernel<8>, dim3(nwg), dim3(256), 0, stream, g, starts, gout, records, offsets, ticket, S, M, Lq, N,
-                     gvalue, gbot);
-  hipLaunchKernelGGL(msda_rows_merge_kernel, dim3(128, (unsigned)N, (unsigned)L), dim3(256), 0, stream, g, starts, S, M, N, gbot, gvalue);
-  return msda_launch_gather(value, shapes, starts, loc, attn, gout, N, S, M, L, Lq, P, gloc, gattn, goff, ldo, glog, ldl, stream);
-}
-
-// workspace of the binned backward: [header 64 B: ticket, max|grad_out|, max|attn|][counts][offsets + 1][cursor] | records | halo
 struct MsdaBinWs { size_t counts, offsets, cursor, records, halo, total; long long nkeys; };
 static bool msda_bin_layout(const MsdaBinGeom& g, int N, int M, int L, int Lq, int P, MsdaBinWs& w) {
   const long long per_image = (long long)Lq * M * L * P;
@@ -2085,13 +1033,6 @@ static int msda_backward_binned(const float* value, const int64_t* shapes, const
   for (int l = 0; l < L; ++l) cells += host_shapes[2 * l] * host_shapes[2 * l + 1];
   if (cells > S) return MSS_ERR_BAD_ARG;
   if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return MSS_ERR_BAD_ARG;
-  // round 5: the cell-sorted path, opt-in (MSS_MSDA_BWD_ROWS=1; tests and A/B): parity-green and bit-reproducible, but slower than
-  // the binned path at every size measured -- 2.71 ms against 1.35 at C4 N = 16 (profiles/r05/msda_bwd_rows.md)
-  if (MSS_ENV_INT("MSS_MSDA_BWD_ROWS", 0) != 0) {
-    rc = msda_backward_rows(value, shapes, starts, host_shapes, loc, attn, gout, N, S, M, L, Lq, P, gvalue, gloc, gattn, ws, ws_bytes, stream,
-                            goff, ldo, glog, ldl);
-    if (rc != MSS_ERR_UNSUPPORTED) return rc;
-  }
   MsdaBinGeom g;
   MsdaBinWs w;
   if (!msda_bin_geom(host_shapes, L, Lq, P, (long long)N * Lq * M * L * P, g) || !msda_bin_layout(g, N, M, L, Lq, P, w)) return MSS_ERR_UNSUPPORTED;
@@ -2149,16 +1090,11 @@ int mss_msda_forward_f32(const float* value, const int64_t* spatial_shapes, cons
   if ((long long)N * Lq * M == 0) return MSS_OK;
   if (!out) return MSS_ERR_BAD_ARG;
   const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-  const size_t smem_per_lp = (size_t)4 * 3 * sizeof(float) * L * P;
-  if (aligned && D == 32 && smem_per_lp * 8 <= 65536)
-    return msda_forward_fast<8>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, N, S, M, L,
-                                Lq, P, out, s);
-  if (aligned && D == 16 && smem_per_lp * 16 <= 65536)
-    return msda_forward_fast<4>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, N, S, M, L,
-                                Lq, P, out, s);
-  if (aligned && D == 64 && smem_per_lp * 4 <= 65536)
-    return msda_forward_fast<16>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, N, S, M, L,
-                                 Lq, P, out, s);
+  rc = MSS_ERR_UNSUPPORTED;             // the record kernel: fp32, head dimension 16 / 32 / 64, value below 4 GB; else the generic one
+  if (aligned && D == 32) rc = msda_forward_rec<8>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, N, S, M, L, Lq, P, out, s);
+  if (aligned && D == 16) rc = msda_forward_rec<4>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, N, S, M, L, Lq, P, out, s);
+  if (aligned && D == 64) rc = msda_forward_rec<16>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, N, S, M, L, Lq, P, out, s);
+  if (rc != MSS_ERR_UNSUPPORTED) return rc;
   return msda_forward<float>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L,
                              Lq, P, out, s);
 }
@@ -2184,17 +1120,13 @@ int mss_msda_forward_fused_save_f32(const float* value, const int64_t* spatial_s
   if ((ld_offsets && ld_offsets < (long long)M * 2 * L * P) || (ld_logits && ld_logits < (long long)M * L * P)) return MSS_ERR_BAD_ARG;
   if (L * P > 20) return MSS_ERR_UNSUPPORTED;           // per-lane sample slots of the in-LDS softmax (as mss_msda_prepare_f32)
   const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-  const size_t smem_per_lp = (size_t)4 * 3 * sizeof(float) * L * P;
   if (!aligned) return MSS_ERR_UNSUPPORTED;
-  if (D == 32 && smem_per_lp * 8 <= 65536)
-    return msda_forward_fast<8>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s,
-                                ld_offsets, ld_logits, sampling_loc_out, attn_weight_out);
-  if (D == 16 && smem_per_lp * 16 <= 65536)
-    return msda_forward_fast<4>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s,
-                                ld_offsets, ld_logits, sampling_loc_out, attn_weight_out);
-  if (D == 64 && smem_per_lp * 4 <= 65536)
-    return msda_forward_fast<16>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s,
-                                 ld_offsets, ld_logits, sampling_loc_out, attn_weight_out);
+  if (D == 32) return msda_forward_rec<8>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s,
+                                          ld_offsets, ld_logits, sampling_loc_out, attn_weight_out);
+  if (D == 16) return msda_forward_rec<4>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s,
+                                          ld_offsets, ld_logits, sampling_loc_out, attn_weight_out);
+  if (D == 64) return msda_forward_rec<16>(value, spatial_shapes, level_start_index, offsets, logits, reference_points, N, S, M, L, Lq, P, out, s,
+                                           ld_offsets, ld_logits, sampling_loc_out, attn_weight_out);
   return MSS_ERR_UNSUPPORTED;
 }
 
@@ -2211,23 +1143,6 @@ int mss_msda_forward_fused_f32(const float* value, const int64_t* spatial_shapes
                                int M, int D, int L, int Lq, int P, float* out, void* stream) {
   return mss_msda_forward_fused_ld_f32(value, spatial_shapes, level_start_index, offsets, 0, logits, 0, reference_points, N, S, M, D,
                                        L, Lq, P, out, stream);
-}
-
-// forward through LDS windows (msda_fwd_window_kernel): `host_shapes` is a HOST copy of spatial_shapes [L][2]; reference_points
-// NULL = sampling_loc / attn_weight given (the op), else raw offsets / logits (the fused form). fp32, D = 32, L <= 8,
-// L*P <= 20, 16-byte aligned value / out; MSS_ERR_UNSUPPORTED otherwise.
-int mss_msda_forward_window_f32(const float* value, const int64_t* host_shapes, const int64_t* level_start_index,
-                                const float* loc_or_offsets, const float* attn_or_logits, const float* reference_points, int N,
-                                int S, int M, int D, int L, int Lq, int P, float* out, void* stream) {
-  if (!host_shapes) return MSS_ERR_BAD_ARG;
-  int rc = msda_check(value, host_shapes, level_start_index, loc_or_offsets, attn_or_logits, N, S, M, D, L, Lq, P);
-  if (rc) return rc;
-  if ((long long)N * Lq * M == 0) return MSS_OK;
-  if (!out) return MSS_ERR_BAD_ARG;
-  const bool aligned = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-  if (!aligned || D != 32 || L > MSDA_WIN_MAXL || L * P > MSDA_MAX_LP) return MSS_ERR_UNSUPPORTED;
-  return msda_forward_window(value, level_start_index, loc_or_offsets, attn_or_logits, reference_points, host_shapes, N, S, M, L,
-                             Lq, P, out, static_cast<hipStream_t>(stream));
 }
 
 int mss_msda_forward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
@@ -2256,11 +1171,6 @@ long long mss_msda_backward_workspace_bytes(const int64_t* host_shapes, int N, i
   if ((unsigned long long)N * Lq * M * D * 4ull >= 0xffffffffull) return 0;
   if ((size_t)4 * 8 * L * P * 4 * sizeof(float) > 65536) return 0;
   if (!msda_bin_geom(host_shapes, L, Lq, P, (long long)N * Lq * M * L * P, g) || !msda_bin_layout(g, N, M, L, Lq, P, w)) return 0;
-  MsdaRowGeom gr;
-  MsdaRowWs wr;
-  if (MSS_ENV_INT("MSS_MSDA_BWD_ROWS", 0) != 0 && msda_row_geom(host_shapes, L, Lq, P, gr) && msda_row_layout(gr, N, M, L, Lq, P, wr) &&
-      wr.total > w.total)
-    return (long long)wr.total;
   return (long long)w.total;
 }
 

@@ -3,6 +3,10 @@
 #pragma once
 #include "mss_common.h"
 
+// gemm_bf16x3.hip: allocate the ticket-counter pool of the split kernels on the current device (idempotent; a no-op while `stream` is
+// being captured). Every producer of weight planes calls it, so the pool exists before anything can launch on those planes.
+void mss_sched_init(hipStream_t stream);
+
 namespace mss_bf16x3 {
 
 constexpr int BK = 16;

@@ -80,3 +80,76 @@ __device__ __forceinline__ void mss_epilogue_store(const f32x16 (&acc)[TM][TN], 
     }
   }
 }
+
+// The same epilogue for 16x16 accumulators of v_mfma_f32_16x16x32_bf16 issued with the WEIGHTS as the first operand (round 6,
+// gemm_bf16x3.hip): D[channel][pixel], lane l holds pixel l & 15 and the four consecutive channels 4 * (l >> 4) .. + 3 -- acc[i][j][r] =
+// y[row_base + 16 i + (l & 15)][col_base + 16 j + 4 (l >> 4) + r]. A lane's four values are one 16-byte store (four lanes cover 64
+// consecutive bytes of a pixel's row, a wave-instruction 16 pixels), the residual and the per-channel affine 16-byte loads.
+// Requires K % 4 == 0, ldy % 4 == 0, 16-byte aligned y (and res / ldres, out_scale / out_shift, stats when given): the caller checks.
+// Statistics: as above, per 64-row group and channel, over the rows < M (TI * 16 == 64).
+template <int TI, int TJ>
+__device__ __forceinline__ void mss_epilogue_store16(const f32x4 (&acc)[TI][TJ], const MssConvArgs& p, float* __restrict__ y,
+                                                     int row_base, int col_base, int lane) {
+  static_assert(TI * 16 == 64, "statistics row groups are 64 rows");
+  const int rl = lane & 15, cq = 4 * (lane >> 4);
+  const bool plain = !p.out_scale && !p.res && !p.out_relu && !p.stats;   // kernel-uniform
+  float* stats_row = (p.stats && row_base < p.M) ? p.stats + (size_t)(row_base >> 6) * 2 * p.K : nullptr;
+  const float floor_v = p.out_relu ? 0.f : -__builtin_huge_valf();
+  int rows[TI];
+  bool ok[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    rows[i] = row_base + i * 16 + rl;
+    ok[i] = rows[i] < p.M;
+    rows[i] = ok[i] ? rows[i] : p.M - 1;                 // clamped: loads stay in bounds, stores are guarded
+  }
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int col = col_base + j * 16 + cq;
+    if (col >= p.K) continue;
+    if (plain) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+        if (ok[i]) *reinterpret_cast<f32x4*>(y + (size_t)rows[i] * p.ldy + col) = acc[i][j];
+      continue;
+    }
+    f32x4 osc = {1.f, 1.f, 1.f, 1.f}, osh = {0.f, 0.f, 0.f, 0.f};
+    if (p.out_scale) {
+      osc = *reinterpret_cast<const f32x4*>(p.out_scale + col);
+      osh = *reinterpret_cast<const f32x4*>(p.out_shift + col);
+    }
+    f32x4 rv[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.res) rv[i] = *reinterpret_cast<const f32x4*>(p.res + (size_t)rows[i] * p.ldres + col);
+    }
+    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const f32x4 lin = acc[i][j] * osc + osh;
+      f32x4 val;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) val[r] = fmaxf(p.res_mask ? (rv[i][r] > 0.f ? lin[r] : 0.f) : lin[r] + rv[i][r], floor_v);
+      if (ok[i]) {
+        *reinterpret_cast<f32x4*>(y + (size_t)rows[i] * p.ldy + col) = val;
+        ssum += val;
+        ssq += val * val;
+      }
+    }
+    if (stats_row) {                       // the 16 lanes of a group hold the 64 rows of these four channels
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          ssum[r] += __shfl_xor(ssum[r], m);
+          ssq[r] += __shfl_xor(ssq[r], m);
+        }
+      }
+      if (rl == 0) {
+        *reinterpret_cast<f32x4*>(stats_row + col) = ssum;
+        *reinterpret_cast<f32x4*>(stats_row + p.K + col) = ssq;
+      }
+    }
+  }
+}

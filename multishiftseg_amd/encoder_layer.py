@@ -290,8 +290,7 @@ def eligible(layer, src, pos, reference_points, spatial_shapes, padding_mask):
             and a.n_heads * a.n_levels * a.n_points > 64 and (a.n_heads * a.n_levels * a.n_points) % 16 == 0
             and layer.activation is F.relu and (not layer.training or (layer.dropout1.p == 0.0 and layer.dropout2.p == 0.0 and layer.dropout3.p == 0.0))
             and layer.linear1.bias is not None and layer.linear2.bias is not None and layer.linear1.out_features % 16 == 0
-            and layer.norm1.elementwise_affine and layer.norm1.bias is not None and layer.norm2.elementwise_affine and layer.norm2.bias is not None
-            and not MSDA.use_window(src.new_empty((1, 1, a.n_heads, 32)), a.n_levels, a.n_points))
+            and layer.norm1.elementwise_affine and layer.norm1.bias is not None and layer.norm2.elementwise_affine and layer.norm2.bias is not None)
 
 
 def encoder_layer(layer, src, pos, reference_points, spatial_shapes, level_start_index, q=None, want_q=False):

@@ -356,16 +356,26 @@ class WinoWeight:
     """Winograd-domain filter U [(tile+2)^2][Kpad][Cp] of a 3x3 weight. `src` (optional): the contiguous [K][C][3][3] weight it comes
     from; with it `t` may start as None and is made on first use -- the split-bf16 route fills its planes straight from `src`
     (w_split_of -> mss_wino_pack_split_bf16x3) and never reads U in fp32 unless the layer has a narrow native tail."""
-    __slots__ = ("_t", "src", "K", "C", "Kpad", "Cp", "tile", "planes")
+    __slots__ = ("_t", "src", "K", "C", "Kpad", "Cp", "tile", "planes", "_src_version")
 
     def __init__(self, t, K, C, Kpad, Cp, tile, src=None):
         assert t is not None or src is not None
         self._t, self.src, self.K, self.C, self.Kpad, self.Cp, self.tile = t, src, K, C, Kpad, Cp, tile
         self.planes = None
+        # `src` may alias the live parameter (detach().contiguous() copies nothing): a lazily made U / planes must come from the SAME
+        # weight version as whatever was made first, or one convolution would mix two versions (ADVICE r05). detach() shares the
+        # version counter, so an in-place update of the parameter (optimizer.step) shows here.
+        self._src_version = None if src is None else src._version
+
+    def _check_fresh(self):
+        if self.src is not None and self.src._version != self._src_version:
+            raise RuntimeError("stale WinoWeight: the weight it was packed from has been modified in place since (version "
+                               f"{self._src_version} -> {self.src._version}); re-pack it (kernels.packed_wino does, through tensor._version)")
 
     @property
     def t(self):
         if self._t is None:
+            self._check_fresh()
             t = torch.empty(((self.tile + 2) ** 2, self.Kpad, self.Cp), device=self.src.device, dtype=torch.float32)
             call("mss_wino_pack_weights_f32", ptr(self.src), ptr(t), self.K, self.C, self.Kpad, self.Cp, self.tile)
             self._t = t
@@ -376,6 +386,7 @@ class WinoWeight:
         not apply (no source weight, a padded Cp, Kpad not a multiple of 128)."""
         if self.src is None or self.Cp != self.C or self.Kpad % 128 or self.C % 16 or self.src.data_ptr() % 16:
             return None
+        self._check_fresh()
         nbytes = _lib.value("mss_gemm_split_weights_bytes", (self.tile + 2) ** 2, self.Kpad, self.C)
         if nbytes <= 0:
             return None

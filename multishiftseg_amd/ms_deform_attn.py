@@ -79,13 +79,8 @@ class _FusedSampleFn(Function):
         value, offsets, logits = value.contiguous(), offsets.contiguous(), logits.contiguous()
         ref = reference_points.contiguous().float()
         out = torch.empty((N, Lq, M * D), device=value.device, dtype=torch.float32)
-        hs = MSDA.host_shapes(spatial_shapes) if MSDA.use_window(value, L, P) else None
-        if hs is not None:
-            call("mss_msda_forward_window_f32", ptr(value), hs, ptr(level_start_index), ptr(offsets), ptr(logits), ptr(ref),
-                 N, S, M, D, L, Lq, P, ptr(out))
-        else:
-            call("mss_msda_forward_fused_f32", ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offsets), ptr(logits),
-                 ptr(ref), N, S, M, D, L, Lq, P, ptr(out))
+        call("mss_msda_forward_fused_f32", ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offsets), ptr(logits),
+             ptr(ref), N, S, M, D, L, Lq, P, ptr(out))
         ctx.save_for_backward(value, spatial_shapes, level_start_index, offsets, logits, ref)
         return out
 

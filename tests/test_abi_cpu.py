@@ -103,3 +103,19 @@ def test_deeplab_module_names(deeplab_params):
     assert list(sd.keys()) == list(deeplab_params.keys())
     for k, v in sd.items():
         assert tuple(v.shape) == tuple(deeplab_params[k].shape), k
+
+
+def test_lazily_packed_wino_weight_refuses_a_modified_source():
+    """a WinoWeight made without U (split route) builds U / planes on first use from `src`, which aliases the live
+    parameter; after an in-place update it must raise instead of mixing two weight versions in one convolution."""
+    import torch
+    from multishiftseg_amd import kernels as K
+    w = torch.nn.Parameter(torch.randn(128, 16, 3, 3))
+    pw = K.WinoWeight(None, 128, 16, 128, 16, 4, src=w.detach().contiguous())
+    pw._check_fresh()
+    with torch.no_grad():
+        w.mul_(0.5)
+    with pytest.raises(RuntimeError, match="stale WinoWeight"):
+        pw.t
+    with pytest.raises(RuntimeError, match="stale WinoWeight"):
+        pw.fused_planes()

@@ -200,18 +200,12 @@ def test_module_golden():
 
 @pytest.fixture
 def force_bwd(monkeypatch):
-    def set_mode(mode):          # "0": atomic scatter kernel, "2": re-scanning owner-computes LDS tiles at any size,
-        if mode in ("b", "r"):   # "b": binned owner-computes path (round 3), "r": cell-sorted rows (round 5, opt-in)
-            monkeypatch.setenv("MSS_MSDA_BWD_BINNED", "1")
-            monkeypatch.setenv("MSS_MSDA_BWD_ROWS", "1" if mode == "r" else "0")
-            monkeypatch.delenv("MSS_MSDA_BWD_LDS", raising=False)
-        else:
-            monkeypatch.setenv("MSS_MSDA_BWD_BINNED", "0")
-            monkeypatch.setenv("MSS_MSDA_BWD_LDS", mode)
+    def set_mode(mode):          # "0": generic scatter-add kernel (memory-side atomics), "b": binned owner-computes path (the default)
+        monkeypatch.setenv("MSS_MSDA_BWD_BINNED", "1" if mode == "b" else "0")
     return set_mode
 
 
-@pytest.mark.parametrize("mode", ["0", "2", "b", "r"])
+@pytest.mark.parametrize("mode", ["0", "b"])
 @pytest.mark.parametrize("N,Lq,shapes", [
     (2, 1500, [(22, 22), (44, 44), (88, 88)]),          # C4 geometry
     (1, 900, [(32, 64), (64, 128)]),                     # wide levels: several column tiles
@@ -219,10 +213,9 @@ def force_bwd(monkeypatch):
     (1, 40000, [(9, 9), (33, 20)]),                      # dense sampling of small levels: 8 x 8 tiles, every halo kind; runs > 64 records
 ])
 def test_backward_formulations_vs_oracle(F, force_bwd, mode, N, Lq, shapes):
-    """The four grad_value formulations (memory-side atomics; tiles owned by a workgroup that re-scans its level, 64-bit
-    fixed point in LDS; the same tiles fed from records binned once by a counting sort, halos merged afterwards; records
-    sorted by cell and added in (query, point) order by the wave that owns the row) and both gather passes against the
-    numpy oracle, with locations spilling over every border."""
+    """The two grad_value formulations the product ships (memory-side atomics, the generic kernel; tiles owned by a workgroup, fed
+    from records binned once by a counting sort, 64-bit fixed point in LDS, halos merged afterwards) and both gather passes
+    against the numpy oracle, with locations spilling over every border."""
     force_bwd(mode)
     rng = np.random.default_rng(len(shapes) * 100 + N)
     shp = np.array(shapes, dtype=np.int64)
@@ -240,7 +233,7 @@ def test_backward_formulations_vs_oracle(F, force_bwd, mode, N, Lq, shapes):
     np.testing.assert_allclose(a.grad.cpu().numpy(), ga, rtol=1e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("mode", ["0", "2", "b", "r"])
+@pytest.mark.parametrize("mode", ["0", "b"])
 def test_backward_zero_fills_rows_no_level_covers(F, force_bwd, mode):
     """a value tensor with more rows than the levels cover -- padding behind the last level and a gap between two
     levels in level_start_index (the functional API allows both) -- must get ZERO gradient on the uncovered rows on every
@@ -286,27 +279,19 @@ def test_owner_backward_is_order_independent_and_matches_atomics_at_full_size(F,
     g[:, ::7] *= 1e-4                                      # 1e4 dynamic range between queries
     from multishiftseg_amd import MultiScaleDeformableAttention as MSDA
     res = {}
-    for mode in ("0", "2", "2b", "b", "bb", "r", "rr"):
+    for mode in ("0", "b", "bb"):
         force_bwd(mode[0])
         res[mode] = MSDA.ms_deform_attn_backward(v, shapes, starts, loc, attn, g, 64)
-    assert torch.equal(res["2"][0], res["2b"][0])          # integer accumulation: same bits every time
-    assert torch.equal(res["b"][0], res["bb"][0])          # ... also when the records arrive in a different order
-    assert torch.equal(res["r"][0], res["rr"][0])          # fp32 sums in (query, point) order: same bits whatever the arrival order
-    assert (res["r"][0] - res["2"][0]).abs().max().item() < 2e-5 * res["0"][0].abs().max().item()
+    assert torch.equal(res["b"][0], res["bb"][0])          # integer accumulation: same bits whatever order the records arrive in
     for i in (1, 2):
-        assert torch.equal(res["r"][i], res["2"][i])
+        assert torch.equal(res["b"][i], res["bb"][i])
     scale = res["0"][0].abs().max().item()
-    assert (res["0"][0] - res["2"][0]).abs().max().item() < 2e-5 * scale
-    # the two owner-computes routes add the same fixed-point integers; only cells on a tile's first row / column differ,
-    # by the float additions of the halo merge
-    assert (res["b"][0] - res["2"][0]).abs().max().item() < 1e-6 * scale
-    for i in (1, 2):
-        assert torch.equal(res["b"][i], res["2"][i])
-    torch.testing.assert_close(res["0"][1], res["2"][1], rtol=1e-3, atol=1e-3 * res["0"][1].abs().max().item())
-    torch.testing.assert_close(res["0"][2], res["2"][2], rtol=1e-3, atol=1e-4 * res["0"][2].abs().max().item())
+    assert (res["0"][0] - res["b"][0]).abs().max().item() < 2e-5 * scale
+    torch.testing.assert_close(res["0"][1], res["b"][1], rtol=1e-3, atol=1e-3 * res["0"][1].abs().max().item())
+    torch.testing.assert_close(res["0"][2], res["b"][2], rtol=1e-3, atol=1e-4 * res["0"][2].abs().max().item())
 
 
-@pytest.mark.parametrize("mode", ["2", "b", "r"])
+@pytest.mark.parametrize("mode", ["b"])
 def test_owner_backward_propagates_non_finite_gradients(F, force_bwd, mode):
     """Fixed-point accumulation cannot represent inf/NaN: a non-finite grad_out must still surface as NaN."""
     force_bwd(mode)
@@ -416,14 +401,10 @@ def test_strided_projection_buffer_is_bitwise_the_dense_tensors(N, Lq, M, D, sha
     loc_k, aw_k = torch.full_like(loc_d, float("nan")), torch.full_like(aw_d, float("nan"))
     rc = _lib.status("mss_msda_forward_fused_save_f32", ptr(value), ptr(shp), ptr(starts), ptr(both), ld, plog, ld, ptr(ref), N, S, M, D, L,
                      Lq, P, ptr(out_k), ptr(loc_k), ptr(aw_k))
-    # MSS_ERR_UNSUPPORTED where the record kernel does not run (MSS_MSDA_REC=0): callers then save nothing and prepare in the backward
-    assert rc in (0, _lib.MSS_ERR_UNSUPPORTED)
-    if rc == 0:
-        assert torch.equal(out_k, out_s)
-        torch.testing.assert_close(loc_k, loc_d, rtol=1e-6, atol=1e-6)
-        torch.testing.assert_close(aw_k, aw_d, rtol=2e-6, atol=1e-7)
-    else:
-        assert os.environ.get("MSS_MSDA_REC") == "0"
+    assert rc == 0
+    assert torch.equal(out_k, out_s)
+    torch.testing.assert_close(loc_k, loc_d, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(aw_k, aw_d, rtol=2e-6, atol=1e-7)
     with pytest.raises(RuntimeError):
         call("mss_msda_prepare_ld_f32", ptr(both), ko - 1, plog, ld, ptr(ref), ptr(shp), N, Lq, M, L, P, ptr(loc_s), ptr(aw_s))
     with pytest.raises(RuntimeError):
@@ -537,37 +518,32 @@ def _encoder_like_inputs(rng, N, shapes, M, P, sigma, Lq=None):
 
 
 @pytest.mark.parametrize("N,shapes,M,P,sigma,Lq", [
-    (2, [(22, 22), (44, 44), (88, 88)], 8, 4, 3.0, None),     # C4 geometry, windows clipped to the row budget
-    (1, [(32, 64), (64, 128), (128, 256)], 8, 4, 1.0, None),  # C5 geometry, bounding boxes fit
+    (2, [(22, 22), (44, 44), (88, 88)], 8, 4, 3.0, None),     # C4 geometry
+    (1, [(32, 64), (64, 128), (128, 256)], 8, 4, 1.0, None),  # C5 geometry
     (2, [(9, 13), (5, 6), (17, 3)], 4, 2, 2.0, None),         # ragged levels, tiles hanging over the edges
-    (1, [(22, 22), (44, 44)], 8, 4, 40.0, None),              # offsets all over the map: most fetches take the global path
+    (1, [(22, 22), (44, 44)], 8, 4, 40.0, None),              # offsets all over the map: most corners out of the image
     (2, [(12, 20), (6, 10)], 8, 4, 2.0, 777),                 # queries are not the pixel grid: 64 consecutive queries per block
     (1, [(3, 5)], 1, 1, 0.5, None),                           # one level, one head, one point
 ])
-def test_window_forward_equals_gather_forward(monkeypatch, N, shapes, M, P, sigma, Lq):
-    """The LDS-window forward (both the op form and the fused offsets/logits form) against the L2-gather kernels it
-    replaces, and against the numpy oracle on a subset of queries."""
+def test_encoder_like_forward_op_and_fused_vs_oracle(N, shapes, M, P, sigma, Lq):
+    """Encoder-shaped inputs (queries = the pixels of the levels, offsets of a few pixels around them; one case with offsets all over
+    the map, one whose queries are not the pixel grid): the op form and the fused offsets/logits form of the forward agree with each
+    other and, on a subset of queries, with the numpy oracle; the host copy of spatial_shapes is cached per tensor object."""
     from multishiftseg_amd import MultiScaleDeformableAttention as MSDA
     from multishiftseg_amd.ms_deform_attn import _FusedSampleFn, _PrepareFn
     rng = np.random.default_rng(23)
     value, off, lg, ref, shp, starts = _encoder_like_inputs(rng, N, shapes, M, P, sigma, Lq)
-    L = len(shapes)
     v, o, g_, r = dev(value), dev(off), dev(lg), dev(ref)
     shp_t, st_t = dev(shp), dev(starts)
     with torch.no_grad():
         loc, attn = _PrepareFn.apply(o, g_, r, shp_t)
-        monkeypatch.setenv("MSS_MSDA_WINDOW", "0")
-        want = MSDA.ms_deform_attn_forward(v, shp_t, st_t, loc, attn, 128)
-        want_f = _FusedSampleFn.apply(v, shp_t, st_t, o, g_, r)
-        monkeypatch.setenv("MSS_MSDA_WINDOW", "1")
-        got = MSDA.ms_deform_attn_forward(v, shp_t, st_t, loc, attn, 128)          # host shapes through the cached copy
-        shp_hint = dev(shp)
-        shp_hint._mss_host = [tuple(int(x) for x in hw) for hw in shapes]          # ... and through the caller's hint
-        got_f = _FusedSampleFn.apply(v, shp_hint, st_t, o, g_, r)
-    assert id(shp_t) in MSDA._HOST_SHAPES
-    scale = want.abs().max().item()
-    assert (got - want).abs().max().item() <= 2e-6 * scale
-    assert (got_f - want_f).abs().max().item() <= 1e-5 * scale
+        got = MSDA.ms_deform_attn_forward(v, shp_t, st_t, loc, attn, 128)
+        got_f = _FusedSampleFn.apply(v, shp_t, st_t, o, g_, r)
+    assert MSDA.host_shapes(shp_t) is MSDA.host_shapes(shp_t) and id(shp_t) in MSDA._HOST_SHAPES
+    shp_hint = dev(shp)
+    shp_hint._mss_host = [tuple(int(x) for x in hw) for hw in shapes]              # the caller's hint: no device read
+    assert list(MSDA.host_shapes(shp_hint)) == [int(x) for hw in shapes for x in hw] and id(shp_hint) not in MSDA._HOST_SHAPES
+    assert (got_f - got).abs().max().item() <= 1e-5 * got.abs().max().item()
     qs = rng.choice(loc.shape[1], size=min(64, loc.shape[1]), replace=False)
     ref_out = omsda.forward(value, shp, starts, loc.cpu().numpy()[:, qs], attn.cpu().numpy()[:, qs])
     np.testing.assert_allclose(got.cpu().numpy()[:, qs], ref_out, rtol=1e-4, atol=1e-5)

@@ -21,35 +21,19 @@ for N, shapes in ((1, [(22, 22), (44, 44), (88, 88)]), (16, [(22, 22), (44, 44),
     loc = (ref[:, :, None, :, None, :] + off / shp.flip(-1)[None, None, None, :, None, :].float()).contiguous()
     attn = torch.softmax(lg, -1).view(N, S, 8, 3, 4).contiguous()
     g = torch.randn(N, S, 256, device="cuda")
-    os.environ["MSS_MSDA_WINDOW"] = "0"
     ms_f = timeit(lambda: MSDA.ms_deform_attn_forward(value, shp, starts, loc, attn, 128), iters=20)
     with torch.no_grad():
         ms_ff = timeit(lambda: _FusedSampleFn.apply(value, shp, starts, off, lg, ref), iters=20)
-    os.environ["MSS_MSDA_WINDOW"] = "1"
     shp._mss_host = shapes
-    win = {}
-    for sigma in (1.0, 3.0, 6.0):        # offsets ~ N(0, sigma) pixels; the other columns use sigma = 3
-        off_s = off * (sigma / 3.0)
-        loc_s = (ref[:, :, None, :, None, :] + off_s / shp.flip(-1)[None, None, None, :, None, :].float()).contiguous()
-        win[f"window_fwd_ms_sigma{sigma:g}"] = round(timeit(lambda: MSDA.ms_deform_attn_forward(value, shp, starts, loc_s, attn, 128), iters=20), 4)
-        with torch.no_grad():
-            win[f"window_fused_ms_sigma{sigma:g}"] = round(timeit(lambda: _FusedSampleFn.apply(value, shp, starts, off_s, lg, ref), iters=20), 4)
     ms_b = timeit(lambda: MSDA.ms_deform_attn_backward(value, shp, starts, loc, attn, g, 128), iters=10)
-    from multishiftseg_amd import _lib
-    os.environ["MSS_MSDA_BWD_ROWS"] = "1"          # the cell-sorted path of round 5 (opt-in: slower)
-    _lib.reset_env_cache()
-    ms_b_rows = timeit(lambda: MSDA.ms_deform_attn_backward(value, shp, starts, loc, attn, g, 128), iters=10)
-    os.environ.pop("MSS_MSDA_BWD_ROWS")
-    _lib.reset_env_cache()
-    os.environ["MSS_MSDA_BWD_BINNED"] = "0"        # the round-2 kernels (re-scanning tiles at N = 16, atomics at N = 1)
-    ms_b_r2 = timeit(lambda: MSDA.ms_deform_attn_backward(value, shp, starts, loc, attn, g, 128), iters=10)
+    os.environ["MSS_MSDA_BWD_BINNED"] = "0"        # the generic scatter-add kernel (memory-side atomics)
+    ms_b_at = timeit(lambda: MSDA.ms_deform_attn_backward(value, shp, starts, loc, attn, g, 128), iters=10)
     os.environ.pop("MSS_MSDA_BWD_BINNED")
     # forward inputs + grad_out + grad_value (zero + read-modify-write >= 2x) + grad_loc + grad_attn
     byt_b = 4 * (N * S * 256 + 3 * N * S * 8 * 12 + N * S * 256 + 2 * N * S * 256 + 3 * N * S * 8 * 12)
     byt = 4 * (N * S * 256 + 3 * N * S * 8 * 12 + N * S * 256)
     gather = N * S * 8 * 48 * 128
     print(json.dumps(dict(kernel="msda", N=N, S=S, compulsory_MB=round(byt / 1e6, 1), fwd_ms=round(ms_f, 4), fused_fwd_ms=round(ms_ff, 4),
-                          bwd_ms=round(ms_b, 4), bwd_cell_sorted_ms=round(ms_b_rows, 4), bwd_round2_ms=round(ms_b_r2, 4), bwd_algorithmic_MB=round(byt_b / 1e6, 1),
+                          bwd_ms=round(ms_b, 4), bwd_atomic_ms=round(ms_b_at, 4), bwd_algorithmic_MB=round(byt_b / 1e6, 1),
                           bwd_GBs=round(byt_b / ms_b / 1e6, 1), bwd_frac_of_8TBs=round(byt_b / ms_b / 1e6 / 8000, 3), fwd_compulsory_GBs=round(byt / ms_f / 1e6, 1), fused_fwd_compulsory_GBs=round(byt / ms_ff / 1e6, 1),
-                          fwd_frac_of_8TBs=round(byt / ms_f / 1e6 / 8000, 3), fwd_L2_gather_GBs=round(gather / ms_f / 1e6, 1), **win,
-                          window_fwd_compulsory_GBs=round(byt / win['window_fwd_ms_sigma3'] / 1e6, 1))), flush=True)
+                          fwd_frac_of_8TBs=round(byt / ms_f / 1e6 / 8000, 3), fwd_L2_gather_GBs=round(gather / ms_f / 1e6, 1))), flush=True)

@@ -1,7 +1,7 @@
 """DIAGNOSTIC (needs the -DMSS_SPLIT_STAMPS build of gemm_bf16x3.hip as MSS_LIB): where the issue time of gemm_nt_bf16x3_kernel's K-step goes.
 Per wave the kernel sums s_memtime deltas over eight stretches of every K-step: top (fragment reads issued, waits included), the six
 fenced segments of 8 MFMAs, and the barrier. Prints the mean cycles per K-step and stretch over all waves.
-usage: make -C multishiftseg_amd/csrc stamps; MSS_LIB=multishiftseg_amd/libmss_hip_stamps.so python tools/stamps_split.py P,T,C,K
+usage: make -C multishiftseg_amd/csrc stamps; MSS_LIB=multishiftseg_amd/csrc/build/libmss_hip_stamps.so python tools/stamps_split.py P,T,C,K
 --dump also prints every workgroup's lifetime. s_memtime counts shader cycles, s_memrealtime 100 MHz (tools/clock_check.py), so the
 quotient per wave is the clock it ran at. Round 5 result (profiles/r05/stamps_split.txt, dynamic_tiles.md): 1.6 GHz inside the kernel;
 static tile walk = bimodal lifetimes (3.3 / 4.85 ms), ticket order = 4.26 - 4.65 ms and 3724 cycles per K-step and wave with two waves
