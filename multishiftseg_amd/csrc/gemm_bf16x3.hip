@@ -11,7 +11,7 @@
 // MFMA, pipe 60 % busy) did not have:
 //  * the WEIGHTS are split once, at pack time (mss_gemm_split_weights_bf16x3), into the exact LDS image of a 128-row operand
 //    block per K-step -- [block][K-step][plane hi|mid|lo][128 rows][16 k], 12 KB each, the two 16-byte halves of a row swapped when
-//    bit 3 of the row is set -- so staging B is a linear 16-byte-per-lane copy with no arithmetic at all;
+//    bit 3 of the row is set (round 6: no swap at all, mss_bf16x3.h) -- so staging B is a linear 16-byte-per-lane copy with no arithmetic at all;
 //  * only the ACTIVATION operand is split in the loader, with v_cvt_pk_bf16_f32 (two conversions per instruction) and mask /
 //    shift re-expansion: 5.5 VALU per element, 8 elements per thread and K-step on the 128 x 256 tile = 1.2 VALU per MFMA measured;
 //  * gemm_nt_kernel's persistent schedule (variant 3): 32-bit offsets, the loader two K-steps ahead across tile boundaries with
@@ -116,6 +116,11 @@ constexpr bool DYN_TILES = true;
 constexpr bool DYN_TILES = false;
 #endif
 constexpr int NT = 256, BM = 128;
+#ifdef MSS_SPLIT_NOPRIO
+constexpr bool MSS_ENV_PRIO = false;     // A/B build without the s_setprio(1) around the three MFMA groups of the 16x16x32 K-step
+#else
+constexpr bool MSS_ENV_PRIO = true;      // measured +2 % on the products of the step (profiles/r06/split_mfma_ab.md)
+#endif
 using mss_bf16x3::BK;
 using mss_bf16x3::ROW_B;
 using mss_bf16x3::PLANE;
@@ -165,12 +170,13 @@ __device__ __forceinline__ int draw_xcd_ticket(int* __restrict__ sched, long lon
 // operand, so the accumulator holds D[channel][pixel]: a lane's four values are four consecutive channels of one pixel, a 16-byte
 // store (mss_epilogue_store16). The weight planes go global -> LDS by LDS-DMA (global_load_lds_dwordx4; they are stored in LDS
 // image order, a wave-instruction copies 1 KB) one K-step ahead, which frees the 24 staging registers for the fragments.
-template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false, bool DYN = false, int MF = 32>
-__global__ __launch_bounds__(NT, (MF == 16 || BN == 256 || (AFFINE && (CONV || ROWAFF))) ? 2 : 3) void gemm_nt_bf16x3_kernel(MssConvArgs p, const unsigned char* __restrict__ wpl,
+template <bool AFFINE, int BN, bool CONV = false, bool ROWAFF = false, bool DYN = false, int MF = 32>
+__global__ __launch_bounds__(NT, (BN == 256 || (AFFINE && (CONV || ROWAFF))) ? 2 : 3) void gemm_nt_bf16x3_kernel(MssConvArgs p, const unsigned char* __restrict__ wpl,
                                                                                long long total_tiles, int tiles_per_batch,
                                                                                int group_m, unsigned blk_bytes, int nblk_total, int* __restrict__ sched) {
   constexpr int NBLK = BN / 128, TN = BN / 64;          // wave tile 64 x (BN / 2)
   constexpr bool M16 = MF == 16;
+  static_assert(!M16 || (!AFFINE && !CONV && !ROWAFF), "the 16x16x32 form is instantiated for products without a prologue only");
   constexpr int TI = 4, TJ = BN / 32;                   // M16: 16-pixel blocks x 16-channel blocks of the wave tile
   constexpr int STAGE = (1 + NBLK) * OPER;              // A block, then NBLK B blocks
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -184,7 +190,8 @@ __global__ __launch_bounds__(NT, (MF == 16 || BN == 256 || (AFFINE && (CONV || R
 
   // ---- loader state (see gemm_nt_kernel, variant 3) ----
   unsigned a_off[2], a_nxt[2], b_off[NBLK], b_nxt[NBLK], s_off = 0, s_nxt = 0, s_off1 = 0, s_nxt1 = 0;   // (s_off1: row 1's affine, ROWAFF)
-  unsigned b_lag[NBLK];                                  // M16: b_off as it was before the last advance() (the DMA runs ONE step ahead)
+  int ld_kb = -1;                                        // M16: b_off runs ONE K-step behind the A loader (the DMA is one step ahead of the MFMAs, the
+                                                         // A registers two): its own step counter, same wrap rule; -1: the first advance() only arms it
   // the A operand of batch entry b starts at p.x + b * x_bs: a UNIFORM 64-bit base per tile (scalar registers) + 32-bit offsets inside
   // the entry, so a batched product may exceed 4 GB as a whole (16 x 700 x 700: the ASPP X' is 5.4 / 12 GB) while each entry stays below
   const char* xb_cur = reinterpret_cast<const char*>(p.x);
@@ -292,20 +299,30 @@ __global__ __launch_bounds__(NT, (MF == 16 || BN == 256 || (AFFINE && (CONV || R
   // s_waitcnt vmcnt(<number of those A loads>), which retires exactly the DMAs.
   const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(smem) +
                             (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
-  auto dma_b = [&](int buf, const unsigned (&off)[NBLK]) {
+  auto dma_piece = [&](int buf, int j, int pl) {        // one plane of one weight block: 1 KB per wave
+    const unsigned dst = lds_wave + (unsigned)(buf * STAGE + (1 + j) * OPER + pl * PLANE);
+    unsigned keep;                                       // M0 is the compiler's to manage: put it back
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(dst), "v"(b_off[j]), "s"(wbase[pl]) : "memory");
+  };
+  auto dma_b = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < NBLK; ++j) {
-      const unsigned d0 = lds_wave + (unsigned)(buf * STAGE + (1 + j) * OPER), d1 = d0 + PLANE, d2 = d0 + 2 * PLANE;
-      unsigned keep;                                     // M0 is the compiler's to manage: put it back
-      asm volatile("s_mov_b32 %0, m0\n\t"
-                   "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
-                   "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\t"
-                   "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %7\n\t"
-                   "s_mov_b32 m0, %0"
-                   : "=&s"(keep) : "s"(d0), "s"(d1), "s"(d2), "v"(off[j]), "s"(wbase[0]), "s"(wbase[1]), "s"(wbase[2]) : "memory");
-    }
+    for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) dma_piece(buf, j, pl);
   };
   constexpr int N_A_LOADS = 2 + (AFFINE ? 2 : 0) + (ROWAFF ? 2 : 0);          // issue_loads_a: what follows the DMAs in a K-step
+  auto advance_b = [&](bool wrap) {
+    if constexpr (M16) {                 // one step behind: b_nxt still describes the tile this cursor wraps into (setup_next runs at tile_end,
+      const bool wrap_b = ++ld_kb == n_it;              // >= 1 K-step after both cursors entered the tile; n_it >= 3)
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) b_off[j] = ld_kb == 0 ? b_off[j] : (wrap_b ? b_nxt[j] : b_off[j] + (unsigned)OPER);
+      ld_kb = wrap_b ? 0 : ld_kb;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) b_off[j] = wrap ? b_nxt[j] : b_off[j] + (unsigned)OPER;
+    }
+  };
   auto advance = [&]() {                 // branch-free: next K-step of this tile, else first K-step of this workgroup's next tile
     const bool wrap = ++ld_k == n_it;
     xb_cur = wrap ? xb_nxt : xb_cur;
@@ -326,21 +343,19 @@ __global__ __launch_bounds__(NT, (MF == 16 || BN == 256 || (AFFINE && (CONV || R
       }
       cur_ok = ok2;
       if (AFFINE) s_off = tap_end ? (unsigned)(chunk * 4 * sizeof(float)) : s_off + BK * (unsigned)sizeof(float);
-#pragma unroll
-      for (int j = 0; j < NBLK; ++j) { if (M16) b_lag[j] = b_off[j]; b_off[j] = wrap ? b_nxt[j] : b_off[j] + (unsigned)OPER; }
+      advance_b(wrap);
       ld_k = wrap ? 0 : ld_k;
       return;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) a_off[j] = wrap ? a_nxt[j] : a_off[j] + BK * (unsigned)sizeof(float);
-#pragma unroll
-    for (int j = 0; j < NBLK; ++j) { if (M16) b_lag[j] = b_off[j]; b_off[j] = wrap ? b_nxt[j] : b_off[j] + (unsigned)OPER; }
+    advance_b(wrap);
     if (AFFINE) s_off = wrap ? s_nxt : s_off + BK * (unsigned)sizeof(float);
     if (ROWAFF) s_off1 = wrap ? s_nxt1 : s_off1 + BK * (unsigned)sizeof(float);
     ld_k = wrap ? 0 : ld_k;
   };
-  // A: 4 bf16 (8 B) per plane at row r, quarter `chunk` of the 32-byte row, halves swapped when bit 3 of r is set
-  const int st_off = row0 * ROW_B + (((chunk >> 1) ^ ((row0 >> 3) & 1)) * 16) + (chunk & 1) * 8;
+  // A: 4 bf16 (8 B) per plane at row r, quarter `chunk` of the 32-byte row, no half swap (mss_bf16x3.h)
+  const int st_off = row0 * ROW_B + ((chunk >> 1) * 16) + (chunk & 1) * 8;
   unsigned st_ok = 3u;                   // (CONV) in-image bits of the K-step being split
   auto split_row = [&](int j, unsigned (&hi)[2], unsigned (&mid)[2], unsigned (&lo)[2]) {
     f32x4 v = areg[j];
@@ -360,6 +375,24 @@ __global__ __launch_bounds__(NT, (MF == 16 || BN == 256 || (AFFINE && (CONV || R
     *reinterpret_cast<u32x2*>(base + 0 * PLANE + st_off + j * 64 * ROW_B) = u32x2{hi[0], hi[1]};
     *reinterpret_cast<u32x2*>(base + 1 * PLANE + st_off + j * 64 * ROW_B) = u32x2{mid[0], mid[1]};
     *reinterpret_cast<u32x2*>(base + 2 * PLANE + st_off + j * 64 * ROW_B) = u32x2{lo[0], lo[1]};
+  };
+  // the same split in stages (M16: row 1's is spread over the DMA segments of group 2, a few VALU behind each block of MFMAs)
+  auto row_value = [&](int j) -> f32x4 {                 // A registers -> prologue affine / ReLU / padding zeros
+    f32x4 v = areg[j];
+    if (AFFINE) {
+      v = (ROWAFF && j == 1) ? v * sreg1 + hreg1 : v * sreg + hreg;
+      v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+    }
+    if (CONV) {
+      const bool in = (st_ok >> j) & 1;
+      v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
+    }
+    return v;
+  };
+  auto term = [&](const f32x4& v, unsigned (&t)[2]) { t[0] = cvt_pk_bf16(v.x, v.y); t[1] = cvt_pk_bf16(v.z, v.w); };
+  auto rest = [&](const f32x4& v, const unsigned (&t)[2]) -> f32x4 {      // v - (its bf16 term): exact
+    return f32x4{v.x - __uint_as_float(t[0] << 16), v.y - __uint_as_float(t[0] & 0xffff0000u),
+                 v.z - __uint_as_float(t[1] << 16), v.w - __uint_as_float(t[1] & 0xffff0000u)};
   };
   auto finish_store_a = [&](int buf) {
 #pragma unroll
@@ -381,7 +414,7 @@ __global__ __launch_bounds__(NT, (MF == 16 || BN == 256 || (AFFINE && (CONV || R
 
   // fragment of v_mfma_f32_32x32x16_bf16: lane = (row l % 32, k-block l / 32), 8 consecutive k = 16 B
   const int frow = lane & 31, fkb = lane >> 5;
-  const int fr_off = frow * ROW_B + ((fkb ^ ((frow >> 3) & 1)) * 16);
+  const int fr_off = frow * ROW_B + fkb * 16;      // (32-row fragments on the linear image: two-way conflicts; this form is the fallback only)
   const int fa_off = wm * 64 * ROW_B + fr_off;
   const int fb_off = OPER + (BN == 256 ? wn * OPER : wn * 64 * ROW_B) + fr_off;
 
@@ -414,31 +447,25 @@ __global__ __launch_bounds__(NT, (MF == 16 || BN == 256 || (AFFINE && (CONV || R
     else mss_epilogue_store<TM, TN>(acc, p, p.y + (size_t)b * p.y_bs, mt * BM + wm * 64, nt * BN + wn * (BN / 2), lane);
   };
   // M16 fragments: lane = (row l & 15 of a 16-row block, k-block l >> 4 of the instruction's four); k-blocks 0, 1 are the two 16-byte
-  // halves of the row in plane P, k-blocks 2, 3 the same halves in plane Q. Same swizzle as the 32-row form (bit 3 of the row swaps the
-  // halves): the 16 lanes of a k-block cover the sixteen 16-byte slots of a 256-byte bank row.
+  // halves of the row in plane P, k-blocks 2, 3 the same halves in plane Q. The image is linear (no half swap,
+  // mss_bf16x3.h): the hardware's ds_read_b128 lane groups then hit sixteen distinct 16-byte slots.
   const int l15 = lane & 15, khalf = (lane >> 4) & 1, up = lane >> 5;
-  const int fr16 = l15 * ROW_B + ((khalf ^ (l15 >> 3)) * 16);
+  const int fr16 = l15 * ROW_B + khalf * 16;
   const int fx16 = wm * 64 * ROW_B + fr16;                                        // X: block 0, pixel rows of this wave
   const int fw16 = OPER + (BN == 256 ? wn * OPER : wn * 64 * ROW_B) + fr16;        // W: this wave's 128 / 64 channels
-  const int x_hm = fx16 + up * PLANE, x_mh = fx16 + (1 - up) * PLANE, x_lh = fx16 + (1 - up) * 2 * PLANE;   // (P | Q) per half wave
-  const int w_hm = fw16 + up * PLANE, w_hl = fw16 + up * 2 * PLANE;
+  const int up_plane = up * PLANE;
   auto step16 = [&](const int buf) {
     const unsigned char* base = smem + buf * STAGE;
-    auto ld_x = [&](int off, bf16x8 (&f)[TI]) {
-#pragma unroll
-      for (int i = 0; i < TI; ++i) f[i] = *reinterpret_cast<const bf16x8*>(base + off + i * 16 * ROW_B);
-    };
+    // the five per-lane fragment addresses (P | Q per half wave) are re-derived in every step from three registers (the empty asm keeps
+    // the compiler from hoisting them out of the loop: five registers live through everything put the prologue kernels into scratch)
+    int upq = up_plane;
+    asm volatile("" : "+v"(upq));
+    const int x_hm = fx16 + upq, x_mh = fx16 + PLANE - upq, x_lh = fx16 + 2 * PLANE - 2 * upq;
+    const int w_hm = fw16 + upq, w_hl = fw16 + 2 * upq;
     auto ld_w = [&](int off, bf16x8 (&f)[TJ]) {
 #pragma unroll
       for (int j = 0; j < TJ; ++j) f[j] = *reinterpret_cast<const bf16x8*>(base + off + j * 16 * ROW_B);
     };
-    auto mm = [&](const bf16x8 (&w)[TJ], const bf16x8 (&x)[TI]) {           // channel block outermost: w[j] dies after TI instructions
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-#pragma unroll
-        for (int i = 0; i < TI; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], x[i], acc16[i][j], 0, 0, 0);
-    };
-    constexpr int G = TI * TJ;                           // MFMAs per group: 32 (128 x 256 tile) / 16
     auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
 #define MSS_PAIR_UP(mask, n, per)                                                                                             \
   _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                                                                        \
@@ -446,40 +473,91 @@ __global__ __launch_bounds__(NT, (MF == 16 || BN == 256 || (AFFINE && (CONV || R
     __builtin_amdgcn_sched_group_barrier((mask), (per), 0);                                                                   \
   }
     bf16x8 xhm[TI], xmh[TI], xlh[TI], whm[TJ], whl[TJ];
-    ld_x(x_hm, xhm); ld_w(w_hm, whm);
+    // the first instruction needs X block 0 and W block 0: read those first (the waits count in issue order), the other X blocks last
+    xhm[0] = *reinterpret_cast<const bf16x8*>(base + x_hm);
+    ld_w(w_hm, whm);
+#pragma unroll
+    for (int i = 1; i < TI; ++i) xhm[i] = *reinterpret_cast<const bf16x8*>(base + x_hm + i * 16 * ROW_B);
     fence();
-    // group 1 (hi hi + mid mid): the split of BOTH staged rows of K-step k+1 (every use of the A registers) + their LDS writes
-    ld_x(x_mh, xmh);
+    if (MSS_ENV_PRIO) __builtin_amdgcn_s_setprio(1);
+    MSS_STAMP(0)
+    // Every use of the A registers is preceded by this FIRST use (an empty asm the compiler must have them ready for): the wait for
+    // the loads (issued in group 2 of the previous step) lands here, in front of this step's DMAs, never behind one.
+    asm volatile("" : "+v"(areg[0]), "+v"(areg[1]));
+    fence();
+    MSS_STAMP(1)
+    // group 1 (hi hi + mid mid), pixel block outermost (X(hi|mid) block i dies after TJ instructions, X(mid|hi) block i is read into
+    // its registers), in fenced mini-segments (inline asm is in no class the group barriers know, and DMA issues in a row keep the wave
+    // out of the matrix pipe for hundreds of cycles): per segment one or two pieces of the weight planes of K-step k+1 by DMA -- as
+    // early as the step allows, they take ~900 cycles to land -- and a stage of staged row 0's split
     unsigned hi[2], mid[2], lo[2];
     st_ok = raw_ok;
-    split_row(0, hi, mid, lo);
-    store_row(buf ^ 1, 0, hi, mid, lo);
-    split_row(1, hi, mid, lo);
-    store_row(buf ^ 1, 1, hi, mid, lo);
-    mm(whm, xhm);
-    constexpr int VAL = 2 * (AFFINE ? 30 : 22), S1 = G - TI - 6;      // VALU of the two splits; MFMA slots left after the reads and writes
-    MSS_PAIR_UP(0x100, TI, 1);
-    MSS_PAIR_UP(0x2, S1, (VAL + S1 - 1) / S1);
-    MSS_PAIR_UP(0x200, 6, 1);
-    fence();
-    // group 2 (mid hi + hi mid): the weight planes of K-step k+1 by DMA, then the A loads of K-step k+2, the fragments of group 3
-    dma_b(buf ^ 1, b_lag);
-    issue_loads_a();
-    ld_x(x_lh, xlh); ld_w(w_hl, whl);
-    mm(whm, xmh);
-    MSS_PAIR_UP(0x20, N_A_LOADS, 1);
-    MSS_PAIR_UP(0x100, TI + TJ < G - N_A_LOADS ? TI + TJ : G - N_A_LOADS, 1);
-    fence();
-    // group 3 (lo hi + hi lo): the loader's bookkeeping
+    constexpr int NDMA = 3 * NBLK;
+    f32x4 v0, r0;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      if (i == 0) { v0 = row_value(0); term(v0, hi); r0 = rest(v0, hi); }
+      if (i == 1) { term(r0, mid); }
+      if (i == 2) { r0 = rest(r0, mid); }
+      if (i == 3) { term(r0, lo); store_row(buf ^ 1, 0, hi, mid, lo); }
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whm[j], xhm[i], acc16[i][j], 0, 0, 0);
+      xmh[i] = *reinterpret_cast<const bf16x8*>(base + x_mh + i * 16 * ROW_B);
+#pragma unroll
+      for (int d = i * NDMA / TI; d < (i + 1) * NDMA / TI; ++d) dma_piece(buf ^ 1, d / 3, d % 3);
+      fence();
+    }
+    MSS_STAMP(2)
+    // group 2 (mid hi + hi mid), channel block outermost, fenced segments of TI instructions: the first one turns row 1's A registers
+    // into values, the second issues the A loads of K-step k+2 (younger than every DMA: the wait before the barrier counts on it), the
+    // others carry the stages of row 1's split; W(hi|lo) block j is read into the registers of W(hi|mid) block j, whose last use the
+    // segment was, X(lo|hi) block 0 at the end
+    f32x4 v1, r1;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      constexpr int ST = TJ >= 8 ? 1 : 2;               // split stages per segment (TJ == 4: two)
+#pragma unroll
+      for (int sg = j * ST; sg < (j + 1) * ST; ++sg) {
+        if (sg == 0) { v1 = row_value(1); }
+        if (sg == 1) { issue_loads_a(); term(v1, hi); }
+        if (sg == 2) r1 = rest(v1, hi);
+        if (sg == 3) term(r1, mid);
+        if (sg == 4) r1 = rest(r1, mid);
+        if (sg == 5) { term(r1, lo); store_row(buf ^ 1, 1, hi, mid, lo); }
+      }
+#pragma unroll
+      for (int i = 0; i < TI; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whm[j], xmh[i], acc16[i][j], 0, 0, 0);
+      whl[j] = *reinterpret_cast<const bf16x8*>(base + w_hl + j * 16 * ROW_B);
+      if (j == TJ - 1) xlh[0] = *reinterpret_cast<const bf16x8*>(base + x_lh);
+      fence();
+    }
+    MSS_STAMP(3)
+    // group 3 (lo hi + hi lo), pixel block outermost: X(lo|hi) block i + 1 is read while block i multiplies; the loader's bookkeeping
     advance();
-    mm(whl, xlh);
-    MSS_PAIR_UP(0x6, G - 1, 3);
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      if (i + 1 < TI) xlh[i + 1] = *reinterpret_cast<const bf16x8*>(base + x_lh + (i + 1) * 16 * ROW_B);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whl[j], xlh[i], acc16[i][j], 0, 0, 0);
+    }
+    _Pragma("unroll") for (int i_ = 0; i_ < TI - 1; ++i_) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      MSS_PAIR_UP(0x6, TJ, 3);
+    }
+    MSS_PAIR_UP(0x6, TJ - 1, 3);
     fence();
 #undef MSS_PAIR_UP
+    if (MSS_ENV_PRIO) __builtin_amdgcn_s_setprio(0);
+    MSS_STAMP(4)
     // the DMAs are older than the N_A_LOADS register loads: this retires them (and this wave's LDS writes) and leaves the loads in flight
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(N_A_LOADS) : "memory");
+    MSS_STAMP(5)
     __builtin_amdgcn_s_barrier();
     asm volatile("" : : : "memory");                     // nothing of the next step moves above the barrier
+    MSS_STAMP(7)
+#ifdef MSS_SPLIT_STAMPS
+    dbg_sum[8] += 1;
+#endif
   };
   // One K-step: the products in an order that needs one new operand plane per group of 2 * TN MFMAs
   //   (A_lo, B_hi) (A_mid, B_hi) (A_hi, B_hi) (A_hi, B_mid) (A_mid, B_mid) (A_hi, B_lo)
@@ -502,22 +580,7 @@ __global__ __launch_bounds__(NT, (MF == 16 || BN == 256 || (AFFINE && (CONV || R
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     };
     bf16x8 a_hi[TM], a_mid[TM], a_lo[TM], b_hi[TN], b_mid[TN], b_lo[TN];
-    if (!SCHED) {
-      ld_a(2, a_lo); ld_b(0, b_hi);
-      ld_a(1, a_mid); ld_a(0, a_hi);
-      st_ok = raw_ok;
-      finish_store(buf ^ 1);               // K-step k+1, requested during step k-1
-      issue_loads();                       // K-step k+2 (possibly of the next tile) into the registers just drained
-      advance();
-      mm(a_lo, b_hi);
-      ld_b(1, b_mid);
-      mm(a_mid, b_hi);
-      mm(a_hi, b_hi);
-      ld_b(2, b_lo);
-      mm(a_hi, b_mid);
-      mm(a_mid, b_mid);
-      mm(a_hi, b_lo);
-    } else {
+    {
       // Left alone, hipcc sinks the global loads of step k+2 to the END of step k and meets them with an `s_waitcnt vmcnt(0)` at the
       // top of step k+1 (the two-steps-ahead loader degenerates to none), and clumps the split arithmetic in front of the MFMAs.
       // Here the step is cut into six segments the scheduler may not move instructions across, one group of 2 * TN MFMAs each,
@@ -593,7 +656,7 @@ __global__ __launch_bounds__(NT, (MF == 16 || BN == 256 || (AFFINE && (CONV || R
   if (CONV) cur_ok = (unsigned)((okb[0] & 1) | ((okb[1] & 1) << 1));
   setup_next();
   issue_loads();
-  if constexpr (M16) dma_b(0, b_off);    // the weight planes of K-step 0 (b_off still describes it)
+  if constexpr (M16) dma_b(0);    // the weight planes of K-step 0 (b_off still describes it)
   st_ok = raw_ok;
   if constexpr (M16) finish_store_a(0); else finish_store(0);
   advance();
@@ -923,7 +986,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
 }
 
 // fp32 weights [batch][Kpad][C] -> three bf16 planes in the LDS image order the kernel copies:
-// byte ((b * Kpad/128 + n / 128) * C/16 + s) * 12288 + plane * 4096 + (n % 128) * 32 + ((h ^ ((n >> 3) & 1)) * 16) holds k = 16 s + 8 h .. + 7
+// byte ((b * Kpad/128 + n / 128) * C/16 + s) * 12288 + plane * 4096 + (n % 128) * 32 + h * 16 holds k = 16 s + 8 h .. + 7
 // taps > 1 (implicit-GEMM layers: w is [taps][Kpad][C]): ONE plane set whose reduction index is tap * C + c (K-step s = tap * C/16 + ...)
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Kpad,
                                                             int C, long long w_bs, long long total, int taps) {
@@ -942,7 +1005,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     split_pair(v0.z, v0.w, hi[1], mid[1], lo[1]);
     split_pair(v1.x, v1.y, hi[2], mid[2], lo[2]);
     split_pair(v1.z, v1.w, hi[3], mid[3], lo[3]);
-    unsigned char* dst = out + ((size_t)(b * (Kpad / 128) + n / 128) * nk + s) * OPER + (n & 127) * ROW_B + ((h ^ ((n >> 3) & 1)) * 16);
+    unsigned char* dst = out + ((size_t)(b * (Kpad / 128) + n / 128) * nk + s) * OPER + (n & 127) * ROW_B + h * 16;
     *reinterpret_cast<u32x4*>(dst) = u32x4{hi[0], hi[1], hi[2], hi[3]};
     *reinterpret_cast<u32x4*>(dst + PLANE) = u32x4{mid[0], mid[1], mid[2], mid[3]};
     *reinterpret_cast<u32x4*>(dst + 2 * PLANE) = u32x4{lo[0], lo[1], lo[2], lo[3]};
@@ -981,7 +1044,7 @@ int split_dev_info(KernelT kern, size_t smem, int fallback_occ, SplitDevInfo (&i
   return MSS_OK;
 }
 
-template <bool AFFINE, int BN, bool SCHED, bool CONV, bool ROWAFF, bool DYN, int MF>
+template <bool AFFINE, int BN, bool CONV, bool ROWAFF, bool DYN, int MF>
 int launch_split_as(const MssConvArgs& p, hipStream_t stream, int* sched) {
   const int batch = p.batch > 1 ? p.batch : 1;
   const int tiles_per_batch = p.mtiles * p.ntiles;
@@ -991,7 +1054,7 @@ int launch_split_as(const MssConvArgs& p, hipStream_t stream, int* sched) {
   static SplitDevInfo info[SCHED_MAXDEV];
   static std::mutex mu;
   SplitDevInfo di;
-  const int rc = split_dev_info(gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF, DYN, MF>, smem, BN == 256 ? 2 : 3, info, mu, di);
+  const int rc = split_dev_info(gemm_nt_bf16x3_kernel<AFFINE, BN, CONV, ROWAFF, DYN, MF>, smem, BN == 256 ? 2 : 3, info, mu, di);
   if (rc != MSS_OK) return rc;
   int per_cu_max = di.occ;
   const int cap = MSS_ENV_INT("MSS_GEMM_WG_PER_CU", 0);                // (A/B) read on every call: mss_env_reset applies
@@ -1008,7 +1071,7 @@ int launch_split_as(const MssConvArgs& p, hipStream_t stream, int* sched) {
   }
   const int group_m = MSS_ENV_INT("MSS_GEMM_GROUP_M", GEMM_GROUP_M_DEFAULT);
   const unsigned blk_bytes = (unsigned)(p.C / BK) * (CONV ? p.R * p.S : 1) * OPER;     // CONV: the taps are part of one long reduction
-  hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN, SCHED, CONV, ROWAFF, DYN, MF>), dim3(grid), dim3(NT), smem, stream, p,
+  hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<AFFINE, BN, CONV, ROWAFF, DYN, MF>), dim3(grid), dim3(NT), smem, stream, p,
                      static_cast<const unsigned char*>(p.w_split), total, tiles_per_batch, group_m, blk_bytes, p.Kpad / 128, sched);
   return mss_launch_status();
 }
@@ -1022,20 +1085,27 @@ bool split_mf16_ok(const MssConvArgs& p) {
   return !p.stats || al(p.stats);
 }
 
-template <bool AFFINE, int BN, bool SCHED, bool CONV, bool ROWAFF, int MF>
+template <bool AFFINE, int BN, bool CONV, bool ROWAFF, int MF>
 int launch_split_mf(const MssConvArgs& p, hipStream_t stream) {
   if constexpr (split_dyn_tiles<AFFINE, BN, CONV, ROWAFF>()) {
     int* sched = MSS_ENV_INT("MSS_GEMM_SPLIT_STATIC", 0) ? nullptr : mss_sched_slot(stream);    // (tests: force the fallback)
-    if (sched) return launch_split_as<AFFINE, BN, SCHED, CONV, ROWAFF, true, MF>(p, stream, sched);
+    if (sched) return launch_split_as<AFFINE, BN, CONV, ROWAFF, true, MF>(p, stream, sched);
   }
-  return launch_split_as<AFFINE, BN, SCHED, CONV, ROWAFF, false, MF>(p, stream, nullptr);   // no slot to be had: the static walk
+  return launch_split_as<AFFINE, BN, CONV, ROWAFF, false, MF>(p, stream, nullptr);   // no slot to be had: the static walk
 }
 
-template <bool AFFINE, int BN, bool SCHED, bool CONV = false, bool ROWAFF = false>
+template <bool AFFINE, int BN, bool CONV = false, bool ROWAFF = false>
 int launch_split(const MssConvArgs& p, hipStream_t stream) {
   // MSS_GEMM_SPLIT_MFMA=32: the round-5 form (one product per v_mfma_f32_32x32x16_bf16) for A/B and for outputs mss_epilogue_store16 cannot take
-  if (SCHED && MSS_ENV_INT("MSS_GEMM_SPLIT_MFMA", 32) == 16 && split_mf16_ok(p)) return launch_split_mf<AFFINE, BN, true, CONV, ROWAFF, 16>(p, stream);
-  return launch_split_mf<AFFINE, BN, SCHED, CONV, ROWAFF, 32>(p, stream);
+  // The 16x16x32 form takes the products WITHOUT a prologue on the 128 x 256 tile -- the Winograd-domain batches and the plain 1x1
+  // layers: measured 1.02-1.08x the 32x32x16 form there (profiles/r06/split_mfma_ab.md). An MFMA of that shape holds the SIMD's vector
+  // issue for 8 of its 16 cycles: the 128-wide tile has the same split arithmetic per K-step behind half as many of them (0.89-1.0x),
+  // and the BatchNorm + ReLU prologue's ten more registers put the wide kernel into scratch inside the K-loop (0.96-0.99x) -- those
+  // stay on the round-5 form. MSS_GEMM_SPLIT_MFMA=160 also runs the 128-wide plain products on the 16x16x32 form (tests, A/B), =32 nothing.
+  const int mf = MSS_ENV_INT("MSS_GEMM_SPLIT_MFMA", 16);
+  if constexpr (!CONV && !AFFINE)
+    if ((mf == 160 || (mf == 16 && BN == 256)) && split_mf16_ok(p)) return launch_split_mf<AFFINE, BN, CONV, ROWAFF, 16>(p, stream);
+  return launch_split_mf<AFFINE, BN, CONV, ROWAFF, 32>(p, stream);
 }
 
 }  // namespace
@@ -1067,15 +1137,12 @@ int mss_gemm_nt_bf16x3_launch(MssConvArgs p, void* stream) {
     const double ew = eff(tiles256, 512), en = eff(2 * tiles256, 768);
     if (ew < 0.8 && en > ew + 0.15) wide = false;
   }
-  const bool sched = MSS_ENV_INT("MSS_GEMM_SPLIT_SCHED", 1) != 0;      // A/B: 0 = the compiler's own order of the K-step
   if (wide) {
     p.ntiles = p.K / 256;
-    if (!sched) return p.in_scale ? launch_split<true, 256, false>(p, s) : launch_split<false, 256, false>(p, s);
-    return p.in_scale ? launch_split<true, 256, true>(p, s) : launch_split<false, 256, true>(p, s);
+    return p.in_scale ? launch_split<true, 256>(p, s) : launch_split<false, 256>(p, s);
   }
   p.ntiles = mss_cdiv(p.K, 128);
-  if (!sched) return p.in_scale ? launch_split<true, 128, false>(p, s) : launch_split<false, 128, false>(p, s);
-  return p.in_scale ? launch_split<true, 128, true>(p, s) : launch_split<false, 128, true>(p, s);
+  return p.in_scale ? launch_split<true, 128>(p, s) : launch_split<false, 128>(p, s);
 }
 
 
@@ -1205,16 +1272,16 @@ int mss_conv_bf16x3_launch(MssConvArgs p, void* stream) {
   if (rowaff_eligible(p)) {
     p.H = p.OH * p.OW;                                   // rows per image
     p.ntiles = mss_cdiv(p.K, 128);
-    return launch_split<true, 128, true, false, true>(p, s);
+    return launch_split<true, 128, false, true>(p, s);
   }
   const long long tiles256 = (long long)p.mtiles * (p.K / 256);
   const bool wide = p.K % 256 == 0 && tiles256 >= 1024;
   if (wide) {
     p.ntiles = p.K / 256;
-    return p.in_scale ? launch_split<true, 256, true, true>(p, s) : launch_split<false, 256, true, true>(p, s);
+    return p.in_scale ? launch_split<true, 256, true>(p, s) : launch_split<false, 256, true>(p, s);
   }
   p.ntiles = mss_cdiv(p.K, 128);
-  return p.in_scale ? launch_split<true, 128, true, true>(p, s) : launch_split<false, 128, true, true>(p, s);
+  return p.in_scale ? launch_split<true, 128, true>(p, s) : launch_split<false, 128, true>(p, s);
 }
 
 extern "C" long long mss_gemm_split_weights_bytes(int batch, int Kpad, int C) {

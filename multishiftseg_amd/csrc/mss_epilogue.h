@@ -93,62 +93,62 @@ __device__ __forceinline__ void mss_epilogue_store16(const f32x4 (&acc)[TI][TJ],
   static_assert(TI * 16 == 64, "statistics row groups are 64 rows");
   const int rl = lane & 15, cq = 4 * (lane >> 4);
   const bool plain = !p.out_scale && !p.res && !p.out_relu && !p.stats;   // kernel-uniform
+  const bool full_rows = row_base + TI * 16 <= p.M;                       // wave-uniform
   float* stats_row = (p.stats && row_base < p.M) ? p.stats + (size_t)(row_base >> 6) * 2 * p.K : nullptr;
   const float floor_v = p.out_relu ? 0.f : -__builtin_huge_valf();
-  int rows[TI];
-  bool ok[TI];
-#pragma unroll
-  for (int i = 0; i < TI; ++i) {
-    rows[i] = row_base + i * 16 + rl;
-    ok[i] = rows[i] < p.M;
-    rows[i] = ok[i] ? rows[i] : p.M - 1;                 // clamped: loads stay in bounds, stores are guarded
-  }
+  // rows past the end (last row tile only): loads are clamped to row M - 1, the value is masked out of the statistics and its store
+  // goes to row M - 1 too -- but only from the lane that OWNS row M - 1 would that be right, so those lanes do not store at all
+  const int last = p.M - 1;
+  const size_t ldy = (size_t)p.ldy;
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int col = col_base + j * 16 + cq;
-    if (col >= p.K) continue;
-    if (plain) {
+    if (col < p.K) {
+      if (plain && full_rows) {
+        float* yp = y + (size_t)(row_base + rl) * ldy + col;
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
-        if (ok[i]) *reinterpret_cast<f32x4*>(y + (size_t)rows[i] * p.ldy + col) = acc[i][j];
-      continue;
-    }
-    f32x4 osc = {1.f, 1.f, 1.f, 1.f}, osh = {0.f, 0.f, 0.f, 0.f};
-    if (p.out_scale) {
-      osc = *reinterpret_cast<const f32x4*>(p.out_scale + col);
-      osh = *reinterpret_cast<const f32x4*>(p.out_shift + col);
-    }
-    f32x4 rv[TI];
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-      rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.res) rv[i] = *reinterpret_cast<const f32x4*>(p.res + (size_t)rows[i] * p.ldres + col);
-    }
-    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-      const f32x4 lin = acc[i][j] * osc + osh;
-      f32x4 val;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) val[r] = fmaxf(p.res_mask ? (rv[i][r] > 0.f ? lin[r] : 0.f) : lin[r] + rv[i][r], floor_v);
-      if (ok[i]) {
-        *reinterpret_cast<f32x4*>(y + (size_t)rows[i] * p.ldy + col) = val;
-        ssum += val;
-        ssq += val * val;
-      }
-    }
-    if (stats_row) {                       // the 16 lanes of a group hold the 64 rows of these four channels
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) {
-          ssum[r] += __shfl_xor(ssum[r], m);
-          ssq[r] += __shfl_xor(ssq[r], m);
+        for (int i = 0; i < TI; ++i) *reinterpret_cast<f32x4*>(yp + (size_t)(i * 16) * ldy) = acc[i][j];
+      } else {
+        f32x4 osc = {1.f, 1.f, 1.f, 1.f}, osh = {0.f, 0.f, 0.f, 0.f};
+        if (p.out_scale) {
+          osc = *reinterpret_cast<const f32x4*>(p.out_scale + col);
+          osh = *reinterpret_cast<const f32x4*>(p.out_shift + col);
         }
-      }
-      if (rl == 0) {
-        *reinterpret_cast<f32x4*>(stats_row + col) = ssum;
-        *reinterpret_cast<f32x4*>(stats_row + p.K + col) = ssq;
+        f32x4 rv[TI];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const int row = row_base + i * 16 + rl;
+          if (p.res) rv[i] = *reinterpret_cast<const f32x4*>(p.res + (size_t)(row < p.M ? row : last) * p.ldres + col);
+        }
+        f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const int row = row_base + i * 16 + rl;
+          const f32x4 lin = acc[i][j] * osc + osh;
+          f32x4 val;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) val[r] = fmaxf(p.res_mask ? (rv[i][r] > 0.f ? lin[r] : 0.f) : lin[r] + rv[i][r], floor_v);
+          if (full_rows || row < p.M) {
+            *reinterpret_cast<f32x4*>(y + (size_t)row * ldy + col) = val;
+            ssum += val;
+            ssq += val * val;
+          }
+        }
+        if (stats_row) {                       // the 16 lanes of a group hold the 64 rows of these four channels
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+              ssum[r] += __shfl_xor(ssum[r], m);
+              ssq[r] += __shfl_xor(ssq[r], m);
+            }
+          }
+          if (rl == 0) {
+            *reinterpret_cast<f32x4*>(stats_row + col) = ssum;
+            *reinterpret_cast<f32x4*>(stats_row + p.K + col) = ssq;
+          }
+        }
       }
     }
   }

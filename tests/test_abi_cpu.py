@@ -119,3 +119,46 @@ def test_lazily_packed_wino_weight_refuses_a_modified_source():
         pw.t
     with pytest.raises(RuntimeError, match="stale WinoWeight"):
         pw.fused_planes()
+
+
+def test_hot_split_gemm_kernels_use_no_scratch():
+    """the split-bf16 kernels run at the 256-register cap of two workgroups per CU, and a spill inside the K-loop
+    shares the vector-memory counter with the tile prefetch (scratch reloads wait with vmcnt(0)). Every instantiation the step's hot
+    products take must be compiled WITHOUT scratch: hipcc's own kernel-resource-usage remarks for gemm_bf16x3.hip, parsed here.
+    Template arguments in the mangled names: <AFFINE, BN, CONV, ROWAFF, DYN (ticket tile order), MF (MFMA shape)>."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc here")
+    src = os.path.join(ROOT, "multishiftseg_amd", "csrc", "gemm_bf16x3.hip")
+    r = subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-c", src, "-o", os.devnull,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=os.path.dirname(src))
+    assert r.returncode == 0, r.stderr[-2000:]
+    usage, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+        for key in ("VGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]"):
+            m = re.search(re.escape(key) + r": (\d+)", line)
+            if m and name and "AGPRs" not in line:
+                usage[name][key] = int(m.group(1))
+
+    def nt(affine, bn, conv, rowaff, dyn, mf):
+        tag = f"gemm_nt_bf16x3_kernelILb{affine}ELi{bn}ELb{conv}ELb{rowaff}ELb{dyn}ELi{mf}E"
+        hits = [v for k, v in usage.items() if tag in k]
+        assert len(hits) == 1, (tag, sorted(usage))
+        return hits[0]
+    hot = {"plain 128x256, 16x16x32": nt(0, 256, 0, 0, 0, 16), "plain 128x128": nt(0, 128, 0, 0, 0, 32),
+           "prologue 128x256, ticket order": nt(1, 256, 0, 0, 1, 32), "prologue 128x128, ticket order": nt(1, 128, 0, 0, 1, 32),
+           "implicit GEMM 128x256": nt(0, 256, 1, 0, 0, 32), "implicit GEMM 128x128": nt(0, 128, 1, 0, 0, 32),
+           "per-sample prologue (ROWAFF)": nt(1, 128, 0, 1, 0, 32)}
+    for k, v in usage.items():
+        if "gemm_tn_bf16x3_kernelILb0ELb0E" in k or "gemm_tn_bf16x3_kernelILb1ELb0E" in k:          # the unmasked weight-gradient kernels
+            hot["TN " + k[-40:]] = v
+    assert len(hot) == 9, sorted(hot)
+    bad = {k: v for k, v in hot.items() if v["ScratchSize [bytes/lane]"] != 0 or v["VGPRs"] > 256}
+    assert not bad, bad
+    assert hot["plain 128x256, 16x16x32"]["Occupancy [waves/SIMD]"] == 2 and hot["plain 128x128"]["Occupancy [waves/SIMD]"] == 3

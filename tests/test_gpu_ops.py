@@ -419,9 +419,7 @@ def _bf16_planes_decode(planes, batch, kpad, c):
     """The three bf16 planes of mss_gemm_split_weights_bf16x3 (include/mss_hip.h) back as float64 [3][batch][kpad][c]."""
     nk = c // 16
     raw = planes.view(torch.int16).view(batch, kpad // 128, nk, 3, 128, 2, 8)       # [b][block][K-step][plane][row][half][8 k]
-    row = torch.arange(128, device=planes.device)
-    swap = ((row >> 3) & 1).bool()
-    raw = torch.where(swap.view(1, 1, 1, 1, 128, 1, 1), raw.flip(5), raw)            # the two 16-byte halves are swapped when bit 3 of the row is set
+    # (rows as they are, k 0..7 then k 8..15: no half swap since round 6, csrc/mss_bf16x3.h)
     bits = (raw.to(torch.int32) & 0xffff) << 16
     vals = bits.view(torch.float32).double()                                        # bf16 -> fp32 is exact
     return vals.permute(3, 0, 1, 4, 2, 5, 6).reshape(3, batch, kpad, c)
