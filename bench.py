@@ -671,7 +671,8 @@ def main():
                            "msda_n16_bwd_frac": m["msda"]["c4_n16"]["backward_frac_of_hbm_peak"], "msda_n1_bwd_ms": m["msda"]["c4_n1"]["backward_ms"],
                            "decoder_n16_fb_ms": d16["forward_backward_ms"], "decoder_n16_fb_ms_bf16x3": d16.get("bf16x3_route", {}).get("forward_backward_ms"),
                            "fused_score_ms": m["fused_score"]["fused_score_ms"], "metric_GBs": m["metric_sweep"]["update_GBs_of_12B_per_pixel"],
-                           "metric_b2_GBs": m["metric_sweep"]["update_batch2_GBs_of_12B_per_pixel"]}
+                           "metric_b2_GBs": m["metric_sweep"]["update_batch2_GBs_of_12B_per_pixel"],
+                           "metric_many_GBs": m["metric_sweep"]["update_many_GBs_of_12B_per_pixel"]}
     out["summary"] = summ_out
     print(json.dumps(out), flush=True)
     if world > 1:

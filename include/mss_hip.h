@@ -476,6 +476,24 @@ int mss_oodm_compact_f32(const float* score, const long long* label, long long n
  * same-address atomics of the form above (they were most of the kernel's time on a 1024 x 2048 map). */
 int mss_oodm_compact_packed_f32(const float* score, const long long* label, long long n, long long id_in, long long id_out,
                                 unsigned int* keys, unsigned long long* packed_count, void* stream);
+/* Round 6: the same on EIGHT counters (the single counter is one address 512 workgroups of a 1024 x 2048 map add to one after the other:
+ * the kernel's 20 us). The 4096-pixel chunks are dealt round-robin onto 8 lanes; lane L owns keys[L * cap, (L + 1) * cap) with
+ * cap = mss_oodm_compact_lanes_cap(n) (keys: 8 * cap slots), its id_in keys from the front of the segment, its id_out keys from the
+ * back; lane_counts (device u64[8], zero on entry)[L] = #id_in | (#id_out << 32) of the lane. n < 2^32. */
+long long mss_oodm_compact_lanes_cap(long long n);
+/* ... and for up to MSS_OODM_BATCH maps in one launch (an evaluation sweep that holds its score maps: test_deeplab.py:84-102 appends
+ * every batch and evaluates at the end): entry m as the arguments of mss_oodm_compact_lanes_f32; entries >= count are ignored. */
+#define MSS_OODM_BATCH 16
+typedef struct MssOodmBatch {
+  const float* score[MSS_OODM_BATCH];
+  const long long* label[MSS_OODM_BATCH];
+  unsigned int* keys[MSS_OODM_BATCH];
+  unsigned long long* lane_counts[MSS_OODM_BATCH];
+  long long n[MSS_OODM_BATCH];
+} MssOodmBatch;
+int mss_oodm_compact_lanes_batch_f32(const MssOodmBatch* batch, int count, long long id_in, long long id_out, void* stream);
+int mss_oodm_compact_lanes_f32(const float* score, const long long* label, long long n, long long id_in, long long id_out,
+                               unsigned int* keys, unsigned long long* lane_counts, void* stream);
 long long mss_oodm_sort_temp_bytes(long long n);
 int mss_oodm_sort_u32(const unsigned int* keys_in, unsigned int* keys_out, long long n, void* temp, long long temp_bytes,
                       void* stream);

@@ -22,6 +22,15 @@ class MssError(RuntimeError):
     pass
 
 
+MSS_OODM_BATCH = 16            # include/mss_hip.h
+
+
+class MssOodmBatch(Structure):
+    """include/mss_hip.h: up to 16 (score, label, keys, lane_counts, n) entries of mss_oodm_compact_lanes_batch_f32."""
+    _fields_ = [("score", c_void_p * MSS_OODM_BATCH), ("label", c_void_p * MSS_OODM_BATCH), ("keys", c_void_p * MSS_OODM_BATCH),
+                ("lane_counts", c_void_p * MSS_OODM_BATCH), ("n", ctypes.c_longlong * MSS_OODM_BATCH)]
+
+
 class MssConvArgs(Structure):
     _fields_ = [
         ("x", c_void_p), ("w", c_void_p), ("y", c_void_p),
@@ -146,7 +155,10 @@ SIGNATURES = {
     "mss_m2f_fused_score_ws_f32": [P, P, I, I, I, I, I, I, I, I, I, I, P, P, P],
     "mss_oodm_compact_f32": [P, P, L, L, L, P, P, P],
     "mss_oodm_compact_packed_f32": [P, P, L, L, L, P, P, P],
+    "mss_oodm_compact_lanes_f32": [P, P, L, L, L, P, P, P],
+    "mss_oodm_compact_lanes_batch_f32": [P, I, L, L, P],
     "mss_oodm_sort_temp_bytes": [L],
+    "mss_oodm_compact_lanes_cap": [L],
     "mss_oodm_sort_u32": [P, P, L, P, L, P],
     "mss_oodm_rank_blocks": [L],
     "mss_oodm_measures_f64": [P, L, P, L, c_double, P, P, P, P],
@@ -174,11 +186,11 @@ SIGNATURES = {
 }
 # entry points that return a plain value rather than a status code
 _VALUE_RETURNING = {"mss_conv2d_wgrad_route", "mss_gemm_split_weights_bytes", "mss_abi_version", "mss_env_reset", "mss_env_generation", "mss_rcl_workspace_bytes", "mss_msda_backward_workspace_bytes", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
-                    "mss_oodm_sort_temp_bytes", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts",
+                    "mss_oodm_sort_temp_bytes", "mss_oodm_compact_lanes_cap", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts",
                     "mss_conv2d_wgrad_workspace_bytes", "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
                     "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats",
                     "mss_groupnorm_stat_offset", "mss_groupnorm_bwd_workspace_floats"}
-_RETURNS_LONGLONG = {"mss_gemm_split_weights_bytes", "mss_rcl_workspace_bytes", "mss_msda_backward_workspace_bytes", "mss_wino_num_tiles", "mss_oodm_sort_temp_bytes", "mss_conv2d_wgrad_workspace_bytes",
+_RETURNS_LONGLONG = {"mss_oodm_compact_lanes_cap", "mss_gemm_split_weights_bytes", "mss_rcl_workspace_bytes", "mss_msda_backward_workspace_bytes", "mss_wino_num_tiles", "mss_oodm_sort_temp_bytes", "mss_conv2d_wgrad_workspace_bytes",
                      "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
                      "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats",
                      "mss_groupnorm_stat_offset", "mss_groupnorm_bwd_workspace_floats"}

@@ -1062,12 +1062,14 @@ int launch_split_as(const MssConvArgs& p, hipStream_t stream, int* sched) {
   // residency (per_cu_max or one less) whose last round of tiles is fuller, as launch_gemm (gemm.hip)
   int grid = 0;
   double best = -1.0;
+  // (round 6: only when that saves more than 15 % of the rounds' slots -- one workgroup per CU leaves a single wave on each SIMD, which
+  // keeps the matrix pipe 52-58 % busy against 72-79 % with two; 36 x 4096 x 512 -> 512, 2304 tiles: 192 -> 204 TFLOP/s at two per CU)
   for (int per_cu = per_cu_max; per_cu >= (per_cu_max > 1 ? per_cu_max - 1 : 1); --per_cu) {
     const long long slots = (long long)per_cu * di.cus;
     const long long g = total < slots ? total : slots;
     const long long rounds = (total + g - 1) / g;
     const double eff = (double)total / (double)(rounds * g);
-    if (eff > best + 0.02) { best = eff; grid = (int)g; }
+    if (eff > best + (per_cu == per_cu_max ? 0.0 : 0.15)) { best = eff; grid = (int)g; }
   }
   const int group_m = MSS_ENV_INT("MSS_GEMM_GROUP_M", GEMM_GROUP_M_DEFAULT);
   const unsigned blk_bytes = (unsigned)(p.C / BK) * (CONV ? p.R * p.S : 1) * OPER;     // CONV: the taps are part of one long reduction

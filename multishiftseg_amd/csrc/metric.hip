@@ -40,17 +40,25 @@ __device__ __forceinline__ uint32_t score_key(float v) {
 // PACKED (r04): both totals in ONE 64-bit counter (id_in count in the low, id_out count in the high 32 bits; n < 2^32) -- one
 // same-address atomic per 4096 pixels instead of two: the 512 + 512 serialised atomics of a 1024 x 2048 map were most of the
 // kernel's 26 us.
+// LANES (r06): the packed counter is still ONE address the 512 workgroups of a 1024 x 2048 map add to one after the other (an
+// atomic with a returned value: ~40 ns each, the kernel's 20 us). With LANES = 8 the 4096-pixel chunks are dealt round-robin onto 8
+// counters, each owning its own segment [lane * cap, (lane + 1) * cap) of the key buffer (cap = its chunks x 4096 pixels, so a
+// segment cannot overflow): inliers from the front of the segment, OOD from its back, eight independent chains of 64 atomics.
 constexpr int ITEMS = 16;
-template <bool PACKED>
-__global__ __launch_bounds__(NT) void oodm_compact_kernel(const float* __restrict__ score, const long long* __restrict__ label,
-                                                          long long n, long long id_in, long long id_out,
-                                                          uint32_t* __restrict__ keys, u64* __restrict__ counts) {
+template <bool PACKED, int LANES = 1>
+__device__ __forceinline__ void oodm_compact_body(const float* __restrict__ score, const long long* __restrict__ label,
+                                                  long long n, long long id_in, long long id_out,
+                                                  uint32_t* __restrict__ keys_all, u64* __restrict__ counts_all, long long cap) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const u64 below = (1ull << lane) - 1;
   __shared__ unsigned wneg[NT / 64], wpos[NT / 64];
   __shared__ u64 base[2];
   const long long chunk = (long long)NT * ITEMS;
   for (long long c0 = (long long)blockIdx.x * chunk; c0 < n; c0 += (long long)gridDim.x * chunk) {
+    const int ln = LANES > 1 ? (int)((c0 / chunk) % LANES) : 0;
+    uint32_t* __restrict__ keys = keys_all + (LANES > 1 ? (size_t)ln * cap : 0);
+    u64* __restrict__ counts = counts_all + ln;
+    const long long seg_n = LANES > 1 ? cap : n;         // OOD keys fill the segment from its last slot downwards
     uint32_t key[ITEMS];
     u64 mneg[ITEMS], mpos[ITEMS];
     unsigned cneg = 0, cpos = 0;
@@ -86,12 +94,29 @@ __global__ __launch_bounds__(NT) void oodm_compact_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       if ((mneg[j] >> lane) & 1) keys[oneg + __popcll(mneg[j] & below)] = key[j];
-      if ((mpos[j] >> lane) & 1) keys[n - 1 - (long long)(opos + __popcll(mpos[j] & below))] = key[j];
+      if ((mpos[j] >> lane) & 1) keys[seg_n - 1 - (long long)(opos + __popcll(mpos[j] & below))] = key[j];
       oneg += __popcll(mneg[j]);
       opos += __popcll(mpos[j]);
     }
     __syncthreads();                                        // wneg / wpos / base are reused by the next chunk
   }
+}
+
+template <bool PACKED, int LANES = 1>
+__global__ __launch_bounds__(NT) void oodm_compact_kernel(const float* __restrict__ score, const long long* __restrict__ label,
+                                                          long long n, long long id_in, long long id_out,
+                                                          uint32_t* __restrict__ keys_all, u64* __restrict__ counts_all, long long cap = 0) {
+  oodm_compact_body<PACKED, LANES>(score, label, n, id_in, id_out, keys_all, counts_all, cap);
+}
+
+// up to MSS_OODM_BATCH maps in ONE launch (blockIdx.y = map): an update is ~8 us of kernel behind ~20 us of host work per call, so a
+// sweep that holds its maps hands them over sixteen at a time (mss_oodm_compact_lanes_batch_f32)
+__global__ __launch_bounds__(NT) void oodm_compact_batch_kernel(MssOodmBatch b, long long id_in, long long id_out) {
+  const int m = blockIdx.y;
+  const long long n = b.n[m];
+  if ((long long)blockIdx.x * NT * ITEMS >= n) return;
+  oodm_compact_body<true, 8>(b.score[m], b.label[m], n, id_in, id_out, b.keys[m], reinterpret_cast<u64*>(b.lane_counts[m]),
+                             (((n + (long long)NT * ITEMS - 1) / ((long long)NT * ITEMS) + 7) / 8) * (long long)NT * ITEMS);
 }
 
 __device__ __forceinline__ long long lower_bound(const uint32_t* __restrict__ a, long long lo, long long hi, uint32_t v) {
@@ -401,6 +426,42 @@ int mss_oodm_compact_packed_f32(const float* score, const long long* label, long
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(oodm_compact_kernel<true>, dim3((unsigned)blocks), dim3(NT), 0, S_(stream), score, label, n, id_in, id_out,
                      keys, packed_count);
+  return mss_launch_status();
+}
+
+// keys: 8 * mss_oodm_compact_lanes_cap(n) slots; lane_counts: device u64[8], zero on entry, ends as #id_in | (#id_out << 32) per lane;
+// lane L's id_in keys are keys[L * cap .. + #id_in), its id_out keys keys[(L + 1) * cap - #id_out .. (L + 1) * cap)
+long long mss_oodm_compact_lanes_cap(long long n) {
+  if (n <= 0) return 0;
+  const long long chunks = (n + (long long)NT * ITEMS - 1) / ((long long)NT * ITEMS);
+  return ((chunks + 7) / 8) * (long long)NT * ITEMS;
+}
+
+int mss_oodm_compact_lanes_f32(const float* score, const long long* label, long long n, long long id_in, long long id_out,
+                               unsigned int* keys, unsigned long long* lane_counts, void* stream) {
+  if (!lane_counts || n < 0 || n >= (1ll << 32) || id_in == id_out) return MSS_ERR_BAD_ARG;
+  if (n == 0) return MSS_OK;
+  if (!score || !label || !keys) return MSS_ERR_BAD_ARG;
+  long long blocks = (n + (long long)NT * ITEMS - 1) / ((long long)NT * ITEMS);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((oodm_compact_kernel<true, 8>), dim3((unsigned)blocks), dim3(NT), 0, S_(stream), score, label, n, id_in, id_out,
+                     keys, lane_counts, mss_oodm_compact_lanes_cap(n));
+  return mss_launch_status();
+}
+
+int mss_oodm_compact_lanes_batch_f32(const MssOodmBatch* batch, int count, long long id_in, long long id_out, void* stream) {
+  if (!batch || count < 0 || count > MSS_OODM_BATCH || id_in == id_out) return MSS_ERR_BAD_ARG;
+  long long most = 0;
+  for (int m = 0; m < count; ++m) {
+    const long long n = batch->n[m];
+    if (n < 0 || n >= (1ll << 32)) return MSS_ERR_BAD_ARG;
+    if (n > 0 && (!batch->score[m] || !batch->label[m] || !batch->keys[m] || !batch->lane_counts[m])) return MSS_ERR_BAD_ARG;
+    if (n > most) most = n;
+  }
+  if (count == 0 || most == 0) return MSS_OK;
+  long long blocks = (most + (long long)NT * ITEMS - 1) / ((long long)NT * ITEMS);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(oodm_compact_batch_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(NT), 0, S_(stream), *batch, id_in, id_out);
   return mss_launch_status();
 }
 

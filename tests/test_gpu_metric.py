@@ -142,3 +142,24 @@ def test_own_radix_sort_equals_torch_sort(monkeypatch, n, kind):
         got = out.to(torch.int64) & 0xffffffff
         assert torch.equal(got, want), route
     assert torch.equal(outs["own"], outs["rocprim"])
+
+
+def test_update_many_equals_update_in_a_loop():
+    """The batched hand-over (16 maps per launch, one key buffer per group) gives the measures of per-map updates -- 37 ragged maps
+    (one empty, one without OOD pixels), so two full groups and a partial one."""
+    from multishiftseg_amd import metric as M
+    g = torch.Generator(device="cuda").manual_seed(5)
+    maps = []
+    for i in range(37):
+        h, w = 17 + 13 * i, 50 + 7 * (i % 5)
+        if i == 9:
+            h = 0
+        lab = (torch.rand(1, h, w, device="cuda", generator=g) < (0.0 if i == 20 else 0.1)).long()
+        lab[torch.rand(1, h, w, device="cuda", generator=g) < 0.05] = 255
+        maps.append((torch.randn(1, h, w, device="cuda", generator=g) + 1.5 * (lab == 1), lab))
+    a, b = M.OODMeter(), M.OODMeter()
+    for s, l in maps:
+        a.update(s, l)
+    b.update_many(maps)
+    ra, rb = a.compute(), b.compute()
+    assert ra is not None and ra == rb
