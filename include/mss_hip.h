@@ -492,6 +492,10 @@ typedef struct MssOodmBatch {
   long long n[MSS_OODM_BATCH];
 } MssOodmBatch;
 int mss_oodm_compact_lanes_batch_f32(const MssOodmBatch* batch, int count, long long id_in, long long id_out, void* stream);
+/* One map's eight lane segments (keys, cap, lane_counts as mss_oodm_compact_lanes_f32 left them) copied to neg_out[0 .. #id_in) and
+ * pos_out[0 .. #id_out) of that map: the sweep's contiguous sort inputs, the caller advancing the two pointers by the map's totals. */
+int mss_oodm_gather_lanes_u32(const unsigned int* keys, long long cap, const unsigned long long* lane_counts, unsigned int* neg_out,
+                              unsigned int* pos_out, void* stream);
 int mss_oodm_compact_lanes_f32(const float* score, const long long* label, long long n, long long id_in, long long id_out,
                                unsigned int* keys, unsigned long long* lane_counts, void* stream);
 long long mss_oodm_sort_temp_bytes(long long n);

@@ -157,6 +157,7 @@ SIGNATURES = {
     "mss_oodm_compact_packed_f32": [P, P, L, L, L, P, P, P],
     "mss_oodm_compact_lanes_f32": [P, P, L, L, L, P, P, P],
     "mss_oodm_compact_lanes_batch_f32": [P, I, L, L, P],
+    "mss_oodm_gather_lanes_u32": [P, L, P, P, P, P],
     "mss_oodm_sort_temp_bytes": [L],
     "mss_oodm_compact_lanes_cap": [L],
     "mss_oodm_sort_u32": [P, P, L, P, L, P],

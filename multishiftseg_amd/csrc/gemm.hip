@@ -271,181 +271,6 @@ __global__ __launch_bounds__(NT, BN == 256 ? 2 : 3) void gemm_nt_kernel(MssConvA
   }
 }
 
-// EXPERIMENT (r03, MSS_GEMM_WP=1): the same 128x256 tile with WAVE-PRIVATE operand staging and no workgroup barrier. Each of
-// the four waves stages the 64 A rows and 128 B rows of its own 64x128 sub-tile in its own LDS region (every operand row is
-// therefore staged twice per workgroup: twice the L2 -> LDS traffic, 96 KB of LDS, ONE workgroup per CU = one wave per SIMD
-// with up to 512 registers), orders its ds_write / ds_read through the LDS pipe's in-order execution, and never waits for
-// another wave. Tests whether the 13 % between this inner loop and the register-only MFMA loop is barrier skew.
-// MODE (ablation, results are garbage for MODE > 0): 1 = no global loads / LDS writes inside the loop (operands frozen on the
-// first K-step), 2 = additionally no fragment reads (register-only MFMA loop + epilogue), 3 = as 2 with all-zero operands
-// (separates what the instruction stream costs from what the data costs: clocks under load depend on operand toggling).
-template <int MODE>
-__global__ __launch_bounds__(NT, 1) void gemm_nt_wp_kernel(MssConvArgs p, long long first_tile, long long total_tiles,
-                                                           int tiles_per_batch) {
-  constexpr int BN = 256, WTN = 128, TN = 4, AR = 64, BR = 128, A_P = AR / 16, B_P = BR / 16;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  float* As = smem + wave * (2 * (AR + BR) * LDK);   // [2][AR][LDK]
-  float* Bs = As + 2 * AR * LDK;                     // [2][BR][LDK]
-  const int chunk = lane & 3, lrow = lane >> 2;      // 16 rows x 4 chunks per pass
-  const int wchunk = (chunk + (lrow >> 2)) & 3;      // rows lrow + 16 j: the same rotation for every pass
-  const int n_it = p.C / BK;
-  const long long stride = gridDim.x;
-  const float* a_ptr[A_P];
-  const float* b_ptr[B_P];
-  long long ld_tile = first_tile + mss_xcd_remap(blockIdx.x, gridDim.x);
-  int ld_k = 0;
-  auto setup = [&](long long t) {
-    const int b = (int)(t / tiles_per_batch);
-    const int v = (int)(t - (long long)b * tiles_per_batch);
-    const int mt = v / p.ntiles, nt = v - mt * p.ntiles;
-#pragma unroll
-    for (int j = 0; j < A_P; ++j) {
-      int row = mt * BM + wm * AR + lrow + j * 16;
-      row = row < p.M ? row : p.M - 1;
-      a_ptr[j] = p.x + (size_t)b * p.x_bs + (size_t)row * p.ldx + chunk * 4;
-    }
-#pragma unroll
-    for (int j = 0; j < B_P; ++j)
-      b_ptr[j] = p.w + (size_t)b * p.w_bs + (size_t)(nt * BN + wn * BR + lrow + j * 16) * p.C + chunk * 4;
-  };
-  // DEPTH register sets: the loader runs DEPTH + 1 K-steps ahead (set s holds the K-step that is stored s steps from now)
-  constexpr int DEPTH = 2;          // the main loop below is written out for 2
-  f32x4 areg[DEPTH][A_P], breg[DEPTH][B_P];
-  auto issue_loads = [&](int set) {
-#pragma unroll
-    for (int j = 0; j < A_P; ++j) areg[set][j] = *reinterpret_cast<const f32x4*>(a_ptr[j]);
-#pragma unroll
-    for (int j = 0; j < B_P; ++j) breg[set][j] = *reinterpret_cast<const f32x4*>(b_ptr[j]);
-  };
-  auto advance = [&]() {
-    if (++ld_k < n_it) {
-#pragma unroll
-      for (int j = 0; j < A_P; ++j) a_ptr[j] += BK;
-#pragma unroll
-      for (int j = 0; j < B_P; ++j) b_ptr[j] += BK;
-    } else {
-      ld_k = 0;
-      ld_tile += stride;
-      setup(ld_tile < total_tiles ? ld_tile : ld_tile - stride);
-    }
-  };
-  auto finish_store = [&](int buf, int set) {
-#pragma unroll
-    for (int j = 0; j < A_P; ++j)
-      *reinterpret_cast<f32x4*>(&As[(buf * AR + lrow + j * 16) * LDK + wchunk * 4]) = areg[set][j];
-#pragma unroll
-    for (int j = 0; j < B_P; ++j)
-      *reinterpret_cast<f32x4*>(&Bs[(buf * BR + lrow + j * 16) * LDK + wchunk * 4]) = breg[set][j];
-  };
-  const int frag_row = lane & 31, frag_h = lane >> 5;
-  const int rot = frag_row >> 2;
-  const float* Abase = &As[frag_row * LDK];
-  const float* Bbase = &Bs[frag_row * LDK];
-  const int koff[2] = {((frag_h + rot) & 3) * 4, ((2 + frag_h + rot) & 3) * 4};
-  f32x4 fa[2][TM], fb[2][TN];
-  auto load_frags = [&](int set, int buf, int kc) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-      fa[set][i] = *reinterpret_cast<const f32x4*>(Abase + (buf * AR + i * 32) * LDK + koff[kc]);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-      fb[set][j] = *reinterpret_cast<const f32x4*>(Bbase + (buf * BR + j * 32) * LDK + koff[kc]);
-  };
-  f32x16 acc[TM][TN];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  };
-  auto mfma_chunk = [&](int set) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][s], fb[set][j][s], acc[i][j], 0, 0, 0);
-  };
-  auto epilogue = [&](long long t) {
-    const int b = (int)(t / tiles_per_batch);
-    const int v = (int)(t - (long long)b * tiles_per_batch);
-    const int mt = v / p.ntiles, nt = v - mt * p.ntiles;
-    mss_epilogue_store<TM, TN>(acc, p, p.y + (size_t)b * p.y_bs, mt * BM + wm * WTM, nt * BN + wn * WTN, lane);
-  };
-  long long cur = ld_tile;
-  setup(ld_tile);
-  issue_loads(0);
-  finish_store(0, 0);
-  advance();
-  issue_loads(0);                        // K-step 1
-  advance();
-  issue_loads(1);                        // K-step 2
-  advance();
-  zero_acc();
-  load_frags(0, 0, 0);
-  if (MODE >= 2) load_frags(1, 0, 1);
-  if (MODE == 3) {
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[s2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[s2][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  int buf = 0, k = 0;
-  auto step = [&](int set) {             // set: the register set holding K-step k+1; it is refilled with K-step k+3
-    if (MODE < 2) load_frags(1, buf, 1);
-    if (MODE < 1) {
-      finish_store(buf ^ 1, set);
-      issue_loads(set);
-      advance();
-    }
-    mfma_chunk(0);
-    if (MODE < 2) load_frags(0, buf ^ 1, 0);   // the wave's own ds_writes above are ahead of these reads in the (in-order) LDS pipe
-    mfma_chunk(1);
-    buf ^= 1;
-  };
-  auto tile_end = [&]() -> bool {         // true: this workgroup has no tile left
-    if (++k < n_it) return false;
-    epilogue(cur);
-    cur += stride;
-    if (cur >= total_tiles) return true;
-    zero_acc();
-    k = 0;
-    return false;
-  };
-  while (true) {                         // unrolled by the number of register sets: no register copies, no dynamic indexing
-    step(0);
-    if (tile_end()) break;
-    step(1);
-    if (tile_end()) break;
-  }
-}
-
-template <int MODE>
-static int launch_gemm_wp(const MssConvArgs& p, hipStream_t stream) {
-  const int batch = p.batch > 1 ? p.batch : 1;
-  const int tiles_per_batch = p.mtiles * p.ntiles;
-  const long long total = (long long)tiles_per_batch * batch;
-  if (total <= 0) return MSS_OK;
-  const size_t smem = (size_t)4 * 2 * (64 + 128) * LDK * sizeof(float);      // 96 KB
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wp_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  const long long g = total < 256 ? total : 256;
-  hipLaunchKernelGGL(gemm_nt_wp_kernel<MODE>, dim3((unsigned)g), dim3(NT), smem, stream, p, 0ll, total, tiles_per_batch);
-  return mss_launch_status();
-}
-
 // A handful of rows (ASPP's image-pooling branch: [N, 4096] x [4096 -> 256], deepv3.py:84-88): one MFMA tile would walk the whole
 // reduction alone (256 K-steps on one or two of 256 CUs: 0.25 ms for 4 MB of weights). Here a WAVE owns one output channel: its
 // weight row streams through the lanes in 16-byte pieces, the <= 8 input rows come from cache, one wave reduction per row.
@@ -502,7 +327,7 @@ int launch_gemm(const MssConvArgs& p, hipStream_t stream, long long first = 0, l
     const long long g = total < slots ? total : slots;
     const long long rounds = (total + g - 1) / g;
     const double eff = (double)total / (double)(rounds * g);
-    if (eff > best + 0.02) { best = eff; grid = (int)g; }
+    if (eff > best + 0.02) { best = eff; grid = (int)g; }     // (r06: re-measured, 36 x 4096 x 512 -> 512 at one per CU 133.5 vs 125 TFLOP/s forced to two; the split kernel differs)
   }
   // the square-ish tile order only for whole launches: the hybrid wide + narrow split (MSS_GEMM_TAIL) relies on tile ranges
   const int group_m = (first == 0 && end == (long long)tiles_per_batch * batch) ? MSS_ENV_INT("MSS_GEMM_GROUP_M", GEMM_GROUP_M_DEFAULT) : 0;
@@ -627,13 +452,6 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
       return p.in_scale ? launch_gemm<true, 2, 128>(q, s, 2 * full, 2 * tiles256) : launch_gemm<false, 2, 128>(q, s, 2 * full, 2 * tiles256);
     }
     p.ntiles = nw;
-    {
-      const int wp = MSS_ENV_INT("MSS_GEMM_WP", 0);    // experiment: wave-private staging, no workgroup barrier (non-affine only)
-      if (wp == 1 && !p.in_scale) return launch_gemm_wp<0>(p, s);
-      if (wp == 2 && !p.in_scale) return launch_gemm_wp<1>(p, s);
-      if (wp == 3 && !p.in_scale) return launch_gemm_wp<2>(p, s);
-      if (wp == 4 && !p.in_scale) return launch_gemm_wp<3>(p, s);
-    }
     if (v3) return p.in_scale ? launch_gemm<true, 3, 256>(p, s) : launch_gemm<false, 3, 256>(p, s);
     return p.in_scale ? launch_gemm<true, 2, 256>(p, s) : launch_gemm<false, 2, 256>(p, s);
   }

@@ -119,6 +119,19 @@ __global__ __launch_bounds__(NT) void oodm_compact_batch_kernel(MssOodmBatch b, 
                              (((n + (long long)NT * ITEMS - 1) / ((long long)NT * ITEMS) + 7) / 8) * (long long)NT * ITEMS);
 }
 
+// One map's eight lane segments -> its slices of the sweep's contiguous id_in / id_out key arrays (what torch.cat did with 16 views per
+// map): lane L's id_in keys to neg_out + (sum of the lanes before it), likewise id_out. The lane counts are read on the device.
+__global__ __launch_bounds__(256) void oodm_gather_lanes_kernel(const uint32_t* __restrict__ keys, long long cap, const u64* __restrict__ lane_counts,
+                                                                uint32_t* __restrict__ neg_out, uint32_t* __restrict__ pos_out) {
+  const int ln = blockIdx.y;
+  u64 nb = 0, pb = 0;
+  for (int l = 0; l < ln; ++l) { nb += lane_counts[l] & 0xffffffffull; pb += lane_counts[l] >> 32; }
+  const u64 a = lane_counts[ln] & 0xffffffffull, b = lane_counts[ln] >> 32;
+  const uint32_t* seg = keys + (size_t)ln * cap;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < a; i += (u64)gridDim.x * 256) neg_out[nb + i] = seg[i];
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < b; i += (u64)gridDim.x * 256) pos_out[pb + i] = seg[cap - b + i];
+}
+
 __device__ __forceinline__ long long lower_bound(const uint32_t* __restrict__ a, long long lo, long long hi, uint32_t v) {
   while (lo < hi) {                                        // first index with a[i] >= v
     const long long mid = (lo + hi) >> 1;
@@ -462,6 +475,16 @@ int mss_oodm_compact_lanes_batch_f32(const MssOodmBatch* batch, int count, long 
   long long blocks = (most + (long long)NT * ITEMS - 1) / ((long long)NT * ITEMS);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(oodm_compact_batch_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(NT), 0, S_(stream), *batch, id_in, id_out);
+  return mss_launch_status();
+}
+
+int mss_oodm_gather_lanes_u32(const unsigned int* keys, long long cap, const unsigned long long* lane_counts, unsigned int* neg_out,
+                              unsigned int* pos_out, void* stream) {
+  if (cap < 0 || (cap > 0 && (!keys || !lane_counts || !neg_out || !pos_out))) return MSS_ERR_BAD_ARG;
+  if (cap == 0) return MSS_OK;
+  long long blocks = (cap + 4095) / 4096;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(oodm_gather_lanes_kernel, dim3((unsigned)blocks, 8), dim3(256), 0, S_(stream), keys, cap, lane_counts, neg_out, pos_out);
   return mss_launch_status();
 }
 

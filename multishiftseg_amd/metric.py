@@ -42,7 +42,7 @@ class OODMeter:
     _CHUNK = 4096                  # pixels a workgroup compacts at a time
 
     def reset(self):
-        self._chunks = []          # (keys [8 cap] u32: per lane inliers at the front, OOD at the back of its segment; cap; pool, row), on device
+        self._chunks = []          # (key buffer, first slot, cap, pool, row): 8 cap u32 slots from `first slot`, per lane inliers at the front, OOD at the back of its segment
         self._pool, self._pool_ptr, self._used = None, 0, 0
 
     def _counters(self, device):
@@ -66,7 +66,7 @@ class OODMeter:
         row = self._counters(score.device)
         call("mss_oodm_compact_lanes_f32", ptr(score), ptr(label), n, self.id_in, self.id_out, ptr(keys),
              ctypes.c_void_p(self._pool_ptr + 8 * self._LANES * row))
-        self._chunks.append((keys, cap, self._pool, row))
+        self._chunks.append((keys, 0, cap, self._pool, row))
 
     def update_many(self, pairs):
         """The same for a sweep that already holds its maps: `pairs` = iterable of (anomaly_score, target) batches, handed to the device
@@ -98,13 +98,12 @@ class OODMeter:
             row = self._counters(dev)
             b.score[m], b.label[m], b.n[m] = score.data_ptr(), label.data_ptr(), n
             b.keys[m], b.lane_counts[m] = kp + 4 * off, self._pool_ptr + 8 * self._LANES * row
-            self._chunks.append((keys[off:off + self._LANES * cap], cap, self._pool, row))
+            self._chunks.append((keys, off, cap, self._pool, row))
             off += self._LANES * cap
         call("mss_oodm_compact_lanes_batch_f32", ctypes.byref(b), len(group), self.id_in, self.id_out)
 
     @staticmethod
-    def _sorted(parts):
-        keys = parts[0] if len(parts) == 1 else torch.cat(parts)
+    def _sorted(keys):
         n = keys.numel()
         out = torch.empty_like(keys)
         temp = torch.empty(_lib.value("mss_oodm_sort_temp_bytes", n), dtype=torch.uint8, device=keys.device)
@@ -116,20 +115,24 @@ class OODMeter:
         if not self._chunks:
             return None
         pools = {}
-        for _, _, pool, _ in self._chunks:
+        for _, _, _, pool, _ in self._chunks:
             pools.setdefault(id(pool), pool)
         host = {k: p.tolist() for k, p in pools.items()}                          # the sweep's only D2H before the result
-        negs, poss = [], []
-        for keys, cap, pool, row in self._chunks:
-            for lane, v in enumerate(host[id(pool)][row]):
-                a, b = v & 0xFFFFFFFF, (v & 0xFFFFFFFFFFFFFFFF) >> 32
-                if a:
-                    negs.append(keys[lane * cap:lane * cap + a])
-                if b:
-                    poss.append(keys[(lane + 1) * cap - b:(lane + 1) * cap])
-        if not negs or not poss:
+        totals = []
+        for _, _, _, pool, row in self._chunks:
+            lanes = host[id(pool)][row]
+            totals.append((sum(v & 0xFFFFFFFF for v in lanes), sum((v & 0xFFFFFFFFFFFFFFFF) >> 32 for v in lanes)))
+        N, P = sum(t[0] for t in totals), sum(t[1] for t in totals)
+        if not N or not P:
             return None
-        pos, neg = self._sorted(poss), self._sorted(negs)
+        dev = self._chunks[0][0].device
+        neg_in, pos_in = torch.empty(N, dtype=torch.int32, device=dev), torch.empty(P, dtype=torch.int32, device=dev)
+        np_, pp_, no, po = neg_in.data_ptr(), pos_in.data_ptr(), 0, 0
+        for (keys, first, cap, pool, row), (a, b) in zip(self._chunks, totals):   # every map's lane segments -> its slice of the two arrays
+            call("mss_oodm_gather_lanes_u32", ctypes.c_void_p(keys.data_ptr() + 4 * first), cap, ctypes.c_void_p(pool.data_ptr() + 8 * self._LANES * row),
+                 ctypes.c_void_p(np_ + 4 * no), ctypes.c_void_p(pp_ + 4 * po))
+            no, po = no + a, po + b
+        pos, neg = self._sorted(pos_in), self._sorted(neg_in)
         P, N = pos.numel(), neg.numel()
         nb = _lib.value("mss_oodm_rank_blocks", P)
         u2 = torch.empty(nb, dtype=torch.int64, device=pos.device)
