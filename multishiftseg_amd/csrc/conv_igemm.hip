@@ -982,7 +982,6 @@ inline void launch_wgrad_reduce(const float* ws, float* dwp, long long slab4, in
   // threads wanted: ~64 k; G split-lanes per element while each lane still has >= 4 splits
   int G = 1;
   while (G < 32 && slab4 * G < 65536 && splits >= 8 * G) G *= 2;
-  if (MSS_ENV_INT("MSS_WGRAD_REDUCE_PAR", 1) == 0) G = 1;
   if (G == 1) {
     long long blocks = (slab4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -1534,12 +1533,8 @@ int launch_wgrad_tn(const MssConvArgs& p, const float* dy, float* dwp, int Cp, f
     hipLaunchKernelGGL(gemm_tn2_wgrad_kernel<128>, dim3(grid), dim3(NT), smem2, stream, dy, p.x, out, P, p.M, p.K, p.C, a_bs,
                        b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
   } else {
-    if (MSS_ENV_INT("MSS_WGRAD_TN_AHEAD", 0) == 2)
-      hipLaunchKernelGGL(gemm_tn_wgrad_kernel<true>, dim3(grid), dim3(NT), smem, stream, dy, p.x, out, P, p.M, p.K, p.C, a_bs,
-                         b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
-    else
-      hipLaunchKernelGGL(gemm_tn_wgrad_kernel<false>, dim3(grid), dim3(NT), smem, stream, dy, p.x, out, P, p.M, p.K, p.C, a_bs,
-                         b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
+    hipLaunchKernelGGL(gemm_tn_wgrad_kernel<false>, dim3(grid), dim3(NT), smem, stream, dy, p.x, out, P, p.M, p.K, p.C, a_bs,
+                       b_bs, p.Kpad, Cp, pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total);
   }
   if (pl.splits > 1) {
     launch_wgrad_reduce(ws, dwp, slab / 4, pl.splits, stream);
@@ -1569,9 +1564,7 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   // read per call (not cached): the parity tests switch routes inside one process (MSS_GEMM=0: every layer on the
   // implicit-GEMM kernel; tests/test_gpu_fullsize.py compares it with the GEMM/Winograd routes)
-  int force_bk = 0, use_gemm = 1;
-  force_bk = MSS_ENV_INT("MSS_CONV_BK", 0);
-  use_gemm = MSS_ENV_INT("MSS_GEMM", 1);
+  const int use_gemm = MSS_ENV_INT("MSS_GEMM", 1);
   if (use_gemm) {
     const int rc = mss_gemm_nt_dispatch(p, stream);
     if (rc >= 0) return rc;
@@ -1579,8 +1572,8 @@ int mss_conv2d_forward_f32(MssConvArgs* args, void* stream) {
   if (mss_conv_bf16x3_eligible(p)) return mss_conv_bf16x3_launch(p, stream);     // the split-bf16 route (args->w_split): gemm_bf16x3.hip, CONV
   // K-step: 16 (41 KB LDS, 144 registers -> 3 workgroups/CU, 3 waves/SIMD) is the faster choice except
   // for the ASPP shape (4096 input channels, 256 output channels), where the 32-deep step wins
-  // (measured: 128 vs 119 TFLOP/s); MSS_CONV_BK=16|32 overrides for experiments.
-  const bool k32 = (p.C % 32 == 0) && (force_bk == 32 || (force_bk != 16 && p.C >= 2048 && p.K <= 256));
+  // (measured: 128 vs 119 TFLOP/s).
+  const bool k32 = p.C % 32 == 0 && p.C >= 2048 && p.K <= 256;
   if (p.K <= 64) {
     (void)k32;
     return launch_conv<256, 64, 16, 4, 1>(p, s);
@@ -1627,7 +1620,6 @@ int mss_conv2d_unpack_wgrad_f32(const float* packed, float* grad, int K, int C, 
 // product its third 128-row tile is 3/4 padding, 71 - 79 TFLOP/s): the first 128 j channels as one product on the wide kernels and
 // the last r on the narrow streaming kernel, each writing its own rows of dwp. Returns the wide part's channel count, 0 = no split.
 static int wgrad_wide_part(const MssConvArgs& p, int Cp) {
-  if (MSS_ENV_INT("MSS_WGRAD_KSPLIT", 1) == 0) return 0;
   const int r = p.K % 128;
   if (p.batch > 1 || p.K <= 128 || r == 0 || r > 64 || Cp != p.C || p.Kpad < p.K) return 0;
   MssConvArgs t = p;

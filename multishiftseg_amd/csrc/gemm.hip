@@ -314,8 +314,6 @@ int launch_gemm(const MssConvArgs& p, hipStream_t stream, long long first = 0, l
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<AFFINE, VARIANT, BN>, NT, smem) != hipSuccess || n < 1) n = 3;
-    const int cap = MSS_ENV_INT("MSS_GEMM_WG_PER_CU", 0);
-    if (cap > 0 && cap < n) n = cap;
     per_cu_max = n;
   }
   // Every workgroup walks ceil(total / grid) tiles: pick the residency (per_cu_max or one less) whose last round is
@@ -343,11 +341,11 @@ int mss_gemm_nt_bf16x3_launch(MssConvArgs p, void* stream);
 // Shapes this kernel takes from mss_conv2d_forward_f32 (conv_igemm.hip); p.M is set.
 // 33..64 output channels over many rows (the 48-channel heads and bot_fine, 1 M pixels) on the persistent kernel with a 128 x 64
 // tile instead of conv_igemm's one-tile-per-workgroup 256 x 64 kernel: 0.203 -> 0.184 ms (256 -> 48) and 0.116 -> 0.087 ms
-// (128 -> 48) at 1 x 512 x 1024 (MSS_GEMM_BN64=0 restores the old route)
+// (128 -> 48) at 1 x 512 x 1024
 static bool gemm_bn64_wanted(const MssConvArgs& p) {
-  // r05: MSS_GEMM_BN64_MINK (default 32 since r05, 33 before): 256 -> 32 over 162 k rows (the tail of the pixel decoder's
+  // r05: from K >= 32 (33 before): 256 -> 32 over 162 k rows (the tail of the pixel decoder's
   // 288-wide projection, 31 TFLOP/s on conv_igemm's 256 x 64 tile)
-  return MSS_ENV_INT("MSS_GEMM_BN64", 1) != 0 && p.K <= 64 && p.K >= MSS_ENV_INT("MSS_GEMM_BN64_MINK", 32) && p.batch <= 1 && p.C / BK >= 3 &&
+  return p.K <= 64 && p.K >= 32 && p.batch <= 1 && p.C / BK >= 3 &&
          p.M >= 16384;
 }
 
@@ -406,10 +404,9 @@ int mss_gemm_nt_dispatch(MssConvArgs p, void* stream) {
                   (unsigned long long)((nb3 - 1) * p.w_bs + (long long)p.Kpad * p.C) * 4ull < 0xffffffffull;
   if (variant == 0) return p.in_scale ? launch_gemm<true, 0, 128>(p, s) : launch_gemm<false, 0, 128>(p, s);
   // 256-wide tiles when the output channels split evenly, the reduction is long enough and there is work for two rounds of
-  // the 512 slots (MSS_GEMM_BN=128|256 forces one). Measured (tools/bench_bgemm.py, bench_1x1.py): 1x1 2048 -> 4096
+  // the 512 slots. Measured (tools/bench_bgemm.py, bench_1x1.py): 1x1 2048 -> 4096
   // 127 -> 133, ASPP 4096 -> 256 123 -> 131, 1024 -> 2048 136 -> 138, C = 304 122 -> 126 TFLOP/s; C = 256: 122 -> 121 (not taken).
-  int bn = 0;
-  bn = MSS_ENV_INT("MSS_GEMM_BN", 0);
+  constexpr int bn = 0;                                  // (the A/B switch that forced one width went in round 6)
   const long long tiles256 = (long long)p.mtiles * (p.K / 256) * (p.batch > 1 ? p.batch : 1);
   bool wide = p.K % 256 == 0 && (bn == 256 || (bn == 0 && tiles256 >= 1024 && p.C >= 256));
   if (wide && bn == 0) {

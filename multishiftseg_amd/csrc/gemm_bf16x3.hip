@@ -1057,8 +1057,6 @@ int launch_split_as(const MssConvArgs& p, hipStream_t stream, int* sched) {
   const int rc = split_dev_info(gemm_nt_bf16x3_kernel<AFFINE, BN, CONV, ROWAFF, DYN, MF>, smem, BN == 256 ? 2 : 3, info, mu, di);
   if (rc != MSS_OK) return rc;
   int per_cu_max = di.occ;
-  const int cap = MSS_ENV_INT("MSS_GEMM_WG_PER_CU", 0);                // (A/B) read on every call: mss_env_reset applies
-  if (cap > 0 && cap < per_cu_max) per_cu_max = cap;
   // residency (per_cu_max or one less) whose last round of tiles is fuller, as launch_gemm (gemm.hip)
   int grid = 0;
   double best = -1.0;
@@ -1124,10 +1122,10 @@ bool mss_gemm_nt_bf16x3_eligible(const MssConvArgs& p) {
 }
 
 // Called by mss_gemm_nt_dispatch (gemm.hip) with p.H (rows per affine group), p.mtiles set; picks the tile width as the native
-// route does (MSS_GEMM_BN=128|256 forces one).
+// route does.
 int mss_gemm_nt_bf16x3_launch(MssConvArgs p, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int bn = MSS_ENV_INT("MSS_GEMM_BN", 0);
+  constexpr int bn = 0;                                  // (the A/B switch that forced one width went in round 6)
   const long long nb = p.batch > 1 ? p.batch : 1;
   const long long tiles256 = (long long)p.mtiles * (p.K / 256) * nb;
   bool wide = p.K % 256 == 0 && (bn == 256 || (bn == 0 && tiles256 >= 1024 && p.C >= 256));
@@ -1256,7 +1254,7 @@ bool mss_conv_bf16x3_eligible(const MssConvArgs& p) {
   if (p.in_relu && !p.in_scale) return false;
   if ((unsigned long long)p.N * p.H * p.W * p.ldx * 4ull >= 0x7fffffffull) return false;   // signed 32-bit pixel offsets
   if ((unsigned long long)taps * p.Kpad * p.C * 6ull >= 0xffffffffull) return false;
-  return (reinterpret_cast<uintptr_t>(p.w_split) & 15) == 0 && MSS_ENV_INT("MSS_CONV_SPLIT", 1) != 0;
+  return (reinterpret_cast<uintptr_t>(p.w_split) & 15) == 0;
 }
 
 // 1x1 / stride-1 layers whose prologue affine is per sample while 128-row tiles straddle images ((OH * OW) % 128 != 0: mod6 / mod7's
@@ -1265,7 +1263,7 @@ static bool rowaff_eligible(const MssConvArgs& p) {
   if (!p.w_split || p.R * p.S != 1 || p.stride != 1 || p.pad != 0 || p.H != p.OH || p.W != p.OW || p.batch > 1) return false;
   if (!p.in_scale || !p.in_ss_stride || (p.OH * p.OW) % BM == 0 || p.K <= 64 || p.Kpad % 128 || p.C % BK || p.C / BK < 3) return false;
   if ((unsigned long long)p.M * p.ldx * 4ull >= 0xffffffffull || (unsigned long long)p.Kpad * p.C * 6ull >= 0xffffffffull) return false;
-  return (reinterpret_cast<uintptr_t>(p.w_split) & 15) == 0 && MSS_ENV_INT("MSS_CONV_SPLIT", 1) != 0;
+  return (reinterpret_cast<uintptr_t>(p.w_split) & 15) == 0;
 }
 
 int mss_conv_bf16x3_launch(MssConvArgs p, void* stream) {

@@ -1116,10 +1116,7 @@ int mss_rcl_loss_device_f32(const MssRclArgs* a, void* workspace, long long work
   if ((rc = rcl_pass1_impl(a, lse, ce_aug, kind, counters, dlogit, stream, false))) return rc;
   const bool select = a->select != 0;
   if (select) {
-    if (MSS_ENV_INT("MSS_RCL_SELECT_MERGED", 1) != 0)
-      rc = mss_rcl_select_merged_f32(ce_aug, (long long)(a->B / 2) * a->H * a->W, counters, a->selection_ratio, hist, 1, sel, stream);
-    else
-      rc = mss_rcl_select_f32(ce_aug, (long long)(a->B / 2) * a->H * a->W, counters, a->selection_ratio, hist, sel, stream);
+    rc = mss_rcl_select_merged_f32(ce_aug, (long long)(a->B / 2) * a->H * a->W, counters, a->selection_ratio, hist, 1, sel, stream);
     if (rc) return rc;
     if ((rc = mss_rcl_pass2_f32(a, lse, ce_aug, kind, sel, counters, 1.0f, dlogit, stream))) return rc;
   } else {

@@ -299,7 +299,7 @@ def encoder_layer(layer, src, pos, reference_points, spatial_shapes, level_start
     elementwise pass of its own any more)."""
     a = layer.self_attn
     # grad mode is always off INSIDE Function.forward: what the caller runs under is read here
-    save_loc = torch.is_grad_enabled() and os.environ.get("MSS_ENCODER_SAVE_LOC", "1") != "0"
+    save_loc = torch.is_grad_enabled()
     geom = (a.n_heads, a.n_levels, a.n_points, layer.norm1.eps, layer.norm2.eps, bool(want_q), save_loc)
     return _EncoderLayerFn.apply(
         src, q, pos, reference_points, spatial_shapes.contiguous(), level_start_index.contiguous(), geom,

@@ -405,7 +405,7 @@ def pack_weight_wino(w, flip=False, tile=2):
         raise TypeError("pack_weight_wino needs a float32 CUDA tensor")
     w = w.detach().contiguous()
     Kpad = _lib.value("mss_conv2d_kpad", K)
-    if gemm_route() == "bf16x3" and Kpad % 128 == 0 and os.environ.get("MSS_WINO_PACK_FUSED", "1") != "0":
+    if gemm_route() == "bf16x3" and Kpad % 128 == 0:
         return WinoWeight(None, K, C, Kpad, C, tile, src=w)          # U in fp32 only if somebody asks for it (WinoWeight.t)
     t = torch.empty(((tile + 2) ** 2, Kpad, C), device=w.device, dtype=torch.float32)
     call("mss_wino_pack_weights_f32", ptr(w), ptr(t), K, C, Kpad, C, tile)
@@ -418,7 +418,7 @@ def packed_wino(param, flip=False, tile=2):
 
 # measured on MI355X (tools/bench_wino.py): F(2x2) 0.87x at 128 channels, 1.24-1.28x at 256, 1.7-2.1x at >= 512;
 # F(4x4) 1.29x at 128 channels, 2.0x at 256, 2.4-3.4x at >= 512; F(6x6): 64 -> 128 at 512x1024 1.50 -> 0.8 ms
-WINOGRAD_MIN_CHANNELS = {2: 256, 4: int(os.environ.get("MSS_WINO_F4_MIN_CHANNELS", "128")), 6: 64}
+WINOGRAD_MIN_CHANNELS = {2: 256, 4: 128, 6: 64}
 WINO_TILE_OF_P = {16: 2, 36: 4, 64: 6}
 
 

@@ -112,9 +112,9 @@ def ffn_relu(x, lin1, lin2):
 
 # Rows below which a call goes to the library GEMM instead. Round 1 used 65536 (N = 1 calls are launch-bound and torch's
 # host path is shorter); the default is now 0: every eligible Linear of the MSDeformAttn module / encoder runs on the
-# repository's own MFMA kernels, N = 1 included (MSS_LINEAR_MIN_ROWS restores a gate for A/B measurements).
+# repository's own MFMA kernels, N = 1 included (the module attribute MIN_ROWS restores a gate for A/B measurements).
 import os
-MIN_ROWS = int(os.environ.get("MSS_LINEAR_MIN_ROWS", "0"))
+MIN_ROWS = 0
 
 
 def linear(x, weight, bias=None, relu=False):

@@ -748,6 +748,36 @@ def test_bf16x3_ticket_kernels_in_two_graphs_replayed_concurrently(K, monkeypatc
 
 
 
+@pytest.mark.parametrize("rows,c,k,batch", [(65536, 512, 1024, 1), (2112, 1024, 512, 16), (777, 256, 256, 5)])
+def test_bf16x3_mfma16_lds_dma_has_no_race(K, monkeypatch, rows, c, k, batch):
+    """The 16x16x32 form stages the weight planes by LDS-DMA and orders them by hand (counted s_waitcnt vmcnt + raw s_barrier; a read
+    placed one wait too early passes whenever the DMA happens to land first -- cdna_hip_programming.md 5, "Read a staged buffer one phase
+    AFTER the wait that retires it"). 60 launches of the same product beside a second stream that keeps the memory system busy: every
+    output bit-identical to the first, and within fp32 rounding of the 32x32x16 form (another summation order, same six products)."""
+    torch.manual_seed(rows)
+    x = torch.randn(batch, rows, c, device="cuda")
+    from multishiftseg_amd import _lib
+    kpad = _lib.value("mss_conv2d_kpad", k)
+    w = torch.zeros(batch, kpad, c, device="cuda")
+    w[:, :k] = torch.randn(batch, k, c, device="cuda") / c ** 0.5
+    monkeypatch.setenv("MSS_GEMM_SPLIT_MFMA", "160")
+    first, _ = _run_gemm(K, x, w, k, split=True)
+    noise = torch.empty(64 << 20, device="cuda")
+    side = torch.cuda.Stream()
+    for it in range(60):
+        with torch.cuda.stream(side):
+            noise.normal_()                                # HBM / L2 traffic beside the launch: DMA latencies vary
+        y, _ = _run_gemm(K, x, w, k, split=True)
+        assert torch.equal(y, first), it
+    torch.cuda.synchronize()
+    monkeypatch.setenv("MSS_GEMM_SPLIT_MFMA", "32")
+    y32, _ = _run_gemm(K, x, w, k, split=True)
+    scale = first.abs().max().item()
+    assert (first.double() - y32.double()).abs().max().item() < 2e-6 * scale
+    assert not torch.equal(first, y32)                     # it really is the other kernel
+
+
+
 def test_bf16x3_route_is_taken_by_the_layer_wrappers(K):
     """kernels.set_gemm_route("bf16x3") / MSS_GEMM_SPLIT=1 must reach the kernel through every wrapper that builds MssConvArgs: a 1x1
     layer, a Winograd layer (with the 304 = 256 + 48 output split, whose 48-channel tail stays on the native narrow tile) and a

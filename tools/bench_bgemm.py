@@ -35,5 +35,5 @@ for (P, T, C, Ko) in CASES:
     fl = 2.0 * P * T * C * Ko
     by = 4.0 * P * T * (C + Ko)
     print(json.dumps(dict(P=P, T=T, C=C, K=Ko, nbuf=NBUF, ms=round(ms, 3), tflops=round(fl / ms / 1e9, 1), GBs=round(by / ms / 1e6, 1),
-                          bk=os.environ.get("MSS_CONV_BK", "policy"))), flush=True)
+                          bk="policy")), flush=True)
     del sets

@@ -22,4 +22,4 @@ for (P, T, C, Ko) in CASES:
     ws, wsb = K._wgrad_workspace(a, C, "cuda")
     ms = timeit(lambda: call("mss_conv2d_wgrad_f32", ctypes.byref(a), ptr(dyt), Ko, ptr(du), C, ptr(ws), wsb), iters=5, warm=2)
     print(json.dumps(dict(P=P, T=T, C=C, K=Ko, ms=round(ms, 3), tflops=round(2.0 * P * T * C * Ko / ms / 1e9, 1), ws_MB=round(wsb / 1e6, 1),
-                          tn=os.environ.get("MSS_WGRAD_TN", "1"), ahead=os.environ.get("MSS_WGRAD_TN_AHEAD", "1"))), flush=True)
+                          tn=os.environ.get("MSS_WGRAD_TN", "1"))), flush=True)

@@ -1,6 +1,6 @@
 """A/B of the Winograd INPUT transform alone on the step's shapes: two settings of one environment switch, alternating (A B A B after a
 long warm-up, best round of each -- see tools/bench_gemm_variant.py for why), TB/s of the algorithmic bytes (x once + X' once).
-    python tools/bench_wino_in.py MSS_WINO_IN_ORDER 0 1"""
+    python tools/bench_wino_in.py MSS_WINO_INPUT_LDS 1 2"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,7 +1,7 @@
 """Round-4 transform micro-benchmarks under an A/B of one environment switch (alternating protocol of tools/bench_gemm_variant.py):
 the fused three-dilation ASPP input transform, the upsample-in-transform of the decoder's first layer, the F(6x6) output transform at
 304 / 256 channels, and the plain input transforms of the step. TB/s of algorithmic bytes; bit-equality of A and B.
-    python tools/bench_wino_r04.py MSS_WINO_XCD 0 1 [aspp|upcat|out|in ...]"""
+    python tools/bench_wino_r04.py MSS_WINO_ASPP3 0 1 [aspp|upcat|out|in ...]"""
 import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
