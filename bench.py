@@ -492,12 +492,12 @@ def main():
             ss_ = prof_s.summary()
             gs = ss_.get("gemm_nt_bf16x3", dict(launches=0, flops=0.0, ms=1.0))
             ach = gs["flops"] / (gs["ms"] * 1e-3) / 1e12 if gs["launches"] else 0.0
-            rf = {"bound": "mfma", "kernel": "gemm_nt_bf16x3_kernel (6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block)",
+            rf = {"bound": "mfma", "kernel": "gemm_nt_bf16x3_kernel (six bf16 products per fp32 product: 3 x v_mfma_f32_16x16x32_bf16 on concatenated planes per 16x16x16 block for the products without a prologue, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block for the prologue / implicit-GEMM kernels)",
                   "achieved": round(ach, 2), "peak": round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1), "unit": "TFLOP/s (fp32-equivalent)",
                   "frac": round(ach / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4), "launches_per_step": gs["launches"] // max(args.steps, 1),
                   "avg_launch_ms": round(gs["ms"] / max(gs["launches"], 1), 4), "kernel_ms_per_step": round(gs["ms"] / max(args.steps, 1), 2),
                   "peak_note": "2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md) / 6 MFMA products per fp32 product; under this load the chip "
-                               "holds ~1.7 GHz of the nominal 2.4 (profiles/r05/pmc_split.md: matrix pipe busy share, effective clock)"}
+                               "holds 1.6 (32x32x16) / 1.85 GHz (16x16x32) of the nominal 2.4 (profiles/r06/pmc_split_mfma32.md, pmc_split_mfma16_linear_image.md: matrix pipe busy share, effective clock)"}
             ppath = os.path.join(ROOT, "profiles", "split_pmc_latest.json")
             if os.path.exists(ppath):
                 try:

@@ -578,7 +578,8 @@ int mss_data_pair_f32(const uint8_t* img, const uint8_t* gen, const uint8_t* tgt
 /* Calibration kernels (bench.py: achievable peaks of this device next to the datasheet ones).
  * mss_peak_mfma_f32: blocks x 4 waves x iters x 16 back-to-back v_mfma_f32_32x32x2_f32 (4096 FLOP
  * each), out >= blocks*256 floats. mss_peak_stream_f32: float4 copy of n floats (8*n bytes moved);
- * variant 0..3 = plain / 4 loads in flight / + nontemporal / + contiguous 16-KB chunks per workgroup. */
+ * variant 0..3 = plain / 4 loads in flight / + nontemporal / + contiguous 16-KB chunks per workgroup; round 6: 4 = write-only (4*n bytes),
+ * 5 = read-only (4*n bytes), 6 = first half of src read, all of dst written (6*n bytes: the 1 : 2 mix of the Winograd input transforms); n % 8 == 0. */
 int mss_peak_mfma_f32(float* out, int blocks, int iters, void* stream);
 /* The same for the bf16 matrix cores under load (the split-bf16 GEMM route's ceiling): register-only loops on pseudo-random operands,
  * blocks x 4 waves x iters x 1 572 864 FLOP; shape 0 = 48 x v_mfma_f32_32x32x16_bf16 per iteration, 1 = 96 x v_mfma_f32_16x16x32_bf16. */

@@ -1097,14 +1097,14 @@ int launch_split_mf(const MssConvArgs& p, hipStream_t stream) {
 template <bool AFFINE, int BN, bool CONV = false, bool ROWAFF = false>
 int launch_split(const MssConvArgs& p, hipStream_t stream) {
   // MSS_GEMM_SPLIT_MFMA=32: the round-5 form (one product per v_mfma_f32_32x32x16_bf16) for A/B and for outputs mss_epilogue_store16 cannot take
-  // The 16x16x32 form takes the products WITHOUT a prologue on the 128 x 256 tile -- the Winograd-domain batches and the plain 1x1
-  // layers: measured 1.02-1.08x the 32x32x16 form there (profiles/r06/split_mfma_ab.md). An MFMA of that shape holds the SIMD's vector
-  // issue for 8 of its 16 cycles: the 128-wide tile has the same split arithmetic per K-step behind half as many of them (0.89-1.0x),
-  // and the BatchNorm + ReLU prologue's ten more registers put the wide kernel into scratch inside the K-loop (0.96-0.99x) -- those
-  // stay on the round-5 form. MSS_GEMM_SPLIT_MFMA=160 also runs the 128-wide plain products on the 16x16x32 form (tests, A/B), =32 nothing.
+  // The 16x16x32 form takes the products WITHOUT a prologue -- the Winograd-domain batches and the plain 1x1 layers / Linears: measured
+  // 1.02-1.08x the 32x32x16 form on the 128 x 256 tile, 1.0-1.07x on the 128-wide one (profiles/r06/split_mfma_ab.md). An MFMA of that
+  // shape holds the SIMD's vector issue for 8 of its 16 cycles, and the BatchNorm + ReLU prologue's ten more registers put the wide
+  // kernel into scratch inside the K-loop (0.96-0.99x): the prologue, implicit-GEMM and per-sample-affine kernels stay on the round-5
+  // form. MSS_GEMM_SPLIT_MFMA=32: that form everywhere (A/B, tests).
   const int mf = MSS_ENV_INT("MSS_GEMM_SPLIT_MFMA", 16);
   if constexpr (!CONV && !AFFINE)
-    if ((mf == 160 || (mf == 16 && BN == 256)) && split_mf16_ok(p)) return launch_split_mf<AFFINE, BN, CONV, ROWAFF, 16>(p, stream);
+    if (mf != 32 && split_mf16_ok(p)) return launch_split_mf<AFFINE, BN, CONV, ROWAFF, 16>(p, stream);
   return launch_split_mf<AFFINE, BN, CONV, ROWAFF, 32>(p, stream);
 }
 

@@ -108,6 +108,8 @@ __global__ __launch_bounds__(256, 2) void peak_mfma_bf16_kernel(float* __restric
 // variant 1: four independent loads in flight per thread before the four stores
 // variant 2: as 1 with nontemporal loads and stores (streaming data is read and written once)
 // variant 3: as 2, a workgroup owns contiguous 16-KB chunks (4 consecutive float4 per lane and pass)
+// variant 4 / 5 / 6 (r06): as 3 but WRITE-only (4 n bytes) / READ-only (4 n bytes) / the first half of src read and all of dst written
+//   (6 n bytes, 1 : 2 -- the direction of the Winograd input transforms, which write 1.78-2.25 bytes per byte read)
 template <int VARIANT>
 __global__ __launch_bounds__(256) void peak_stream_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst,
                                                           long long n4) {
@@ -128,6 +130,29 @@ __global__ __launch_bounds__(256) void peak_stream_kernel(const f32x4* __restric
     }
     const long long done = n4 / chunk * chunk;
     for (i = done + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+    return;
+  }
+  if (VARIANT >= 4) {          // r06: the two directions apart, and the Winograd input transforms' mix (contiguous 16-KB chunks as 3)
+    const long long chunk = 256 * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    const long long lim = VARIANT == 6 ? n4 / 2 : n4;       // 6: the first half of src is read, all of dst written (1 : 2)
+    for (long long c = (long long)blockIdx.x * chunk; c + chunk <= lim; c += (long long)gridDim.x * chunk) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = VARIANT == 4 ? f32x4{1.f, 2.f, 3.f, (float)c} : __builtin_nontemporal_load(&src[c + u * 256 + threadIdx.x]);
+      if (VARIANT == 5) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sum += v[u];
+        continue;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v[u], &dst[c + u * 256 + threadIdx.x]);
+      if (VARIANT == 6) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v[u], &dst[n4 / 2 + c + u * 256 + threadIdx.x]);
+      }
+    }
+    if (VARIANT == 5 && sum.x + sum.y + sum.z + sum.w == 12345.678f) dst[0] = sum;     // (keeps the loads alive)
     return;
   }
   for (; i + 3 * stride < n4; i += 4 * stride) {
@@ -210,9 +235,9 @@ int mss_peak_mfma_bf16(float* out, int blocks, int iters, int shape, void* strea
   return mss_launch_status();
 }
 
-// copies n floats (n % 4 == 0); bytes moved = 8 * n. variant: see peak_stream_kernel (tools/peaks.py reports the best).
+// copies n floats (n % 8 == 0); bytes moved = 8 * n for variants 0-3, 4 n / 4 n / 6 n for 4 / 5 / 6: see peak_stream_kernel (tools/peaks.py).
 int mss_peak_stream_f32(const float* src, float* dst, long long n, int variant, void* stream) {
-  if (!src || !dst || n <= 0 || n % 4 || variant < 0 || variant > 3) return MSS_ERR_BAD_ARG;
+  if (!src || !dst || n <= 0 || n % 8 || variant < 0 || variant > 6) return MSS_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const f32x4* a = reinterpret_cast<const f32x4*>(src);
   f32x4* b = reinterpret_cast<f32x4*>(dst);
@@ -221,7 +246,10 @@ int mss_peak_stream_f32(const float* src, float* dst, long long n, int variant, 
     case 0: hipLaunchKernelGGL(peak_stream_kernel<0>, grid, block, 0, s, a, b, n / 4); break;
     case 1: hipLaunchKernelGGL(peak_stream_kernel<1>, grid, block, 0, s, a, b, n / 4); break;
     case 2: hipLaunchKernelGGL(peak_stream_kernel<2>, grid, block, 0, s, a, b, n / 4); break;
-    default: hipLaunchKernelGGL(peak_stream_kernel<3>, grid, block, 0, s, a, b, n / 4); break;
+    case 3: hipLaunchKernelGGL(peak_stream_kernel<3>, grid, block, 0, s, a, b, n / 4); break;
+    case 4: hipLaunchKernelGGL(peak_stream_kernel<4>, grid, block, 0, s, a, b, n / 4); break;
+    case 5: hipLaunchKernelGGL(peak_stream_kernel<5>, grid, block, 0, s, a, b, n / 4); break;
+    default: hipLaunchKernelGGL(peak_stream_kernel<6>, grid, block, 0, s, a, b, n / 4); break;
   }
   return mss_launch_status();
 }

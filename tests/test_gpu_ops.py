@@ -760,7 +760,7 @@ def test_bf16x3_mfma16_lds_dma_has_no_race(K, monkeypatch, rows, c, k, batch):
     kpad = _lib.value("mss_conv2d_kpad", k)
     w = torch.zeros(batch, kpad, c, device="cuda")
     w[:, :k] = torch.randn(batch, k, c, device="cuda") / c ** 0.5
-    monkeypatch.setenv("MSS_GEMM_SPLIT_MFMA", "160")
+    monkeypatch.setenv("MSS_GEMM_SPLIT_MFMA", "16")
     first, _ = _run_gemm(K, x, w, k, split=True)
     noise = torch.empty(64 << 20, device="cuda")
     side = torch.cuda.Stream()

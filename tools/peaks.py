@@ -46,6 +46,17 @@ def measure():
         res[f"stream_copy_v{variant}_GBs"] = 5 * 8.0 * n / (s.elapsed_time(e) * 1e-3) / 1e9
         best = max(best, res[f"stream_copy_v{variant}_GBs"])
     res["stream_copy_GBs"] = best
+    # r06: the two directions apart and the 1 : 2 read : write mix of the Winograd input transforms (bytes: 4 n, 4 n, 6 n)
+    for variant, name, byt in ((4, "stream_write_only_GBs", 4.0), (5, "stream_read_only_GBs", 4.0), (6, "stream_read1_write2_GBs", 6.0)):
+        call("mss_peak_stream_f32", ptr(a), ptr(b), n, variant)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(5):
+            call("mss_peak_stream_f32", ptr(a), ptr(b), n, variant)
+        e.record()
+        torch.cuda.synchronize()
+        res[name] = 5 * byt * n / (s.elapsed_time(e) * 1e-3) / 1e9
     return res
 
 

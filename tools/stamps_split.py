@@ -41,7 +41,7 @@ steps = arr[:, 8:9]
 per = arr[:, :8] / steps
 names16 = ["top (12 fragment reads)", "first touch of the A registers", "group 1 (DMA, row 0 split)", "group 2 (A loads, row 1 split)", "group 3 (bookkeeping)",
            "wait for the DMAs + LDS writes", "-", "barrier"]
-names = names16 if os.environ.get("MSS_GEMM_SPLIT_MFMA", "16") != "32" and Ko % 256 == 0 else ["top (10 fragment reads)", "seg1 B LDS writes", "seg2 B loads + b_mid", "seg3 split row 0", "seg4 split row 1 + A loads + b_lo", "seg5 bookkeeping", "seg6", "barrier"]
+names = names16 if os.environ.get("MSS_GEMM_SPLIT_MFMA", "16") != "32" else ["top (10 fragment reads)", "seg1 B LDS writes", "seg2 B loads + b_mid", "seg3 split row 0", "seg4 split row 1 + A loads + b_lo", "seg5 bookkeeping", "seg6", "barrier"]
 tot = per.sum(1).mean()
 clock = float(np.median(arr[:, 9] / arr[:, 10])) * 0.1          # s_memtime ticks per s_memrealtime tick (100 MHz) -> GHz
 wg_ms = float(np.median(arr[:, 10])) / 1e5                      # a wave's lifetime in 100 MHz ticks -> ms
