@@ -106,21 +106,11 @@ int* mss_sched_slot(hipStream_t stream) {
 
 namespace {
 
-// The tile order of the persistent kernels: the static walk t, t + grid, ... unless built with -DMSS_SPLIT_DYNAMIC_TILES (tickets, see
-// gemm_nt_bf16x3_kernel; `make dynamic_tiles` builds that library for A/B). A compile-time switch: as a run-time one it cost 100
-// spilled registers. Measured (profiles/r05/dynamic_tiles.md): the ticket order equalises the workgroups' lifetimes and changes the
-// launch time by +1 % .. -8 %, because the workgroup the static order leaves alone on its SIMDs runs almost twice as fast there.
-#ifdef MSS_SPLIT_DYNAMIC_TILES
-constexpr bool DYN_TILES = true;
-#else
-constexpr bool DYN_TILES = false;
-#endif
+// The tile order of the persistent kernels is the static walk t, t + grid, ... except where split_dyn_tiles() says tickets (the NT
+// kernels with a prologue, see gemm_nt_bf16x3_kernel). Measured in round 5 with an all-tickets A/B build that round 6 removed
+// (profiles/r05/dynamic_tiles.md): the ticket order equalises the workgroups' lifetimes and changes the launch time by +1 % .. -8 %,
+// because the workgroup the static order leaves alone on its SIMDs runs almost twice as fast there.
 constexpr int NT = 256, BM = 128;
-#ifdef MSS_SPLIT_NOPRIO
-constexpr bool MSS_ENV_PRIO = false;     // A/B build without the s_setprio(1) around the three MFMA groups of the 16x16x32 K-step
-#else
-constexpr bool MSS_ENV_PRIO = true;      // measured +2 % on the products of the step (profiles/r06/split_mfma_ab.md)
-#endif
 using mss_bf16x3::BK;
 using mss_bf16x3::ROW_B;
 using mss_bf16x3::PLANE;
@@ -479,7 +469,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || (AFFINE && (CONV || ROWAFF))) ? 2
 #pragma unroll
     for (int i = 1; i < TI; ++i) xhm[i] = *reinterpret_cast<const bf16x8*>(base + x_hm + i * 16 * ROW_B);
     fence();
-    if (MSS_ENV_PRIO) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);                       // (+2 % on the products of the step, profiles/r06/split_mfma_ab.md)
     MSS_STAMP(0)
     // Every use of the A registers is preceded by this FIRST use (an empty asm the compiler must have them ready for): the wait for
     // the loads (issued in group 2 of the previous step) lands here, in front of this step's DMAs, never behind one.
@@ -547,7 +537,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || (AFFINE && (CONV || ROWAFF))) ? 2
     MSS_PAIR_UP(0x6, TJ - 1, 3);
     fence();
 #undef MSS_PAIR_UP
-    if (MSS_ENV_PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
     MSS_STAMP(4)
     // the DMAs are older than the N_A_LOADS register loads: this retires them (and this wave's LDS writes) and leaves the loads in flight
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(N_A_LOADS) : "memory");
@@ -732,8 +722,7 @@ template <bool AFFINE, bool MASKED>
 __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                                 float* __restrict__ out, int P, int M, long long a_bs, long long b_bs, int Kpad,
                                                                 int Cp, int ktiles, int ctiles, int splits, int tps, long long total_tiles,
-                                                                const float* __restrict__ scale, const float* __restrict__ shift, int relu,
-                                                                int* __restrict__ sched) {
+                                                                const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
   constexpr int NBLK = 2, TN = 4, BN = 256;
   constexpr int STAGE = (1 + NBLK) * OPER;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -781,15 +770,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
     o = (unsigned)(((size_t)(row0 + rg * 8) * ld + col) * sizeof(float));
     if (AFFINE) so = is_a ? 0u : (unsigned)((ct * BN + 4 * cq) * sizeof(float));     // (dy lanes load a valid vector and ignore it)
   };
-  // dynamic tile order, as in gemm_nt_bf16x3_kernel
-  int* tk_slot = reinterpret_cast<int*>(smem + 2 * STAGE);
-  long long nxt_tile = 0;
-  int tiles_done = 0;
-  auto draw_ticket = [&](int slot) {
-    if (DYN_TILES && tid == 0) tk_slot[slot] = draw_xcd_ticket(sched, total_tiles);
-  };
   auto setup_next = [&]() {
-    const long long t = DYN_TILES ? nxt_tile : ld_tile + stride;
+    const long long t = ld_tile + stride;
     setup_off(t < total_tiles ? t : ld_tile, nxt, s_nxt, vf_nxt, row_nxt, nit_nxt, slab_nxt);
   };
   f32x4 raw[8], sreg, hreg;
@@ -936,12 +918,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
   };
 
   long long cur = ld_tile;
-  if constexpr (DYN_TILES) {
-    draw_ticket(0);
-    __syncthreads();
-    nxt_tile = __builtin_amdgcn_readfirstlane(tk_slot[0]);
-    draw_ticket(1);
-  }
   setup_off(ld_tile, off, s_off, vf, row_ld, ld_nit, slab);
   setup_next();
   issue_loads();
@@ -956,16 +932,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
   auto tile_end = [&]() -> bool {
     if (++k < cur_nit) return false;
     epilogue(cur);
-    if constexpr (DYN_TILES) {
-      cur = nxt_tile;
-      nxt_tile = __builtin_amdgcn_readfirstlane(tk_slot[(tiles_done + 1) & 1]);
-      if (cur >= total_tiles) return true;
-      draw_ticket(tiles_done & 1);
-      ++tiles_done;
-    } else {
-      cur += stride;
-      if (cur >= total_tiles) return true;
-    }
+    cur += stride;
+    if (cur >= total_tiles) return true;
     zero_acc();
     k = 0;
     cur_nit = (int)((cur / ((long long)ktiles * ctiles)) % splits) == splits - 1 ? nit_last : nit_full;
@@ -978,10 +946,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_bf16x3_kernel(const float* __re
     if (tile_end()) break;
     step(1);
     if (tile_end()) break;
-  }
-  if (DYN_TILES && tid == 0 && atomicAdd(sched + 8, 1) == (int)gridDim.x - 1) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) __atomic_store_n(sched + i, 0, __ATOMIC_RELAXED);
   }
 }
 
@@ -1019,7 +983,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 // The 128-wide kernel with a prologue: 175 registers in the static form (two workgroups per CU), 165 in the ticket form -- three
 // workgroups per CU like the plain 128-wide kernel (the per-sample-affine variant spills there and stays as it was).
 template <bool AFFINE, int BN, bool CONV, bool ROWAFF>
-constexpr bool split_dyn_tiles() { return DYN_TILES || (AFFINE && !CONV && !ROWAFF); }
+constexpr bool split_dyn_tiles() { return AFFINE && !CONV && !ROWAFF; }
 
 // occupancy / CU count / the raised dynamic-LDS limit of one kernel instantiation, PER DEVICE (function attributes are per device; a
 // process may drive several): filled on the first launch on that device under a mutex
@@ -1227,11 +1191,9 @@ int mss_wgrad_tn_bf16x3_launch(const MssConvArgs& p, const float* dy, int lddy, 
   const int grid = (int)(pl.total < slots ? pl.total : slots);
   const long long a_bs = p.batch > 1 ? p.y_bs : 0, b_bs = p.batch > 1 ? p.x_bs : 0;
   const bool masked = p.M % 16 != 0 || (pl.splits > 1 && p.M - (pl.splits - 1) * pl.tps < 48);
-  int* sched = DYN_TILES ? mss_sched_slot(s) : nullptr;
-  if (DYN_TILES && !sched) return MSS_ERR_UNSUPPORTED;
 #define TN_LAUNCH(AFF, MSK, SC, SH, RL)                                                                                                      \
   hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<AFF, MSK>), dim3(grid), dim3(NT), smem, s, dy, lddy, p.x, p.C, out, P, p.M, a_bs, b_bs, p.Kpad, Cp, \
-                     pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, SC, SH, RL, sched)
+                     pl.ktiles, pl.ctiles, pl.splits, pl.tps, pl.total, SC, SH, RL)
   if (p.in_scale) {
     if (masked) TN_LAUNCH(true, true, p.in_scale, p.in_shift, p.in_relu); else TN_LAUNCH(true, false, p.in_scale, p.in_shift, p.in_relu);
   } else {
