@@ -121,22 +121,30 @@ def test_lazily_packed_wino_weight_refuses_a_modified_source():
         pw.fused_planes()
 
 
-def test_hot_split_gemm_kernels_use_no_scratch():
-    """VERDICT r05 next #2: the split-bf16 kernels run at the 256-register cap of two workgroups per CU, and a spill inside the K-loop
-    shares the vector-memory counter with the tile prefetch (scratch reloads wait with vmcnt(0)). Every instantiation the step's hot
-    products take must be compiled WITHOUT scratch: hipcc's own kernel-resource-usage remarks for gemm_bf16x3.hip, parsed here.
-    Template arguments in the mangled names: <AFFINE, BN, CONV, ROWAFF, DYN (ticket tile order), MF (MFMA shape)>."""
-    import re
+@pytest.fixture(scope="module")
+def split_gemm_compile(tmp_path_factory):
+    """gemm_bf16x3.hip compiled ONCE for gfx950 (device side only): hipcc's kernel-resource-usage remarks and the assembly text."""
     import shutil
     import subprocess
     if shutil.which("hipcc") is None:
         pytest.skip("no hipcc here")
     src = os.path.join(ROOT, "multishiftseg_amd", "csrc", "gemm_bf16x3.hip")
-    r = subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-c", src, "-o", os.devnull,
+    out = tmp_path_factory.mktemp("split_gemm") / "gemm_bf16x3.s"
+    r = subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "--cuda-device-only", "-S", src, "-o", str(out),
                         "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=os.path.dirname(src))
     assert r.returncode == 0, r.stderr[-2000:]
+    return r.stderr, out.read_text()
+
+
+def test_hot_split_gemm_kernels_use_no_scratch(split_gemm_compile):
+    """VERDICT r05 next #2: the split-bf16 kernels run at the 256-register cap of two workgroups per CU, and a spill inside the K-loop
+    shares the vector-memory counter with the tile prefetch (scratch reloads wait with vmcnt(0)). Every instantiation the step's hot
+    products take must be compiled WITHOUT scratch: hipcc's own kernel-resource-usage remarks for gemm_bf16x3.hip, parsed here.
+    Template arguments in the mangled names: <AFFINE, BN, CONV, ROWAFF, DYN (ticket tile order), MF (MFMA shape)>."""
+    import re
+    remarks, _ = split_gemm_compile
     usage, name = {}, None
-    for line in r.stderr.splitlines():
+    for line in remarks.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = m.group(1)
@@ -162,3 +170,36 @@ def test_hot_split_gemm_kernels_use_no_scratch():
     bad = {k: v for k, v in hot.items() if v["ScratchSize [bytes/lane]"] != 0 or v["VGPRs"] > 256}
     assert not bad, bad
     assert hot["plain 128x256, 16x16x32"]["Occupancy [waves/SIMD]"] == 2 and hot["plain 128x128, 16x16x32"]["Occupancy [waves/SIMD]"] == 3
+
+
+def test_lds_dma_wait_counts_exactly_the_a_tile_loads(split_gemm_compile):
+    """The 16x16x32 split kernels bring the B tile in with LDS-DMA and close every K-step with `s_waitcnt vmcnt(N_A_LOADS)`: the
+    vector-memory counter retires in order, so that wait covers the DMA pieces only if EXACTLY N_A_LOADS (2) vector-memory
+    instructions - the next A tile's two 16-byte loads - were issued after the last DMA piece. A compiler that splits a load, sinks
+    another one below the DMA or inserts a scratch access would turn the wait into a race without any build error; this reads the
+    generated gfx950 assembly and checks the instruction order at every such wait (prologue, steady state, tile switch)."""
+    import re
+    _, asm = split_gemm_compile
+    lines = asm.split("\n")
+    vmem = re.compile(r"^\s+((?:global|buffer|scratch|flat)_\w+)")
+    func, waits = None, {}
+    for i, line in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            func = m.group(1)
+        if "s_waitcnt vmcnt(2) lgkmcnt(0)" not in line:
+            continue
+        ops, j = [], i - 1
+        while j > 0 and "global_load_lds_dwordx4" not in lines[j]:
+            assert not re.match(r"^_Z\w+:", lines[j]), (func, "no LDS-DMA before the counted wait")
+            m = vmem.match(lines[j])
+            if m:
+                ops.append(m.group(1))
+            j -= 1
+        waits.setdefault(func, []).append(ops)
+    m16 = {k: v for k, v in waits.items() if "gemm_nt_bf16x3_kernel" in k and "ELi16EEE" in k}
+    assert len(m16) == 2, sorted(waits)                                     # the 128x256 and 128x128 plain kernels
+    for k, per_wait in m16.items():
+        assert len(per_wait) >= 2, (k, per_wait)                            # at least the tile prologue and the steady-state step
+        for ops in per_wait:
+            assert ops == ["global_load_dwordx4", "global_load_dwordx4"], (k, ops)
