@@ -1,5 +1,6 @@
 #!/bin/bash
-# Everything profiles/rNN quotes for the final tree, in one gpurun call from the repo root:  tools/collect_round.sh <dir under gpurun_out>
+# Everything profiles/rNN quotes for the final tree, in one gpurun call from the repo root:
+#   gpurun -- 'MSS_TREE=<commit> tools/collect_round.sh <dir under gpurun_out>'   (the box has no .git: MSS_TREE labels the traffic profile)
 #  * round/            : tools/profile_round.sh on the NATIVE route (kernel statistics of the step, FETCH_SIZE / WRITE_SIZE passes)
 #  * stats_split/      : rocprofv3 --kernel-trace --stats of the same step on the split-bf16 route (MSS_GEMM_SPLIT=1)
 #  * pmc_split_nt|tn/  : SQ counters of gemm_nt_bf16x3_kernel / gemm_tn_bf16x3_kernel (separate --pmc passes)
