@@ -440,16 +440,19 @@ def test_bf16x3_weight_planes_are_an_exact_three_term_split(K, batch, kpad, c):
     assert (mid.abs()[nz] <= w.double().abs()[nz] * 2.0 ** -8).all() and (lo.abs()[nz] <= w.double().abs()[nz] * 2.0 ** -16).all()
 
 
-def _run_gemm(K, x, w, k, split, in_affine=None, out_affine=None, out_relu=False, res=None, res_mask=False, want_stats=False):
-    """x [batch][rows][c], w [batch][kpad][c] (rows >= k zero) through mss_conv2d_forward_f32 on the chosen GEMM route."""
+def _run_gemm(K, x, w, k, split, in_affine=None, out_affine=None, out_relu=False, res=None, res_mask=False, want_stats=False, y=None):
+    """x [batch][rows][c], w [batch][kpad][c] (rows >= k zero) through mss_conv2d_forward_f32 on the chosen GEMM route.
+    `y`: an output VIEW [batch][rows][k] with unit stride in k (row pitch and start address are the view's) instead of a fresh tensor."""
     import ctypes
     from multishiftseg_amd import _lib
     from multishiftseg_amd._lib import MssConvArgs, call, ptr
     batch, rows, c = x.shape
     kpad = w.shape[1]
-    y = torch.full((batch, rows, k), float("nan"), device="cuda")
+    if y is None:
+        y = torch.full((batch, rows, k), float("nan"), device="cuda")
+    assert y.shape == (batch, rows, k) and y.stride(2) == 1
     a = MssConvArgs()
-    a.x, a.w, a.y = ptr(x), ptr(w), ptr(y)
+    a.x, a.w, a.y = ptr(x), ptr(w), y.data_ptr()
     planes = K.split_planes(w, kpad, c) if split else None
     a.w_split = ptr(planes)
     if in_affine is not None:
@@ -464,10 +467,10 @@ def _run_gemm(K, x, w, k, split, in_affine=None, out_affine=None, out_relu=False
         stats = torch.empty((-(-rows // 64), 2, k), device="cuda")
         a.stats = ptr(stats)
     a.N, a.H, a.W, a.C, a.ldx = 1, 1, rows, c, c
-    a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, rows, k, kpad, k
+    a.OH, a.OW, a.K, a.Kpad, a.ldy = 1, rows, k, kpad, y.stride(1)
     a.R, a.S, a.stride, a.dil, a.pad = 1, 1, 1, 1, 0
     if batch > 1:
-        a.batch, a.x_bs, a.w_bs, a.y_bs = batch, rows * c, kpad * c, rows * k
+        a.batch, a.x_bs, a.w_bs, a.y_bs = batch, rows * c, kpad * c, y.stride(0)
     assert _lib.value("mss_conv2d_forward_route", ctypes.byref(a)) == (3 if split else 1)
     call("mss_conv2d_forward_f32", ctypes.byref(a))
     return y, stats
@@ -498,6 +501,37 @@ def test_bf16x3_gemm_is_fp32_accurate(K, rows, c, k, batch):
     assert e32 < 2e-6 and e3 < 2e-6 and e3 < 2 * e32 + 1e-7, (e32, e3)
     assert (y3.double() - y32.double()).abs().max().item() < 4e-6 * scale       # every element, not only the sampled rows
     assert not torch.equal(y32, y3)          # it really is a different evaluation
+
+
+@pytest.mark.parametrize("rows,c,k,batch,pitch,lead", [
+    (1000, 256, 130, 1, 130, 0),       # 130 output channels: rows are 8-byte aligned only -> the 32x32x16 form with scalar stores
+    (900, 128, 128, 2, 131, 1),        # a column window of a wider buffer, start and pitch off the 16-byte grid
+    (1300, 256, 256, 2, 260, 4),       # 16-byte aligned window with a pitch wider than the product: the 16x16x32 form's float4 stores
+    (700, 512, 192, 1, 200, 8)])       # padded column tile (192 of 256) inside an aligned window
+def test_bf16x3_gemm_into_an_output_window(K, rows, c, k, batch, pitch, lead):
+    """The 16x16x32 split kernels store 16 bytes per lane and are taken only when the output's start, pitch and batch stride sit on the
+    16-byte grid (split_mf16_ok, gemm_bf16x3.hip); everything else goes to the 32x32x16 kernels' 4-byte stores. Both ways the product
+    lands in a WINDOW of a larger buffer: the window against float64 and against the native route, the rest of the buffer untouched."""
+    from multishiftseg_amd import _lib
+    torch.manual_seed(rows + k)
+    x = torch.randn(batch, rows, c, device="cuda")
+    kpad = _lib.value("mss_conv2d_kpad", k)
+    w = torch.zeros(batch, kpad, c, device="cuda")
+    w[:, :k] = torch.randn(batch, k, c, device="cuda") / c ** 0.5
+    ref = torch.einsum("bmc,bkc->bmk", x.double(), w[:, :k].double())
+    scale = ref.abs().max().item()
+    out = {}
+    for split in (False, True):
+        buf = torch.full((batch, rows + 2, pitch), 7.0, device="cuda")
+        win = buf[:, 1:rows + 1, lead:lead + k] if lead + k <= pitch else None
+        assert win is not None and win.data_ptr() % 16 == (4 * (pitch + lead)) % 16
+        _run_gemm(K, x, w, k, split=split, y=win)
+        assert (win.double() - ref).abs().max().item() < 2e-6 * scale, split
+        outside = buf.clone()
+        outside[:, 1:rows + 1, lead:lead + k] = 7.0
+        assert (outside == 7.0).all(), ("wrote outside its window", split)
+        out[split] = win.clone()
+    assert (out[True].double() - out[False].double()).abs().max().item() < 4e-6 * scale
 
 
 @pytest.mark.parametrize("rows,c,k,per_sample", [(1500, 256, 384, False), (3 * 128 * 5, 128, 256, True), (40000, 512, 1024, False),
