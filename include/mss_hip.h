@@ -27,7 +27,8 @@ extern "C" {
                                   mss_wino_input_transform_aspp3_f32, mss_msda_prepare_backward_ld_f32, mss_rcl_pairs_device2_f32, mss_rcl_loss_device_f32, mss_m2f_fused_score_ws_f32, mss_oodm_compact_packed_f32,
                                   6 (late round 4, additive): mss_msda_forward_fused_ld_f32, mss_msda_prepare_ld_f32, mss_add_layernorm_q_f32, mss_add_layernorm_bwd_sum2_f32, mss_msda_forward_fused_save_f32, mss_msda_backward_binned_proj_f32, mss_gap_from_partials_f32;
                                   7 (round 5): MssConvArgs.w_split + mss_gemm_split_weights_bf16x3 (the split-bf16 GEMM route);
-                                  8 (round 6): mss_msda_forward_window_f32 removed (the measured-slower LDS-window forward left the product) */
+                                  8 (round 6): mss_msda_forward_window_f32 removed (the measured-slower LDS-window forward left the product); additive: the mss_oodm_*lanes* entry points,
+                                  mss_gemm_split_last_mfma */
 int mss_abi_version(void);
 
 /* The MSS_* environment switches (A/B experiments, test routes; none is needed in production) are read once per call site and
@@ -180,6 +181,10 @@ int mss_gemm_split_weights_bf16x3(const float* w, void* planes, int batch, int K
  * > 64 output channels and one prologue affine): w [taps][Kpad][C] from mss_conv2d_pack_weights_f32 (taps = R*S <= 9) -> planes of
  * mss_gemm_split_weights_bytes(taps, Kpad, C) bytes with the taps folded into ONE reduction of taps*C; mss_conv2d_forward_route answers 4. */
 int mss_conv_split_weights_bf16x3(const float* w, void* planes, int taps, int Kpad, int C, void* stream);
+/* Which matrix instruction the LAST split-bf16 GEMM launched by the calling thread used: 16 = v_mfma_f32_16x16x32_bf16 on concatenated
+ * planes with the weights brought in by LDS-DMA (products without a prologue whose output start, pitch and batch stride sit on the
+ * 16-byte grid), 32 = v_mfma_f32_32x32x16_bf16 (everything else), 0 = none yet. Observability for tests and profiling labels only. */
+int mss_gemm_split_last_mfma(void);
 /* w [K][C][R][S] (nn.Conv2d.weight) -> packed [R*S][Kpad][Cp] (zero padded).
  * flip=1 packs the data-gradient filter instead (K<->C swapped, taps rotated 180 degrees);
  * then Kpad/Cp refer to the swapped roles. */

@@ -89,6 +89,7 @@ SIGNATURES = {
     "mss_conv2d_forward_f32": [POINTER(MssConvArgs), P],
     "mss_conv2d_kpad": [I],
     "mss_conv2d_forward_route": [POINTER(MssConvArgs)],
+    "mss_gemm_split_last_mfma": [],
     "mss_gemm_split_weights_bytes": [I, I, I],
     "mss_gemm_split_weights_bf16x3": [P, P, I, I, I, L, P],
     "mss_conv_split_weights_bf16x3": [P, P, I, I, I, P],
@@ -186,7 +187,7 @@ SIGNATURES = {
     "mss_peak_scatter_f32": [P, P, L, I, I, L, P],
 }
 # entry points that return a plain value rather than a status code
-_VALUE_RETURNING = {"mss_conv2d_wgrad_route", "mss_gemm_split_weights_bytes", "mss_abi_version", "mss_env_reset", "mss_env_generation", "mss_rcl_workspace_bytes", "mss_msda_backward_workspace_bytes", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
+_VALUE_RETURNING = {"mss_gemm_split_last_mfma", "mss_conv2d_wgrad_route", "mss_gemm_split_weights_bytes", "mss_abi_version", "mss_env_reset", "mss_env_generation", "mss_rcl_workspace_bytes", "mss_msda_backward_workspace_bytes", "mss_conv2d_kpad", "mss_conv2d_forward_route", "mss_rcl_num_compact_blocks", "mss_wino_num_tiles",
                     "mss_oodm_sort_temp_bytes", "mss_oodm_compact_lanes_cap", "mss_oodm_rank_blocks", "mss_wino_output_stats_parts",
                     "mss_conv2d_wgrad_workspace_bytes", "mss_col_reduce_accum_doubles", "mss_colsum_workspace_floats",
                     "mss_add_layernorm_bwd_workspace_floats", "mss_groupnorm_workspace_floats",

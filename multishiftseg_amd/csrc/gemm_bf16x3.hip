@@ -1055,8 +1055,11 @@ bool split_mf16_ok(const MssConvArgs& p) {
   return !p.stats || al(p.stats);
 }
 
+thread_local int split_last_mfma = 0;      // mss_gemm_split_last_mfma()
+
 template <bool AFFINE, int BN, bool CONV, bool ROWAFF, int MF>
 int launch_split_mf(const MssConvArgs& p, hipStream_t stream) {
+  split_last_mfma = MF;
   if constexpr (split_dyn_tiles<AFFINE, BN, CONV, ROWAFF>()) {
     int* sched = MSS_ENV_INT("MSS_GEMM_SPLIT_STATIC", 0) ? nullptr : mss_sched_slot(stream);    // (tests: force the fallback)
     if (sched) return launch_split_as<AFFINE, BN, CONV, ROWAFF, true, MF>(p, stream, sched);
@@ -1079,6 +1082,8 @@ int launch_split(const MssConvArgs& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" int mss_gemm_split_last_mfma(void) { return split_last_mfma; }
 
 // Shapes the split route takes: what gemm_nt_kernel's 128- / 256-wide variant-3 kernels take (p.M, p.mtiles set by the caller) with
 // the weights' planes inside 32-bit byte offsets.

@@ -526,6 +526,9 @@ def test_bf16x3_gemm_into_an_output_window(K, rows, c, k, batch, pitch, lead):
         win = buf[:, 1:rows + 1, lead:lead + k] if lead + k <= pitch else None
         assert win is not None and win.data_ptr() % 16 == (4 * (pitch + lead)) % 16
         _run_gemm(K, x, w, k, split=split, y=win)
+        if split:                                  # the form really follows the window's alignment
+            aligned = k % 4 == 0 and pitch % 4 == 0 and lead % 4 == 0
+            assert _lib.value("mss_gemm_split_last_mfma") == (16 if aligned else 32)
         assert (win.double() - ref).abs().max().item() < 2e-6 * scale, split
         outside = buf.clone()
         outside[:, 1:rows + 1, lead:lead + k] = 7.0
