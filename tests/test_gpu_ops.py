@@ -799,6 +799,7 @@ def test_bf16x3_mfma16_lds_dma_has_no_race(K, monkeypatch, rows, c, k, batch):
     w[:, :k] = torch.randn(batch, k, c, device="cuda") / c ** 0.5
     monkeypatch.setenv("MSS_GEMM_SPLIT_MFMA", "16")
     first, _ = _run_gemm(K, x, w, k, split=True)
+    assert _lib.value("mss_gemm_split_last_mfma") == 16
     noise = torch.empty(64 << 20, device="cuda")
     side = torch.cuda.Stream()
     for it in range(60):
@@ -809,6 +810,7 @@ def test_bf16x3_mfma16_lds_dma_has_no_race(K, monkeypatch, rows, c, k, batch):
     torch.cuda.synchronize()
     monkeypatch.setenv("MSS_GEMM_SPLIT_MFMA", "32")
     y32, _ = _run_gemm(K, x, w, k, split=True)
+    assert _lib.value("mss_gemm_split_last_mfma") == 32
     scale = first.abs().max().item()
     assert (first.double() - y32.double()).abs().max().item() < 2e-6 * scale
     assert not torch.equal(first, y32)                     # it really is the other kernel
